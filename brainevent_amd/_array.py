@@ -1,0 +1,98 @@
+"""Array plumbing: device buffers are torch ROCm tensors; numpy in -> numpy out.
+
+PyTorch is used only for device memory, streams and (in ``_dist``) process groups.
+"""
+import ctypes
+from typing import Any, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import require_device
+
+BE_F32, BE_F64, BE_F16, BE_BF16 = 0, 1, 2, 3
+BE_SPIKE_BOOL, BE_SPIKE_FLOAT = 0, 1
+
+_W_CODE = {torch.float32: BE_F32, torch.float64: BE_F64, torch.float16: BE_F16, torch.bfloat16: BE_BF16}
+_W_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16', torch.bfloat16: 'bf16'}
+
+
+def is_array(x: Any) -> bool:
+    return isinstance(x, (np.ndarray, torch.Tensor, np.generic, list, tuple, int, float, bool))
+
+
+def wants_numpy(*xs) -> bool:
+    """Result type follows the inputs: torch tensor if any operand is one, else numpy."""
+    return not any(isinstance(x, torch.Tensor) for x in xs)
+
+
+def device() -> torch.device:
+    require_device()
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def to_device(x, dtype=None) -> torch.Tensor:
+    """Contiguous tensor on the current HIP device (zero-copy for tensors already there)."""
+    dev = device()
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        a = np.asarray(x)
+        if a.dtype == np.float64 and dtype is None and not isinstance(x, (np.ndarray, np.generic)):
+            a = a.astype(np.float32)   # python floats default to f32 like jnp.asarray
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if t.device != dev:
+        t = t.to(dev)
+    return t.contiguous()
+
+
+def to_result(t: torch.Tensor, as_numpy: bool):
+    if as_numpy:
+        if t.dtype == torch.bfloat16:
+            return t.float().cpu().numpy()
+        return t.cpu().numpy()
+    return t
+
+
+def wcode(t: torch.Tensor) -> int:
+    try:
+        return _W_CODE[t.dtype]
+    except KeyError:
+        raise AssertionError('Weights must be a floating-point type.')
+
+
+def wsuffix(t: torch.Tensor) -> str:
+    return _W_SUFFIX[t.dtype]
+
+
+def spikes_to_device(v) -> Tuple[torch.Tensor, int]:
+    """Event buffer + spike dtype code.
+
+    bool / int8 / uint8 are 1-byte "active when != 0" buffers; float32 is "active when > 0";
+    other float widths are thresholded to bool first, other integers are cast to bool
+    (reference ``brainevent/_dense/binary.py:162-163``, ``brainevent/_fcn/binary.py:285``).
+    """
+    t = to_device(v)
+    if t.dtype in (torch.bool, torch.uint8, torch.int8):
+        return t, BE_SPIKE_BOOL
+    if t.dtype == torch.float32:
+        return t, BE_SPIKE_FLOAT
+    if t.dtype.is_floating_point:
+        return (t > 0), BE_SPIKE_BOOL
+    return (t != 0), BE_SPIKE_BOOL
+
+
+def ptr(t) -> ctypes.c_void_p:
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes: int) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device())

@@ -1,0 +1,480 @@
+"""CSR / CSC containers and the event-driven CSR products ``binary_csrmv`` / ``binary_csrmm``.
+
+Reference surface being mirrored (read as text, nothing imported):
+  * ``brainevent/_csr/main.py:182-277`` (constructor contract), ``:1595-1776`` (``CSR.__matmul__`` /
+    ``__rmatmul__``), ``:2509-2696`` (``CSC`` mirror of the same), ``:58-88`` / ``:148-161`` (the
+    per-matrix binary workspace that is built on first use and cached in ``buffers``);
+  * ``brainevent/_csr/binary.py:128-260`` (``binary_csrmv``), ``:264-384`` (``binary_csrmm``),
+    ``:827-987`` / ``:1452-1607`` (``*_p_call`` validation), ``:387-489`` / ``:1029-1160`` (CPU semantics).
+
+Semantics (``e(x)`` = ``x`` for bool, ``x > 0`` for float):
+  transpose=True : ``y[j] = sum_{i: e(v[i])} A[i, j]``        (scatter over active rows)
+  transpose=False: ``y[i] = sum_j A[i, j] * e(v[j])``          (gather)
+
+The per-matrix workspace of the reference (a task queue sized by ``hybrid_task_capacity``) becomes
+here a :class:`ScatterPlan` — the post-sliced row-segment layout consumed by the LDS-accumulating
+scatter kernel (see ``csrc/be_csr.hip``).  ``workspace=None`` selects the preprocessing-free
+"direct" kernel (global atomics).
+"""
+import ctypes
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _array as A
+from ._error import MathError
+from ._event import BinaryArray
+from ._lib import check, fn
+from ._misc import _as_indptr, _as_int32_indices, _check_compressed_structure
+from ._op import OpKernel
+
+__all__ = ['CSR', 'CSC', 'ScatterPlan', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p', 'binary_csrmm_p',
+           'binary_csrmv_p_call', 'binary_csrmm_p_call']
+
+c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+
+
+# =====================================================================================================
+# scatter plan (per-matrix workspace)
+# =====================================================================================================
+class ScatterPlan:
+    """Post-sliced row segments of a CSR / fixed-number-connectivity matrix (device resident).
+
+    Built once per matrix (structure + weights), reused by every ``spk @ matrix`` call.  Fields:
+    ``seg_ptr`` uint32 ``[n_slices*m + 1]`` (units of 4 entries), ``idx16`` uint16 ``[total]``,
+    ``w32`` f32 ``[total]`` (hetero only), ``slice_shift``, ``scale_exp`` (fixed-point exponent).
+    """
+
+    #: default slice widths: hetero accumulators are 8 B (2^14 * 8 = 128 KiB of LDS), homo are 4 B
+    HETERO_SHIFT = 14
+    HOMO_SHIFT = 15
+
+    def __init__(self, m, k, homo, slice_shift, seg_ptr, idx16, w32, total, scale_exp, weight_dtype):
+        self.m, self.k, self.homo = int(m), int(k), bool(homo)
+        self.slice_shift = int(slice_shift)
+        self.n_slices = (self.k + (1 << self.slice_shift) - 1) >> self.slice_shift
+        self.seg_ptr, self.idx16, self.w32 = seg_ptr, idx16, w32
+        self.total = int(total)
+        self.scale_exp = int(scale_exp)
+        self.weight_dtype = weight_dtype
+        self._ws: Dict[int, torch.Tensor] = {}
+
+    # -- sizing ---------------------------------------------------------------------------------
+    @staticmethod
+    def default_shift(k: int, homo: bool) -> int:
+        cap = ScatterPlan.HOMO_SHIFT if homo else ScatterPlan.HETERO_SHIFT
+        need = max(4, int(math.ceil(math.log2(max(int(k), 2)))))
+        return min(cap, need)
+
+    def default_parts(self) -> int:
+        # one 1024-thread workgroup per CU: aim for ~256 workgroups in total
+        return int(max(1, min(64, 256 // max(self.n_slices, 1))))
+
+    def nbytes(self) -> int:
+        n = self.seg_ptr.numel() * 4 + self.idx16.numel() * 2
+        if self.w32 is not None:
+            n += self.w32.numel() * 4
+        return n
+
+    def workspace(self, parts: int) -> torch.Tensor:
+        ws = self._ws.get(parts)
+        if ws is None:
+            f = fn('be_binary_csrmv_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_int, c_int])
+            ws = A.workspace(f(self.m, self.k, self.slice_shift, parts, int(self.homo)))
+            self._ws = {parts: ws}
+        return ws
+
+    # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def build(cls, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], *, shape,
+              row_len: int = -1, slice_shift: Optional[int] = None) -> 'ScatterPlan':
+        """Build the plan on the device.  ``indptr=None`` + ``row_len`` describes fixed-length rows."""
+        m, k = int(shape[0]), int(shape[1])
+        weights = A.to_device(weights).reshape(-1)
+        indices = A.to_device(indices).reshape(-1)
+        assert indices.dtype == torch.int32
+        homo = weights.numel() == 1
+        if slice_shift is None:
+            slice_shift = cls.default_shift(k, homo)
+        n_slices = (k + (1 << slice_shift) - 1) >> slice_shift
+        dev = A.device()
+        st = A.stream_ptr()
+        is64 = int(indptr is not None and indptr.dtype == torch.int64)
+        if indptr is not None:
+            indptr = A.to_device(indptr)
+        seg_ptr = torch.empty(n_slices * m + 1, dtype=torch.int32, device=dev)   # bit pattern = uint32
+        f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int])
+        scratch = A.workspace(f_scr(m, k, slice_shift))
+        total = c_i64(0)
+        f_cnt = fn('be_scatter_plan_count', c_int,
+                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
+        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, A.ptr(seg_ptr), A.ptr(scratch),
+                    scratch.numel(), ctypes.byref(total), st), 'be_scatter_plan_count')
+        total = int(total.value)
+        idx16 = torch.empty(max(total, 4), dtype=torch.int16, device=dev)
+        w32 = None if homo else torch.empty(max(total, 4), dtype=torch.float32, device=dev)
+        maxabs = torch.zeros(1, dtype=torch.int32, device=dev)
+        f_fill = fn('be_scatter_plan_fill', c_int,
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp])
+        check(f_fill(A.ptr(weights), int(homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, m, k,
+                     slice_shift, A.ptr(seg_ptr), total, A.ptr(idx16), A.ptr(w32), A.ptr(maxabs), st),
+              'be_scatter_plan_fill')
+        scale_exp = 0
+        if not homo:
+            bits = int(maxabs.item()) & 0xFFFFFFFF
+            if bits >= 0x7F800000:
+                raise MathError("ScatterPlan: weights contain inf/nan; use the direct route (workspace=None).")
+            wmax = float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+            # |w| <= wmax < 2^e ;  sums of at most m terms must stay below 2^62
+            e = math.frexp(wmax)[1] if wmax > 0 else 0
+            scale_exp = 62 - e - max(1, int(math.ceil(math.log2(m + 1))))
+        return cls(m, k, homo, slice_shift, seg_ptr, idx16, w32, total, scale_exp, weights.dtype)
+
+
+def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes: torch.Tensor, sd: int, out: torch.Tensor,
+               parts: Optional[int] = None) -> None:
+    parts = plan.default_parts() if parts is None else int(parts)
+    ws = plan.workspace(parts)
+    f = fn('be_binary_csrmv_t_plan', c_int,
+           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp])
+    check(f(A.ptr(weights), int(plan.homo), A.wcode(out), A.ptr(plan.idx16), A.ptr(plan.w32), A.ptr(plan.seg_ptr),
+            A.ptr(spikes), sd, A.ptr(out), plan.m, plan.k, plan.slice_shift, parts, plan.scale_exp, A.ptr(ws),
+            ws.numel(), A.stream_ptr()), 'be_binary_csrmv_t_plan')
+
+
+# =====================================================================================================
+# functional ops
+# =====================================================================================================
+def _variant(homo: bool, w: torch.Tensor, sd: int) -> str:
+    return f"{'homo' if homo else 'hetero'}_{A.wsuffix(w)}_{'bool' if sd == A.BE_SPIKE_BOOL else 'float'}"
+
+
+_CSRMV_ARGS = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]
+
+
+def _binary_csrmv_hip(weights, indices, indptr, vector, *, shape, transpose, workspace=None):
+    m, k = int(shape[0]), int(shape[1])
+    spikes, sd = A.spikes_to_device(vector)
+    homo = weights.numel() == 1
+    out_len = k if transpose else m
+    out = torch.empty(out_len, dtype=weights.dtype, device=weights.device)
+    if out_len == 0:
+        return out
+    if (m == 0 or k == 0 or indices.numel() == 0):
+        return out.zero_()
+    is64 = int(indptr.dtype == torch.int64)
+    if transpose:
+        if isinstance(workspace, ScatterPlan):
+            assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
+            _plan_call(workspace, weights, spikes, sd, out)
+            return out
+        f_ws = fn('be_binary_csrmv_t_workspace_bytes', c_i64, [c_i64, c_i64, c_int])
+        ws = A.workspace(f_ws(m, k, A.wcode(weights)))
+        f = fn('be_binary_csrmv_t_' + _variant(homo, weights, sd), c_int, _CSRMV_ARGS)
+    else:
+        f_ws = fn('be_binary_csrmv_nt_workspace_bytes', c_i64, [c_i64, c_i64])
+        ws = A.workspace(f_ws(m, k))
+        f = fn('be_binary_csrmv_nt_' + _variant(homo, weights, sd), c_int, _CSRMV_ARGS)
+    check(f(A.ptr(weights), A.ptr(indices), A.ptr(indptr), is64, A.ptr(spikes), A.ptr(out), m, k, A.ptr(ws),
+            ws.numel(), A.stream_ptr()), f.__name__)
+    return out
+
+
+binary_csrmv_p = OpKernel('binary_csrmv')
+binary_csrmv_p.def_kernel('hip', 'gpu', _binary_csrmv_hip, asdefault=True)
+binary_csrmv_p.def_tags('csr', 'binary')
+
+
+def _check_csr_structure_dtypes(indices, indptr):
+    assert indices.dtype == torch.int32, f"indices must be int32; got {indices.dtype}."
+    assert indptr.dtype in (torch.int32, torch.int64), f"indptr must be int32 or int64; got {indptr.dtype}."
+
+
+def binary_csrmv_p_call(weights, indices, indptr, vector, workspace=None, *, shape, transpose, backend=None):
+    """Validate, then dispatch (reference ``brainevent/_csr/binary.py:827-987``).  Returns a 1-tuple."""
+    assert indptr.ndim == 1, "Indptr must be 1D."
+    assert indices.ndim == 1, "Indices must be 1D."
+    _check_csr_structure_dtypes(indices, indptr)
+    if transpose:
+        assert shape[0] == vector.shape[0], "Shape mismatch for transpose operation."
+    else:
+        assert shape[1] == vector.shape[0], "Shape mismatch for non-transpose operation."
+    assert weights.dtype.is_floating_point, 'Weights must be a floating-point type.'
+    if weights.ndim == 0:
+        weights = weights.reshape(1)
+    return (binary_csrmv_p(weights, indices, indptr, vector, shape=shape, transpose=transpose, workspace=workspace,
+                           backend=backend),)
+
+
+def binary_csrmv(data, indices, indptr, v, *, shape, workspace=None, transpose: bool = False,
+                 backend: Optional[str] = None):
+    """Event-driven ``A @ v`` (``transpose=False``) or ``A.T @ v`` (``transpose=True``) for CSR ``A``.
+
+    Same keyword signature as the reference (``brainevent/_csr/binary.py:128-138``); ``workspace`` is a
+    :class:`ScatterPlan` prepared by the ``CSR`` / ``CSC`` classes, or ``None`` for the direct kernel.
+    Output dtype = ``data`` dtype; output length ``shape[1]`` if ``transpose`` else ``shape[0]``.
+    """
+    as_np = A.wants_numpy(data, indices, indptr, v)
+    w = A.to_device(data)
+    idx = A.to_device(indices)
+    ptr_ = A.to_device(indptr)
+    if idx.dtype != torch.int32:
+        idx = _as_int32_indices(idx, None, 'binary_csrmv', check_values=False)
+    if ptr_.dtype not in (torch.int32, torch.int64):
+        ptr_ = _as_indptr(ptr_, idx.shape[0], 'auto', 'binary_csrmv')
+    vec = v if isinstance(v, torch.Tensor) else np.asarray(v)
+    res = binary_csrmv_p_call(w, idx, ptr_, vec, workspace, shape=tuple(shape), transpose=transpose, backend=backend)[0]
+    return A.to_result(res, as_np)
+
+
+def _binary_csrmm_hip(weights, indices, indptr, B, *, shape, transpose, workspace=None):
+    # column-at-a-time, as the reference's SRAW route does on the host
+    # (brainevent/_csr/binary_csrmm_hybrid.cu:16-57); a fused batch kernel is a later round.
+    Bt = A.to_device(B)
+    n = Bt.shape[1]
+    out_rows = int(shape[1] if transpose else shape[0])
+    out = torch.empty((out_rows, n), dtype=weights.dtype, device=weights.device)
+    for l in range(n):
+        out[:, l] = _binary_csrmv_hip(weights, indices, indptr, Bt[:, l].contiguous(), shape=shape,
+                                      transpose=transpose, workspace=workspace)
+    return out
+
+
+binary_csrmm_p = OpKernel('binary_csrmm')
+binary_csrmm_p.def_kernel('hip', 'gpu', _binary_csrmm_hip, asdefault=True)
+binary_csrmm_p.def_tags('csr', 'binary')
+
+
+def binary_csrmm_p_call(weights, indices, indptr, B, workspace=None, *, shape, transpose, backend=None):
+    """Validation of the matrix-operand op (reference ``brainevent/_csr/binary.py:1452-1607``)."""
+    assert indptr.ndim == 1, "Indptr must be 1D."
+    assert indices.ndim == 1, "Indices must be 1D."
+    _check_csr_structure_dtypes(indices, indptr)
+    assert B.ndim == 2, "B must be 2D."
+    if transpose:
+        assert shape[0] == B.shape[0], "Shape mismatch for transpose operation."
+    else:
+        assert shape[1] == B.shape[0], "Shape mismatch for non-transpose operation."
+    assert weights.dtype.is_floating_point, 'Weights must be a floating-point type.'
+    if weights.ndim == 0:
+        weights = weights.reshape(1)
+    return (binary_csrmm_p(weights, indices, indptr, B, shape=shape, transpose=transpose, workspace=workspace,
+                           backend=backend),)
+
+
+def binary_csrmm(data, indices, indptr, B, *, shape, workspace=None, transpose: bool = False,
+                 backend: Optional[str] = None):
+    """Event-driven ``A @ B`` / ``A.T @ B`` with a binary matrix ``B[rows, cols]``
+    (reference ``brainevent/_csr/binary.py:264-384``): ``C[j, l] = sum_i A[i, j] * e(B[i, l])``."""
+    as_np = A.wants_numpy(data, indices, indptr, B)
+    w = A.to_device(data)
+    idx = A.to_device(indices)
+    ptr_ = A.to_device(indptr)
+    if idx.dtype != torch.int32:
+        idx = _as_int32_indices(idx, None, 'binary_csrmm', check_values=False)
+    if ptr_.dtype not in (torch.int32, torch.int64):
+        ptr_ = _as_indptr(ptr_, idx.shape[0], 'auto', 'binary_csrmm')
+    Bm = B if isinstance(B, torch.Tensor) else np.asarray(B)
+    res = binary_csrmm_p_call(w, idx, ptr_, Bm, workspace, shape=tuple(shape), transpose=transpose, backend=backend)[0]
+    return A.to_result(res, as_np)
+
+
+# =====================================================================================================
+# containers
+# =====================================================================================================
+#: matrices with fewer stored elements than this use the direct kernel (plan build is not worth it)
+PLAN_MIN_NNZ = 1 << 22
+#: below this average number of entries per (row, slice) segment the plan degenerates into pointer chasing
+PLAN_MIN_SEGMENT = 8
+
+
+class CompressedSparseData:
+    """Common base of :class:`CSR` and :class:`CSC` (reference ``_csr/main.py:182-277``)."""
+    _compressed_format = 'csr'
+
+    def __init__(self, data, indices=None, indptr=None, *, shape, backend: Optional[str] = None,
+                 buffers: Optional[Dict] = None, indptr_dtype="auto", check_structure: bool = True):
+        if indices is None and indptr is None:
+            args = data
+        else:
+            args = (data, indices, indptr)
+        assert len(args) == 3, "Expected three arguments: data, indices, indptr."
+        data_arr, indices_arg, indptr_arg = args
+        fmt = type(self)._compressed_format
+        shape = (int(shape[0]), int(shape[1]))
+        secondary_dim = shape[1] if fmt == 'csr' else shape[0]
+        context = f"{fmt.upper()} constructor"
+        self._numpy_result = A.wants_numpy(data_arr, indices_arg, indptr_arg)
+        self.data = A.to_device(data_arr)
+        self.indices = _as_int32_indices(A.to_device(indices_arg), secondary_dim, context, check_values=check_structure)
+        nse = self.indices.shape[0]
+        self.indptr = _as_indptr(A.to_device(indptr_arg), nse, indptr_dtype, context)
+        if check_structure:
+            _check_compressed_structure(self.indices, self.indptr, shape, format=fmt, check_values=True)
+        self.shape = shape
+        self.backend = backend
+        self.buffers: Dict = dict(buffers) if buffers else {}
+
+    @classmethod
+    def _from_parts(cls, data, indices, indptr, *, shape, backend=None, buffers=None, numpy_result=None):
+        obj = cls((data, indices, indptr), shape=shape, backend=backend, buffers=buffers, check_structure=False)
+        if numpy_result is not None:
+            obj._numpy_result = numpy_result
+        return obj
+
+    # -- properties ------------------------------------------------------------------------------
+    @property
+    def nse(self) -> int:
+        return int(self.indices.shape[0])
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def ndim(self) -> int:
+        return 2
+
+    def with_data(self, data):
+        """Same structure, new weights (cached plans are dropped: they embed the weights)."""
+        data = A.to_device(data)
+        assert data.shape == self.data.shape
+        return type(self)._from_parts(data, self.indices, self.indptr, shape=self.shape, backend=self.backend,
+                                       numpy_result=self._numpy_result)
+
+    def todense(self):
+        """Dense ``(shape)`` copy; duplicates are summed (host-side helper for tests / small matrices)."""
+        idx = self.indices.cpu().numpy()
+        ptr_ = self.indptr.cpu().numpy()
+        w = self.data.float().cpu().numpy() if self.data.dtype == torch.bfloat16 else self.data.cpu().numpy()
+        primary = np.repeat(np.arange(len(ptr_) - 1), np.diff(ptr_))
+        vals = np.broadcast_to(w.reshape(-1), idx.shape) if w.size == 1 else w
+        out = np.zeros(self.shape, dtype=vals.dtype)
+        if type(self)._compressed_format == 'csr':
+            np.add.at(out, (primary, idx), vals)
+        else:
+            np.add.at(out, (idx, primary), vals)
+        return out
+
+    # -- per-matrix workspace ----------------------------------------------------------------------
+    def _plan_shape(self) -> Tuple[int, int]:
+        """(rows, cols) of the stored compressed structure (CSC stores the transpose)."""
+        return self.shape if type(self)._compressed_format == 'csr' else self.shape[::-1]
+
+    def _scatter_workspace(self) -> Optional[ScatterPlan]:
+        """Plan for the scatter direction, built on first use and cached in ``buffers``
+        (reference ``_ensure_binary_workspace_and_get``, ``_csr/main.py:148-161``)."""
+        if 'scatter_plan' in self.buffers:
+            return self.buffers['scatter_plan']
+        m, k = self._plan_shape()
+        plan = None
+        if self.nse >= PLAN_MIN_NNZ and m > 0 and k > 0:
+            homo = self.data.numel() == 1
+            shift = ScatterPlan.default_shift(k, homo)
+            n_slices = (k + (1 << shift) - 1) >> shift
+            if self.nse / (m * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096 and \
+                    self.data.dtype != torch.float64:
+                plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
+        self.buffers['scatter_plan'] = plan
+        return plan
+
+    def prepare(self):
+        """Build the scatter workspace now (otherwise it is built by the first ``spk @ matrix``)."""
+        self._scatter_workspace()
+        return self
+
+    def _res(self, t):
+        return A.to_result(t, self._numpy_result)
+
+
+def _event_value(other: BinaryArray):
+    return other.value
+
+
+class CSR(CompressedSparseData):
+    """Compressed sparse row matrix with event-driven products (reference ``_csr/main.py:977``)."""
+    _compressed_format = 'csr'
+
+    def __matmul__(self, other):      # csr @ other
+        if isinstance(other, BinaryArray):
+            v = _event_value(other)
+            if v.ndim == 1:
+                r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, None, shape=self.shape,
+                                        transpose=False, backend=self.backend)[0]
+            elif v.ndim == 2:
+                r = binary_csrmm_p_call(self.data, self.indices, self.indptr, v, None, shape=self.shape,
+                                        transpose=False, backend=self.backend)[0]
+            else:
+                raise NotImplementedError(f"matmul with object of shape {v.shape}")
+            return self._res(r) if A.wants_numpy(v) else r
+        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+
+    def __rmatmul__(self, other):     # other @ csr
+        if isinstance(other, BinaryArray):
+            v = _event_value(other)
+            ws = self._scatter_workspace()
+            if v.ndim == 1:
+                r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, ws, shape=self.shape, transpose=True,
+                                        backend=self.backend)[0]
+            elif v.ndim == 2:
+                r = binary_csrmm_p_call(self.data, self.indices, self.indptr, v.T, ws, shape=self.shape,
+                                        transpose=True, backend=self.backend)[0].T
+            else:
+                raise NotImplementedError(f"matmul with object of shape {v.shape}")
+            return self._res(r) if A.wants_numpy(v) else r
+        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+
+    def transpose(self, axes=None):
+        assert axes is None, "transpose does not support axes argument."
+        return CSC._from_parts(self.data, self.indices, self.indptr, shape=self.shape[::-1], backend=self.backend,
+                               numpy_result=self._numpy_result)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+
+class CSC(CompressedSparseData):
+    """Compressed sparse column matrix (reference ``_csr/main.py:1890``): ``indices`` are row ids,
+    ``indptr`` has ``shape[1] + 1`` entries — i.e. the CSR arrays of the transpose."""
+    _compressed_format = 'csc'
+
+    def __matmul__(self, other):      # csc @ other : scatter over the active columns
+        if isinstance(other, BinaryArray):
+            v = _event_value(other)
+            ws = self._scatter_workspace()
+            if v.ndim == 1:
+                r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, ws, shape=self.shape[::-1],
+                                        transpose=True, backend=self.backend)[0]
+            elif v.ndim == 2:
+                r = binary_csrmm_p_call(self.data, self.indices, self.indptr, v, ws, shape=self.shape[::-1],
+                                        transpose=True, backend=self.backend)[0]
+            else:
+                raise NotImplementedError(f"matmul with object of shape {v.shape}")
+            return self._res(r) if A.wants_numpy(v) else r
+        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+
+    def __rmatmul__(self, other):     # other @ csc : gather
+        if isinstance(other, BinaryArray):
+            v = _event_value(other)
+            if v.ndim == 1:
+                r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, None, shape=self.shape[::-1],
+                                        transpose=False, backend=self.backend)[0]
+            elif v.ndim == 2:
+                r = binary_csrmm_p_call(self.data, self.indices, self.indptr, v.T, None, shape=self.shape[::-1],
+                                        transpose=False, backend=self.backend)[0].T
+            else:
+                raise NotImplementedError(f"matmul with object of shape {v.shape}")
+            return self._res(r) if A.wants_numpy(v) else r
+        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+
+    def transpose(self, axes=None):
+        assert axes is None, "transpose does not support axes argument."
+        return CSR._from_parts(self.data, self.indices, self.indptr, shape=self.shape[::-1], backend=self.backend,
+                               numpy_result=self._numpy_result)
+
+    @property
+    def T(self):
+        return self.transpose()

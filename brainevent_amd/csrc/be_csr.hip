@@ -1,0 +1,736 @@
+// be_csr.hip — event-driven CSR / fixed-number-connectivity matrix-vector products for gfx950.
+//
+// Computes what the reference's CPU kernel `_csrmv_numba_kernel` computes
+// (reference brainevent/_csr/binary.py:387-489, read as text):
+//   transpose=True  : out[:] = 0; for active row i: for j in row i: out[indices[j]] += w[j]
+//   transpose=False : out[i] = sum_{j in row i} w[j] * e(spikes[indices[j]])
+// with w[j] = weights[0] for homogeneous weights.
+//
+// Two scatter routes exist because of one measured fact (tools/ubench, MI355X): random-address
+// global f32 atomics retire at ~21 G/s chip-wide (they execute memory-side), i.e. ~2 % of what the
+// HBM stream of indices+weights could feed.  LDS *integer* atomics retire at ~3-4.7 T/s
+// (ds_add_u64 / ds_add_u32), LDS *float* atomics only at ~0.2 T/s.  So:
+//   * direct route  : no preprocessing, one wave per active row, global atomics.  Any CSR.
+//   * planned route : the matrix is re-laid out once per matrix by output slice
+//                     ("post-sliced row segments", uint16 local columns).  One workgroup owns one
+//                     slice's accumulators in LDS and streams only the active rows' segments for
+//                     that slice; sums are 64-bit fixed point (hetero) or integer counts (homo), so
+//                     results are order independent and bitwise reproducible.
+#include "be_common.h"
+#include <cmath>
+#include <type_traits>
+
+namespace {
+
+// =================================================================================================
+// spike vector helpers
+// =================================================================================================
+template <typename SP>
+__global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
+                                                        uint32_t* __restrict__ active, uint32_t* __restrict__ count) {
+  // wave-level ballot + one counter atomic per wave that saw a spike; order of ids is unspecified
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_round = (n + 63) & ~(int64_t)63;   // keep whole waves in the loop so __ballot is full
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const bool a = (i < n) && SP::active(spikes[i]);
+    const unsigned long long mask = __ballot(a);
+    if (mask == 0ull) continue;
+    const int lane = lane_id();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (a) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+  }
+}
+
+template <typename SP>
+__global__ void __launch_bounds__(256) k_pack_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
+                                                     uint32_t* __restrict__ bits) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_round = (n + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const bool a = (i < n) && SP::active(spikes[i]);
+    const unsigned long long mask = __ballot(a);
+    const int lane = lane_id();
+    const int64_t word = i >> 5;   // lane 0 -> low word, lane 32 -> high word
+    if (lane == 0) bits[word] = (uint32_t)mask;
+    if (lane == 32 && (i < n)) bits[word] = (uint32_t)(mask >> 32);
+  }
+}
+
+// =================================================================================================
+// direct scatter: one wave per active row, global atomics
+// =================================================================================================
+template <typename W, bool HOMO, typename ACC>
+__global__ void __launch_bounds__(256) k_csrmv_t_direct(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                        RowPtr rp, const uint32_t* __restrict__ active,
+                                                        const uint32_t* __restrict__ n_active_p, ACC* __restrict__ out) {
+  const uint32_t n_active = *n_active_p;
+  const int lane = lane_id();
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  ACC w0 = ACC(0);
+  if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
+  for (uint32_t a = wave; a < n_active; a += n_waves) {
+    const int64_t r = active[a];
+    const int64_t b = rp.at(r), e = rp.at(r + 1);
+    for (int64_t j = b + lane; j < e; j += 64) {
+      const ACC w = HOMO ? w0 : (ACC)WTraits<W>::load(weights, j);
+      atomicAdd(out + indices[j], w);
+    }
+  }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_convert_from_f32(const float* __restrict__ src, W* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) WTraits<W>::store(dst, i, src[i]);
+}
+
+// =================================================================================================
+// gather (transpose=False): lanes-per-row groups, bit-packed spikes in LDS when they fit
+// =================================================================================================
+template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
+__global__ void __launch_bounds__(256) k_csrmv_nt(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                  RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
+                                                  W* __restrict__ out, int64_t m) {
+  extern __shared__ uint32_t bits_s[];
+  const uint32_t* bits = bits_g;
+  if (BITS_IN_LDS) {
+    for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) bits_s[i] = bits_g[i];
+    __syncthreads();
+    bits = bits_s;
+  }
+  using ACC = typename WTraits<W>::acc;
+  constexpr int GROUPS = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const int64_t group = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
+  const int64_t n_groups = (int64_t)gridDim.x * GROUPS;
+  ACC w0 = ACC(0);
+  if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
+  // rows are dealt to groups round-robin; all lanes of a wave run the same number of iterations
+  const int64_t m_round = (m + n_groups - 1) / n_groups * n_groups;
+  for (int64_t r = group; r < m_round; r += n_groups) {
+    ACC acc = ACC(0);
+    int cnt = 0;
+    if (r < m) {
+      const int64_t b = rp.at(r), e = rp.at(r + 1);
+      for (int64_t j = b + sub; j < e; j += LPR) {
+        const uint32_t c = (uint32_t)indices[j];
+        const bool on = (bits[c >> 5] >> (c & 31)) & 1u;
+        if (HOMO) cnt += on ? 1 : 0;
+        else if (on) acc += (ACC)WTraits<W>::load(weights, j);
+      }
+    }
+    if (HOMO) {
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, LPR);
+      acc = (ACC)cnt * w0;
+    } else {
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
+    }
+    if (sub == 0 && r < m) WTraits<W>::store(out, r, acc);
+  }
+}
+
+// =================================================================================================
+// scatter plan: count -> scan -> fill
+// =================================================================================================
+constexpr int kMaxSlices = 4096;   // LDS histogram capacity of the plan kernels
+
+// one workgroup per row (grid-stride): per-slice histogram of the row, rounded up to multiples of 4
+__global__ void __launch_bounds__(256) k_plan_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
+                                                    int slice_shift, int n_slices, uint32_t* __restrict__ cnt4) {
+  __shared__ uint32_t hist[kMaxSlices];
+  for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) hist[s] = 0;
+    __syncthreads();
+    const int64_t b = rp.at(r), e = rp.at(r + 1);
+    for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[((uint32_t)indices[j]) >> slice_shift], 1u);
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) cnt4[(int64_t)s * m + r] = (hist[s] + 3u) >> 2;
+    __syncthreads();
+  }
+}
+
+// three-pass exclusive scan of a uint32 array (sums carried in uint64 so overflow is detectable)
+constexpr int kScanChunk = 2048;   // elements per workgroup of 256 threads (8 each)
+
+__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t* __restrict__ a, int64_t n, uint64_t* __restrict__ sums) {
+  __shared__ uint64_t red[256];
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk;
+  uint64_t s = 0;
+  for (int i = threadIdx.x; i < kScanChunk; i += 256) {
+    const int64_t j = base + i;
+    if (j < n) s += a[j];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+
+// single workgroup: exclusive scan of the block sums in place; sums[n_blocks] = grand total
+__global__ void __launch_bounds__(1024) k_scan_sums(uint64_t* __restrict__ sums, int64_t n_blocks) {
+  __shared__ uint64_t part[1024];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_blocks; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const uint64_t v = (i < n_blocks) ? sums[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+      uint64_t t = 0;
+      if ((int)threadIdx.x >= off) t = part[threadIdx.x - off];
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n_blocks) sums[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[n_blocks] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ a, int64_t n, const uint64_t* __restrict__ sums) {
+  __shared__ uint32_t tsum[256];
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
+  uint32_t v[8];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = (base + i < n) ? a[base + i] : 0u;
+    s += v[i];
+  }
+  tsum[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    uint32_t t = 0;
+    if ((int)threadIdx.x >= off) t = tsum[threadIdx.x - off];
+    __syncthreads();
+    tsum[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = (uint32_t)sums[blockIdx.x] + tsum[threadIdx.x] - s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (base + i < n) a[base + i] = run;
+    run += v[i];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a[n] = (uint32_t)sums[gridDim.x];
+}
+
+// one workgroup per row (grid-stride): place every entry of the row into its (slice, row) segment
+template <typename W, bool HOMO>
+__global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
+                                                   int64_t m, int slice_shift, int n_slices,
+                                                   const uint32_t* __restrict__ seg_ptr, uint16_t* __restrict__ idx16,
+                                                   float* __restrict__ w32, uint32_t* __restrict__ maxabs_bits) {
+  __shared__ uint32_t cur[kMaxSlices];
+  __shared__ uint32_t seg_base[kMaxSlices];
+  const uint32_t mask = (1u << slice_shift) - 1u;
+  uint32_t my_max = 0;
+  for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
+      cur[s] = 0;
+      seg_base[s] = seg_ptr[(int64_t)s * m + r];
+    }
+    __syncthreads();
+    const int64_t b = rp.at(r), e = rp.at(r + 1);
+    for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) {
+      const uint32_t c = (uint32_t)indices[j];
+      const uint32_t s = c >> slice_shift;
+      const uint32_t rank = atomicAdd(&cur[s], 1u);
+      const int64_t pos = (int64_t)seg_base[s] * 4 + rank;
+      idx16[pos] = (uint16_t)(c & mask);
+      if (!HOMO) {
+        const float w = (float)WTraits<W>::load(weights, j);
+        w32[pos] = w;
+        const uint32_t ab = __float_as_uint(w) & 0x7fffffffu;
+        my_max = ab > my_max ? ab : my_max;
+      }
+    }
+    __syncthreads();
+  }
+  if (!HOMO) {
+    // non-negative float bit patterns order like unsigned integers (NaN/Inf sort above every finite value)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = __shfl_down(my_max, off, 64);
+      my_max = o > my_max ? o : my_max;
+    }
+    if (lane_id() == 0 && my_max != 0) atomicMax(maxabs_bits, my_max);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fill_u16(uint16_t* __restrict__ p, int64_t n, uint16_t v) {
+  // n is a multiple of 4 and p is 8-byte aligned: store 4 entries at a time
+  const uint32_t vv = (uint32_t)v | ((uint32_t)v << 16);
+  uint2* p4 = reinterpret_cast<uint2*>(p);
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p4[i] = make_uint2(vv, vv);
+}
+
+// =================================================================================================
+// planned scatter step
+// =================================================================================================
+template <bool HOMO> struct PlanAcc;
+template <> struct PlanAcc<true> { using type = uint32_t; };
+template <> struct PlanAcc<false> { using type = unsigned long long; };
+
+template <bool HOMO>
+__device__ __forceinline__ void plan_add4(typename PlanAcc<HOMO>::type* acc, uint2 iv, float4 wv, double scale) {
+  const uint32_t i0 = iv.x & 0xffffu, i1 = iv.x >> 16, i2 = iv.y & 0xffffu, i3 = iv.y >> 16;
+  if (HOMO) {
+    atomicAdd(&acc[i0], 1u);
+    atomicAdd(&acc[i1], 1u);
+    atomicAdd(&acc[i2], 1u);
+    atomicAdd(&acc[i3], 1u);
+  } else {
+    atomicAdd(&acc[i0], (unsigned long long)__double2ll_rn((double)wv.x * scale));
+    atomicAdd(&acc[i1], (unsigned long long)__double2ll_rn((double)wv.y * scale));
+    atomicAdd(&acc[i2], (unsigned long long)__double2ll_rn((double)wv.z * scale));
+    atomicAdd(&acc[i3], (unsigned long long)__double2ll_rn((double)wv.w * scale));
+  }
+}
+
+// grid = n_slices * parts workgroups of 1024 threads; workgroup (slice, part) owns 2^slice_shift (+1 pad)
+// accumulators in LDS and walks the active rows at list positions part, part+parts, ...
+template <bool HOMO>
+__global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restrict__ idx4, const float4* __restrict__ w4,
+                                                          const uint32_t* __restrict__ seg_ptr,
+                                                          const uint32_t* __restrict__ active,
+                                                          const uint32_t* __restrict__ n_active_p, int64_t m,
+                                                          int slice_shift, int parts, double scale,
+                                                          typename PlanAcc<HOMO>::type* __restrict__ partial) {
+  using acc_t = typename PlanAcc<HOMO>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
+  const int S = 1 << slice_shift;
+  const int slice = blockIdx.x / parts;
+  const int part = blockIdx.x - slice * parts;
+  for (int i = threadIdx.x; i <= S; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+
+  const uint32_t n_active = *n_active_p;
+  const uint32_t* sp = seg_ptr + (int64_t)slice * m;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+
+  for (uint64_t t0 = 0;; t0 += 64) {
+    // lane l looks up the segment bounds of this wave's (t0 + l)-th row
+    const uint64_t a = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * (t0 + lane));
+    const bool valid = a < n_active;
+    const unsigned long long vmask = __ballot(valid);
+    if (vmask == 0ull) break;
+    uint32_t b4 = 0, e4 = 0;
+    if (valid) {
+      const uint32_t r = active[a];
+      b4 = sp[r];
+      e4 = sp[r + 1];
+    }
+    const int nvalid = __popcll(vmask);   // valid lanes form a prefix: a grows with the lane
+    for (int i = 0; i < nvalid; i += 4) {
+      // four segments in flight: issue their first 64x4 entries, then accumulate
+      uint32_t base[4], len[4];
+      uint2 iv[4] = {};
+      float4 wv[4] = {};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int src = (i + q) & 63;
+        base[q] = __builtin_amdgcn_readlane(b4, src);
+        len[q] = (i + q < nvalid) ? (__builtin_amdgcn_readlane(e4, src) - base[q]) : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((uint32_t)lane < len[q]) {
+          iv[q] = idx4[(uint64_t)base[q] + lane];
+          if (!HOMO) wv[q] = w4[(uint64_t)base[q] + lane];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((uint32_t)lane < len[q]) plan_add4<HOMO>(acc, iv[q], wv[q], scale);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // long segments: remaining 256-entry chunks
+        for (uint32_t o = 64 + lane; o < len[q]; o += 64) {
+          const uint2 ivt = idx4[(uint64_t)base[q] + o];
+          float4 wvt = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!HOMO) wvt = w4[(uint64_t)base[q] + o];
+          plan_add4<HOMO>(acc, ivt, wvt, scale);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  acc_t* dst = partial + (int64_t)blockIdx.x * S;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) dst[i] = acc[i];
+}
+
+// out[j] = sum over the parts of slice(j)
+template <typename W, bool HOMO>
+__global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO>::type* __restrict__ partial, int parts,
+                                                     int slice_shift, int64_t k, double inv_scale,
+                                                     const W* __restrict__ weights, W* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int S = 1 << slice_shift;
+  typename WTraits<W>::acc w0 = 0;
+  if (HOMO) w0 = WTraits<W>::load(weights, 0);
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < k; j += stride) {
+    const int64_t slice = j >> slice_shift;
+    const int loc = (int)(j & (S - 1));
+    const typename PlanAcc<HOMO>::type* p = partial + (slice * parts) * S + loc;
+    if (HOMO) {
+      uint32_t c = 0;
+      for (int q = 0; q < parts; ++q) c += p[(int64_t)q * S];
+      WTraits<W>::store(out, j, (typename WTraits<W>::acc)c * w0);
+    } else {
+      unsigned long long s = 0;
+      for (int q = 0; q < parts; ++q) s += p[(int64_t)q * S];
+      WTraits<W>::store_d(out, j, (double)(long long)s * inv_scale);
+    }
+  }
+}
+
+// =================================================================================================
+// host-side launch helpers
+// =================================================================================================
+inline int grid_for(int64_t n, int block, int cap) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+struct DirectWs {   // workspace of the direct scatter route / plan step
+  uint32_t* count;    // 256 B
+  uint32_t* active;   // m * 4
+  float* acc32;       // k * 4 (f16 / bf16 outputs only)
+};
+
+inline int64_t direct_ws_bytes(int64_t m, int64_t k, int wdtype) {
+  int64_t b = 256 + be_align_up(m * 4, 256);
+  if (wdtype == BE_F16 || wdtype == BE_BF16) b += be_align_up(k * 4, 256);
+  return b;
+}
+
+template <typename SP>
+int launch_compact(const void* spikes, int64_t n, uint32_t* active, uint32_t* count, hipStream_t st) {
+  BE_HIP(hipMemsetAsync(count, 0, 4, st));
+  if (n == 0) return BE_OK;
+  hipLaunchKernelGGL(k_compact_spikes<SP>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
+                     static_cast<const typename SP::type*>(spikes), n, active, count);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+int compact_any(const void* spikes, int sd, int64_t n, uint32_t* active, uint32_t* count, hipStream_t st) {
+  if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, active, count, st);
+  if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, active, count, st);
+  be_set_error("unknown spike dtype");
+  return BE_ERR_INVALID;
+}
+
+template <typename SP>
+int launch_pack(const void* spikes, int64_t n, uint32_t* bits, hipStream_t st) {
+  if (n == 0) return BE_OK;
+  hipLaunchKernelGGL(k_pack_spikes<SP>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
+                     static_cast<const typename SP::type*>(spikes), n, bits);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+int pack_any(const void* spikes, int sd, int64_t n, uint32_t* bits, hipStream_t st) {
+  if (sd == BE_SPIKE_BOOL) return launch_pack<SpikeBool>(spikes, n, bits, st);
+  if (sd == BE_SPIKE_FLOAT) return launch_pack<SpikeFloat>(spikes, n, bits, st);
+  be_set_error("unknown spike dtype");
+  return BE_ERR_INVALID;
+}
+
+template <typename W, bool HOMO>
+int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const void* spikes, int sd, void* out,
+                   int64_t m, int64_t k, void* ws, hipStream_t st) {
+  unsigned char* wsb = static_cast<unsigned char*>(ws);
+  uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
+  constexpr bool via_f32 = std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value;
+  using ACC = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
+  ACC* acc = via_f32 ? reinterpret_cast<ACC*>(wsb + 256 + be_align_up(m * 4, 256)) : static_cast<ACC*>(out);
+  if (k > 0) BE_HIP(hipMemsetAsync(acc, 0, (size_t)k * sizeof(ACC), st));
+  int rc = compact_any(spikes, sd, m, active, count, st);
+  if (rc != BE_OK) return rc;
+  if (m > 0 && k > 0) {
+    hipLaunchKernelGGL((k_csrmv_t_direct<W, HOMO, ACC>), dim3(2048), dim3(256), 0, st, static_cast<const W*>(weights),
+                       indices, rp, active, count, acc);
+    BE_LAUNCH_CHECK();
+  }
+  if (via_f32 && k > 0) {
+    hipLaunchKernelGGL(k_convert_from_f32<W>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(acc), static_cast<W*>(out), k);
+    BE_LAUNCH_CHECK();
+  }
+  return BE_OK;
+}
+
+template <typename W, bool HOMO, int LPR>
+int csrmv_nt_launch(const void* weights, const int32_t* indices, RowPtr rp, const uint32_t* bits, int64_t n_words,
+                    void* out, int64_t m, hipStream_t st) {
+  constexpr int GROUPS = 256 / LPR;
+  const size_t lds = (size_t)n_words * 4;
+  const int grid = grid_for(m, GROUPS, 256 * 8);
+  if (lds <= 150 * 1024) {
+    auto kern = k_csrmv_nt<W, HOMO, LPR, true>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, static_cast<const W*>(weights), indices, rp, bits, n_words,
+                       static_cast<W*>(out), m);
+  } else {
+    hipLaunchKernelGGL((k_csrmv_nt<W, HOMO, LPR, false>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),
+                       indices, rp, bits, n_words, static_cast<W*>(out), m);
+  }
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+template <typename W, bool HOMO>
+int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
+             void* out, int64_t m, int64_t k, void* ws, hipStream_t st) {
+  uint32_t* bits = static_cast<uint32_t*>(ws);
+  const int64_t n_words = (k + 31) / 32;
+  int rc = pack_any(spikes, sd, k, bits, st);
+  if (rc != BE_OK) return rc;
+  if (m == 0) return BE_OK;
+  const int64_t avg = nnz_hint / (m > 0 ? m : 1);
+  if (avg <= 8) return csrmv_nt_launch<W, HOMO, 4>(weights, indices, rp, bits, n_words, out, m, st);
+  if (avg <= 48) return csrmv_nt_launch<W, HOMO, 16>(weights, indices, rp, bits, n_words, out, m, st);
+  return csrmv_nt_launch<W, HOMO, 64>(weights, indices, rp, bits, n_words, out, m, st);
+}
+
+#define BE_DISPATCH_W(wdtype, HOMO_FLAG, CALL)                                  \
+  switch (wdtype) {                                                              \
+    case BE_F32:  { using W = float;          if (HOMO_FLAG) { constexpr bool HOMO = true; CALL; } else { constexpr bool HOMO = false; CALL; } } break; \
+    case BE_F64:  { using W = double;         if (HOMO_FLAG) { constexpr bool HOMO = true; CALL; } else { constexpr bool HOMO = false; CALL; } } break; \
+    case BE_F16:  { using W = __half;         if (HOMO_FLAG) { constexpr bool HOMO = true; CALL; } else { constexpr bool HOMO = false; CALL; } } break; \
+    case BE_BF16: { using W = __hip_bfloat16; if (HOMO_FLAG) { constexpr bool HOMO = true; CALL; } else { constexpr bool HOMO = false; CALL; } } break; \
+    default: be_set_error("unknown weight dtype"); return BE_ERR_INVALID;       \
+  }
+
+inline bool check_rows(const void* indptr, int64_t row_len) { return indptr != nullptr || row_len >= 0; }
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream) {
+  BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
+  BE_REQUIRE(n == 0 || (spikes && bits), BE_ERR_INVALID, "null pointer");
+  return pack_any(spikes, spike_dtype, n, bits, static_cast<hipStream_t>(stream));
+}
+
+int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,
+                      be_stream_t stream) {
+  BE_REQUIRE(n >= 0 && n <= 0xffffffffll, BE_ERR_INVALID, "n out of range");
+  BE_REQUIRE(count && (n == 0 || (spikes && active_ids)), BE_ERR_INVALID, "null pointer");
+  return compact_any(spikes, spike_dtype, n, active_ids, count, static_cast<hipStream_t>(stream));
+}
+
+int64_t be_binary_csrmv_t_workspace_bytes(int64_t m, int64_t k, int wdtype) { return direct_ws_bytes(m, k, wdtype); }
+
+int be_binary_csrmv_t(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                      int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                      int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(m >= 0 && k >= 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
+  BE_REQUIRE(k == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
+  BE_REQUIRE(m == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= direct_ws_bytes(m, k, wdtype), BE_ERR_WORKSPACE,
+             "workspace too small");
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BE_DISPATCH_W(wdtype, homo, return (csrmv_t_direct<W, HOMO>(weights, indices, rp, spikes, spike_dtype, out, m, k, workspace, st)));
+  return BE_OK;
+}
+
+int64_t be_binary_csrmv_nt_workspace_bytes(int64_t m, int64_t k) { (void)m; return be_align_up(((k + 31) / 32 + 2) * 4, 256); }
+
+int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                       int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                       int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(m >= 0 && k >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
+  BE_REQUIRE(m == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
+  BE_REQUIRE(k == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_binary_csrmv_nt_workspace_bytes(m, k), BE_ERR_WORKSPACE,
+             "workspace too small");
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // average row length steers the lanes-per-row choice; for CSR it needs indptr[m] which lives on the
+  // device, so the caller's row_len doubles as a hint (row_len >= 0: exact for fixed rows, a hint for CSR)
+  const int64_t nnz_hint = (row_len >= 0 ? row_len : 64) * m;
+  BE_DISPATCH_W(wdtype, homo, return (csrmv_nt<W, HOMO>(weights, indices, rp, nnz_hint, spikes, spike_dtype, out, m, k, workspace, st)));
+  return BE_OK;
+}
+
+// ---------------------------------------------------------------- scatter plan
+static inline int n_slices_of(int64_t k, int slice_shift) { return (int)((k + (1ll << slice_shift) - 1) >> slice_shift); }
+
+int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift) {
+  const int64_t n = (int64_t)n_slices_of(k, slice_shift) * m;
+  const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
+  return be_align_up((n_blocks + 2) * 8, 256);
+}
+
+int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
+                          int64_t k, int slice_shift, uint32_t* seg_ptr, void* scratch, int64_t scratch_bytes,
+                          int64_t* total_entries_host, be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  const int n_slices = n_slices_of(k, slice_shift);
+  BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
+  BE_REQUIRE(seg_ptr && scratch && total_entries_host, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift), BE_ERR_WORKSPACE, "scratch too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  const int64_t n = (int64_t)n_slices * m;
+  hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m, slice_shift, n_slices, seg_ptr);
+  BE_LAUNCH_CHECK();
+  uint64_t* sums = static_cast<uint64_t*>(scratch);
+  const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
+  BE_REQUIRE(n_blocks < (1ll << 31), BE_ERR_RANGE, "plan index too large");
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, st, seg_ptr, n, sums);
+  BE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, n_blocks);
+  BE_LAUNCH_CHECK();
+  uint64_t total4 = 0;
+  BE_HIP(hipMemcpyAsync(&total4, sums + n_blocks, 8, hipMemcpyDeviceToHost, st));
+  BE_HIP(hipStreamSynchronize(st));
+  BE_REQUIRE(total4 < (1ull << 32), BE_ERR_RANGE, "matrix too large for a 32-bit segment index");
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_blocks), dim3(256), 0, st, seg_ptr, n, sums);
+  BE_LAUNCH_CHECK();
+  *total_entries_host = (int64_t)(total4 * 4);
+  return BE_OK;
+}
+
+int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
+                         const uint32_t* seg_ptr, int64_t total_entries, uint16_t* idx16, float* w32,
+                         uint32_t* maxabs_bits, be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(total_entries >= 0 && (total_entries & 3) == 0, BE_ERR_INVALID, "total_entries must be a multiple of 4");
+  BE_REQUIRE(seg_ptr && maxabs_bits && (total_entries == 0 || idx16), BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(homo || total_entries == 0 || (w32 && weights), BE_ERR_INVALID, "hetero plan needs weights and w32");
+  const int n_slices = n_slices_of(k, slice_shift);
+  BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  BE_HIP(hipMemsetAsync(maxabs_bits, 0, 4, st));
+  if (total_entries == 0) return BE_OK;
+  hipLaunchKernelGGL(k_fill_u16, dim3(grid_for(total_entries / 4, 256, 4096)), dim3(256), 0, st, idx16, total_entries,
+                     (uint16_t)(1u << slice_shift));
+  BE_LAUNCH_CHECK();
+  if (!homo) BE_HIP(hipMemsetAsync(w32, 0, (size_t)total_entries * 4, st));
+  const int grid = grid_for(m, 1, 256 * 16);
+  BE_DISPATCH_W(wdtype, homo,
+                hipLaunchKernelGGL((k_plan_fill<W, HOMO>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),
+                                   indices, rp, m, slice_shift, n_slices, seg_ptr, idx16, w32, maxabs_bits));
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo) {
+  const int64_t n_slices = n_slices_of(k, slice_shift);
+  const int64_t acc_bytes = homo ? 4 : 8;
+  return 256 + be_align_up(m * 4, 256) + be_align_up(n_slices * parts * (1ll << slice_shift) * acc_bytes, 256);
+}
+
+int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
+                           const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k,
+                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(parts >= 1 && parts <= 64, BE_ERR_INVALID, "parts must be in [1, 64]");
+  BE_REQUIRE(seg_ptr && spikes && out && idx16, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(homo ? weights != nullptr : w32 != nullptr, BE_ERR_INVALID, "missing weights");
+  BE_REQUIRE(homo || (scale_exp > -1000 && scale_exp < 1000), BE_ERR_INVALID, "scale_exp out of range");
+  const int64_t S = 1ll << slice_shift;
+  const size_t lds = (size_t)(S + 1) * (homo ? 4 : 8);
+  BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
+  BE_REQUIRE(workspace != nullptr &&
+                 workspace_bytes >= be_binary_csrmv_t_plan_workspace_bytes(m, k, slice_shift, parts, homo),
+             BE_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned char* wsb = static_cast<unsigned char*>(workspace);
+  uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
+  void* partial = wsb + 256 + be_align_up(m * 4, 256);
+  const int n_slices = n_slices_of(k, slice_shift);
+  int rc = compact_any(spikes, spike_dtype, m, active, count, st);
+  if (rc != BE_OK) return rc;
+  const double scale = ldexp(1.0, scale_exp), inv_scale = ldexp(1.0, -scale_exp);
+  const dim3 grid((unsigned)(n_slices * parts)), block(1024);
+  if (homo) {
+    auto kern = k_plan_accumulate<true>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const uint2*>(idx16),
+                       reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
+                       static_cast<uint32_t*>(partial));
+  } else {
+    auto kern = k_plan_accumulate<false>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const uint2*>(idx16),
+                       reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
+                       static_cast<unsigned long long*>(partial));
+  }
+  BE_LAUNCH_CHECK();
+  const int rgrid = grid_for(k, 256, 2048);
+  BE_DISPATCH_W(wdtype, homo,
+                hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid), dim3(256), 0, st,
+                                   static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, slice_shift, k,
+                                   inv_scale, static_cast<const W*>(weights), static_cast<W*>(out)));
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+// ---------------------------------------------------------------- per-variant symbols
+#define BE_DEF_CSRMV_VARIANT(W, WD, S, SD)                                                                              \
+  int be_binary_csrmv_t_homo_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,         \
+                                       const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,       \
+                                       be_stream_t st) {                                                                 \
+    return be_binary_csrmv_t(weights, 1, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);              \
+  }                                                                                                                      \
+  int be_binary_csrmv_t_hetero_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,       \
+                                         const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,     \
+                                         be_stream_t st) {                                                               \
+    return be_binary_csrmv_t(weights, 0, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);              \
+  }                                                                                                                      \
+  int be_binary_csrmv_nt_homo_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,        \
+                                        const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,      \
+                                        be_stream_t st) {                                                                \
+    return be_binary_csrmv_nt(weights, 1, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);             \
+  }                                                                                                                      \
+  int be_binary_csrmv_nt_hetero_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,      \
+                                          const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,    \
+                                          be_stream_t st) {                                                              \
+    return be_binary_csrmv_nt(weights, 0, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);             \
+  }
+
+BE_FOR_ALL_VARIANTS(BE_DEF_CSRMV_VARIANT)
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""GPU parity tests for the CSR hot path: HIP kernels (through the C ABI) vs the numpy oracle.
+
+Tolerance: fp32 accumulated currents within rtol=1e-5 (atol 1e-5 absorbs cancellation), the
+north-star bound; homogeneous integer-count cases are compared exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-5
+
+
+def rand_csr(rng, m, k, row_lens, dtype=np.float32, homo=False):
+    row_lens = np.asarray(row_lens, dtype=np.int64)
+    indptr = np.concatenate([[0], np.cumsum(row_lens)]).astype(np.int32)
+    nnz = int(indptr[-1])
+    indices = rng.integers(0, k, nnz).astype(np.int32)
+    w = np.asarray([1.5], dtype=dtype) if homo else rng.uniform(0.1, 1.0, nnz).astype(dtype)
+    return w, indices, indptr
+
+
+def spikes_of(rng, n, p, kind):
+    s = rng.random(n) < p
+    if kind == 'bool':
+        return s
+    if kind == 'u8':
+        return s.astype(np.uint8)
+    return np.where(s, rng.uniform(0.5, 2.0, n), -rng.uniform(0.0, 1.0, n)).astype(np.float32)
+
+
+TOL = {np.float32: (1e-5, 1e-5), np.float64: (1e-10, 1e-10), np.float16: (2e-3, 2e-3)}
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'u8', 'float'])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64, np.float16])
+def test_csrmv_direct_random(be, oracle, transpose, homo, kind, dtype):
+    rng = np.random.default_rng(7)
+    m, k = 300, 257
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(0, 40, m), dtype=dtype, homo=homo)
+    v = spikes_of(rng, m if transpose else k, 0.3, kind)
+    got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=transpose)
+    # oracle accumulates in f64 for the f16 case so the comparison isolates the kernel's f32 accumulate
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), transpose)
+    rtol, atol = TOL[dtype]
+    assert got.dtype == dtype and got.shape == ((k,) if transpose else (m,))
+    np.testing.assert_allclose(got.astype(np.float64), ref, rtol=rtol, atol=atol)
+
+
+def test_csrmv_bf16_torch(be, oracle):
+    rng = np.random.default_rng(3)
+    m, k = 128, 200
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(1, 30, m))
+    v = spikes_of(rng, m, 0.5, 'bool')
+    wt = torch.tensor(w, device='cuda').to(torch.bfloat16)
+    got = be.binary_csrmv(wt, torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda'),
+                          torch.tensor(v, device='cuda'), shape=(m, k), transpose=True)
+    assert isinstance(got, torch.Tensor) and got.dtype == torch.bfloat16
+    ref = oracle.binary_csrmv(wt.float().cpu().numpy().astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+def test_csrmv_ragged_and_empty_rows(be, oracle, transpose):
+    # row-length sweep of the reference's GPU regression test (brainevent/_csr/binary_test.py:1442-1476)
+    lens = [0, 1, 33, 0, 200, 64, 0, 7, 512, 90, 0, 31, 63, 65, 128]
+    rng = np.random.default_rng(11)
+    m, k = len(lens), 300
+    w, idx, ptr = rand_csr(rng, m, k, lens, dtype=np.float64)
+    v = np.ones(m if transpose else k, dtype=bool)
+    got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=transpose)
+    ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), transpose)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+    if not transpose:   # empty rows are written, not left uninitialised
+        assert got[0] == 0 and got[3] == 0 and got[6] == 0 and got[10] == 0
+
+
+@pytest.mark.parametrize('nnz_per_row', [4, 15, 16, 64, 511, 512, 1024])
+def test_csrmv_gather_tiers(be, oracle, nnz_per_row):
+    # tier-straddling sweep (brainevent/_csr/binary_test.py:1405-1437)
+    rng = np.random.default_rng(nnz_per_row)
+    m, k = 96, 2048
+    w, idx, ptr = rand_csr(rng, m, k, [nnz_per_row] * m, dtype=np.float64)
+    v = spikes_of(rng, k, 0.4, 'bool')
+    got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=False)
+    np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, v, (m, k), False), rtol=1e-10, atol=1e-10)
+
+
+def test_csrmv_int64_indptr(be, oracle):
+    rng = np.random.default_rng(5)
+    m, k = 64, 100
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(0, 20, m))
+    v = spikes_of(rng, m, 0.5, 'bool')
+    for tr, vv in ((True, v), (False, spikes_of(rng, k, 0.5, 'bool'))):
+        got = be.binary_csrmv(w, idx, ptr.astype(np.int64), vv, shape=(m, k), transpose=tr)
+        np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, vv, (m, k), tr), rtol=RTOL, atol=ATOL)
+
+
+def test_csrmv_empty(be):
+    w = np.ones(1, np.float32)
+    out = be.binary_csrmv(w, np.zeros(0, np.int32), np.zeros(4, np.int32), np.ones(3, bool), shape=(3, 5), transpose=True)
+    assert out.shape == (5,) and not out.any()
+    out = be.binary_csrmv(w, np.zeros(0, np.int32), np.zeros(4, np.int32), np.ones(5, bool), shape=(3, 5), transpose=False)
+    assert out.shape == (3,) and not out.any()
+
+
+# ---------------------------------------------------------------------------------------------------
+# planned (post-sliced, LDS-accumulating) scatter route
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'float'])
+@pytest.mark.parametrize('shift,parts', [(4, 1), (6, 3), (10, 2), (14, 4)])
+def test_csrmv_plan_matches_oracle(be, oracle, homo, kind, shift, parts):
+    from brainevent_amd._csr import ScatterPlan, _plan_call
+    from brainevent_amd import _array as A
+    if homo and shift == 14:
+        shift = 15
+    rng = np.random.default_rng(100 + shift)
+    m, k = 500, 3000
+    lens = rng.integers(0, 300, m)
+    lens[::7] = 0
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+    if not homo:
+        w = rng.normal(0, 1, w.shape).astype(np.float32)   # mixed signs
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift)
+    assert plan.total % 4 == 0 and plan.total >= idx.size
+    v = spikes_of(rng, m, 0.2, kind)
+    spikes, sd = A.spikes_to_device(v)
+    out = torch.empty(k, dtype=torch.float32, device='cuda')
+    _plan_call(plan, A.to_device(w), spikes, sd, out, parts=parts)
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    # order independent accumulation: bitwise identical on repeat and for another part count
+    out2 = torch.empty_like(out)
+    _plan_call(plan, A.to_device(w), spikes, sd, out2, parts=max(1, parts - 1) if parts > 1 else 5)
+    assert torch.equal(out, out2)
+
+
+def test_csrmv_plan_homo_counts_exact(be, oracle):
+    from brainevent_amd._csr import ScatterPlan, _plan_call
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(42)
+    m, k = 2000, 70000
+    w, idx, ptr = rand_csr(rng, m, k, [400] * m, homo=True)
+    w[:] = 1.0
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k))
+    assert plan.slice_shift == 15 and plan.n_slices == 3
+    v = spikes_of(rng, m, 0.1, 'bool')
+    spikes, sd = A.spikes_to_device(v)
+    out = torch.empty(k, dtype=torch.float32, device='cuda')
+    _plan_call(plan, A.to_device(w), spikes, sd, out)
+    ref = np.zeros(k, np.int64)
+    row_of = np.repeat(np.arange(m), 400)
+    np.add.at(ref, idx[v[row_of]], 1)
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), ref)
+
+
+def test_csr_class_uses_plan_and_matches(be, oracle, monkeypatch):
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(9)
+    m, k = 600, 40000
+    w, idx, ptr = rand_csr(rng, m, k, [300] * m)
+    csr = be.CSR((w, idx, ptr), shape=(m, k))
+    v = spikes_of(rng, m, 0.1, 'bool')
+    got = be.BinaryArray(v) @ csr
+    assert isinstance(csr.buffers['scatter_plan'], C.ScatterPlan)
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
+    # gather direction and CSC mirrors
+    v2 = spikes_of(rng, k, 0.1, 'bool')
+    np.testing.assert_allclose(csr @ be.BinaryArray(v2), oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v2, (m, k), False),
+                               rtol=RTOL, atol=ATOL)
+    csc = csr.T   # shape (k, m): csc @ v (len m) scatters, v2 @ csc gathers
+    np.testing.assert_allclose(csc @ be.BinaryArray(v), ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(be.BinaryArray(v2) @ csc, oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v2, (m, k), False),
+                               rtol=RTOL, atol=ATOL)
