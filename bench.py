@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py — synaptic updates/s of the event-driven scatter  BinaryArray(spikes) @ CSR  on MI355X.
+
+Headline workload (BASELINE.json configs[1], "C2"): CSR f32, N = 1M pre x 1M post, 1 % connectivity
+(10 000 stored synapses per row, heterogeneous weights), Bernoulli 1 % firing, synthetic data generated
+on the device with the reference's own generator family (brainevent/_csr/binary.py:771-777:
+indptr = arange(n+1) * n_conn, indices ~ U{0..n_post-1}, weights ~ U[0,1)).
+
+One "step" = one  spk @ csr  (spike compaction + LDS-accumulating scatter + partial reduction) on one
+fresh spike vector (a batch of 100 pre-generated vectors is cycled, as brainevent/_csr/initialize.py:115-125
+does).  Inputs are resident in HBM when the timed region starts.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): the matrix is partitioned by
+post-neuron slice; every step each rank contributes the spikes of its 1/G of the pre population and one
+all-gather rebuilds the full spike vector on every rank (the only exchange of the path); outputs are
+disjoint, no reduction.  Default is weak scaling: every rank owns a full C2-sized post slice
+(n_pre x n_post_per_gpu), so per-GPU work is fixed; `--scaling strong` splits the 1M posts across ranks.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--n', type=int, default=1_000_000, help='pre = post population per GPU shard')
+    ap.add_argument('--conn', type=float, default=0.01)
+    ap.add_argument('--fire', type=float, default=0.01)
+    ap.add_argument('--homo', action='store_true', help='homogeneous weight (4 B/update) instead of hetero f32')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
+    ap.add_argument('--parts', type=int, default=0)
+    ap.add_argument('--shift', type=int, default=0)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def gen_csr_on_device(n_pre, n_post, n_conn, homo, seed, dev):
+    """Reference generator family, on the device, in row blocks (nnz can exceed 2^31)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    nnz = n_pre * n_conn
+    indices = torch.empty(nnz, dtype=torch.int32, device=dev)
+    weights = torch.ones(1, dtype=torch.float32, device=dev) if homo else torch.empty(nnz, dtype=torch.float32, device=dev)
+    blk = max(1, (1 << 28) // max(n_conn, 1)) * n_conn
+    for lo in range(0, nnz, blk):
+        hi = min(nnz, lo + blk)
+        indices[lo:hi] = torch.randint(0, n_post, (hi - lo,), dtype=torch.int32, device=dev, generator=g)
+        if not homo:
+            weights[lo:hi].uniform_(0.0, 1.0, generator=g)
+    indptr = torch.arange(n_pre + 1, dtype=torch.int64, device=dev) * n_conn
+    return weights, indices, indptr
+
+
+def cpu_baseline(args, n_post, n_conn):
+    """The oracle's C restatement of the reference's serial numba scatter loop
+    (brainevent/_csr/binary.py:446-451), 1 thread, on a bounded row sample of the same workload:
+    same n_post, same row length, same firing rate, fewer pre rows (only active rows are ever touched,
+    so the per-update cost is that of the full problem)."""
+    from oracle import oracle_c
+    oracle_c.build()
+    rows = max(1000, min(args.n, int(2.5e8 // max(n_conn, 1))))   # <= 2.5e8 stored synapses (2 GB)
+    rng = np.random.default_rng(0)
+    indices = rng.integers(0, n_post, rows * n_conn, dtype=np.int32)
+    indptr = np.arange(rows + 1, dtype=np.int64) * n_conn
+    w = np.ones(1, np.float32) if args.homo else rng.random(rows * n_conn, dtype=np.float32)
+    spikes = [(rng.random(rows) < args.fire) for _ in range(8)]
+    upd = 0
+    t_used = 0.0
+    steps = 0
+    oracle_c.csrmv_f32(w, indices, indptr, spikes[0], (rows, n_post), True)   # warm
+    while t_used < args.cpu_seconds and steps < 10000:
+        s = spikes[steps % len(spikes)]
+        t0 = time.perf_counter()
+        oracle_c.csrmv_f32(w, indices, indptr, s, (rows, n_post), True)
+        t_used += time.perf_counter() - t0
+        upd += int(s.sum()) * n_conn
+        steps += 1
+    return {
+        'value': upd / t_used / 1e9, 'unit': 'Geff/s', 'cores': 1, 'kind': 'port',
+        'sample': f'{rows} of {args.n} pre rows (n_post={n_post}, {n_conn} synapses/row, fire={args.fire}), '
+                  f'{steps} steps, C port of the reference numba loop _csr/binary.py:446-451, gcc -O3 -march=native',
+        'host_cpus': os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import brainevent_amd as be
+    from brainevent_amd import _csr as C, _lib
+
+    n_pre = args.n
+    n_post_total = args.n * world if args.scaling == 'weak' else args.n
+    n_post = n_post_total // world                     # this rank's post slice
+    n_conn = max(1, int(n_post * args.conn))           # stored synapses per (row, shard)
+    t_setup = time.perf_counter()
+    weights, indices, indptr = gen_csr_on_device(n_pre, n_post, n_conn, args.homo, 1234 + rank, dev)
+    csr = be.CSR((weights, indices, indptr), shape=(n_pre, n_post), check_structure=False)
+    plan_bytes = 0
+    if args.route == 'plan':
+        shift = args.shift or C.ScatterPlan.default_shift(n_post, args.homo)
+        csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post), slice_shift=shift)
+        plan = csr.buffers['scatter_plan']
+        plan_bytes = plan.nbytes()
+        if args.parts:
+            plan.default_parts = lambda: args.parts
+    else:
+        csr.buffers['scatter_plan'] = None
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    # spike batch: each rank draws the spikes of its own 1/world of the pre population
+    n_batch = 100
+    g = torch.Generator(device=dev)
+    g.manual_seed(999 + rank)
+    n_local = n_pre // world
+    local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
+    full = torch.empty(n_pre, dtype=torch.bool, device=dev)
+    if world > 1:
+        counts = torch.empty(n_batch, dtype=torch.int64, device=dev)
+        for b in range(n_batch):
+            dist.all_gather_into_tensor(full.view(torch.uint8), local_spikes[b].view(torch.uint8))
+            counts[b] = full.sum()
+        active_per_vec = counts.cpu().numpy()
+    else:
+        active_per_vec = local_spikes.sum(dim=1).cpu().numpy()
+
+    def step(i):
+        s = local_spikes[i % n_batch]
+        if world > 1:
+            dist.all_gather_into_tensor(full.view(torch.uint8), s.view(torch.uint8))
+            s = full
+        return be.BinaryArray(s) @ csr
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    prof_enable = _lib.fn('be_profile_enable', ctypes.c_int, [ctypes.c_int])
+    prof_read = _lib.fn('be_profile_read', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
+    _lib.check(prof_enable(args.steps), 'be_profile_enable')
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_float * args.steps)()
+    n_rec = prof_read(ctypes.cast(ms, ctypes.c_void_p), args.steps)
+    prof_enable(0)
+    kern_ms = float(np.mean(ms[:n_rec])) if n_rec > 0 else None
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # exact work done in the timed steps (all ranks see the same full spike vector)
+    upd_per_rank = sum(int(active_per_vec[(args.warmup + i) % n_batch]) for i in range(args.steps)) * n_conn
+    total_upd = upd_per_rank * world
+    value = total_upd / elapsed / 1e9
+    checksum = float(out.double().sum().item())
+
+    if rank == 0:
+        bytes_per_upd = 4 if args.homo else 8           # int32 index (+ f32 weight)
+        mean_active = float(np.mean([active_per_vec[(args.warmup + i) % n_batch] for i in range(args.steps)]))
+        alg_bytes = bytes_per_upd * mean_active * n_conn + n_pre * 1 + n_post * 4 + 16 * mean_active
+        roof = None
+        if kern_ms:
+            achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    key = f"{'homo' if args.homo else 'hetero'}_n{args.n}"
+                    traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
+                except Exception:
+                    traffic = None
+            roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'kernel': 'k_plan_accumulate' if args.route == 'plan' else 'k_csrmv_t_direct',
+                    'kernel_ms': round(kern_ms, 5), 'algorithmic_bytes_per_launch': int(alg_bytes)}
+        line = {
+            'metric': 'synaptic updates/sec (Geff/s), BinaryArray @ CSR scatter',
+            'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': args.scaling,
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f"BinaryArray({args.fire:g} fire) @ CSR f32 {'homo' if args.homo else 'hetero'}, "
+                                   f"{n_pre} pre x {n_post_total} post, {args.conn:g} density "
+                                   f"({n_conn} synapses/row/shard), route={args.route}",
+                       'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
+                       'parallelism': f'post-slice x{world}' + (' + spike all-gather' if world > 1 else ''),
+                       'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
+                       'mean_active_rows': mean_active, 'checksum': checksum},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                line['cpu_baseline'] = cpu_baseline(args, n_post, n_conn)
+            except Exception as e:   # the CPU leg must never sink the GPU number
+                line['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

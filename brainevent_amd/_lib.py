@@ -129,11 +129,21 @@ def require_device() -> None:
             "(the CPU oracle under oracle/ is test infrastructure, not a backend).")
 
 
+_fn_cache = {}
+
+
 def fn(name: str, restype=ctypes.c_int, argtypes=None):
-    f = getattr(lib(), name)
-    f.restype = restype
-    if argtypes is not None:
-        f.argtypes = argtypes
+    """Symbol ``name`` with its prototype set (cached: the hot path calls this every step)."""
+    f = _fn_cache.get(name)
+    if f is None:
+        try:
+            f = getattr(lib(), name)
+        except AttributeError as e:
+            raise KernelLoadError(f"{lib_path()} does not export {name}") from e
+        f.restype = restype
+        if argtypes is not None:
+            f.argtypes = argtypes
+        _fn_cache[name] = f
     return f
 
 

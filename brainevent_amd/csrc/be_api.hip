@@ -25,3 +25,69 @@ int be_device_count(void) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// in-library kernel timing: HIP event pairs recorded around the dominant kernel of an op, on the
+// stream that kernel is launched on (bench.py reads them back for the roofline figure).
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+#include <mutex>
+
+namespace {
+std::mutex g_prof_mu;
+std::vector<hipEvent_t> g_prof_ev;   // 2 * capacity events
+int g_prof_cap = 0;
+int g_prof_n = 0;
+}  // namespace
+
+// called by the launch helpers; returns the slot or -1
+int be_prof_begin(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_n >= g_prof_cap) return -1;
+  const int slot = g_prof_n++;
+  if (hipEventRecord(g_prof_ev[2 * slot], st) != hipSuccess) return -1;
+  return slot;
+}
+void be_prof_end(int slot, hipStream_t st) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_prof_ev[2 * slot + 1], st);
+}
+
+extern "C" {
+
+int be_profile_enable(int max_records) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
+  g_prof_ev.clear();
+  g_prof_cap = 0;
+  g_prof_n = 0;
+  if (max_records <= 0) return BE_OK;
+  g_prof_ev.resize(2 * (size_t)max_records);
+  for (auto& e : g_prof_ev) {
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+      be_set_error(std::string("be_profile_enable: ") + hipGetErrorString(rc));
+      return BE_ERR_HIP;
+    }
+  }
+  g_prof_cap = max_records;
+  return BE_OK;
+}
+
+int be_profile_read(float* ms_host, int capacity) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = g_prof_n < capacity ? g_prof_n : capacity;
+  for (int i = 0; i < n; ++i) {
+    hipError_t rc = hipEventSynchronize(g_prof_ev[2 * i + 1]);
+    if (rc == hipSuccess) rc = hipEventElapsedTime(&ms_host[i], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]);
+    if (rc != hipSuccess) {
+      be_set_error(std::string("be_profile_read: ") + hipGetErrorString(rc));
+      return BE_ERR_HIP;
+    }
+  }
+  g_prof_n = 0;
+  return n;
+}
+
+}  // extern "C"

@@ -18,6 +18,9 @@
 #include "../../include/brainevent_amd.h"   // BE_OK / BE_ERR_* codes
 
 void be_set_error(const std::string& msg);
+// optional HIP-event timing of an op's dominant kernel (be_api.hip); slot -1 = profiling off
+int be_prof_begin(hipStream_t st);
+void be_prof_end(int slot, hipStream_t st);
 
 #define BE_REQUIRE(cond, code, msg)                                                    \
   do {                                                                                 \

@@ -685,6 +685,7 @@ int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint
   if (rc != BE_OK) return rc;
   const double scale = ldexp(1.0, scale_exp), inv_scale = ldexp(1.0, -scale_exp);
   const dim3 grid((unsigned)(n_slices * parts)), block(1024);
+  const int prof = be_prof_begin(st);
   if (homo) {
     auto kern = k_plan_accumulate<true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -698,6 +699,7 @@ int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint
                        reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
                        static_cast<unsigned long long*>(partial));
   }
+  be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   const int rgrid = grid_for(k, 256, 2048);
   BE_DISPATCH_W(wdtype, homo,

@@ -56,6 +56,11 @@ int be_version(void);                 /* 10000*major + 100*minor + patch */
 const char* be_last_error(void);      /* thread-local, valid until the next failing call on this thread */
 int be_device_count(void);            /* number of visible HIP devices, or a negative BE_ERR_* */
 const char* be_build_arch(void);      /* "gfx950" */
+/* HIP-event timing of each op's dominant kernel, recorded on the op's own stream.
+ * enable(n) arms n record slots (0 disarms); read() synchronises and returns the number of
+ * records copied to ms_host (kernel durations in milliseconds, in call order) and rearms. */
+int be_profile_enable(int max_records);
+int be_profile_read(float* ms_host, int capacity);
 
 /* ------------------------------------------------------------------------------------------------
  * event vector helpers (replace: brainevent/_jit_scalar/binary_jitsmv.cu:107-125 `_pack_bool_kern`
