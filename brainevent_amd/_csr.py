@@ -130,6 +130,7 @@ class ScatterPlan:
             # |w| <= wmax < 2^e ;  sums of at most m terms must stay below 2^62
             e = math.frexp(wmax)[1] if wmax > 0 else 0
             scale_exp = 62 - e - max(1, int(math.ceil(math.log2(m + 1))))
+            scale_exp = max(-90, min(150, scale_exp))   # 2^(scale_exp-32) must be a normal f32
         return cls(m, k, homo, slice_shift, seg_ptr, idx16, w32, total, scale_exp, weights.dtype)
 
 
