@@ -78,12 +78,13 @@ class ScatterPlan:
             n += self.w32.numel() * 4
         return n
 
-    def workspace(self, parts: int) -> torch.Tensor:
-        ws = self._ws.get(parts)
+    def workspace(self, parts: int, n_batch: int = 1) -> torch.Tensor:
+        key = (parts, n_batch)
+        ws = self._ws.get(key)
         if ws is None:
-            f = fn('be_binary_csrmv_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_int, c_int])
-            ws = A.workspace(f(self.m, self.k, self.slice_shift, parts, int(self.homo)))
-            self._ws = {parts: ws}
+            f = fn('be_binary_csrmm_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int])
+            ws = A.workspace(f(self.m, self.k, n_batch, self.slice_shift, parts, int(self.homo)))
+            self._ws = {key: ws}
         return ws
 
     # -- construction ---------------------------------------------------------------------------
@@ -134,15 +135,20 @@ class ScatterPlan:
         return cls(m, k, homo, slice_shift, seg_ptr, idx16, w32, total, scale_exp, weights.dtype)
 
 
-def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes: torch.Tensor, sd: int, out: torch.Tensor,
+def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor, sd: int, out_bm: torch.Tensor,
                parts: Optional[int] = None) -> None:
+    """Planned scatter for a batch: ``spikes_bm`` is ``[n_batch, m]`` (or ``[m]``), ``out_bm`` ``[n_batch, k]``."""
+    nb = 1 if spikes_bm.ndim == 1 else int(spikes_bm.shape[0])
     parts = plan.default_parts() if parts is None else int(parts)
-    ws = plan.workspace(parts)
-    f = fn('be_binary_csrmv_t_plan', c_int,
-           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp])
-    check(f(A.ptr(weights), int(plan.homo), A.wcode(out), A.ptr(plan.idx16), A.ptr(plan.w32), A.ptr(plan.seg_ptr),
-            A.ptr(spikes), sd, A.ptr(out), plan.m, plan.k, plan.slice_shift, parts, plan.scale_exp, A.ptr(ws),
-            ws.numel(), A.stream_ptr()), 'be_binary_csrmv_t_plan')
+    if nb > 1:
+        parts = max(1, min(parts, 512 // (plan.n_slices * nb)))
+    ws = plan.workspace(parts, nb)
+    f = fn('be_binary_csrmm_t_plan', c_int,
+           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64,
+            c_vp])
+    check(f(A.ptr(weights), int(plan.homo), A.wcode(out_bm), A.ptr(plan.idx16), A.ptr(plan.w32), A.ptr(plan.seg_ptr),
+            A.ptr(spikes_bm), sd, A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, parts, plan.scale_exp, A.ptr(ws),
+            ws.numel(), A.stream_ptr()), 'be_binary_csrmm_t_plan')
 
 
 # =====================================================================================================
@@ -152,35 +158,42 @@ def _variant(homo: bool, w: torch.Tensor, sd: int) -> str:
     return f"{'homo' if homo else 'hetero'}_{A.wsuffix(w)}_{'bool' if sd == A.BE_SPIKE_BOOL else 'float'}"
 
 
-_CSRMV_ARGS = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]
+_CSRMM_ARGS = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]
 
 
-def _binary_csrmv_hip(weights, indices, indptr, vector, *, shape, transpose, workspace=None):
+def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, workspace=None):
+    """Run the CSR kernels on a batch-major spike matrix ``[n_batch, len]`` -> ``[n_batch, out_len]``."""
     m, k = int(shape[0]), int(shape[1])
-    spikes, sd = A.spikes_to_device(vector)
+    nb = int(spikes_bm.shape[0])
     homo = weights.numel() == 1
     out_len = k if transpose else m
-    out = torch.empty(out_len, dtype=weights.dtype, device=weights.device)
-    if out_len == 0:
+    out = torch.empty((nb, out_len), dtype=weights.dtype, device=weights.device)
+    if out_len == 0 or nb == 0:
         return out
-    if (m == 0 or k == 0 or indices.numel() == 0):
+    if m == 0 or k == 0 or indices.numel() == 0:
         return out.zero_()
     is64 = int(indptr.dtype == torch.int64)
     if transpose:
         if isinstance(workspace, ScatterPlan):
             assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
-            _plan_call(workspace, weights, spikes, sd, out)
+            _plan_call(workspace, weights, spikes_bm, sd, out)
             return out
-        f_ws = fn('be_binary_csrmv_t_workspace_bytes', c_i64, [c_i64, c_i64, c_int])
-        ws = A.workspace(f_ws(m, k, A.wcode(weights)))
-        f = fn('be_binary_csrmv_t_' + _variant(homo, weights, sd), c_int, _CSRMV_ARGS)
+        f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
+        ws = A.workspace(f_ws(m, k, nb, A.wcode(weights)))
+        f = fn('be_binary_csrmm_t_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
     else:
-        f_ws = fn('be_binary_csrmv_nt_workspace_bytes', c_i64, [c_i64, c_i64])
-        ws = A.workspace(f_ws(m, k))
-        f = fn('be_binary_csrmv_nt_' + _variant(homo, weights, sd), c_int, _CSRMV_ARGS)
-    check(f(A.ptr(weights), A.ptr(indices), A.ptr(indptr), is64, A.ptr(spikes), A.ptr(out), m, k, A.ptr(ws),
+        f_ws = fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
+        ws = A.workspace(f_ws(m, k, nb))
+        f = fn('be_binary_csrmm_nt_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
+    check(f(A.ptr(weights), A.ptr(indices), A.ptr(indptr), is64, A.ptr(spikes_bm), A.ptr(out), m, k, nb, A.ptr(ws),
             ws.numel(), A.stream_ptr()), f.__name__)
     return out
+
+
+def _binary_csrmv_hip(weights, indices, indptr, vector, *, shape, transpose, workspace=None):
+    spikes, sd = A.spikes_to_device(vector)
+    return _csr_batched(weights, indices, indptr, spikes.reshape(1, -1), sd, shape=shape, transpose=transpose,
+                        workspace=workspace)[0]
 
 
 binary_csrmv_p = OpKernel('binary_csrmv')
@@ -231,16 +244,13 @@ def binary_csrmv(data, indices, indptr, v, *, shape, workspace=None, transpose: 
 
 
 def _binary_csrmm_hip(weights, indices, indptr, B, *, shape, transpose, workspace=None):
-    # column-at-a-time, as the reference's SRAW route does on the host
-    # (brainevent/_csr/binary_csrmm_hybrid.cu:16-57); a fused batch kernel is a later round.
-    Bt = A.to_device(B)
-    n = Bt.shape[1]
-    out_rows = int(shape[1] if transpose else shape[0])
-    out = torch.empty((out_rows, n), dtype=weights.dtype, device=weights.device)
-    for l in range(n):
-        out[:, l] = _binary_csrmv_hip(weights, indices, indptr, Bt[:, l].contiguous(), shape=shape,
-                                      transpose=transpose, workspace=workspace)
-    return out
+    # one launch per stage for the whole batch (gridDim.y = columns of B); the kernels take the spike
+    # matrix batch-major and emit a batch-major result, transposed back here exactly like the reference
+    # does around its SRAW kernels (brainevent/_csr/binary.py:1263-1286).
+    Bt, sd = A.spikes_to_device(B)
+    out_bm = _csr_batched(weights, indices, indptr, Bt.T.contiguous(), sd, shape=shape, transpose=transpose,
+                          workspace=workspace)
+    return out_bm.T
 
 
 binary_csrmm_p = OpKernel('binary_csrmm')

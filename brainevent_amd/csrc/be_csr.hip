@@ -33,7 +33,11 @@ constexpr int kCompactPerThread = 16;
 
 template <typename SP>
 __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
-                                                        uint32_t* __restrict__ active, uint32_t* __restrict__ count) {
+                                                        uint32_t* __restrict__ active, uint32_t* __restrict__ count,
+                                                        int64_t active_stride) {
+  spikes += (int64_t)blockIdx.y * n;          // batch-major spike matrix [n_batch, n]
+  active += (int64_t)blockIdx.y * active_stride;
+  count += blockIdx.y;
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t block_base;
   const int64_t tile = (int64_t)blockIdx.x * (256 * kCompactPerThread);
@@ -81,7 +85,9 @@ __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type*
 
 template <typename SP>
 __global__ void __launch_bounds__(256) k_pack_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
-                                                     uint32_t* __restrict__ bits) {
+                                                     uint32_t* __restrict__ bits, int64_t words_stride) {
+  spikes += (int64_t)blockIdx.y * n;
+  bits += (int64_t)blockIdx.y * words_stride;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n_round = (n + 63) & ~(int64_t)63;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
@@ -100,8 +106,11 @@ __global__ void __launch_bounds__(256) k_pack_spikes(const typename SP::type* __
 template <typename W, bool HOMO, typename ACC>
 __global__ void __launch_bounds__(256) k_csrmv_t_direct(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                         RowPtr rp, const uint32_t* __restrict__ active,
-                                                        const uint32_t* __restrict__ n_active_p, ACC* __restrict__ out) {
-  const uint32_t n_active = *n_active_p;
+                                                        const uint32_t* __restrict__ n_active_p, ACC* __restrict__ out,
+                                                        int64_t active_stride, int64_t k) {
+  active += (int64_t)blockIdx.y * active_stride;
+  out += (int64_t)blockIdx.y * k;
+  const uint32_t n_active = n_active_p[blockIdx.y];
   const int lane = lane_id();
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -130,6 +139,8 @@ template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(256) k_csrmv_nt(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                   RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
                                                   W* __restrict__ out, int64_t m) {
+  bits_g += (int64_t)blockIdx.y * n_words;    // batch-major bitmaps and outputs
+  out += (int64_t)blockIdx.y * m;
   extern __shared__ uint32_t bits_s[];
   const uint32_t* bits = bits_g;
   if (BITS_IN_LDS) {
@@ -427,13 +438,16 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
                                                           const uint32_t* __restrict__ active,
                                                           const uint32_t* __restrict__ n_active_p, int64_t m,
                                                           int slice_shift, int parts, float scale,
-                                                          typename PlanAcc<HOMO>::type* __restrict__ partial) {
+                                                          typename PlanAcc<HOMO>::type* __restrict__ partial,
+                                                          int64_t active_stride) {
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   const int S = 1 << slice_shift;
   const int slice = blockIdx.x / parts;
   const int part = blockIdx.x - slice * parts;
+  active += (int64_t)blockIdx.y * active_stride;
+  partial += (int64_t)blockIdx.y * gridDim.x * S;
   {
     uint4* z = reinterpret_cast<uint4*>(smem_raw);
     const int n16 = (int)(((size_t)(S + 1) * sizeof(acc_t) + 15) / 16);
@@ -441,7 +455,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
   }
   __syncthreads();
 
-  const uint32_t n_active = *n_active_p;
+  const uint32_t n_active = n_active_p[blockIdx.y];
   const uint32_t* sp = seg_ptr + (int64_t)slice * m;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   // list position of this lane's row in batch b of this wave
@@ -501,7 +515,9 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO>::type* __restrict__ partial, int parts,
                                                      int slice_shift, int64_t k, double inv_scale,
-                                                     const W* __restrict__ weights, W* __restrict__ out) {
+                                                     const W* __restrict__ weights, W* __restrict__ out, int64_t partial_stride) {
+  partial += (int64_t)blockIdx.y * partial_stride;
+  out += (int64_t)blockIdx.y * k;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int S = 1 << slice_shift;
   typename WTraits<W>::acc w0 = 0;
@@ -523,7 +539,10 @@ __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO
 }
 
 // =================================================================================================
-// host-side launch helpers
+// host-side launch helpers.  Every op takes a batch: spikes are batch-major [n_batch, len], outputs
+// batch-major [n_batch, out_len]; the *mv entry points are the n_batch = 1 case, the *mm entry points
+// launch the same kernels with gridDim.y = n_batch (one launch per stage for the whole batch — the
+// reference loops over the columns on the host, brainevent/_csr/binary_csrmm_hybrid.cu:16-57).
 // =================================================================================================
 inline int grid_for(int64_t n, int block, int cap) {
   int64_t g = (n + block - 1) / block;
@@ -532,72 +551,77 @@ inline int grid_for(int64_t n, int block, int cap) {
   return (int)g;
 }
 
-struct DirectWs {   // workspace of the direct scatter route / plan step
-  uint32_t* count;    // 256 B
-  uint32_t* active;   // m * 4
-  float* acc32;       // k * 4 (f16 / bf16 outputs only)
-};
+constexpr int kMaxBatch = 65535;
 
-inline int64_t direct_ws_bytes(int64_t m, int64_t k, int wdtype) {
-  int64_t b = 256 + be_align_up(m * 4, 256);
-  if (wdtype == BE_F16 || wdtype == BE_BF16) b += be_align_up(k * 4, 256);
+inline int64_t counts_bytes(int64_t nb) { return be_align_up(nb * 4, 256); }
+inline int64_t active_stride_of(int64_t m) { return be_align_up(m * 4, 256) / 4; }   // in uint32 elements
+
+inline int64_t direct_ws_bytes(int64_t m, int64_t k, int wdtype, int64_t nb) {
+  int64_t b = counts_bytes(nb) + nb * active_stride_of(m) * 4;
+  if (wdtype == BE_F16 || wdtype == BE_BF16) b += be_align_up(nb * k * 4, 256);
   return b;
 }
 
 template <typename SP>
-int launch_compact(const void* spikes, int64_t n, uint32_t* active, uint32_t* count, hipStream_t st) {
-  BE_HIP(hipMemsetAsync(count, 0, 4, st));
-  if (n == 0) return BE_OK;
+int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, int64_t active_stride, uint32_t* count,
+                   hipStream_t st) {
+  BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
+  if (n == 0 || nb == 0) return BE_OK;
   const int64_t tiles = (n + 256 * kCompactPerThread - 1) / (256 * kCompactPerThread);
-  hipLaunchKernelGGL(k_compact_spikes<SP>, dim3((unsigned)tiles), dim3(256), 0, st,
-                     static_cast<const typename SP::type*>(spikes), n, active, count);
+  hipLaunchKernelGGL(k_compact_spikes<SP>, dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
+                     static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
-int compact_any(const void* spikes, int sd, int64_t n, uint32_t* active, uint32_t* count, hipStream_t st) {
-  if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, active, count, st);
-  if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, active, count, st);
+int compact_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* active, int64_t active_stride,
+                uint32_t* count, hipStream_t st) {
+  if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, nb, active, active_stride, count, st);
+  if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, nb, active, active_stride, count, st);
   be_set_error("unknown spike dtype");
   return BE_ERR_INVALID;
 }
 
 template <typename SP>
-int launch_pack(const void* spikes, int64_t n, uint32_t* bits, hipStream_t st) {
-  if (n == 0) return BE_OK;
-  hipLaunchKernelGGL(k_pack_spikes<SP>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
-                     static_cast<const typename SP::type*>(spikes), n, bits);
+int launch_pack(const void* spikes, int64_t n, int64_t nb, uint32_t* bits, int64_t words_stride, hipStream_t st) {
+  if (n == 0 || nb == 0) return BE_OK;
+  hipLaunchKernelGGL(k_pack_spikes<SP>, dim3(grid_for(n, 256, 2048), (unsigned)nb), dim3(256), 0, st,
+                     static_cast<const typename SP::type*>(spikes), n, bits, words_stride);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
-int pack_any(const void* spikes, int sd, int64_t n, uint32_t* bits, hipStream_t st) {
-  if (sd == BE_SPIKE_BOOL) return launch_pack<SpikeBool>(spikes, n, bits, st);
-  if (sd == BE_SPIKE_FLOAT) return launch_pack<SpikeFloat>(spikes, n, bits, st);
+int pack_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* bits, int64_t words_stride, hipStream_t st) {
+  if (sd == BE_SPIKE_BOOL) return launch_pack<SpikeBool>(spikes, n, nb, bits, words_stride, st);
+  if (sd == BE_SPIKE_FLOAT) return launch_pack<SpikeFloat>(spikes, n, nb, bits, words_stride, st);
   be_set_error("unknown spike dtype");
   return BE_ERR_INVALID;
 }
 
 template <typename W, bool HOMO>
 int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const void* spikes, int sd, void* out,
-                   int64_t m, int64_t k, void* ws, hipStream_t st) {
+                   int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
   unsigned char* wsb = static_cast<unsigned char*>(ws);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
-  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + counts_bytes(nb));
+  const int64_t astride = active_stride_of(m);
   constexpr bool via_f32 = std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value;
   using ACC = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
-  ACC* acc = via_f32 ? reinterpret_cast<ACC*>(wsb + 256 + be_align_up(m * 4, 256)) : static_cast<ACC*>(out);
-  if (k > 0) BE_HIP(hipMemsetAsync(acc, 0, (size_t)k * sizeof(ACC), st));
-  int rc = compact_any(spikes, sd, m, active, count, st);
+  ACC* acc = via_f32 ? reinterpret_cast<ACC*>(wsb + counts_bytes(nb) + nb * astride * 4) : static_cast<ACC*>(out);
+  if (k > 0 && nb > 0) BE_HIP(hipMemsetAsync(acc, 0, (size_t)k * nb * sizeof(ACC), st));
+  int rc = compact_any(spikes, sd, m, nb, active, astride, count, st);
   if (rc != BE_OK) return rc;
-  if (m > 0 && k > 0) {
-    hipLaunchKernelGGL((k_csrmv_t_direct<W, HOMO, ACC>), dim3(2048), dim3(256), 0, st, static_cast<const W*>(weights),
-                       indices, rp, active, count, acc);
+  if (m > 0 && k > 0 && nb > 0) {
+    const int gx = nb >= 8 ? 512 : 2048;
+    const int prof = be_prof_begin(st);
+    hipLaunchKernelGGL((k_csrmv_t_direct<W, HOMO, ACC>), dim3(gx, (unsigned)nb), dim3(256), 0, st,
+                       static_cast<const W*>(weights), indices, rp, active, count, acc, astride, k);
+    be_prof_end(prof, st);
     BE_LAUNCH_CHECK();
   }
-  if (via_f32 && k > 0) {
-    hipLaunchKernelGGL(k_convert_from_f32<W>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(acc), static_cast<W*>(out), k);
+  if (via_f32 && k > 0 && nb > 0) {
+    hipLaunchKernelGGL(k_convert_from_f32<W>, dim3(grid_for(k * nb, 256, 2048)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(acc), static_cast<W*>(out), k * nb);
     BE_LAUNCH_CHECK();
   }
   return BE_OK;
@@ -605,35 +629,37 @@ int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const
 
 template <typename W, bool HOMO, int LPR>
 int csrmv_nt_launch(const void* weights, const int32_t* indices, RowPtr rp, const uint32_t* bits, int64_t n_words,
-                    void* out, int64_t m, hipStream_t st) {
+                    void* out, int64_t m, int64_t nb, hipStream_t st) {
   constexpr int GROUPS = 256 / LPR;
   const size_t lds = (size_t)n_words * 4;
-  const int grid = grid_for(m, GROUPS, 256 * 8);
+  const int grid = grid_for(m, GROUPS, nb >= 8 ? 256 : 256 * 8);
+  const int prof = be_prof_begin(st);
   if (lds <= 150 * 1024) {
     auto kern = k_csrmv_nt<W, HOMO, LPR, true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, static_cast<const W*>(weights), indices, rp, bits, n_words,
-                       static_cast<W*>(out), m);
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(256), lds, st, static_cast<const W*>(weights), indices, rp,
+                       bits, n_words, static_cast<W*>(out), m);
   } else {
-    hipLaunchKernelGGL((k_csrmv_nt<W, HOMO, LPR, false>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),
-                       indices, rp, bits, n_words, static_cast<W*>(out), m);
+    hipLaunchKernelGGL((k_csrmv_nt<W, HOMO, LPR, false>), dim3(grid, (unsigned)nb), dim3(256), 0, st,
+                       static_cast<const W*>(weights), indices, rp, bits, n_words, static_cast<W*>(out), m);
   }
+  be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
 template <typename W, bool HOMO>
 int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
-             void* out, int64_t m, int64_t k, void* ws, hipStream_t st) {
+             void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
   uint32_t* bits = static_cast<uint32_t*>(ws);
   const int64_t n_words = (k + 31) / 32;
-  int rc = pack_any(spikes, sd, k, bits, st);
+  int rc = pack_any(spikes, sd, k, nb, bits, n_words, st);
   if (rc != BE_OK) return rc;
-  if (m == 0) return BE_OK;
+  if (m == 0 || nb == 0) return BE_OK;
   const int64_t avg = nnz_hint / (m > 0 ? m : 1);
-  if (avg <= 8) return csrmv_nt_launch<W, HOMO, 4>(weights, indices, rp, bits, n_words, out, m, st);
-  if (avg <= 48) return csrmv_nt_launch<W, HOMO, 16>(weights, indices, rp, bits, n_words, out, m, st);
-  return csrmv_nt_launch<W, HOMO, 64>(weights, indices, rp, bits, n_words, out, m, st);
+  if (avg <= 8) return csrmv_nt_launch<W, HOMO, 4>(weights, indices, rp, bits, n_words, out, m, nb, st);
+  if (avg <= 48) return csrmv_nt_launch<W, HOMO, 16>(weights, indices, rp, bits, n_words, out, m, nb, st);
+  return csrmv_nt_launch<W, HOMO, 64>(weights, indices, rp, bits, n_words, out, m, nb, st);
 }
 
 #define BE_DISPATCH_W(wdtype, HOMO_FLAG, CALL)                                  \
@@ -657,53 +683,76 @@ extern "C" {
 int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream) {
   BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
   BE_REQUIRE(n == 0 || (spikes && bits), BE_ERR_INVALID, "null pointer");
-  return pack_any(spikes, spike_dtype, n, bits, static_cast<hipStream_t>(stream));
+  return pack_any(spikes, spike_dtype, n, 1, bits, (n + 31) / 32, static_cast<hipStream_t>(stream));
 }
 
 int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,
                       be_stream_t stream) {
   BE_REQUIRE(n >= 0 && n <= 0xffffffffll, BE_ERR_INVALID, "n out of range");
   BE_REQUIRE(count && (n == 0 || (spikes && active_ids)), BE_ERR_INVALID, "null pointer");
-  return compact_any(spikes, spike_dtype, n, active_ids, count, static_cast<hipStream_t>(stream));
+  return compact_any(spikes, spike_dtype, n, 1, active_ids, 0, count, static_cast<hipStream_t>(stream));
 }
 
-int64_t be_binary_csrmv_t_workspace_bytes(int64_t m, int64_t k, int wdtype) { return direct_ws_bytes(m, k, wdtype); }
+int64_t be_binary_csrmm_t_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int wdtype) {
+  return direct_ws_bytes(m, k, wdtype, n_batch);
+}
+int64_t be_binary_csrmv_t_workspace_bytes(int64_t m, int64_t k, int wdtype) { return direct_ws_bytes(m, k, wdtype, 1); }
+
+int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                      int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                      int64_t k, int64_t n_batch, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(m >= 0 && k >= 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
+  BE_REQUIRE(k == 0 || n_batch == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
+  BE_REQUIRE(m == 0 || n_batch == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= direct_ws_bytes(m, k, wdtype, n_batch), BE_ERR_WORKSPACE,
+             "workspace too small");
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BE_DISPATCH_W(wdtype, homo, return (csrmv_t_direct<W, HOMO>(weights, indices, rp, spikes, spike_dtype, out, m, k, n_batch, workspace, st)));
+  return BE_OK;
+}
 
 int be_binary_csrmv_t(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                       int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
                       int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
-  BE_REQUIRE(m >= 0 && k >= 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
-  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
-  BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
-  BE_REQUIRE(k == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
-  BE_REQUIRE(m == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
-  BE_REQUIRE(workspace != nullptr && workspace_bytes >= direct_ws_bytes(m, k, wdtype), BE_ERR_WORKSPACE,
-             "workspace too small");
-  RowPtr rp{indptr, indptr_is_i64, row_len};
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  BE_DISPATCH_W(wdtype, homo, return (csrmv_t_direct<W, HOMO>(weights, indices, rp, spikes, spike_dtype, out, m, k, workspace, st)));
-  return BE_OK;
+  return be_binary_csrmm_t(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, spikes, spike_dtype, out, m, k,
+                           1, workspace, workspace_bytes, stream);
 }
 
-int64_t be_binary_csrmv_nt_workspace_bytes(int64_t m, int64_t k) { (void)m; return be_align_up(((k + 31) / 32 + 2) * 4, 256); }
+int64_t be_binary_csrmm_nt_workspace_bytes(int64_t m, int64_t k, int64_t n_batch) {
+  (void)m;
+  return be_align_up((((k + 31) / 32) * n_batch + 2) * 4, 256);
+}
+int64_t be_binary_csrmv_nt_workspace_bytes(int64_t m, int64_t k) { return be_binary_csrmm_nt_workspace_bytes(m, k, 1); }
 
-int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+int be_binary_csrmm_nt(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                        int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
-                       int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+                       int64_t k, int64_t n_batch, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m >= 0 && k >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
-  BE_REQUIRE(m == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
-  BE_REQUIRE(k == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
-  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_binary_csrmv_nt_workspace_bytes(m, k), BE_ERR_WORKSPACE,
-             "workspace too small");
+  BE_REQUIRE(m == 0 || n_batch == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
+  BE_REQUIRE(k == 0 || n_batch == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_binary_csrmm_nt_workspace_bytes(m, k, n_batch),
+             BE_ERR_WORKSPACE, "workspace too small");
   RowPtr rp{indptr, indptr_is_i64, row_len};
   hipStream_t st = static_cast<hipStream_t>(stream);
   // average row length steers the lanes-per-row choice; for CSR it needs indptr[m] which lives on the
   // device, so the caller's row_len doubles as a hint (row_len >= 0: exact for fixed rows, a hint for CSR)
   const int64_t nnz_hint = (row_len >= 0 ? row_len : 64) * m;
-  BE_DISPATCH_W(wdtype, homo, return (csrmv_nt<W, HOMO>(weights, indices, rp, nnz_hint, spikes, spike_dtype, out, m, k, workspace, st)));
+  BE_DISPATCH_W(wdtype, homo, return (csrmv_nt<W, HOMO>(weights, indices, rp, nnz_hint, spikes, spike_dtype, out, m, k, n_batch, workspace, st)));
   return BE_OK;
+}
+
+int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                       int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                       int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  return be_binary_csrmm_nt(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, spikes, spike_dtype, out, m,
+                            k, 1, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------- scatter plan
@@ -775,17 +824,22 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   return BE_OK;
 }
 
-int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo) {
+int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int parts, int homo) {
   const int64_t n_slices = n_slices_of(k, slice_shift);
   const int64_t acc_bytes = homo ? 4 : 8;
-  return 256 + be_align_up(m * 4, 256) + be_align_up(n_slices * parts * (1ll << slice_shift) * acc_bytes, 256);
+  return counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
+         be_align_up(n_batch * n_slices * parts * (1ll << slice_shift) * acc_bytes, 256);
+}
+int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo) {
+  return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, parts, homo);
 }
 
-int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
+int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
                            const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k,
-                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
-                           be_stream_t stream) {
+                           int64_t n_batch, int slice_shift, int parts, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(parts >= 1 && parts <= 64, BE_ERR_INVALID, "parts must be in [1, 64]");
   BE_REQUIRE(seg_ptr && spikes && out && idx16, BE_ERR_INVALID, "null pointer");
@@ -795,67 +849,89 @@ int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint
   const size_t lds = ((size_t)(S + 1) * (homo ? 4 : 8) + 15) & ~(size_t)15;
   BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
   BE_REQUIRE(workspace != nullptr &&
-                 workspace_bytes >= be_binary_csrmv_t_plan_workspace_bytes(m, k, slice_shift, parts, homo),
+                 workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, parts, homo),
              BE_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
-  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
-  void* partial = wsb + 256 + be_align_up(m * 4, 256);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + counts_bytes(n_batch));
+  const int64_t astride = active_stride_of(m);
+  void* partial = wsb + counts_bytes(n_batch) + n_batch * astride * 4;
   const int n_slices = n_slices_of(k, slice_shift);
-  int rc = compact_any(spikes, spike_dtype, m, active, count, st);
+  int rc = compact_any(spikes, spike_dtype, m, n_batch, active, astride, count, st);
   if (rc != BE_OK) return rc;
   const float scale = ldexpf(1.0f, scale_exp - 32);   // see fixed_from_f32
   const double inv_scale = ldexp(1.0, -scale_exp);
-  const dim3 grid((unsigned)(n_slices * parts)), block(1024);
+  const dim3 grid((unsigned)(n_slices * parts), (unsigned)n_batch), block(1024);
   const int prof = be_prof_begin(st);
   if (homo) {
     auto kern = k_plan_accumulate<true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const uint2*>(idx16),
                        reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
-                       static_cast<uint32_t*>(partial));
+                       static_cast<uint32_t*>(partial), astride);
   } else {
     auto kern = k_plan_accumulate<false>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const uint2*>(idx16),
                        reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
-                       static_cast<unsigned long long*>(partial));
+                       static_cast<unsigned long long*>(partial), astride);
   }
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
-  const int rgrid = grid_for(k, 256, 2048);
+  const int rgrid = grid_for(k, 256, n_batch >= 8 ? 256 : 2048);
+  const int64_t pstride = (int64_t)n_slices * parts * S;
   BE_DISPATCH_W(wdtype, homo,
-                hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid), dim3(256), 0, st,
+                hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid, (unsigned)n_batch), dim3(256), 0, st,
                                    static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, slice_shift, k,
-                                   inv_scale, static_cast<const W*>(weights), static_cast<W*>(out)));
+                                   inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
+int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
+                           const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k,
+                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           be_stream_t stream) {
+  return be_binary_csrmm_t_plan(weights, homo, wdtype, idx16, w32, seg_ptr, spikes, spike_dtype, out, m, k, 1, slice_shift,
+                                parts, scale_exp, workspace, workspace_bytes, stream);
+}
+
 // ---------------------------------------------------------------- per-variant symbols
-#define BE_DEF_CSRMV_VARIANT(W, WD, S, SD)                                                                              \
-  int be_binary_csrmv_t_homo_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,         \
-                                       const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,       \
-                                       be_stream_t st) {                                                                 \
-    return be_binary_csrmv_t(weights, 1, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);              \
-  }                                                                                                                      \
-  int be_binary_csrmv_t_hetero_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,       \
-                                         const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,     \
-                                         be_stream_t st) {                                                               \
-    return be_binary_csrmv_t(weights, 0, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);              \
-  }                                                                                                                      \
-  int be_binary_csrmv_nt_homo_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,        \
-                                        const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,      \
-                                        be_stream_t st) {                                                                \
-    return be_binary_csrmv_nt(weights, 1, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);             \
-  }                                                                                                                      \
-  int be_binary_csrmv_nt_hetero_##W##_##S(const void* weights, const int32_t* indices, const void* indptr, int i64,      \
-                                          const void* spikes, void* out, int64_t m, int64_t k, void* ws, int64_t wsb,    \
-                                          be_stream_t st) {                                                              \
-    return be_binary_csrmv_nt(weights, 0, WD, indices, indptr, i64, -1, spikes, SD, out, m, k, ws, wsb, st);             \
+#define BE_DEF_CSR_VARIANT(W, WD, S, SD)                                                                               \
+  int be_binary_csrmv_t_homo_##W##_##S(BE_CSR_MV_ARGS) {                                                                \
+    return be_binary_csrmm_t(weights, 1, WD, indices, indptr, indptr_is_i64, -1, spikes, SD, out, m, k, 1, workspace,   \
+                             workspace_bytes, stream);                                                                  \
+  }                                                                                                                     \
+  int be_binary_csrmv_t_hetero_##W##_##S(BE_CSR_MV_ARGS) {                                                              \
+    return be_binary_csrmm_t(weights, 0, WD, indices, indptr, indptr_is_i64, -1, spikes, SD, out, m, k, 1, workspace,   \
+                             workspace_bytes, stream);                                                                  \
+  }                                                                                                                     \
+  int be_binary_csrmv_nt_homo_##W##_##S(BE_CSR_MV_ARGS) {                                                               \
+    return be_binary_csrmm_nt(weights, 1, WD, indices, indptr, indptr_is_i64, -1, spikes, SD, out, m, k, 1, workspace,  \
+                              workspace_bytes, stream);                                                                 \
+  }                                                                                                                     \
+  int be_binary_csrmv_nt_hetero_##W##_##S(BE_CSR_MV_ARGS) {                                                             \
+    return be_binary_csrmm_nt(weights, 0, WD, indices, indptr, indptr_is_i64, -1, spikes, SD, out, m, k, 1, workspace,  \
+                              workspace_bytes, stream);                                                                 \
+  }                                                                                                                     \
+  int be_binary_csrmm_t_homo_##W##_##S(BE_CSR_MM_ARGS) {                                                                \
+    return be_binary_csrmm_t(weights, 1, WD, indices, indptr, indptr_is_i64, -1, spikes_bm, SD, out_bm, m, k, n_batch,  \
+                             workspace, workspace_bytes, stream);                                                       \
+  }                                                                                                                     \
+  int be_binary_csrmm_t_hetero_##W##_##S(BE_CSR_MM_ARGS) {                                                              \
+    return be_binary_csrmm_t(weights, 0, WD, indices, indptr, indptr_is_i64, -1, spikes_bm, SD, out_bm, m, k, n_batch,  \
+                             workspace, workspace_bytes, stream);                                                       \
+  }                                                                                                                     \
+  int be_binary_csrmm_nt_homo_##W##_##S(BE_CSR_MM_ARGS) {                                                               \
+    return be_binary_csrmm_nt(weights, 1, WD, indices, indptr, indptr_is_i64, -1, spikes_bm, SD, out_bm, m, k, n_batch, \
+                              workspace, workspace_bytes, stream);                                                      \
+  }                                                                                                                     \
+  int be_binary_csrmm_nt_hetero_##W##_##S(BE_CSR_MM_ARGS) {                                                             \
+    return be_binary_csrmm_nt(weights, 0, WD, indices, indptr, indptr_is_i64, -1, spikes_bm, SD, out_bm, m, k, n_batch, \
+                              workspace, workspace_bytes, stream);                                                      \
   }
 
-BE_FOR_ALL_VARIANTS(BE_DEF_CSRMV_VARIANT)
+BE_FOR_ALL_VARIANTS(BE_DEF_CSR_VARIANT)
 
 }  // extern "C"

@@ -73,20 +73,33 @@ int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* 
                       be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * binary_csrmv, transpose=True  (scatter):  out[indices[j]] += w[j]  for every active row
+ * Batch convention (all *mm entry points): spikes_bm is batch-major [n_batch, len] and out_bm is
+ * batch-major [n_batch, out_len] — the physical layout the reference's SRAW kernels also emit
+ * (brainevent/_csr/binary.py:1263-1286, brainevent/_fcn/binary.py:867-889: "Python transposes back").
+ * The *mv entry points are the n_batch = 1 case of the same kernels.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------------------------------
+ * binary_csrmv / binary_csrmm, transpose=True (scatter):  out[indices[j]] += w[j]  for every active row
  * replaces: binary_csrmv_wat_hybrid_{homo,hetero}_{f32,f64,f16,bf16}_{bool,float}
- *           (brainevent/_csr/binary_csrmv_hybrid.cu:619-632, 789-821)
- * and, with indptr == NULL and row_len = n_conn, binary_fcnmv_scatter_{homo,hetero}_bool_{…}
- *           (brainevent/_fcn/binary_fcnmv.cu:55-137, 207-217).
- *   weights : [nnz] (hetero) or [1] (homo), dtype wdtype;  out : [k] dtype wdtype (fully written)
- *   spikes  : [m];  indices : [nnz] int32 in [0,k);  indptr : [m+1] or NULL (then rows are row_len long)
- *   workspace : >= be_binary_csrmv_t_workspace_bytes(m, k, wdtype) bytes, 256-byte aligned
+ *           (brainevent/_csr/binary_csrmv_hybrid.cu:619-632, 789-821),
+ *           binary_csrmm_sraw_hybrid_{…} (brainevent/_csr/binary_csrmm_hybrid.cu:16-57, 469-530)
+ * and, with indptr == NULL and row_len = n_conn, binary_fcnmv_scatter_{…} / binary_fcnmm_sraw_{…}
+ *           (brainevent/_fcn/binary_fcnmv.cu:55-137, 207-217; brainevent/_fcn/binary_fcnmm.cu:486-529, 835-857).
+ *   weights : [nnz] (hetero) or [1] (homo), dtype wdtype;  out : [n_batch, k] dtype wdtype (fully written)
+ *   spikes  : [n_batch, m];  indices : [nnz] int32 in [0,k);  indptr : [m+1] or NULL (rows are row_len long)
+ *   workspace : >= be_binary_csrmm_t_workspace_bytes(m, k, n_batch, wdtype) bytes, 256-byte aligned
  * "direct" route: no preprocessing, global float atomics.
  * ---------------------------------------------------------------------------------------------- */
 int64_t be_binary_csrmv_t_workspace_bytes(int64_t m, int64_t k, int wdtype);
+int64_t be_binary_csrmm_t_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int wdtype);
 int be_binary_csrmv_t(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                       int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out,
                       int64_t m, int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                      int indptr_is_i64, int64_t row_len, const void* spikes_bm, int spike_dtype, void* out_bm,
+                      int64_t m, int64_t k, int64_t n_batch, void* workspace, int64_t workspace_bytes,
+                      be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * post-sliced scatter plan (the MI355X-native layout behind `spk @ CSR` / `spk @ FixedNumPerPre`).
@@ -113,47 +126,77 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
                          const uint32_t* seg_ptr, int64_t total_entries, uint16_t* idx16, float* w32,
                          uint32_t* maxabs_bits, be_stream_t stream);
 
-/* planned scatter step: out[k] (dtype wdtype, fully written) from spikes[m].
+/* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
  *   weights : device pointer to weights[0] (homo only; may be NULL for hetero)
  *   scale_exp : fixed-point exponent chosen by the caller from max|w| and m (hetero only): every stored
  *               weight is accumulated as round(w * 2^scale_exp) in a 64-bit integer (order independent,
  *               bitwise reproducible); |w|max * 2^scale_exp * m must stay below 2^62.
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
- *   workspace : >= be_binary_csrmv_t_plan_workspace_bytes(m, k, slice_shift, parts, homo) bytes
+ *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, parts, homo) bytes
  */
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo);
+int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int parts,
+                                               int homo);
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
                            const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m,
                            int64_t k, int slice_shift, int parts, int scale_exp, void* workspace,
                            int64_t workspace_bytes, be_stream_t stream);
+int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
+                           const uint32_t* seg_ptr, const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m,
+                           int64_t k, int64_t n_batch, int slice_shift, int parts, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * binary_csrmv, transpose=False (gather):  out[i] = sum_j w[j] * e(spikes[indices[j]])
- * replaces: binary_csrmv_nt_auto_{homo,hetero}_{…}_{bool,float} (brainevent/_csr/binary_csrmv.cu:437-486)
- *   spikes : [k];  out : [m];  workspace >= be_binary_csrmv_nt_workspace_bytes(m, k)
+ * binary_csrmv / binary_csrmm, transpose=False (gather):  out[i] = sum_j w[j] * e(spikes[indices[j]])
+ * replaces: binary_csrmv_nt_auto_{homo,hetero}_{…}_{bool,float} (brainevent/_csr/binary_csrmv.cu:437-486),
+ *           binary_csrmm_nt_auto_{…} (brainevent/_csr/binary_csrmm.cu:328-392) and, with indptr == NULL,
+ *           the gather direction of binary_fcnmv / binary_fcnmm (brainevent/_fcn/binary.py:201-253, 731-766).
+ *   spikes : [n_batch, k];  out : [n_batch, m];  workspace >= be_binary_csrmm_nt_workspace_bytes(m, k, n_batch)
  * ---------------------------------------------------------------------------------------------- */
 int64_t be_binary_csrmv_nt_workspace_bytes(int64_t m, int64_t k);
+int64_t be_binary_csrmm_nt_workspace_bytes(int64_t m, int64_t k, int64_t n_batch);
 int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                        int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out,
                        int64_t m, int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+int be_binary_csrmm_nt(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                       int indptr_is_i64, int64_t row_len, const void* spikes_bm, int spike_dtype, void* out_bm,
+                       int64_t m, int64_t k, int64_t n_batch, void* workspace, int64_t workspace_bytes,
+                       be_stream_t stream);
 
 /* per-variant symbols (same grammar as the reference's `// @BE` names); thin wrappers of the above */
-#define BE_DECL_CSRMV_VARIANT(W, WD, S, SD)                                                                   \
-  int be_binary_csrmv_t_homo_##W##_##S(const void* weights, const int32_t* indices, const void* indptr,        \
-                                       int indptr_is_i64, const void* spikes, void* out, int64_t m, int64_t k, \
-                                       void* workspace, int64_t workspace_bytes, be_stream_t stream);          \
-  int be_binary_csrmv_t_hetero_##W##_##S(const void* weights, const int32_t* indices, const void* indptr,      \
-                                         int indptr_is_i64, const void* spikes, void* out, int64_t m,          \
-                                         int64_t k, void* workspace, int64_t workspace_bytes,                  \
-                                         be_stream_t stream);                                                  \
-  int be_binary_csrmv_nt_homo_##W##_##S(const void* weights, const int32_t* indices, const void* indptr,       \
-                                        int indptr_is_i64, const void* spikes, void* out, int64_t m,           \
-                                        int64_t k, void* workspace, int64_t workspace_bytes,                   \
-                                        be_stream_t stream);                                                   \
-  int be_binary_csrmv_nt_hetero_##W##_##S(const void* weights, const int32_t* indices, const void* indptr,     \
-                                          int indptr_is_i64, const void* spikes, void* out, int64_t m,         \
-                                          int64_t k, void* workspace, int64_t workspace_bytes,                 \
-                                          be_stream_t stream);
+#define BE_CSR_MV_ARGS const void *weights, const int32_t *indices, const void *indptr, int indptr_is_i64,       \
+                       const void *spikes, void *out, int64_t m, int64_t k, void *workspace,                      \
+                       int64_t workspace_bytes, be_stream_t stream
+#define BE_CSR_MM_ARGS const void *weights, const int32_t *indices, const void *indptr, int indptr_is_i64,       \
+                       const void *spikes_bm, void *out_bm, int64_t m, int64_t k, int64_t n_batch,                \
+                       void *workspace, int64_t workspace_bytes, be_stream_t stream
+/* fixed-number connectivity: indices is [n_pre, n_conn] row-major, weights same shape or [1]
+ * (brainevent/_fcn/binary_fcnmv.cu:207-251, binary_fcnmm.cu:835-857, 993-1023).
+ * scatter: spikes [n_batch, n_pre] -> out [n_batch, n_post];  gather: spikes [n_batch, n_post] -> out [n_batch, n_pre] */
+#define BE_FCN_MV_ARGS const void *weights, const int32_t *indices, const void *spikes, void *out,               \
+                       int64_t n_pre, int64_t n_post, int64_t n_conn, void *workspace, int64_t workspace_bytes,   \
+                       be_stream_t stream
+#define BE_FCN_MM_ARGS const void *weights, const int32_t *indices, const void *spikes_bm, void *out_bm,         \
+                       int64_t n_pre, int64_t n_post, int64_t n_conn, int64_t n_batch, void *workspace,           \
+                       int64_t workspace_bytes, be_stream_t stream
+
+#define BE_DECL_VARIANT(W, WD, S, SD)                            \
+  int be_binary_csrmv_t_homo_##W##_##S(BE_CSR_MV_ARGS);           \
+  int be_binary_csrmv_t_hetero_##W##_##S(BE_CSR_MV_ARGS);         \
+  int be_binary_csrmv_nt_homo_##W##_##S(BE_CSR_MV_ARGS);          \
+  int be_binary_csrmv_nt_hetero_##W##_##S(BE_CSR_MV_ARGS);        \
+  int be_binary_csrmm_t_homo_##W##_##S(BE_CSR_MM_ARGS);           \
+  int be_binary_csrmm_t_hetero_##W##_##S(BE_CSR_MM_ARGS);         \
+  int be_binary_csrmm_nt_homo_##W##_##S(BE_CSR_MM_ARGS);          \
+  int be_binary_csrmm_nt_hetero_##W##_##S(BE_CSR_MM_ARGS);        \
+  int be_binary_fcnmv_scatter_homo_##W##_##S(BE_FCN_MV_ARGS);     \
+  int be_binary_fcnmv_scatter_hetero_##W##_##S(BE_FCN_MV_ARGS);   \
+  int be_binary_fcnmv_gather_homo_##W##_##S(BE_FCN_MV_ARGS);      \
+  int be_binary_fcnmv_gather_hetero_##W##_##S(BE_FCN_MV_ARGS);    \
+  int be_binary_fcnmm_scatter_homo_##W##_##S(BE_FCN_MM_ARGS);     \
+  int be_binary_fcnmm_scatter_hetero_##W##_##S(BE_FCN_MM_ARGS);   \
+  int be_binary_fcnmm_gather_homo_##W##_##S(BE_FCN_MM_ARGS);      \
+  int be_binary_fcnmm_gather_hetero_##W##_##S(BE_FCN_MM_ARGS);
 
 #define BE_FOR_ALL_VARIANTS(X) \
   X(f32, BE_F32, bool, BE_SPIKE_BOOL)   X(f32, BE_F32, float, BE_SPIKE_FLOAT)   \
@@ -161,7 +204,7 @@ int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t*
   X(f16, BE_F16, bool, BE_SPIKE_BOOL)   X(f16, BE_F16, float, BE_SPIKE_FLOAT)   \
   X(bf16, BE_BF16, bool, BE_SPIKE_BOOL) X(bf16, BE_BF16, float, BE_SPIKE_FLOAT)
 
-BE_FOR_ALL_VARIANTS(BE_DECL_CSRMV_VARIANT)
+BE_FOR_ALL_VARIANTS(BE_DECL_VARIANT)
 
 #ifdef __cplusplus
 }

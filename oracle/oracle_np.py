@@ -59,3 +59,27 @@ def binary_csrmm(weights, indices, indptr, B, shape, transpose):
     if not cols:
         return np.zeros((rows, 0), dtype=np.asarray(weights).dtype)
     return np.stack(cols, axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# fixed-number connectivity  (brainevent/_fcn/binary.py:156-253 mv, :677-766 mm)
+# ----------------------------------------------------------------------------------------------------
+def binary_fcnmv(weights, indices, spikes, shape, transpose):
+    """transpose: posts[indices[i, j]] += w[i, j] for active i (:167-200);
+    else posts[i] = sum_j w[i, j] * e(spikes[indices[i, j]]) (:201-253)."""
+    indices = np.asarray(indices)
+    n_rows, n_conn = indices.shape
+    weights = np.asarray(weights)
+    w = weights.reshape(-1) if weights.size == 1 else weights.reshape(-1)
+    indptr = np.arange(n_rows + 1, dtype=np.int64) * n_conn
+    return binary_csrmv(w, indices.reshape(-1), indptr, spikes, (n_rows, shape[1]), transpose)
+
+
+def binary_fcnmm(weights, indices, matrix, shape, transpose):
+    """Matrix operand (:677-766): column-wise application; result (shape[1], n) if transpose else (shape[0], n)."""
+    matrix = np.asarray(matrix)
+    cols = [binary_fcnmv(weights, indices, matrix[:, l], shape, transpose) for l in range(matrix.shape[1])]
+    rows = shape[1] if transpose else shape[0]
+    if not cols:
+        return np.zeros((rows, 0), dtype=np.asarray(weights).dtype)
+    return np.stack(cols, axis=1)

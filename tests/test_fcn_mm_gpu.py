@@ -1,0 +1,106 @@
+"""GPU parity: batched CSR products (binary_csrmm) and fixed-number connectivity (binary_fcnmv / binary_fcnmm)."""
+import numpy as np
+import pytest
+import torch
+
+from test_csr_gpu import rand_csr, spikes_of, RTOL, ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'float'])
+def test_csrmm_matches_oracle(be, oracle, transpose, homo, kind):
+    rng = np.random.default_rng(21)
+    m, k, n = 150, 220, 7
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(0, 30, m), homo=homo)
+    rows = m if transpose else k
+    B = np.stack([spikes_of(rng, rows, 0.3, kind) for _ in range(n)], axis=1)
+    got = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=transpose)
+    ref = oracle.binary_csrmm(w.astype(np.float64), idx, ptr, B, (m, k), transpose)
+    assert got.shape == ((k if transpose else m), n)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
+
+
+def test_csrmm_planned_batch(be, oracle, monkeypatch):
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(22)
+    m, k, n = 400, 40000, 5
+    w, idx, ptr = rand_csr(rng, m, k, [200] * m)
+    csr = be.CSR((w, idx, ptr), shape=(m, k))
+    S = np.stack([spikes_of(rng, m, 0.2, 'bool') for _ in range(n)], axis=0)      # [n, m] @ csr -> [n, k]
+    got = be.BinaryArray(S) @ csr
+    assert isinstance(csr.buffers['scatter_plan'], C.ScatterPlan) and got.shape == (n, k)
+    ref = oracle.binary_csrmm(w.astype(np.float64), idx, ptr, S.T, (m, k), True).T
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
+    S2 = np.stack([spikes_of(rng, k, 0.2, 'bool') for _ in range(n)], axis=1)     # csr @ [k, n] -> [m, n]
+    got2 = csr @ be.BinaryArray(S2)
+    np.testing.assert_allclose(got2, oracle.binary_csrmm(w.astype(np.float64), idx, ptr, S2, (m, k), False), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'float'])
+@pytest.mark.parametrize('n_conn', [1, 5, 64, 130])
+def test_fcnmv_matches_oracle(be, oracle, transpose, homo, kind, n_conn):
+    rng = np.random.default_rng(n_conn)
+    n_pre, n_post = 211, 333
+    idx = rng.integers(0, n_post, (n_pre, n_conn)).astype(np.int32)
+    w = np.asarray([0.7], np.float32) if homo else rng.uniform(0.1, 1, (n_pre, n_conn)).astype(np.float32)
+    s = spikes_of(rng, n_pre if transpose else n_post, 0.3, kind)
+    got = be.binary_fcnmv(w, idx, s, shape=(n_pre, n_post), transpose=transpose)
+    ref = oracle.binary_fcnmv(w.astype(np.float64), idx, s, (n_pre, n_post), transpose)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+def test_fcnmm_matches_oracle(be, oracle, transpose):
+    rng = np.random.default_rng(5)
+    n_pre, n_post, n_conn, n = 90, 120, 17, 6
+    idx = rng.integers(0, n_post, (n_pre, n_conn)).astype(np.int32)
+    w = rng.uniform(0.1, 1, (n_pre, n_conn)).astype(np.float32)
+    M = np.stack([spikes_of(rng, n_pre if transpose else n_post, 0.4, 'float') for _ in range(n)], axis=1)
+    got = be.binary_fcnmm(w, idx, M, shape=(n_pre, n_post), transpose=transpose)
+    ref = oracle.binary_fcnmm(w.astype(np.float64), idx, M, (n_pre, n_post), transpose)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
+
+
+def test_fcn_docstring_kats(be):
+    # brainevent/_fcn/binary.py:124-130 and :646-654
+    idx = np.array([[0, 1], [1, 2]], np.int32)
+    w = np.array([1.0], np.float32)
+    out = be.binary_fcnmv(w, idx, np.array([True, False, True]), shape=(2, 3), transpose=False)
+    np.testing.assert_array_equal(out, [1.0, 1.0])
+    M = np.array([[True, False], [False, True], [True, True]])
+    out = be.binary_fcnmm(w, idx, M, shape=(2, 3), transpose=False)
+    np.testing.assert_array_equal(out, [[1, 1], [1, 2]])
+
+
+def test_fixed_num_classes(be, oracle, monkeypatch):
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(8)
+    n_pre, n_post, n_conn = 300, 40000, 128
+    idx = rng.integers(0, n_post, (n_pre, n_conn)).astype(np.int32)
+    w = rng.uniform(0.1, 1, (n_pre, n_conn)).astype(np.float32)
+    conn = be.FixedNumPerPre((w, idx), shape=(n_pre, n_post))
+    s = spikes_of(rng, n_pre, 0.2, 'bool')
+    got = be.BinaryArray(s) @ conn                      # favourable: scatter (planned)
+    assert isinstance(conn.buffers['scatter_plan'], C.ScatterPlan)
+    np.testing.assert_allclose(got, oracle.binary_fcnmv(w.astype(np.float64), idx, s, (n_pre, n_post), True), rtol=RTOL, atol=ATOL)
+    s2 = spikes_of(rng, n_post, 0.2, 'bool')
+    got2 = conn @ be.BinaryArray(s2)                    # unfavourable: gather
+    np.testing.assert_allclose(got2, oracle.binary_fcnmv(w.astype(np.float64), idx, s2, (n_pre, n_post), False), rtol=RTOL, atol=ATOL)
+    post = conn.T                                       # FixedNumPerPost, shape (n_post, n_pre)
+    assert isinstance(post, be.FixedNumPerPost) and post.shape == (n_post, n_pre)
+    np.testing.assert_allclose(post @ be.BinaryArray(s), got, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(be.BinaryArray(s2) @ post, got2, rtol=RTOL, atol=ATOL)
+    # dense equivalence
+    np.testing.assert_allclose(got, s.astype(np.float32) @ conn.todense(), rtol=1e-4, atol=1e-4)
+    # 2-D operands
+    S = np.stack([spikes_of(rng, n_pre, 0.2, 'bool') for _ in range(3)], axis=0)
+    np.testing.assert_allclose(be.BinaryArray(S) @ conn, S.astype(np.float32) @ conn.todense(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        be.FixedNumPerPre((w, idx + n_post), shape=(n_pre, n_post))
