@@ -14,3 +14,5 @@ from ._csr import (CSR, CSC, ScatterPlan, binary_csrmv, binary_csrmm, binary_csr
                    binary_csrmv_p_call, binary_csrmm_p_call)
 from ._fcn import (FixedNumConn, FixedNumPerPre, FixedNumPerPost, binary_fcnmv, binary_fcnmm, binary_fcnmv_p,
                    binary_fcnmm_p, binary_fcnmv_p_call, binary_fcnmm_p_call)
+from ._dense import (binary_densemv, binary_densemm, binary_densemv_p, binary_densemm_p, binary_densemv_p_call,
+                     binary_densemm_p_call)

@@ -1,0 +1,517 @@
+// be_dense.hip — event-driven dense products  BinaryArray @ ndarray  for gfx950 (vector path).
+//
+// Computes what the reference's CPU kernels compute (brainevent/_dense/binary.py:168-211 mv,
+// :579-632 mm, read as text):
+//   transpose=True : weights[k, n], spikes[k, nb]  ->  out[n, nb] = sum_{i : e(s[i, b])} weights[i, :]
+//   transpose=False: weights[m, k], spikes[k, nb]  ->  out[m, nb] = sum_{j : e(s[j, b])} weights[:, j]
+// Physical layouts here are batch-major (spikes_bm [nb, k], out_bm [nb, n|m]) like the reference's CUDA
+// kernels emit (brainevent/_dense/binary_densemm.cu:50-93, "Python transposes", _dense/binary.py:980-987).
+//
+// The contraction is HBM-bound on the weight rows that carry at least one spike (arithmetic intensity
+// <= 2*nb flop per weight byte), so the design goal is to read every needed weight byte exactly once,
+// 16 B per lane, and to skip rows without spikes:
+//   transpose=True : spikes -> per-row batch masks -> ordered per-batch-group row lists; one wave owns
+//                    (column strip, group of 4 batches, row part) and keeps 4 x VEC f32 accumulators in
+//                    registers; partial sums per row part are reduced in a fixed order (deterministic).
+//   transpose=False: one wave per weight row streams it with 16 B loads against the mask vector
+//                    (or gathers only the active columns when fewer than 1/16 of them are active).
+// The MFMA kernel for the fp16/bf16 batched case lives in be_dense_mfma.hip.
+#include "be_common.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+constexpr int kGroup = 4;        // batches per wave in the transpose=True kernel
+constexpr int kMaxChunk = 32;    // batches per pass (one uint32 mask per row)
+
+template <typename W> struct Vec16 { static constexpr int n = 16 / sizeof(W); };
+
+// ------------------------------------------------------------------------------------------------
+// spikes_bm[nb, k] (rows b0 .. b0+nc) -> mask[k], bit b set iff spike (b0+b, k) active
+// ------------------------------------------------------------------------------------------------
+template <typename SP>
+__global__ void __launch_bounds__(256) k_dense_masks(const typename SP::type* __restrict__ spikes, int64_t k, int nc,
+                                                     uint32_t* __restrict__ mask) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) {
+    uint32_t mk = 0;
+    for (int b = 0; b < nc; ++b) mk |= (SP::active(spikes[(int64_t)b * k + i]) ? 1u : 0u) << b;
+    mask[i] = mk;
+  }
+}
+
+// ordered compaction of the rows whose sub-mask for batch group g (= blockIdx.y) is non-zero.
+// entry = row | submask << 28  (rows < 2^28).  Three passes: per-tile counts, scan, write.
+constexpr int kTile = 2048;   // rows per workgroup (256 threads x 8)
+
+__device__ __forceinline__ uint32_t submask_of(uint32_t mk, int g) { return (mk >> (kGroup * g)) & ((1u << kGroup) - 1u); }
+
+__global__ void __launch_bounds__(256) k_gl_count(const uint32_t* __restrict__ mask, int64_t k, uint32_t* __restrict__ tile_cnt) {
+  __shared__ uint32_t red[4];
+  const int g = blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * 8;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (base + i < k && submask_of(mask[base + i], g)) ++c;
+  c = wave_sum(c);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[(int64_t)g * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup per group: exclusive scan of that group's tile counts; count[g] = total
+__global__ void __launch_bounds__(1024) k_gl_scan(uint32_t* __restrict__ tile_cnt, int64_t n_tiles, uint32_t* __restrict__ count) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t carry;
+  uint32_t* tc = tile_cnt + (int64_t)blockIdx.x * n_tiles;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_tiles; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t v = (i < n_tiles) ? tc[i] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t t = 0;
+      if ((int)threadIdx.x >= off) t = part[threadIdx.x - off];
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n_tiles) tc[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_gl_write(const uint32_t* __restrict__ mask, int64_t k,
+                                                  const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ lists,
+                                                  int64_t list_stride) {
+  __shared__ uint32_t wave_tot[4];
+  const int g = blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * 8;
+  uint32_t sm[8];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sm[i] = (base + i < k) ? submask_of(mask[base + i], g) : 0u;
+    c += sm[i] ? 1u : 0u;
+  }
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+  uint32_t pos = tile_off[(int64_t)g * gridDim.x + blockIdx.x] + wave_off + incl - c;
+  uint32_t* out = lists + (int64_t)g * list_stride;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (sm[i]) out[pos++] = (uint32_t)(base + i) | (sm[i] << 28);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose=True accumulate: wave task = (strip, group); blockIdx.y = row part
+// ------------------------------------------------------------------------------------------------
+template <typename W, int VEC> struct RowLoad;
+template <typename W> struct RowLoad<W, 1> {
+  using ACC = typename WTraits<W>::acc;
+  __device__ static __forceinline__ void load(const W* p, ACC (&v)[1]) { v[0] = (ACC)WTraits<W>::load(p, 0); }
+};
+template <> struct RowLoad<float, 4> {
+  __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+template <> struct RowLoad<double, 2> {
+  __device__ static __forceinline__ void load(const double* p, double (&v)[2]) {
+    const double2 t = *reinterpret_cast<const double2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  }
+};
+template <> struct RowLoad<__half, 8> {
+  __device__ static __forceinline__ void load(const __half* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const __half2 h = *reinterpret_cast<const __half2*>(&w[i]);
+      const float2 f = __half22float2(h);
+      v[2 * i] = f.x; v[2 * i + 1] = f.y;
+    }
+  }
+};
+template <> struct RowLoad<__hip_bfloat16, 8> {
+  __device__ static __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+};
+
+template <typename W, int VEC>
+__global__ void __launch_bounds__(256) k_densemm_t(const W* __restrict__ weights, int64_t n, const uint32_t* __restrict__ lists,
+                                                   int64_t list_stride, const uint32_t* __restrict__ count, int n_groups,
+                                                   int nc, typename WTraits<W>::acc* __restrict__ partial, int64_t nb_total,
+                                                   int b0) {
+  using ACC = typename WTraits<W>::acc;
+  const int lane = lane_id();
+  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_strips = (n + 64 * VEC - 1) / (64 * VEC);
+  if (task >= n_strips * n_groups) return;
+  const int g = (int)(task % n_groups);
+  const int64_t strip = task / n_groups;
+  const int64_t col = strip * (64 * VEC) + (int64_t)lane * VEC;
+  const bool in = col < n;            // VEC > 1 only when n % VEC == 0, so a lane is all-in or all-out
+  const uint32_t cnt = count[g];
+  const uint32_t* list = lists + (int64_t)g * list_stride;
+  const int part = blockIdx.y, parts = gridDim.y;
+
+  ACC acc[kGroup][VEC];
+#pragma unroll
+  for (int b = 0; b < kGroup; ++b)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[b][v] = ACC(0);
+
+  // rows of this part: a = part, part + parts, ...  (4 loads in flight)
+  uint32_t a = part;
+  for (; a + 3u * parts < cnt; a += 4u * parts) {
+    uint32_t e[4];
+    ACC w[4][VEC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = list[a + q * parts];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (in) RowLoad<W, VEC>::load(weights + (int64_t)(e[q] & 0x0fffffffu) * n + col, w[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t sm = e[q] >> 28;
+#pragma unroll
+      for (int b = 0; b < kGroup; ++b)
+        if (sm & (1u << b)) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[b][v] += w[q][v];
+        }
+    }
+  }
+  for (; a < cnt; a += parts) {
+    const uint32_t e = list[a];
+    ACC w[VEC];
+    if (in) RowLoad<W, VEC>::load(weights + (int64_t)(e & 0x0fffffffu) * n + col, w);
+    const uint32_t sm = e >> 28;
+#pragma unroll
+    for (int b = 0; b < kGroup; ++b)
+      if (sm & (1u << b)) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[b][v] += w[v];
+      }
+  }
+  if (!in) return;
+#pragma unroll
+  for (int b = 0; b < kGroup; ++b) {
+    const int bb = kGroup * g + b;
+    if (bb >= nc) break;
+    ACC* dst = partial + ((int64_t)part * nb_total + b0 + bb) * n + col;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) dst[v] = acc[b][v];
+  }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_dense_reduce(const typename WTraits<W>::acc* __restrict__ partial, int parts,
+                                                      int64_t total, W* __restrict__ out) {
+  using ACC = typename WTraits<W>::acc;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    ACC s = ACC(0);
+    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * total + i];
+    WTraits<W>::store(out, i, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose=False: one wave per weight row
+// ------------------------------------------------------------------------------------------------
+template <typename W, int VEC, int NBT>
+__global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weights, int64_t m, int64_t k,
+                                                    const uint32_t* __restrict__ mask, const uint32_t* __restrict__ ulist,
+                                                    const uint32_t* __restrict__ ucount, int nc, W* __restrict__ out_bm,
+                                                    int b0) {
+  using ACC = typename WTraits<W>::acc;
+  const int lane = lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t n_union = ucount[0];
+  const bool gather = (int64_t)n_union * 16 < k;   // few active columns: touch only their 64-B sectors
+  for (int64_t r = wave; r < m; r += n_waves) {
+    const W* row = weights + r * k;
+    ACC acc[NBT];
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) acc[b] = ACC(0);
+    if (gather) {
+      for (uint32_t a = lane; a < n_union; a += 64) {
+        const uint32_t j = ulist[a] & 0x0fffffffu;
+        const uint32_t mk = mask[j];
+        const ACC w = (ACC)WTraits<W>::load(row, j);
+#pragma unroll
+        for (int b = 0; b < NBT; ++b) acc[b] += ((mk >> b) & 1u) ? w : ACC(0);
+      }
+    } else {
+      for (int64_t j = (int64_t)lane * VEC; j < k; j += 64 * VEC) {
+        ACC w[VEC];
+        RowLoad<W, VEC>::load(row + j, w);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const uint32_t mk = mask[j + v];
+          if (mk) {
+#pragma unroll
+            for (int b = 0; b < NBT; ++b) acc[b] += ((mk >> b) & 1u) ? w[v] : ACC(0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
+      ACC s = acc[b];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if (lane == 0 && b < nc) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + r, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+inline int grid_cap(int64_t n, int block, int cap) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+struct DenseWs {
+  uint32_t* mask;      // k
+  uint32_t* lists;     // (n_groups_max + 1) * k   (group lists; the last one is the union list for NT)
+  uint32_t* tile_cnt;  // (n_groups_max + 1) * n_tiles
+  uint32_t* count;     // 16
+  void* partial;
+};
+
+inline int64_t n_tiles_of(int64_t k) { return (k + kTile - 1) / kTile; }
+constexpr int kMaxGroups = kMaxChunk / kGroup;   // 8
+
+inline int parts_for(int64_t n, int vec, int n_groups) {
+  const int64_t tasks = ((n + 64 * vec - 1) / (64 * vec)) * n_groups;
+  const int64_t wgs = (tasks + 3) / 4;
+  int64_t p = 1024 / (wgs > 0 ? wgs : 1);
+  if (p < 1) p = 1;
+  if (p > 16) p = 16;
+  return (int)p;
+}
+
+inline int64_t dense_ws_bytes(int64_t rows_w, int64_t cols_w, int64_t nb, int transpose, int wdtype) {
+  // the contraction dimension: rows (transpose) or columns of the weight matrix
+  const int64_t k = transpose ? rows_w : cols_w;
+  int64_t b = be_align_up(k * 4, 256);                                   // mask
+  b += be_align_up((int64_t)(kMaxGroups + 1) * k * 4, 256);              // lists
+  b += be_align_up((int64_t)(kMaxGroups + 1) * n_tiles_of(k) * 4, 256);  // tile counts
+  b += 256;                                                              // counts
+  if (transpose) {
+    const int64_t acc = (wdtype == BE_F64) ? 8 : 4;
+    b += be_align_up((int64_t)16 * nb * cols_w * acc, 256);              // partial (<= 16 parts)
+  }
+  return b;
+}
+
+inline DenseWs carve(void* ws, int64_t k) {
+  unsigned char* p = static_cast<unsigned char*>(ws);
+  DenseWs d;
+  d.mask = reinterpret_cast<uint32_t*>(p); p += be_align_up(k * 4, 256);
+  d.lists = reinterpret_cast<uint32_t*>(p); p += be_align_up((int64_t)(kMaxGroups + 1) * k * 4, 256);
+  d.tile_cnt = reinterpret_cast<uint32_t*>(p); p += be_align_up((int64_t)(kMaxGroups + 1) * n_tiles_of(k) * 4, 256);
+  d.count = reinterpret_cast<uint32_t*>(p); p += 256;
+  d.partial = p;
+  return d;
+}
+
+template <typename SP>
+int build_lists(const void* spikes_chunk, int64_t k, int nc, int n_groups, const DenseWs& d, hipStream_t st) {
+  hipLaunchKernelGGL(k_dense_masks<SP>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                     static_cast<const typename SP::type*>(spikes_chunk), k, nc, d.mask);
+  BE_LAUNCH_CHECK();
+  const int64_t nt = n_tiles_of(k);
+  hipLaunchKernelGGL(k_gl_count, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt);
+  BE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gl_scan, dim3(n_groups), dim3(1024), 0, st, d.tile_cnt, nt, d.count);
+  BE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt, d.lists, k);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+template <typename W, int VEC>
+int densemm_t_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t k, int64_t n, int64_t nb, void* ws,
+                  hipStream_t st) {
+  using ACC = typename WTraits<W>::acc;
+  DenseWs d = carve(ws, k);
+  ACC* partial = static_cast<ACC*>(d.partial);
+  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
+  int parts_used = 1;
+  // parts must be the same for every chunk so that one reduce pass serves the whole batch
+  parts_used = parts_for(n, VEC, (int)((std::min<int64_t>(nb, kMaxChunk) + kGroup - 1) / kGroup));
+  const int prof = be_prof_begin(st);
+  for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
+    const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
+    const int n_groups = (nc + kGroup - 1) / kGroup;
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    int rc = (sd == BE_SPIKE_FLOAT) ? build_lists<SpikeFloat>(chunk, k, nc, n_groups, d, st)
+                                    : build_lists<SpikeBool>(chunk, k, nc, n_groups, d, st);
+    if (rc != BE_OK) return rc;
+    const int64_t tasks = ((n + 64 * VEC - 1) / (64 * VEC)) * n_groups;
+    hipLaunchKernelGGL((k_densemm_t<W, VEC>), dim3((unsigned)((tasks + 3) / 4), parts_used), dim3(256), 0, st, weights, n,
+                       d.lists, k, d.count, n_groups, nc, partial, nb, (int)b0);
+    BE_LAUNCH_CHECK();
+  }
+  be_prof_end(prof, st);
+  hipLaunchKernelGGL(k_dense_reduce<W>, dim3(grid_cap(nb * n, 256, 2048)), dim3(256), 0, st, partial, parts_used, nb * n,
+                     out_bm);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+template <typename W, int VEC, int NBT>
+int densemm_nt_launch(const W* weights, int64_t m, int64_t k, const DenseWs& d, int nc, W* out_bm, int b0, hipStream_t st) {
+  hipLaunchKernelGGL((k_densemm_nt<W, VEC, NBT>), dim3(grid_cap(m, 4, 256 * 8)), dim3(256), 0, st, weights, m, k, d.mask,
+                     d.lists + (int64_t)kMaxGroups * k, d.count + kMaxGroups, nc, out_bm, b0);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+// union list = "group" of all 32 bits: reuse the list kernels with one pseudo group by OR-ing sub-masks
+__global__ void __launch_bounds__(256) k_union_flags(const uint32_t* __restrict__ mask, int64_t k, uint32_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) flag[i] = mask[i] ? 1u : 0u;
+}
+
+template <typename W, int VEC>
+int densemm_nt_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t m, int64_t k, int64_t nb, void* ws,
+                   hipStream_t st) {
+  DenseWs d = carve(ws, k);
+  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
+  const int64_t nt = n_tiles_of(k);
+  uint32_t* flag = d.lists;                                     // scratch: first list slot holds 0/1 flags
+  uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;          // union list in the last slot
+  uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
+  const int prof = be_prof_begin(st);
+  for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
+    const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    if (sd == BE_SPIKE_FLOAT)
+      hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const float*>(chunk), k, nc, d.mask);
+    else
+      hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const uint8_t*>(chunk), k, nc, d.mask);
+    BE_LAUNCH_CHECK();
+    // ordered union list of active columns (submask_of(flag, 0) = flag & 0xF = 0/1)
+    hipLaunchKernelGGL(k_union_flags, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st, d.mask, k, flag);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gl_count, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile, ulist, k);
+    BE_LAUNCH_CHECK();
+    int rc;
+    if (nc == 1) rc = densemm_nt_launch<W, VEC, 1>(weights, m, k, d, nc, out_bm, (int)b0, st);
+    else if (nc <= 8) rc = densemm_nt_launch<W, VEC, 8>(weights, m, k, d, nc, out_bm, (int)b0, st);
+    else rc = densemm_nt_launch<W, VEC, 32>(weights, m, k, d, nc, out_bm, (int)b0, st);
+    if (rc != BE_OK) return rc;
+  }
+  be_prof_end(prof, st);
+  return BE_OK;
+}
+
+template <typename W>
+int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm, int64_t rows_w, int64_t cols_w,
+                int64_t nb, int transpose, void* ws, hipStream_t st) {
+  const W* w = static_cast<const W*>(weights);
+  W* o = static_cast<W*>(out_bm);
+  constexpr int V = Vec16<W>::n;
+  const bool vec_ok = (cols_w % V == 0) && ((reinterpret_cast<uintptr_t>(weights) & 15) == 0);
+  if (transpose) {
+    if (vec_ok) return densemm_t_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+    return densemm_t_vec<W, 1>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+  }
+  if (vec_ok) return densemm_nt_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+  return densemm_nt_vec<W, 1>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t be_binary_densemm_workspace_bytes(int64_t rows_w, int64_t cols_w, int64_t n_batch, int transpose, int wdtype) {
+  return dense_ws_bytes(rows_w, cols_w, n_batch, transpose, wdtype);
+}
+
+int be_binary_densemm(const void* weights, int wdtype, const void* spikes_bm, int spike_dtype, void* out_bm,
+                      int64_t rows_w, int64_t cols_w, int64_t n_batch, int transpose, void* workspace,
+                      int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(rows_w >= 0 && cols_w >= 0 && n_batch >= 0, BE_ERR_INVALID, "bad shape");
+  const int64_t k = transpose ? rows_w : cols_w;
+  BE_REQUIRE(k < (1ll << 28), BE_ERR_RANGE, "contraction dimension must be < 2^28");
+  const int64_t out_len = transpose ? cols_w : rows_w;
+  if (out_len == 0 || n_batch == 0) return BE_OK;
+  BE_REQUIRE(out_bm != nullptr, BE_ERR_INVALID, "out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t esz = (wdtype == BE_F64) ? 8 : (wdtype == BE_F32 ? 4 : 2);
+  if (k == 0) {
+    BE_HIP(hipMemsetAsync(out_bm, 0, (size_t)out_len * n_batch * esz, st));
+    return BE_OK;
+  }
+  BE_REQUIRE(weights && spikes_bm, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(spike_dtype == BE_SPIKE_BOOL || spike_dtype == BE_SPIKE_FLOAT, BE_ERR_INVALID, "unknown spike dtype");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= dense_ws_bytes(rows_w, cols_w, n_batch, transpose, wdtype),
+             BE_ERR_WORKSPACE, "workspace too small");
+  switch (wdtype) {
+    case BE_F32: return densemm_any<float>(weights, spikes_bm, spike_dtype, out_bm, rows_w, cols_w, n_batch, transpose, workspace, st);
+    case BE_F64: return densemm_any<double>(weights, spikes_bm, spike_dtype, out_bm, rows_w, cols_w, n_batch, transpose, workspace, st);
+    case BE_F16: return densemm_any<__half>(weights, spikes_bm, spike_dtype, out_bm, rows_w, cols_w, n_batch, transpose, workspace, st);
+    case BE_BF16: return densemm_any<__hip_bfloat16>(weights, spikes_bm, spike_dtype, out_bm, rows_w, cols_w, n_batch, transpose, workspace, st);
+    default: be_set_error("be_binary_densemm: unknown weight dtype"); return BE_ERR_INVALID;
+  }
+}
+
+#define BE_DEF_DENSE_VARIANT(W, WD, S, SD)                                                                              \
+  int be_binary_densemv_transpose_##W##_##S(BE_DENSE_MV_ARGS) {                                                          \
+    return be_binary_densemm(weights, WD, spikes, SD, out, rows_w, cols_w, 1, 1, workspace, workspace_bytes, stream);    \
+  }                                                                                                                      \
+  int be_binary_densemv_no_transpose_##W##_##S(BE_DENSE_MV_ARGS) {                                                       \
+    return be_binary_densemm(weights, WD, spikes, SD, out, rows_w, cols_w, 1, 0, workspace, workspace_bytes, stream);    \
+  }                                                                                                                      \
+  int be_binary_densemm_transpose_##W##_##S(BE_DENSE_MM_ARGS) {                                                          \
+    return be_binary_densemm(weights, WD, spikes_bm, SD, out_bm, rows_w, cols_w, n_batch, 1, workspace, workspace_bytes, \
+                             stream);                                                                                    \
+  }                                                                                                                      \
+  int be_binary_densemm_no_transpose_##W##_##S(BE_DENSE_MM_ARGS) {                                                       \
+    return be_binary_densemm(weights, WD, spikes_bm, SD, out_bm, rows_w, cols_w, n_batch, 0, workspace, workspace_bytes, \
+                             stream);                                                                                    \
+  }
+
+BE_FOR_ALL_VARIANTS(BE_DEF_DENSE_VARIANT)
+
+}  // extern "C"

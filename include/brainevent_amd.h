@@ -163,7 +163,27 @@ int be_binary_csrmm_nt(const void* weights, int homo, int wdtype, const int32_t*
                        int64_t m, int64_t k, int64_t n_batch, void* workspace, int64_t workspace_bytes,
                        be_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * binary_densemv / binary_densemm  (BinaryArray @ ndarray)
+ * replaces: binary_densemv_{transpose,no_transpose}_{f32..bf16}_{bool,float} (brainevent/_dense/binary_densemv.cu:52-149),
+ *           binary_densemm_{transpose,no_transpose}_{…} (brainevent/_dense/binary_densemm.cu:50-162) and the cuBLAS
+ *           variants binary_dense{mv,mm}_cublas_{nt,t}_f32_bool (brainevent/_dense/binary_dense_cublas.cu:139-212).
+ *   weights : [rows_w, cols_w] row-major, dtype wdtype
+ *   transpose = 1: spikes_bm [n_batch, rows_w] -> out_bm [n_batch, cols_w],  out[b, j] = sum_{i: e(s[b,i])} W[i, j]
+ *   transpose = 0: spikes_bm [n_batch, cols_w] -> out_bm [n_batch, rows_w],  out[b, i] = sum_{j: e(s[b,j])} W[i, j]
+ *   workspace >= be_binary_densemm_workspace_bytes(rows_w, cols_w, n_batch, transpose, wdtype)
+ * Sums are accumulated in f32 (f64 for f64 weights) in a fixed order: results are reproducible.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t be_binary_densemm_workspace_bytes(int64_t rows_w, int64_t cols_w, int64_t n_batch, int transpose, int wdtype);
+int be_binary_densemm(const void* weights, int wdtype, const void* spikes_bm, int spike_dtype, void* out_bm,
+                      int64_t rows_w, int64_t cols_w, int64_t n_batch, int transpose, void* workspace,
+                      int64_t workspace_bytes, be_stream_t stream);
+
 /* per-variant symbols (same grammar as the reference's `// @BE` names); thin wrappers of the above */
+#define BE_DENSE_MV_ARGS const void *weights, const void *spikes, void *out, int64_t rows_w, int64_t cols_w,      \
+                         void *workspace, int64_t workspace_bytes, be_stream_t stream
+#define BE_DENSE_MM_ARGS const void *weights, const void *spikes_bm, void *out_bm, int64_t rows_w, int64_t cols_w, \
+                         int64_t n_batch, void *workspace, int64_t workspace_bytes, be_stream_t stream
 #define BE_CSR_MV_ARGS const void *weights, const int32_t *indices, const void *indptr, int indptr_is_i64,       \
                        const void *spikes, void *out, int64_t m, int64_t k, void *workspace,                      \
                        int64_t workspace_bytes, be_stream_t stream
@@ -196,7 +216,11 @@ int be_binary_csrmm_nt(const void* weights, int homo, int wdtype, const int32_t*
   int be_binary_fcnmm_scatter_homo_##W##_##S(BE_FCN_MM_ARGS);     \
   int be_binary_fcnmm_scatter_hetero_##W##_##S(BE_FCN_MM_ARGS);   \
   int be_binary_fcnmm_gather_homo_##W##_##S(BE_FCN_MM_ARGS);      \
-  int be_binary_fcnmm_gather_hetero_##W##_##S(BE_FCN_MM_ARGS);
+  int be_binary_fcnmm_gather_hetero_##W##_##S(BE_FCN_MM_ARGS);    \
+  int be_binary_densemv_transpose_##W##_##S(BE_DENSE_MV_ARGS);    \
+  int be_binary_densemv_no_transpose_##W##_##S(BE_DENSE_MV_ARGS); \
+  int be_binary_densemm_transpose_##W##_##S(BE_DENSE_MM_ARGS);    \
+  int be_binary_densemm_no_transpose_##W##_##S(BE_DENSE_MM_ARGS);
 
 #define BE_FOR_ALL_VARIANTS(X) \
   X(f32, BE_F32, bool, BE_SPIKE_BOOL)   X(f32, BE_F32, float, BE_SPIKE_FLOAT)   \

@@ -83,3 +83,22 @@ def binary_fcnmm(weights, indices, matrix, shape, transpose):
     if not cols:
         return np.zeros((rows, 0), dtype=np.asarray(weights).dtype)
     return np.stack(cols, axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# dense  (brainevent/_dense/binary.py:168-211 mv, :579-632 mm)
+# ----------------------------------------------------------------------------------------------------
+def binary_densemv(weights, spikes, transpose):
+    """transpose: posts += weights[i] for active i (:178-190); else posts += weights[:, i] (:193-206)."""
+    weights = np.asarray(weights)
+    act = active(spikes)
+    return weights[act].sum(axis=0, dtype=weights.dtype) if transpose else weights[:, act].sum(axis=1, dtype=weights.dtype)
+
+
+def binary_densemm(weights, spikes, transpose):
+    """out[:, i_n] = sum of weights rows (transpose, :589-606) / columns (:609-632) active in spikes[:, i_n]."""
+    spikes = np.asarray(spikes)
+    cols = [binary_densemv(weights, spikes[:, l], transpose) for l in range(spikes.shape[1])]
+    weights = np.asarray(weights)
+    rows = weights.shape[1] if transpose else weights.shape[0]
+    return np.stack(cols, axis=1) if cols else np.zeros((rows, 0), weights.dtype)

@@ -1,0 +1,84 @@
+"""GPU parity for BinaryArray @ dense (binary_densemv / binary_densemm) against the numpy oracle and the
+reference's known-answer tests (brainevent/_event/binary_test.py:45-129)."""
+import numpy as np
+import pytest
+import torch
+
+from test_csr_gpu import spikes_of
+
+pytestmark = pytest.mark.gpu
+TOL = {np.float32: 1e-5, np.float64: 1e-12, np.float16: 2e-3}
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'u8', 'float'])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64, np.float16])
+@pytest.mark.parametrize('shape', [(37, 53), (64, 128), (300, 1000)])
+def test_densemv(be, oracle, transpose, kind, dtype, shape):
+    rng = np.random.default_rng(shape[0])
+    W = rng.normal(0, 1, shape).astype(dtype)
+    k = shape[0] if transpose else shape[1]
+    s = spikes_of(rng, k, 0.3, kind)
+    got = be.binary_densemv(W, s, transpose=transpose)
+    ref = oracle.binary_densemv(W.astype(np.float64), s, transpose)
+    assert got.dtype == dtype
+    np.testing.assert_allclose(got.astype(np.float64), ref, rtol=TOL[dtype], atol=TOL[dtype] * 10)
+
+
+@pytest.mark.parametrize('p', [0.01, 0.5])
+def test_densemv_nt_gather_and_stream_paths(be, oracle, p):
+    rng = np.random.default_rng(1)
+    W = rng.normal(0, 1, (200, 4096)).astype(np.float32)
+    s = spikes_of(rng, 4096, p, 'bool')
+    np.testing.assert_allclose(be.binary_densemv(W, s, transpose=False), oracle.binary_densemv(W.astype(np.float64), s, False),
+                               rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('transpose', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'float'])
+@pytest.mark.parametrize('dtype', [np.float32, np.float16])
+@pytest.mark.parametrize('nb', [1, 3, 8, 33])
+def test_densemm(be, oracle, transpose, kind, dtype, nb):
+    rng = np.random.default_rng(nb)
+    shape = (96, 264)
+    W = rng.normal(0, 1, shape).astype(dtype)
+    k = shape[0] if transpose else shape[1]
+    S = np.stack([spikes_of(rng, k, 0.25, kind) for _ in range(nb)], axis=1)
+    got = be.binary_densemm(W, S, transpose=transpose)
+    ref = oracle.binary_densemm(W.astype(np.float64), S, transpose)
+    assert got.shape == ref.shape and got.dtype == dtype
+    np.testing.assert_allclose(got.astype(np.float64), ref, rtol=TOL[dtype], atol=TOL[dtype] * 10)
+
+
+def test_densemm_bf16_torch(be, oracle):
+    rng = np.random.default_rng(0)
+    W = torch.tensor(rng.normal(0, 1, (128, 512)), dtype=torch.bfloat16, device='cuda')
+    S = torch.tensor(rng.random((128, 16)) < 0.2, device='cuda')
+    got = be.binary_densemm(W, S, transpose=True)
+    ref = oracle.binary_densemm(W.float().cpu().numpy().astype(np.float64), S.cpu().numpy(), True)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (512, 16)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=1e-2, atol=5e-2)
+
+
+def test_binaryarray_dense_kats(be):
+    # brainevent/_event/binary_test.py:45-99 and the docstrings at brainevent/_event/binary.py:183-185, :258-261
+    W = np.array([[1., 2.], [3., 4.], [5., 6.]], np.float32)
+    np.testing.assert_array_equal(be.BinaryArray(np.array([0, 1, 1], np.uint8)) @ W, [8., 10.])
+    np.testing.assert_array_equal(be.BinaryArray(np.array([True, False, True])) @ W, [6., 8.])
+    np.testing.assert_array_equal(be.BinaryArray(np.array([[0, 1, 1], [1, 0, 1]], np.uint8)) @ W, [[8., 10.], [6., 8.]])
+    W2 = np.array([[1., 2., 3.], [4., 5., 6.]], np.float32)
+    np.testing.assert_array_equal(W2 @ be.BinaryArray(np.array([0, 1, 1], np.uint8)), [5., 11.])
+    np.testing.assert_array_equal(W2 @ be.BinaryArray(np.array([True, False, True])), [4., 10.])
+    np.testing.assert_array_equal(W2 @ be.BinaryArray(np.array([[0, 1], [1, 0], [1, 1]], np.uint8)), [[5., 4.], [11., 10.]])
+
+
+def test_binaryarray_dense_errors(be):
+    W = np.ones((3, 2), np.float32)
+    with pytest.raises(AssertionError):
+        be.BinaryArray(np.array([1, 0], np.uint8)) @ W             # dim mismatch
+    with pytest.raises(AssertionError):
+        be.BinaryArray(np.array([1, 0, 1], np.uint8)) @ np.ones(3, np.float32)   # 1-D right operand
+    with pytest.raises(be.MathError):
+        be.BinaryArray(np.asarray(1, np.uint8)) @ W                # 0-D
+    with pytest.raises(be.MathError):
+        be.BinaryArray(np.ones((2, 2, 3), np.uint8)) @ W           # 3-D
