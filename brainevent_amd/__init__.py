@@ -16,3 +16,8 @@ from ._fcn import (FixedNumConn, FixedNumPerPre, FixedNumPerPost, binary_fcnmv, 
                    binary_fcnmm_p, binary_fcnmv_p_call, binary_fcnmm_p_call)
 from ._dense import (binary_densemv, binary_densemm, binary_densemv_p, binary_densemm_p, binary_densemv_p_call,
                      binary_densemm_p_call)
+from ._jitc import (JITCScalarR, JITCScalarC, JITCUniformR, JITCUniformC, JITCNormalR, JITCNormalC,
+                    binary_jitsmv, binary_jitsmm, binary_jitumv, binary_jitumm, binary_jitnmv, binary_jitnmm,
+                    binary_jitsmv_p, binary_jitsmm_p, binary_jitumv_p, binary_jitumm_p, binary_jitnmv_p, binary_jitnmm_p,
+                    binary_jitsmv_p_call, binary_jitsmm_p_call, binary_jitumv_p_call, binary_jitumm_p_call,
+                    binary_jitnmv_p_call, binary_jitnmm_p_call)

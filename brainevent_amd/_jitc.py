@@ -1,0 +1,451 @@
+"""Just-in-time connectivity matrices: ``JITC{Scalar,Uniform,Normal}{R,C}`` and ``binary_jit{s,u,n}{mv,mm}``.
+
+Reference surface mirrored (read as text):
+  * scalar : ``brainevent/_jit_scalar/main.py:89-252`` (constructor), ``:885-1065`` (``R`` dispatch), ``:1069+`` (``C``),
+             ``brainevent/_jit_scalar/binary.py:44-167`` (``binary_jitsmv``), ``:171-286`` (``binary_jitsmm``),
+             ``:688-795`` / ``:1247+`` (``*_p_call`` validation), ``:289-421`` / ``:833-957`` (CPU semantics);
+  * uniform: ``brainevent/_jit_uniform/main.py:78-190``, ``brainevent/_jit_uniform/binary.py:44-289``, ``:292-415``;
+  * normal : ``brainevent/_jit_normal/main.py:78-190``, ``brainevent/_jit_normal/binary.py:44-300``, ``:307-410``;
+  * ``seed`` / ``clen``: ``brainevent/_data.py:1181-1245`` (``clen = ceil(2 / prob)`` as int32).
+
+``corder`` alone selects the kernel (``True`` = gather over output rows, ``False`` = scatter over the active
+input rows); ``transpose`` only fixes which side of ``shape`` is the output.  ``prob == 0`` yields zeros
+(the reference's binary ops leave it undefined; its golden model and float twins return zeros).
+The matrix drawn by the ``mv`` ops (lane stride 32) differs from the one drawn by the ``mm`` ops (stride 4),
+exactly as in the reference (``brainevent/_misc.py:32-38``).
+"""
+import ctypes
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _array as A
+from ._event import BinaryArray
+from ._lib import check, fn
+from ._op import OpKernel
+
+__all__ = [
+    'JITCScalarR', 'JITCScalarC', 'JITCUniformR', 'JITCUniformC', 'JITCNormalR', 'JITCNormalC',
+    'binary_jitsmv', 'binary_jitsmm', 'binary_jitumv', 'binary_jitumm', 'binary_jitnmv', 'binary_jitnmm',
+    'binary_jitsmv_p', 'binary_jitsmm_p', 'binary_jitumv_p', 'binary_jitumm_p', 'binary_jitnmv_p', 'binary_jitnmm_p',
+    'binary_jitsmv_p_call', 'binary_jitsmm_p_call', 'binary_jitumv_p_call', 'binary_jitumm_p_call',
+    'binary_jitnmv_p_call', 'binary_jitnmm_p_call',
+]
+
+c_i64, c_int, c_vp, c_dbl, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_uint32
+_MV_ARGS = [c_dbl, c_dbl, c_i64, c_u32, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_vp]
+_MM_ARGS = [c_dbl, c_dbl, c_i64, c_u32, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]
+_FAMILY = {'s': 0, 'u': 1, 'n': 2}
+
+
+def _initialize_seed(seed=None) -> int:
+    """``int32 (1,)`` seed of the reference (``_data.py:1181-1209``), kept as a python int (low 32 bits key the RNG)."""
+    if seed is None:
+        seed = int(np.random.randint(0, int(1e8)))
+    if isinstance(seed, torch.Tensor):
+        seed = seed.reshape(-1)[0].item()
+    return int(np.asarray(seed).reshape(-1)[0])
+
+
+def _initialize_conn_length(prob) -> int:
+    """``ceil(2 / prob)`` as int32 (``_data.py:1212-1245``); 0 stands for ``prob == 0``."""
+    prob = float(np.asarray(prob).reshape(-1)[0]) if not isinstance(prob, torch.Tensor) else float(prob.reshape(-1)[0].item())
+    if prob == 0.0:
+        return 0
+    return int(min(math.ceil(2.0 / prob), np.iinfo(np.int32).max))
+
+
+def _scalar(x) -> float:
+    if isinstance(x, torch.Tensor):
+        return float(x.reshape(-1)[0].item())
+    return float(np.asarray(x).reshape(-1)[0])
+
+
+def _weight_dtype(*ws) -> torch.dtype:
+    """Output dtype = dtype of the weight parameters (python floats act as f32, like ``jnp.asarray``)."""
+    dts = []
+    for w in ws:
+        if isinstance(w, torch.Tensor):
+            dts.append(w.dtype)
+        elif isinstance(w, (np.ndarray, np.generic)):
+            dts.append(torch.from_numpy(np.zeros(1, dtype=np.asarray(w).dtype)).dtype)
+    if not dts:
+        return torch.float32
+    dt = dts[0]
+    for d in dts[1:]:
+        dt = torch.promote_types(dt, d)
+    assert dt.is_floating_point, 'Weights must be a floating-point type.'
+    return dt
+
+
+def _fixed_scale_exp(wmax: float, n_rows: int) -> int:
+    e = math.frexp(wmax)[1] if wmax > 0 else 0
+    s = 62 - e - max(1, int(math.ceil(math.log2(n_rows + 1))))
+    return max(-90, min(150, s))
+
+
+def _jit_params(family: str, a, b):
+    """(w0, w1, |w| bound) of the C ABI for each family."""
+    if family == 's':
+        w = _scalar(a)
+        return w, 0.0, abs(w)
+    if family == 'u':
+        lo, hi = _scalar(a), _scalar(b)
+        return lo, hi - lo, max(abs(lo), abs(hi))
+    loc, scale = _scalar(a), _scalar(b)
+    return loc, scale, abs(loc) + 6.5 * abs(scale)     # |normal01| <= 6.37 after the 1e-10 clamp
+
+
+def _jitmv_hip(family, a, b, clen, vector, seed, *, shape, transpose, corder, out_dtype):
+    spikes, sd = A.spikes_to_device(vector)
+    in_len = int(shape[0] if transpose else shape[1])
+    out_len = int(shape[1] if transpose else shape[0])
+    out = torch.empty(out_len, dtype=out_dtype, device=A.device())
+    if out_len == 0:
+        return out
+    w0, w1, wmax = _jit_params(family, a, b)
+    gather = 1 if corder else 0
+    f_ws = fn('be_binary_jitmv_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
+    ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, gather))
+    name = f"be_binary_jit{family}mv_{'notrans' if corder else 'trans'}_{A.wsuffix(out)}"
+    f = fn(name, c_int, _MV_ARGS)
+    check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(spikes), sd, A.ptr(out), int(shape[1]), in_len, out_len,
+            _fixed_scale_exp(wmax, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    return out
+
+
+def _jitmm_hip(family, a, b, clen, B, seed, *, shape, transpose, corder, out_dtype):
+    Bt, sd = A.spikes_to_device(B)
+    n = int(Bt.shape[1])
+    in_len = int(shape[0] if transpose else shape[1])
+    out_len = int(shape[1] if transpose else shape[0])
+    out_bm = torch.empty((n, out_len), dtype=out_dtype, device=A.device())
+    if out_len == 0 or n == 0:
+        return out_bm.T
+    w0, w1, _ = _jit_params(family, a, b)
+    f_ws = fn('be_binary_jitmm_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
+    ws = A.workspace(f_ws(in_len, out_len, n))
+    name = f"be_binary_jit{family}mm_{'notrans' if corder else 'trans'}_{A.wsuffix(out_bm)}"
+    f = fn(name, c_int, _MM_ARGS)
+    check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(Bt.T.contiguous()), sd, A.ptr(out_bm), int(shape[1]), in_len,
+            out_len, n, A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    return out_bm.T
+
+
+def _make_ops(family: str, label: str):
+    mv_p = OpKernel(f'binary_jit{family}mv')
+    mm_p = OpKernel(f'binary_jit{family}mm')
+
+    def mv_hip(a, b, clen, vector, seed, *, shape, transpose, corder, out_dtype):
+        return _jitmv_hip(family, a, b, clen, vector, seed, shape=shape, transpose=transpose, corder=corder,
+                          out_dtype=out_dtype)
+
+    def mm_hip(a, b, clen, B, seed, *, shape, transpose, corder, out_dtype):
+        return _jitmm_hip(family, a, b, clen, B, seed, shape=shape, transpose=transpose, corder=corder,
+                          out_dtype=out_dtype)
+
+    mv_p.def_kernel('hip', 'gpu', mv_hip, asdefault=True)
+    mm_p.def_kernel('hip', 'gpu', mm_hip, asdefault=True)
+    mv_p.def_tags(f'jit_{label}', 'binary')
+    mm_p.def_tags(f'jit_{label}', 'binary')
+    return mv_p, mm_p
+
+
+binary_jitsmv_p, binary_jitsmm_p = _make_ops('s', 'scalar')
+binary_jitumv_p, binary_jitumm_p = _make_ops('u', 'uniform')
+binary_jitnmv_p, binary_jitnmm_p = _make_ops('n', 'normal')
+
+
+def _check_mv(vector, shape, transpose):
+    assert len(shape) == 2, "The matrix shape should be a tuple of two integers."
+    assert vector.ndim == 1, f"The vector should be a 1D array, but got {vector.ndim}D."
+    if transpose:
+        assert shape[0] == len(vector), f"The matrix shape and vector length do not match. {tuple(vector.shape)} @ {shape}"
+    else:
+        assert shape[1] == len(vector), f"The matrix shape and vector length do not match. {shape} @ {tuple(vector.shape)}"
+
+
+def _check_mm(B, shape, transpose):
+    assert len(shape) == 2, "The matrix shape should be a tuple of two integers."
+    assert B.ndim == 2, "The input matrix B should be a 2D array."
+    if transpose:
+        assert shape[0] == B.shape[0], f"The matrix shape and B shape do not match. {tuple(B.shape)} @ {shape}"
+    else:
+        assert shape[1] == B.shape[0], f"The matrix shape and B shape do not match. {shape} @ {tuple(B.shape)}"
+
+
+def _arr(x):
+    return x if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+# ---- scalar ------------------------------------------------------------------------------------------
+def binary_jitsmv_p_call(weight, clen, vector, seed, *, shape, transpose, corder, backend=None):
+    _check_mv(vector, shape, transpose)
+    return [binary_jitsmv_p(weight, None, clen, vector, seed, shape=tuple(shape), transpose=transpose, corder=corder,
+                            out_dtype=_weight_dtype(weight), backend=backend)]
+
+
+def binary_jitsmm_p_call(weight, clen, B, seed, *, shape, transpose, corder, backend=None):
+    _check_mm(B, shape, transpose)
+    return [binary_jitsmm_p(weight, None, clen, B, seed, shape=tuple(shape), transpose=transpose, corder=corder,
+                            out_dtype=_weight_dtype(weight), backend=backend)]
+
+
+def binary_jitsmv(weight, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False,
+                  corder: bool = True, backend: Optional[str] = None):
+    """``y = M @ v`` / ``y = M.T @ v`` with ``M`` drawn on the fly (connection probability ``prob``, constant
+    ``weight``); same signature as ``brainevent/_jit_scalar/binary.py:44-54``."""
+    as_np = A.wants_numpy(weight, vector)
+    r = binary_jitsmv_p_call(weight, _initialize_conn_length(prob), _arr(vector), _initialize_seed(seed), shape=shape,
+                             transpose=transpose, corder=corder, backend=backend)[0]
+    return A.to_result(r, as_np)
+
+
+def binary_jitsmm(weight, prob, B, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+                  backend: Optional[str] = None):
+    """``Y = M @ B`` / ``Y = M.T @ B`` (``brainevent/_jit_scalar/binary.py:171-286``); the mm walk draws its own matrix."""
+    as_np = A.wants_numpy(weight, B)
+    r = binary_jitsmm_p_call(weight, _initialize_conn_length(prob), _arr(B), _initialize_seed(seed), shape=shape,
+                             transpose=transpose, corder=corder, backend=backend)[0]
+    return A.to_result(r, as_np)
+
+
+# ---- uniform -----------------------------------------------------------------------------------------
+def binary_jitumv_p_call(w_low, w_high, clen, vector, seed, *, shape, transpose, corder, backend=None):
+    _check_mv(vector, shape, transpose)
+    return [binary_jitumv_p(w_low, w_high, clen, vector, seed, shape=tuple(shape), transpose=transpose, corder=corder,
+                            out_dtype=_weight_dtype(w_low, w_high), backend=backend)]
+
+
+def binary_jitumm_p_call(w_low, w_high, clen, B, seed, *, shape, transpose, corder, backend=None):
+    _check_mm(B, shape, transpose)
+    return [binary_jitumm_p(w_low, w_high, clen, B, seed, shape=tuple(shape), transpose=transpose, corder=corder,
+                            out_dtype=_weight_dtype(w_low, w_high), backend=backend)]
+
+
+def binary_jitumv(w_low, w_high, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False,
+                  corder: bool = True, backend: Optional[str] = None):
+    """JIT connectivity with per-edge weights ``U(w_low, w_high)`` (``brainevent/_jit_uniform/binary.py:44-164``)."""
+    as_np = A.wants_numpy(w_low, w_high, vector)
+    r = binary_jitumv_p_call(w_low, w_high, _initialize_conn_length(prob), _arr(vector), _initialize_seed(seed),
+                             shape=shape, transpose=transpose, corder=corder, backend=backend)[0]
+    return A.to_result(r, as_np)
+
+
+def binary_jitumm(w_low, w_high, prob, B, seed: Optional[int] = None, *, shape, transpose: bool = False,
+                  corder: bool = True, backend: Optional[str] = None):
+    as_np = A.wants_numpy(w_low, w_high, B)
+    r = binary_jitumm_p_call(w_low, w_high, _initialize_conn_length(prob), _arr(B), _initialize_seed(seed), shape=shape,
+                             transpose=transpose, corder=corder, backend=backend)[0]
+    return A.to_result(r, as_np)
+
+
+# ---- normal ------------------------------------------------------------------------------------------
+def binary_jitnmv_p_call(w_loc, w_scale, clen, vector, seed, *, shape, transpose, corder, backend=None):
+    _check_mv(vector, shape, transpose)
+    return [binary_jitnmv_p(w_loc, w_scale, clen, vector, seed, shape=tuple(shape), transpose=transpose, corder=corder,
+                            out_dtype=_weight_dtype(w_loc, w_scale), backend=backend)]
+
+
+def binary_jitnmm_p_call(w_loc, w_scale, clen, B, seed, *, shape, transpose, corder, backend=None):
+    _check_mm(B, shape, transpose)
+    return [binary_jitnmm_p(w_loc, w_scale, clen, B, seed, shape=tuple(shape), transpose=transpose, corder=corder,
+                            out_dtype=_weight_dtype(w_loc, w_scale), backend=backend)]
+
+
+def binary_jitnmv(w_loc, w_scale, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False,
+                  corder: bool = True, backend: Optional[str] = None):
+    """JIT connectivity with per-edge weights ``N(w_loc, w_scale)`` (``brainevent/_jit_normal/binary.py:44-174``)."""
+    as_np = A.wants_numpy(w_loc, w_scale, vector)
+    r = binary_jitnmv_p_call(w_loc, w_scale, _initialize_conn_length(prob), _arr(vector), _initialize_seed(seed),
+                             shape=shape, transpose=transpose, corder=corder, backend=backend)[0]
+    return A.to_result(r, as_np)
+
+
+def binary_jitnmm(w_loc, w_scale, prob, B, seed: Optional[int] = None, *, shape, transpose: bool = False,
+                  corder: bool = True, backend: Optional[str] = None):
+    as_np = A.wants_numpy(w_loc, w_scale, B)
+    r = binary_jitnmm_p_call(w_loc, w_scale, _initialize_conn_length(prob), _arr(B), _initialize_seed(seed), shape=shape,
+                             transpose=transpose, corder=corder, backend=backend)[0]
+    return A.to_result(r, as_np)
+
+
+# =====================================================================================================
+# containers
+# =====================================================================================================
+def _validate_prob(prob) -> float:
+    p = np.asarray(prob.cpu() if isinstance(prob, torch.Tensor) else prob)
+    if p.size != 1:
+        raise ValueError(f"prob must be a scalar, but got shape {p.shape}.")
+    p = float(p.item())
+    if not np.isfinite(p):
+        raise ValueError(f"prob must be finite, but got {p}.")
+    if not (0. <= p <= 1.):
+        raise ValueError(f"prob must be in [0, 1], but got {p}.")
+    return p
+
+
+class JITCMatrix:
+    """Common base of the six JIT-connectivity containers."""
+    _family = 's'
+    _is_row = True          # R classes: logical orientation == generator orientation; C classes: transposed
+
+    def __init__(self, params, *, shape, corder: bool = False, backend: Optional[str] = None,
+                 buffers: Optional[Dict] = None):
+        *weights, prob, seed = params
+        self._weights = tuple(weights)
+        self.prob = prob
+        _validate_prob(prob)
+        self.seed = _initialize_seed(seed)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.corder = bool(corder)
+        self.backend = backend
+        self.buffers: Dict = dict(buffers) if buffers else {}
+
+    @property
+    def dtype(self):
+        return _weight_dtype(*self._weights)
+
+    ndim = property(lambda self: 2)
+
+    def __repr__(self):
+        return (f"{type(self).__name__}(shape={self.shape}, weights={self._weights}, prob={self.prob}, "
+                f"seed={self.seed}, corder={self.corder}, backend={self.backend})")
+
+    # -- family hooks ------------------------------------------------------------------------------
+    def _mv(self, v, *, shape, transpose, corder):
+        f = {'s': binary_jitsmv_p_call, 'u': binary_jitumv_p_call, 'n': binary_jitnmv_p_call}[self._family]
+        args = self._weights if self._family != 's' else (self._weights[0],)
+        return f(*args, _initialize_conn_length(self.prob), v, self.seed, shape=shape, transpose=transpose,
+                 corder=corder, backend=self.backend)[0]
+
+    def _mm(self, B, *, shape, transpose, corder):
+        f = {'s': binary_jitsmm_p_call, 'u': binary_jitumm_p_call, 'n': binary_jitnmm_p_call}[self._family]
+        args = self._weights if self._family != 's' else (self._weights[0],)
+        return f(*args, _initialize_conn_length(self.prob), B, self.seed, shape=shape, transpose=transpose,
+                 corder=corder, backend=self.backend)[0]
+
+    def _out(self, r, v):
+        as_np = A.wants_numpy(v, *self._weights)
+        return A.to_result(r, as_np)
+
+    # -- dispatch (reference _jit_scalar/main.py:885-1065 for R, :1069+ for C) ---------------------
+    def __matmul__(self, other):
+        if not isinstance(other, BinaryArray):
+            raise NotImplementedError("only BinaryArray operands are on the accelerated path (float jit ops are out of scope).")
+        v = other.value
+        if self._is_row:
+            shape, transpose, corder = self.shape, False, self.corder
+        else:
+            shape, transpose, corder = self.shape[::-1], True, self.corder
+        if v.ndim == 1:
+            return self._out(self._mv(v, shape=shape, transpose=transpose, corder=corder), v)
+        if v.ndim == 2:
+            return self._out(self._mm(v, shape=shape, transpose=transpose, corder=corder), v)
+        raise NotImplementedError(f"matmul with object of shape {v.shape}")
+
+    def __rmatmul__(self, other):
+        if not isinstance(other, BinaryArray):
+            raise NotImplementedError("only BinaryArray operands are on the accelerated path (float jit ops are out of scope).")
+        v = other.value
+        if self._is_row:
+            shape, transpose, corder = self.shape, True, not self.corder
+        else:
+            shape, transpose, corder = self.shape[::-1], False, not self.corder
+        if v.ndim == 1:
+            return self._out(self._mv(v, shape=shape, transpose=transpose, corder=corder), v)
+        if v.ndim == 2:
+            return self._out(self._mm(v.T, shape=shape, transpose=transpose, corder=corder).T, v)
+        raise NotImplementedError(f"matmul with object of shape {v.shape}")
+
+    def _params(self):
+        return (*self._weights, self.prob, self.seed)
+
+    def transpose(self, axes=None):
+        assert axes is None, "transpose does not support axes argument."
+        return self._transposed_cls(self._params(), shape=self.shape[::-1], corder=not self.corder,
+                                    backend=self.backend, buffers=self.buffers)
+
+    T = property(lambda self: self.transpose())
+
+
+def _unpack(first, rest, n):
+    if all(r is None for r in rest):
+        data = tuple(first)
+    else:
+        data = (first, *rest)
+    assert len(data) == n, f"Expected {n} parameters, got {len(data)}."
+    return data
+
+
+class _ScalarInit(JITCMatrix):
+    _family = 's'
+
+    def __init__(self, weight, prob=None, seed=None, *, shape, corder: bool = False, backend: Optional[str] = None,
+                 buffers: Optional[Dict] = None):
+        super().__init__(_unpack(weight, (prob, seed), 3), shape=shape, corder=corder, backend=backend, buffers=buffers)
+
+    weight = property(lambda self: self._weights[0])
+    data = property(lambda self: self._weights[0])
+
+    def with_data(self, data):
+        return type(self)((data, self.prob, self.seed), shape=self.shape, corder=self.corder, backend=self.backend)
+
+
+class _UniformInit(JITCMatrix):
+    _family = 'u'
+
+    def __init__(self, low, high=None, prob=None, seed=None, *, shape, corder: bool = False,
+                 backend: Optional[str] = None, buffers: Optional[Dict] = None):
+        data = _unpack(low, (high, prob, seed), 4)
+        if _scalar(data[0]) > _scalar(data[1]):
+            raise ValueError("wlow must be <= whigh element-wise.")
+        super().__init__(data, shape=shape, corder=corder, backend=backend, buffers=buffers)
+
+    wlow = property(lambda self: self._weights[0])
+    whigh = property(lambda self: self._weights[1])
+
+
+class _NormalInit(JITCMatrix):
+    _family = 'n'
+
+    def __init__(self, loc, scale=None, prob=None, seed=None, *, shape, corder: bool = False,
+                 backend: Optional[str] = None, buffers: Optional[Dict] = None):
+        super().__init__(_unpack(loc, (scale, prob, seed), 4), shape=shape, corder=corder, backend=backend,
+                         buffers=buffers)
+
+    wloc = property(lambda self: self._weights[0])
+    wscale = property(lambda self: self._weights[1])
+
+
+class JITCScalarR(_ScalarInit):
+    """Row-oriented homogeneous-weight JIT matrix (reference ``_jit_scalar/main.py:558``)."""
+    _is_row = True
+
+
+class JITCScalarC(_ScalarInit):
+    """Column-oriented twin (reference ``_jit_scalar/main.py:1069``)."""
+    _is_row = False
+
+
+class JITCUniformR(_UniformInit):
+    _is_row = True
+
+
+class JITCUniformC(_UniformInit):
+    _is_row = False
+
+
+class JITCNormalR(_NormalInit):
+    _is_row = True
+
+
+class JITCNormalC(_NormalInit):
+    _is_row = False
+
+
+JITCScalarR._transposed_cls, JITCScalarC._transposed_cls = JITCScalarC, JITCScalarR
+JITCUniformR._transposed_cls, JITCUniformC._transposed_cls = JITCUniformC, JITCUniformR
+JITCNormalR._transposed_cls, JITCNormalC._transposed_cls = JITCNormalC, JITCNormalR

@@ -1,0 +1,615 @@
+// be_jitc.hip — just-in-time connectivity products (BinaryArray @ JITC{Scalar,Uniform,Normal}{R,C}) for gfx950.
+//
+// The connectivity is never stored: it is regenerated from (seed, row, chunk, lane) with the reference's
+// "light_rng" sampler, reproduced here bit for bit (uint32 arithmetic):
+//   mix32 / xorshift32 / mulhi-bounded / stationary initial q     brainevent/_numba_random.py:385-421, :489-502
+//   per-edge weight hashes uniform01 (24-bit) / normal01 (Acklam)  brainevent/_numba_random.py:424-486
+//   walk: for (row, chunk_id, lane < stride): q0 = initial_q; local_j = lane + stride*q; q += 1 + bounded(next, cl-1)
+//         brainevent/_jit_scalar/binary.py:340-416 (mv, stride 32), :875-949 (mm, stride 4);
+//         chunk_size = ceil(shape[1] / 4) always (brainevent/_misc.py:74-122)
+//   `corder` alone picks the kernel: True -> gather over output rows ("notrans"), False -> scatter over
+//   active input rows ("trans")  (brainevent/_jit_scalar/binary.py:434-439).
+// The lane stride (32 / 4) is part of the drawn matrix, so a 64-wide wavefront never walks with stride 64:
+// it runs two 32-lane tasks (gather) or 64 independent single-lane walks (scatter).
+//
+// MI355X mapping:
+//   gather  : workgroup = (row block, chunk); the chunk's bit-packed spikes are staged in LDS (<= 150 KB),
+//             each half-wave owns one output row (lane = residue class), deterministic per-chunk partials.
+//   scatter : outputs are partitioned by (chunk, residue class lane): a walk (row, chunk, lane) only ever
+//             touches columns  chunk_start + lane + 32 q, so one workgroup owns the accumulators of one class
+//             in LDS (indexed by q) and each of its threads walks one active row at a time — no redundant RNG
+//             work, no global atomics (random global f32 atomics retire at ~21 G/s on this chip, LDS integer
+//             atomics at > 3 T/s).  Sums are integer counts (scalar weight) or 64-bit fixed point
+//             (uniform / normal), hence order independent and bitwise reproducible.
+#include "be_common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+enum { MODE_SCALAR = 0, MODE_UNIFORM = 1, MODE_NORMAL = 2 };
+
+// ------------------------------------------------------------------------------------------------ light_rng
+__device__ __forceinline__ uint32_t lr_next(uint32_t x) {
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+  return x == 0u ? 0x6d2b79f5u : x;
+}
+__device__ __forceinline__ uint32_t lr_bounded(uint32_t r, uint32_t bound) { return __umulhi(r, bound); }
+__device__ __forceinline__ uint32_t lr_init(uint32_t seed, uint32_t row, uint32_t chunk, uint32_t lane) {
+  uint32_t x = seed ^ 0xd1b54a35u;
+  x ^= row * 0x85ebca6bu;
+  x ^= chunk * 0xc2b2ae35u;
+  x ^= lane * 0x27d4eb2du;
+  x = be_mix32(x);
+  return x == 0u ? 0x6d2b79f5u : x;
+}
+__device__ __forceinline__ uint32_t lr_initial_q(uint32_t& state, uint32_t cl) {
+  const uint32_t n = cl - 1u;
+  for (;;) {
+    state = lr_next(state);
+    const uint32_t q = lr_bounded(state, n);
+    state = lr_next(state);
+    const uint32_t gate = lr_bounded(state, n);
+    if (gate < n - q) return q;
+  }
+}
+__device__ __forceinline__ float lr_uniform01(uint32_t seed, uint32_t row, uint32_t col) {
+  uint32_t h = seed ^ 0xa0761d65u;
+  h ^= row * 0xe7037ed1u;
+  h ^= col * 0x8ebc6af1u;
+  h = be_mix32(h);
+  return (float)(h & 0x00ffffffu) * (1.0f / 16777216.0f);
+}
+// No FMA contraction in the weight formulas: the reference evaluates them one rounded f32 operation at a
+// time (numpy golden model, brainevent/_numba_random.py:433-486); the Acklam rational cancels heavily, so a
+// fused multiply-add changes a weight by ~1e-5 relative.
+__device__ __forceinline__ float lr_normal01(uint32_t seed, uint32_t row, uint32_t col) {
+#pragma clang fp contract(off)
+  float u = lr_uniform01(seed, row, col);
+  const float lo = 1e-10f, hi = (float)(1.0 - 1e-10);
+  u = u < lo ? lo : (u > hi ? hi : u);
+  const float a1 = -39.696830f, a2 = 220.94609f, a3 = -275.92851f, a4 = 138.35775f, a5 = -30.664799f, a6 = 2.5066283f;
+  const float b1 = -54.476099f, b2 = 161.58584f, b3 = -155.69898f, b4 = 66.801312f, b5 = -13.280681f;
+  const float c1 = -0.007784894f, c2 = -0.32239646f, c3 = -2.4007583f, c4 = -2.5497325f, c5 = 4.3746641f, c6 = 2.9381640f;
+  const float d1 = 0.007784696f, d2 = 0.32246713f, d3 = 2.4451342f, d4 = 3.7544087f;
+  float z;
+  if (u < 0.02425f) {
+    const float v = sqrtf(-2.0f * logf(u));
+    z = -((((((c1 * v + c2) * v + c3) * v + c4) * v + c5) * v + c6) / ((((d1 * v + d2) * v + d3) * v + d4) * v + 1.0f));
+  } else if (u > 0.97575f) {
+    const float v = sqrtf(-2.0f * logf(1.0f - u));
+    z = (((((c1 * v + c2) * v + c3) * v + c4) * v + c5) * v + c6) / ((((d1 * v + d2) * v + d3) * v + d4) * v + 1.0f);
+  } else {
+    const float v = u - 0.5f, r = v * v;
+    z = (((((a1 * r + a2) * r + a3) * r + a4) * r + a5) * r + a6) * v /
+        (((((b1 * r + b2) * r + b3) * r + b4) * r + b5) * r + 1.0f);
+  }
+  return z;
+}
+
+struct JitP {
+  uint32_t seed, cl;        // cl already clamped to >= 2
+  int64_t chunk_size;       // ceil(shape[1] / 4)
+  int64_t walk_len;         // length of the walk dimension (vector length for gather, output length for scatter)
+  int n_chunks;             // ceil(walk_len / chunk_size)
+  int stride;               // 32 (mv) or 4 (mm)
+  double w0, w1;            // scalar: weight, -- | uniform: low, span | normal: loc, scale
+};
+
+// edge weight in the arithmetic type A (float or double); (row, col) are the RNG-orientation coordinates
+template <int MODE, typename A>
+__device__ __forceinline__ A edge_weight(const JitP& p, uint32_t row, uint32_t col) {
+#pragma clang fp contract(off)
+  if (MODE == MODE_UNIFORM) return (A)p.w0 + (A)lr_uniform01(p.seed, row, col) * (A)p.w1;
+  if (MODE == MODE_NORMAL) return (A)p.w0 + (A)lr_normal01(p.seed, row, col) * (A)p.w1;
+  return (A)p.w0;
+}
+
+// ------------------------------------------------------------------------------------------------ gather (mv)
+// partial[chunk * m + row]: uint32 counts (scalar) or double sums (uniform / normal)
+template <int MODE> struct GatherAcc { using type = double; };
+template <> struct GatherAcc<MODE_SCALAR> { using type = uint32_t; };
+
+template <int MODE, bool BITS_IN_LDS>
+__global__ void __launch_bounds__(256) k_jit_mv_gather(JitP p, const uint32_t* __restrict__ bits, int64_t m,
+                                                       typename GatherAcc<MODE>::type* __restrict__ partial) {
+  using AccT = typename GatherAcc<MODE>::type;
+  extern __shared__ uint32_t bits_s[];
+  const int chunk = blockIdx.y;
+  const int64_t cs = (int64_t)chunk * p.chunk_size;
+  const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+  const int64_t width = ce - cs;
+  const int64_t w_first = cs >> 5;
+  const uint32_t* bsrc = bits;
+  int64_t w_off = 0;
+  if (BITS_IN_LDS) {
+    const int64_t n_w = ((ce + 31) >> 5) - w_first;
+    for (int64_t i = threadIdx.x; i < n_w; i += blockDim.x) bits_s[i] = bits[w_first + i];
+    __syncthreads();
+    bsrc = bits_s;
+    w_off = w_first;
+  }
+  const uint32_t l = threadIdx.x & 31u;
+  const int64_t half = threadIdx.x >> 5;
+  const int64_t rows_per_iter = (int64_t)gridDim.x * 8;
+  const int64_t m_round = (m + rows_per_iter - 1) / rows_per_iter * rows_per_iter;
+  for (int64_t row = (int64_t)blockIdx.x * 8 + half; row < m_round; row += rows_per_iter) {
+    AccT acc = AccT(0);
+    if (row < m) {
+      uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+      uint32_t q = lr_initial_q(state, p.cl);
+      uint64_t lj = (uint64_t)l + 32ull * q;
+      while ((int64_t)lj < width) {
+        const int64_t j = cs + (int64_t)lj;
+        const bool on = (bsrc[(j >> 5) - w_off] >> (j & 31)) & 1u;
+        if (on) {
+          if (MODE == MODE_SCALAR) acc += 1;
+          else acc += (AccT)edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)j);
+        }
+        state = lr_next(state);
+        q = q + 1u + lr_bounded(state, p.cl - 1u);
+        lj = (uint64_t)l + 32ull * q;
+      }
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_down(acc, off, 32);
+    if (l == 0 && row < m) partial[(int64_t)chunk * m + row] = acc;
+  }
+}
+
+template <int MODE, typename W>
+__global__ void __launch_bounds__(256) k_jit_gather_reduce(const typename GatherAcc<MODE>::type* __restrict__ partial,
+                                                           int n_chunks, int64_t m, double w0, W* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
+    if (MODE == MODE_SCALAR) {
+      uint64_t c = 0;
+      for (int ch = 0; ch < n_chunks; ++ch) c += (uint64_t)partial[(int64_t)ch * m + r];
+      WTraits<W>::store_d(out, r, (double)c * w0);     // count * weight, one rounding (numba: f64 count * w)
+    } else {
+      double s = 0.0;
+      for (int ch = 0; ch < n_chunks; ++ch) s += (double)partial[(int64_t)ch * m + r];
+      WTraits<W>::store_d(out, r, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ scatter (mv)
+template <int MODE> struct ScatterAcc { using type = unsigned long long; };
+template <> struct ScatterAcc<MODE_SCALAR> { using type = uint32_t; };
+
+__device__ __forceinline__ unsigned long long jit_fixed_from_f32(float w, float scale) {
+  // same construction as fixed_from_f32 in be_csr.hip: w * 2^scale_exp split into (hi, lo) words in f32
+  const float t = w * scale;
+  const float hf = floorf(t);
+  const int hi = (int)hf;
+  const unsigned lo = (unsigned)((t - hf) * 4294967296.0f);
+  return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+
+// grid.x = n_classes * pieces * parts.  class = chunk * 32 + lane residue.
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t* __restrict__ active,
+                                                         const uint32_t* __restrict__ n_active_p, int pieces, int parts,
+                                                         uint32_t piece_len, float fx_scale,
+                                                         typename ScatterAcc<MODE>::type* __restrict__ partial) {
+  using AccT = typename ScatterAcc<MODE>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  AccT* acc = reinterpret_cast<AccT*>(smem_raw);
+  const int part = blockIdx.x % parts;
+  const int piece = (blockIdx.x / parts) % pieces;
+  const int cls = blockIdx.x / (parts * pieces);
+  const uint32_t chunk = cls >> 5, l = cls & 31u;
+  const int64_t cs = (int64_t)chunk * p.chunk_size;
+  const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+  const int64_t width = ce - cs;
+  // positions q with l + 32 q < width
+  const int64_t Q = width > (int64_t)l ? (width - l + 31) / 32 : 0;
+  const int64_t q_begin = (int64_t)piece * piece_len;
+  const int64_t q_end = q_begin + piece_len < Q ? q_begin + piece_len : Q;
+  for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  const uint32_t n_active = n_active_p[0];
+  if (q_begin < q_end) {
+    for (uint64_t a = (uint64_t)part * blockDim.x + threadIdx.x; a < n_active; a += (uint64_t)parts * blockDim.x) {
+      const uint32_t row = active[a];
+      uint32_t state = lr_init(p.seed, row, chunk, l);
+      uint32_t q = lr_initial_q(state, p.cl);
+      while ((int64_t)q < q_end) {
+        if ((int64_t)q >= q_begin) {
+          if (MODE == MODE_SCALAR) {
+            atomicAdd(&acc[q - (uint32_t)q_begin], (AccT)1);
+          } else {
+            const uint32_t j = (uint32_t)(cs + l + 32ll * q);
+            atomicAdd(&acc[q - (uint32_t)q_begin], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j), fx_scale));
+          }
+        }
+        state = lr_next(state);
+        q = q + 1u + lr_bounded(state, p.cl - 1u);
+      }
+    }
+  }
+  __syncthreads();
+  AccT* dst = partial + (int64_t)blockIdx.x * piece_len;
+  for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) dst[i] = acc[i];
+}
+
+template <int MODE, typename W>
+__global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename ScatterAcc<MODE>::type* __restrict__ partial,
+                                                            JitP p, int pieces, int parts, uint32_t piece_len,
+                                                            double inv_scale, W* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.walk_len; j += stride) {
+    const int64_t chunk = j / p.chunk_size;
+    const int64_t local = j - chunk * p.chunk_size;
+    const int64_t l = local & 31, q = local >> 5;
+    const int64_t piece = q / piece_len, i = q - piece * piece_len;
+    const int64_t cls = chunk * 32 + l;
+    const typename ScatterAcc<MODE>::type* src = partial + ((cls * pieces + piece) * parts) * (int64_t)piece_len + i;
+    if (MODE == MODE_SCALAR) {
+      uint64_t c = 0;
+      for (int q2 = 0; q2 < parts; ++q2) c += src[(int64_t)q2 * piece_len];
+      WTraits<W>::store_d(out, j, (double)c * p.w0);
+    } else {
+      unsigned long long s = 0;
+      for (int q2 = 0; q2 < parts; ++q2) s += src[(int64_t)q2 * piece_len];
+      WTraits<W>::store_d(out, j, (double)(long long)s * inv_scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ mm (stride 4)
+// one thread per generator row; spike matrix as per-row column masks (<= 32 columns per pass).
+// gather : out_bm[c, row] = sum over edges j of row with bit c of mask[j] set
+// scatter: for rows with mask != 0: out_bm[c, j] += w for every edge j and every set bit c (global atomics)
+template <int MODE, typename A>
+__global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
+                                                       A* __restrict__ out_bm) {
+  const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < m; row += stride_t) {
+    A acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = A(0);
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+      const int64_t cs = (int64_t)chunk * p.chunk_size;
+      const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+      const int64_t width = ce - cs;
+      for (uint32_t l = 0; l < (uint32_t)p.stride; ++l) {
+        uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+        uint32_t q = lr_initial_q(state, p.cl);
+        uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
+        while ((int64_t)lj < width) {
+          const int64_t j = cs + (int64_t)lj;
+          const uint32_t mk = mask[j];
+          if (mk) {
+            const A w = (MODE == MODE_SCALAR) ? A(1) : edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)j);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc[c] += ((mk >> c) & 1u) ? w : A(0);
+          }
+          state = lr_next(state);
+          q = q + 1u + lr_bounded(state, p.cl - 1u);
+          lj = (uint64_t)l + (uint64_t)p.stride * q;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < nc) out_bm[(int64_t)c * m + row] = (MODE == MODE_SCALAR) ? (A)(acc[c] * (A)p.w0) : acc[c];
+  }
+}
+
+template <int MODE, typename A>
+__global__ void __launch_bounds__(256) k_jit_mm_scatter(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
+                                                        A* __restrict__ out_bm) {
+  const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
+  const int64_t k = p.walk_len;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < m; row += stride_t) {
+    const uint32_t mk = mask[row];
+    if (!mk) continue;
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+      const int64_t cs = (int64_t)chunk * p.chunk_size;
+      const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+      const int64_t width = ce - cs;
+      for (uint32_t l = 0; l < (uint32_t)p.stride; ++l) {
+        uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+        uint32_t q = lr_initial_q(state, p.cl);
+        uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
+        while ((int64_t)lj < width) {
+          const int64_t j = cs + (int64_t)lj;
+          const A w = edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)j);
+          uint32_t mm = mk;
+          while (mm) {
+            const int c = __ffs(mm) - 1;
+            mm &= mm - 1;
+            if (c < nc) atomicAdd(out_bm + (int64_t)c * k + j, w);
+          }
+          state = lr_next(state);
+          q = q + 1u + lr_bounded(state, p.cl - 1u);
+          lj = (uint64_t)l + (uint64_t)p.stride * q;
+        }
+      }
+    }
+  }
+}
+
+template <typename SP>
+__global__ void __launch_bounds__(256) k_jit_masks(const typename SP::type* __restrict__ spikes_bm, int64_t len, int nc,
+                                                   uint32_t* __restrict__ mask) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    uint32_t mk = 0;
+    for (int b = 0; b < nc; ++b) mk |= (SP::active(spikes_bm[(int64_t)b * len + i]) ? 1u : 0u) << b;
+    mask[i] = mk;
+  }
+}
+
+template <typename A, typename W>
+__global__ void __launch_bounds__(256) k_jit_convert(const A* __restrict__ src, W* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) WTraits<W>::store_d(dst, i, (double)src[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ host
+inline int gcap(int64_t n, int block, int cap) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t clen, int stride, double w0, double w1) {
+  JitP p;
+  p.seed = seed;
+  p.cl = (uint32_t)(clen < 2 ? 2 : clen);
+  p.chunk_size = std::max<int64_t>(1, (shape1 + 3) / 4);
+  p.walk_len = walk_len;
+  p.n_chunks = (int)((walk_len + p.chunk_size - 1) / p.chunk_size);
+  p.stride = stride;
+  p.w0 = w0;
+  p.w1 = w1;
+  return p;
+}
+
+constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators per scatter workgroup (128 KiB)
+
+struct ScatterGeom { int n_classes, pieces, parts; uint32_t piece_len; };
+inline ScatterGeom scatter_geom(const JitP& p, bool scalar) {
+  ScatterGeom g;
+  g.n_classes = p.n_chunks * 32;
+  const int64_t Qmax = (std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32;
+  const uint32_t cap = scalar ? kPieceU32 : kPieceU64;
+  g.pieces = (int)std::max<int64_t>(1, (Qmax + cap - 1) / cap);
+  const int64_t per_piece = (Qmax + g.pieces - 1) / g.pieces;
+  g.piece_len = (uint32_t)std::max<int64_t>(4, (per_piece + 3) & ~3ll);
+  int parts = 512 / std::max(1, g.n_classes * g.pieces);
+  g.parts = std::max(1, std::min(parts, 16));
+  return g;
+}
+
+}  // namespace
+
+// compaction kernel of be_csr.hip (spikes -> active ids + count), n_batch = 1
+extern "C" int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,
+                                 be_stream_t stream);
+extern "C" int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
+
+namespace {
+
+template <int MODE, typename W>
+int jit_mv_gather(const JitP& p, const void* spikes, int sd, void* out, int64_t m, void* ws, hipStream_t st) {
+  using AccT = typename GatherAcc<MODE>::type;
+  unsigned char* wsb = static_cast<unsigned char*>(ws);
+  uint32_t* bits = reinterpret_cast<uint32_t*>(wsb);
+  const int64_t n_words = (p.walk_len + 31) / 32;
+  AccT* partial = reinterpret_cast<AccT*>(wsb + be_align_up((n_words + 2) * 4, 256));
+  int rc = be_pack_spikes(spikes, sd, p.walk_len, bits, st);
+  if (rc != BE_OK) return rc;
+  const size_t lds = (size_t)(((std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32) + 2) * 4;
+  const dim3 grid(gcap(m, 8, 1024), p.n_chunks);
+  const int prof = be_prof_begin(st);
+  if (lds <= 150 * 1024) {
+    auto kern = k_jit_mv_gather<MODE, true>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, bits, m, partial);
+  } else {
+    hipLaunchKernelGGL((k_jit_mv_gather<MODE, false>), grid, dim3(256), 0, st, p, bits, m, partial);
+  }
+  be_prof_end(prof, st);
+  BE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_jit_gather_reduce<MODE, W>), dim3(gcap(m, 256, 2048)), dim3(256), 0, st, partial, p.n_chunks, m,
+                     p.w0, static_cast<W*>(out));
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+template <int MODE, typename W>
+int jit_mv_scatter(const JitP& p, const void* spikes, int sd, void* out, int64_t m, int scale_exp, void* ws,
+                   hipStream_t st) {
+  using AccT = typename ScatterAcc<MODE>::type;
+  unsigned char* wsb = static_cast<unsigned char*>(ws);
+  uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
+  AccT* partial = reinterpret_cast<AccT*>(wsb + 256 + be_align_up(m * 4, 256));
+  int rc = be_compact_spikes(spikes, sd, m, active, count, st);
+  if (rc != BE_OK) return rc;
+  const ScatterGeom g = scatter_geom(p, MODE == MODE_SCALAR);
+  const size_t lds = (size_t)g.piece_len * sizeof(AccT);
+  auto kern = k_jit_mv_scatter<MODE>;
+  BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const float fx_scale = ldexpf(1.0f, scale_exp - 32);
+  const int prof = be_prof_begin(st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.n_classes * g.pieces * g.parts)), dim3(1024), lds, st, p, active, count,
+                     g.pieces, g.parts, g.piece_len, fx_scale, partial);
+  be_prof_end(prof, st);
+  BE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_jit_scatter_reduce<MODE, W>), dim3(gcap(p.walk_len, 256, 2048)), dim3(256), 0, st, partial, p,
+                     g.pieces, g.parts, g.piece_len, ldexp(1.0, -scale_exp), static_cast<W*>(out));
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+inline int64_t jit_mv_ws_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int gather) {
+  if (gather) {
+    const int64_t n_words = (in_len + 31) / 32;
+    const int64_t chunk = std::max<int64_t>(1, (shape1 + 3) / 4);
+    const int64_t n_chunks = (in_len + chunk - 1) / chunk;
+    return be_align_up((n_words + 2) * 4, 256) + be_align_up(std::max<int64_t>(1, n_chunks) * out_len * 8, 256);
+  }
+  JitP p = make_params(shape1, out_len, 0, 2, 32, 0, 0);
+  const ScatterGeom g = scatter_geom(p, false);
+  const ScatterGeom gs = scatter_geom(p, true);
+  const int64_t a = (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len * 8;
+  const int64_t b = (int64_t)gs.n_classes * gs.pieces * gs.parts * gs.piece_len * 4;
+  return 256 + be_align_up(in_len * 4, 256) + be_align_up(std::max(a, b), 256);
+}
+
+template <int MODE>
+int jit_mv_dispatch(const JitP& p, int wdtype, const void* spikes, int sd, void* out, int64_t in_len, int64_t out_len,
+                    int gather, int scale_exp, void* ws, hipStream_t st) {
+#define BE_JIT_CASE(WT)                                                                       \
+  return gather ? jit_mv_gather<MODE, WT>(p, spikes, sd, out, out_len, ws, st)                \
+                : jit_mv_scatter<MODE, WT>(p, spikes, sd, out, in_len, scale_exp, ws, st)
+  switch (wdtype) {
+    case BE_F32: BE_JIT_CASE(float);
+    case BE_F64: BE_JIT_CASE(double);
+    case BE_F16: BE_JIT_CASE(__half);
+    case BE_BF16: BE_JIT_CASE(__hip_bfloat16);
+    default: be_set_error("unknown weight dtype"); return BE_ERR_INVALID;
+  }
+#undef BE_JIT_CASE
+}
+
+template <int MODE, typename A>
+int jit_mm_run(const JitP& p, const uint32_t* mask, int64_t rows, int nc, int gather, A* out_bm, hipStream_t st) {
+  if (gather)
+    hipLaunchKernelGGL((k_jit_mm_gather<MODE, A>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
+  else
+    hipLaunchKernelGGL((k_jit_mm_scatter<MODE, A>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int gather) {
+  return jit_mv_ws_bytes(shape1, in_len, out_len, gather);
+}
+
+int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                    int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
+                    void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
+  BE_REQUIRE(in_len >= 0 && out_len >= 0 && shape1 >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(in_len < (1ll << 32) && out_len < (1ll << 32), BE_ERR_RANGE, "dimensions must fit uint32 for the RNG keys");
+  if (out_len == 0) return BE_OK;
+  BE_REQUIRE(out != nullptr, BE_ERR_INVALID, "out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t esz = (wdtype == BE_F64) ? 8 : (wdtype == BE_F32 ? 4 : 2);
+  if (in_len == 0 || clen <= 0) {   // empty walk or prob == 0: all zeros (documented choice)
+    BE_HIP(hipMemsetAsync(out, 0, (size_t)out_len * esz, st));
+    return BE_OK;
+  }
+  BE_REQUIRE(spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= jit_mv_ws_bytes(shape1, in_len, out_len, gather),
+             BE_ERR_WORKSPACE, "workspace too small");
+  BE_REQUIRE(gather || mode == MODE_SCALAR || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID,
+             "scale_exp out of range");
+  const JitP p = make_params(shape1, gather ? in_len : out_len, seed, clen, 32, w0, w1);
+  switch (mode) {
+    case MODE_SCALAR: return jit_mv_dispatch<MODE_SCALAR>(p, wdtype, spikes, spike_dtype, out, in_len, out_len, gather, scale_exp, workspace, st);
+    case MODE_UNIFORM: return jit_mv_dispatch<MODE_UNIFORM>(p, wdtype, spikes, spike_dtype, out, in_len, out_len, gather, scale_exp, workspace, st);
+    default: return jit_mv_dispatch<MODE_NORMAL>(p, wdtype, spikes, spike_dtype, out, in_len, out_len, gather, scale_exp, workspace, st);
+  }
+}
+
+int64_t be_binary_jitmm_workspace_bytes(int64_t in_len, int64_t out_len, int64_t n_batch) {
+  return be_align_up(in_len * 4, 256) + be_align_up(std::max<int64_t>(1, n_batch) * out_len * 8, 256);
+}
+
+// spikes_bm [n_batch, in_len] -> out_bm [n_batch, out_len]; gather: generator rows = out_len, walk over in_len;
+// scatter: generator rows = in_len, walk over out_len.  Works in passes of 32 batch columns.
+int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes_bm,
+                    int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,
+                    int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
+  BE_REQUIRE(in_len >= 0 && out_len >= 0 && shape1 >= 0 && n_batch >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(in_len < (1ll << 32) && out_len < (1ll << 32), BE_ERR_RANGE, "dimensions must fit uint32 for the RNG keys");
+  if (out_len == 0 || n_batch == 0) return BE_OK;
+  BE_REQUIRE(out_bm != nullptr, BE_ERR_INVALID, "out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t esz = (wdtype == BE_F64) ? 8 : (wdtype == BE_F32 ? 4 : 2);
+  if (in_len == 0 || clen <= 0) {
+    BE_HIP(hipMemsetAsync(out_bm, 0, (size_t)out_len * n_batch * esz, st));
+    return BE_OK;
+  }
+  BE_REQUIRE(spikes_bm != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_binary_jitmm_workspace_bytes(in_len, out_len, n_batch),
+             BE_ERR_WORKSPACE, "workspace too small");
+  unsigned char* wsb = static_cast<unsigned char*>(workspace);
+  uint32_t* mask = reinterpret_cast<uint32_t*>(wsb);
+  void* scratch = wsb + be_align_up(in_len * 4, 256);
+  const JitP p = make_params(shape1, gather ? in_len : out_len, seed, clen, 4, w0, w1);
+  const int64_t gen_rows = gather ? out_len : in_len;
+  const bool f64 = (wdtype == BE_F64);
+  const bool direct = (wdtype == BE_F32 || wdtype == BE_F64);   // kernels write f32 / f64; f16 / bf16 via f32 scratch
+  void* dst = direct ? out_bm : scratch;
+  const size_t asz = f64 ? 8 : 4;
+  if (!gather) BE_HIP(hipMemsetAsync(dst, 0, (size_t)out_len * n_batch * asz, st));
+  const size_t spk_sz = (spike_dtype == BE_SPIKE_FLOAT) ? 4 : 1;
+  const int prof = be_prof_begin(st);
+  for (int64_t b0 = 0; b0 < n_batch; b0 += 32) {
+    const int nc = (int)std::min<int64_t>(32, n_batch - b0);
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * in_len * spk_sz;
+    if (spike_dtype == BE_SPIKE_FLOAT)
+      hipLaunchKernelGGL(k_jit_masks<SpikeFloat>, dim3(gcap(in_len, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const float*>(chunk), in_len, nc, mask);
+    else
+      hipLaunchKernelGGL(k_jit_masks<SpikeBool>, dim3(gcap(in_len, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const uint8_t*>(chunk), in_len, nc, mask);
+    BE_LAUNCH_CHECK();
+    void* o = static_cast<unsigned char*>(dst) + (size_t)b0 * out_len * asz;
+    int rc;
+#define BE_JITMM(MODE_)                                                                                                  \
+    rc = f64 ? jit_mm_run<MODE_, double>(p, mask, gen_rows, nc, gather, static_cast<double*>(o), st)                     \
+             : jit_mm_run<MODE_, float>(p, mask, gen_rows, nc, gather, static_cast<float*>(o), st)
+    if (mode == MODE_SCALAR) { BE_JITMM(MODE_SCALAR); }
+    else if (mode == MODE_UNIFORM) { BE_JITMM(MODE_UNIFORM); }
+    else { BE_JITMM(MODE_NORMAL); }
+#undef BE_JITMM
+    if (rc != BE_OK) return rc;
+  }
+  be_prof_end(prof, st);
+  if (!direct) {
+    const int64_t n = out_len * n_batch;
+    if (wdtype == BE_F16)
+      hipLaunchKernelGGL((k_jit_convert<float, __half>), dim3(gcap(n, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const float*>(scratch), static_cast<__half*>(out_bm), n);
+    else
+      hipLaunchKernelGGL((k_jit_convert<float, __hip_bfloat16>), dim3(gcap(n, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const float*>(scratch), static_cast<__hip_bfloat16*>(out_bm), n);
+    BE_LAUNCH_CHECK();
+  }
+  return BE_OK;
+}
+
+#define BE_DEF_JIT_VARIANT(F, M, W, WD)                                                                               \
+  int be_binary_jit##F##mv_notrans_##W(BE_JIT_MV_ARGS) {                                                               \
+    return be_binary_jitmv(M, w0, w1, WD, clen, seed, spikes, spike_dtype, out, shape1, in_len, out_len, 1, scale_exp,  \
+                           workspace, workspace_bytes, stream);                                                        \
+  }                                                                                                                    \
+  int be_binary_jit##F##mv_trans_##W(BE_JIT_MV_ARGS) {                                                                 \
+    return be_binary_jitmv(M, w0, w1, WD, clen, seed, spikes, spike_dtype, out, shape1, in_len, out_len, 0, scale_exp,  \
+                           workspace, workspace_bytes, stream);                                                        \
+  }                                                                                                                    \
+  int be_binary_jit##F##mm_notrans_##W(BE_JIT_MM_ARGS) {                                                               \
+    return be_binary_jitmm(M, w0, w1, WD, clen, seed, spikes_bm, spike_dtype, out_bm, shape1, in_len, out_len, n_batch, \
+                           1, workspace, workspace_bytes, stream);                                                     \
+  }                                                                                                                    \
+  int be_binary_jit##F##mm_trans_##W(BE_JIT_MM_ARGS) {                                                                 \
+    return be_binary_jitmm(M, w0, w1, WD, clen, seed, spikes_bm, spike_dtype, out_bm, shape1, in_len, out_len, n_batch, \
+                           0, workspace, workspace_bytes, stream);                                                     \
+  }
+
+BE_FOR_JIT_VARIANTS(BE_DEF_JIT_VARIANT)
+
+}  // extern "C"

@@ -179,6 +179,53 @@ int be_binary_densemm(const void* weights, int wdtype, const void* spikes_bm, in
                       int64_t rows_w, int64_t cols_w, int64_t n_batch, int transpose, void* workspace,
                       int64_t workspace_bytes, be_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * JIT-connectivity products (the matrix is regenerated on the fly, never stored)
+ * replaces: jit_scalar_binary_jitsmv.{pack_bool,notrans_*,trans_*} (brainevent/_jit_scalar/binary_jitsmv.cu:107-321),
+ *           jit_scalar_binary_jitsmm.{pack,notrans_*,trans_*} (brainevent/_jit_scalar/binary_jitsmm.cu),
+ *           and the uniform / normal twins (brainevent/_jit_uniform/binary_jitumv.cu:77-213, binary_jitumm.cu;
+ *           brainevent/_jit_normal/binary_jitnmv.cu:105-312, binary_jitnmm.cu).
+ *   mode    : 0 scalar (w = w0), 1 uniform (w = w0 + u01(seed,row,col) * w1, i.e. w0 = low, w1 = high - low),
+ *             2 normal (w = w0 + n01(seed,row,col) * w1, i.e. w0 = loc, w1 = scale)
+ *   clen    : ceil(2 / prob) as the reference computes it (brainevent/_data.py:1212-1245); values < 2 act as 2;
+ *             clen <= 0 (prob = 0) yields zeros
+ *   shape1  : shape[1] of the logical matrix — keys the chunk width ceil(shape1 / 4) (brainevent/_misc.py:74-122)
+ *   gather  : 1 = "notrans" kernel (corder=True): RNG rows are the out_len outputs, the walk runs over in_len;
+ *             0 = "trans" kernel (corder=False): RNG rows are the in_len inputs (only active ones are walked),
+ *             the walk runs over out_len
+ *   scale_exp : (scatter, modes 1 and 2) fixed-point exponent: edge weights are summed as round(w * 2^scale_exp)
+ *             in 64-bit integers; the caller guarantees |w|max * 2^scale_exp * in_len < 2^62
+ *   mv walks with lane stride 32, mm with lane stride 4 (a different matrix, as in the reference:
+ *   brainevent/_misc.py:32-38)
+ * ---------------------------------------------------------------------------------------------- */
+int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int gather);
+int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                    int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather,
+                    int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+int64_t be_binary_jitmm_workspace_bytes(int64_t in_len, int64_t out_len, int64_t n_batch);
+int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes_bm,
+                    int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,
+                    int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+
+/* named per-family / per-dtype symbols: be_binary_jit{s,u,n}{mv,mm}_{notrans,trans}_{f32,f64,f16,bf16} */
+#define BE_JIT_MV_ARGS double w0, double w1, int64_t clen, uint32_t seed, const void *spikes, int spike_dtype,    \
+                       void *out, int64_t shape1, int64_t in_len, int64_t out_len, int scale_exp,                 \
+                       void *workspace, int64_t workspace_bytes, be_stream_t stream
+#define BE_JIT_MM_ARGS double w0, double w1, int64_t clen, uint32_t seed, const void *spikes_bm, int spike_dtype, \
+                       void *out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,            \
+                       void *workspace, int64_t workspace_bytes, be_stream_t stream
+#define BE_DECL_JIT_FAMILY(F, W)                        \
+  int be_binary_jit##F##mv_notrans_##W(BE_JIT_MV_ARGS);  \
+  int be_binary_jit##F##mv_trans_##W(BE_JIT_MV_ARGS);    \
+  int be_binary_jit##F##mm_notrans_##W(BE_JIT_MM_ARGS);  \
+  int be_binary_jit##F##mm_trans_##W(BE_JIT_MM_ARGS);
+#define BE_FOR_JIT_VARIANTS(X)                                  \
+  X(s, 0, f32, BE_F32) X(s, 0, f64, BE_F64) X(s, 0, f16, BE_F16) X(s, 0, bf16, BE_BF16) \
+  X(u, 1, f32, BE_F32) X(u, 1, f64, BE_F64) X(u, 1, f16, BE_F16) X(u, 1, bf16, BE_BF16) \
+  X(n, 2, f32, BE_F32) X(n, 2, f64, BE_F64) X(n, 2, f16, BE_F16) X(n, 2, bf16, BE_BF16)
+#define BE_DECL_JIT_VARIANT(F, M, W, WD) BE_DECL_JIT_FAMILY(F, W)
+BE_FOR_JIT_VARIANTS(BE_DECL_JIT_VARIANT)
+
 /* per-variant symbols (same grammar as the reference's `// @BE` names); thin wrappers of the above */
 #define BE_DENSE_MV_ARGS const void *weights, const void *spikes, void *out, int64_t rows_w, int64_t cols_w,      \
                          void *workspace, int64_t workspace_bytes, be_stream_t stream

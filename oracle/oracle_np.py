@@ -102,3 +102,168 @@ def binary_densemm(weights, spikes, transpose):
     weights = np.asarray(weights)
     rows = weights.shape[1] if transpose else weights.shape[0]
     return np.stack(cols, axis=1) if cols else np.zeros((rows, 0), weights.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------
+# light_rng  (brainevent/_numba_random.py:385-502) — uint32 arithmetic with C wraparound
+# ----------------------------------------------------------------------------------------------------
+_M32 = 0xFFFFFFFF
+
+
+def lr_mix32(x):
+    """:385-393"""
+    x &= _M32
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & _M32
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & _M32
+    x ^= x >> 16
+    return x
+
+
+def lr_bounded(r, bound):
+    """:396-398  (r * bound) >> 32"""
+    return ((r & _M32) * (bound & _M32)) >> 32
+
+
+def lr_next(x):
+    """:401-409  xorshift32 (13, 17, 5); 0 -> 0x6d2b79f5"""
+    x &= _M32
+    x ^= (x << 13) & _M32
+    x ^= x >> 17
+    x ^= (x << 5) & _M32
+    return 0x6d2b79f5 if x == 0 else x
+
+
+def lr_init(seed, row, chunk_id, lane):
+    """:412-421"""
+    x = (seed & _M32) ^ 0xd1b54a35
+    x ^= ((row & _M32) * 0x85ebca6b) & _M32
+    x ^= ((chunk_id & _M32) * 0xc2b2ae35) & _M32
+    x ^= ((lane & _M32) * 0x27d4eb2d) & _M32
+    x = lr_mix32(x)
+    return 0x6d2b79f5 if x == 0 else x
+
+
+def lr_initial_q(state, cl):
+    """:489-502  stationary residual, two draws per rejection round; returns (q, state)"""
+    n = (cl - 1) & _M32
+    while True:
+        state = lr_next(state)
+        q = lr_bounded(state, n)
+        state = lr_next(state)
+        gate = lr_bounded(state, n)
+        if gate < ((n - q) & _M32):
+            return q, state
+
+
+def lr_uniform01(seed, row, col):
+    """:424-430  24-bit uniform variate of an edge (float32)"""
+    h = (seed & _M32) ^ 0xa0761d65
+    h ^= ((row & _M32) * 0xe7037ed1) & _M32
+    h ^= ((col & _M32) * 0x8ebc6af1) & _M32
+    h = lr_mix32(h)
+    return np.float32(h & 0x00FFFFFF) * np.float32(1.0 / 16777216.0)
+
+
+def lr_normal01(seed, row, col):
+    """:433-486  Acklam probit of the 24-bit hash, evaluated in float32"""
+    f = np.float32
+    u = f(lr_uniform01(seed, row, col))
+    lo, hi = f(1e-10), f(1.0 - 1e-10)
+    u = lo if u < lo else (hi if u > hi else u)
+    a1, a2, a3, a4, a5, a6 = f(-39.696830), f(220.94609), f(-275.92851), f(138.35775), f(-30.664799), f(2.5066283)
+    b1, b2, b3, b4, b5 = f(-54.476099), f(161.58584), f(-155.69898), f(66.801312), f(-13.280681)
+    c1, c2, c3, c4, c5, c6 = f(-0.007784894), f(-0.32239646), f(-2.4007583), f(-2.5497325), f(4.3746641), f(2.9381640)
+    d1, d2, d3, d4 = f(0.007784696), f(0.32246713), f(2.4451342), f(3.7544087)
+    one = f(1.0)
+    if u < f(0.02425):
+        v = f(np.sqrt(f(-2.0) * np.log(u)))
+        z = f((((((c1 * v + c2) * v + c3) * v + c4) * v + c5) * v + c6) / ((((d1 * v + d2) * v + d3) * v + d4) * v + one))
+        z = f(-z)
+    elif u > f(0.97575):
+        v = f(np.sqrt(f(-2.0) * np.log(one - u)))
+        z = f((((((c1 * v + c2) * v + c3) * v + c4) * v + c5) * v + c6) / ((((d1 * v + d2) * v + d3) * v + d4) * v + one))
+    else:
+        v = f(u - f(0.5))
+        r = f(v * v)
+        z = f((((((a1 * r + a2) * r + a3) * r + a4) * r + a5) * r + a6) * v /
+              (((((b1 * r + b2) * r + b3) * r + b4) * r + b5) * r + one))
+    return f(z)
+
+
+def conn_length(prob):
+    """brainevent/_data.py:1212-1245 (ceil(2/prob) as int32); 0 stands for prob == 0
+    (brainevent/_jit_uniform/_test_util.py:72-76)."""
+    prob = float(prob)
+    if prob == 0.0:
+        return 0
+    return max(2, int(math.ceil(2.0 / prob)))
+
+
+def default_chunk_size(n_cols, target_chunks=4):
+    """brainevent/_misc.py:74-122"""
+    return max(1, (int(n_cols) + int(target_chunks) - 1) // int(target_chunks))
+
+
+def jit_iter_edges(seed, clen, n_rows, walk_len, stride, chunk_size):
+    """Yield (rng_row, rng_col) of every generated edge: the walk of
+    brainevent/_jit_scalar/binary.py:340-377 (gather) / :381-416 (scatter); rows are the walk owners."""
+    cl = max(2, int(clen))
+    n_chunks = 0 if walk_len <= 0 else (int(walk_len) + chunk_size - 1) // chunk_size
+    for row in range(int(n_rows)):
+        for chunk_id in range(n_chunks):
+            cs = chunk_id * chunk_size
+            width = min(cs + chunk_size, int(walk_len)) - cs
+            for lane in range(int(stride)):
+                state = lr_init(seed, row, chunk_id, lane)
+                q, state = lr_initial_q(state, cl)
+                lj = lane + stride * q
+                while lj < width:
+                    yield row, cs + lj
+                    state = lr_next(state)
+                    q = q + 1 + lr_bounded(state, cl - 1)
+                    lj = lane + stride * q
+
+
+def jit_generator_matrix(mode, w0, w1, prob, seed, *, shape, transpose, corder, matrix_mode='mv', dtype=np.float64):
+    """Dense G[rng_row, rng_col] in the RNG orientation: rows = walk owners.
+    gather (corder=True): rows = outputs, cols = inputs; scatter: rows = inputs, cols = outputs.
+    mode: 's' (w0), 'u' (w0 + u01 * (w1 - w0)), 'n' (w0 + n01 * w1); duplicates cannot occur (q strictly grows)."""
+    in_len = shape[0] if transpose else shape[1]
+    out_len = shape[1] if transpose else shape[0]
+    n_rows, walk = (out_len, in_len) if corder else (in_len, out_len)
+    G = np.zeros((n_rows, walk), dtype=dtype)
+    clen = conn_length(prob)
+    if clen == 0:
+        return G
+    stride = MV_STRIDE if matrix_mode == 'mv' else MM_STRIDE
+    cs = default_chunk_size(shape[1])
+    seed &= _M32
+    for r, c in jit_iter_edges(seed, clen, n_rows, walk, stride, cs):
+        if mode == 's':
+            G[r, c] = w0
+        elif mode == 'u':
+            G[r, c] = dtype(w0) + dtype(lr_uniform01(seed, r, c)) * (dtype(w1) - dtype(w0))
+        else:
+            G[r, c] = dtype(w0) + dtype(lr_normal01(seed, r, c)) * dtype(w1)
+    return G
+
+
+def binary_jitmv(mode, w0, w1, prob, vector, seed, *, shape, transpose, corder, wdtype=np.float32):
+    """binary_jit{s,u,n}mv (brainevent/_jit_scalar/binary.py:289-421, _jit_uniform/binary.py:292-415,
+    _jit_normal/binary.py:307-410) evaluated through the dense generator matrix: every edge weight is
+    formed in the weight dtype (as the numba kernels do: ``w_low0 + u01 * span``), sums run in float64
+    (numba: ``out = np.float64(0.)``)."""
+    G = jit_generator_matrix(mode, w0, w1, prob, seed, shape=shape, transpose=transpose, corder=corder, matrix_mode='mv',
+                             dtype=wdtype).astype(np.float64)
+    act = active(vector).astype(np.float64)
+    return G @ act if corder else G.T @ act
+
+
+def binary_jitmm(mode, w0, w1, prob, B, seed, *, shape, transpose, corder, wdtype=np.float32):
+    """binary_jit{s,u,n}mm (brainevent/_jit_scalar/binary.py:833-957): stride-4 matrix, shared by all columns."""
+    G = jit_generator_matrix(mode, w0, w1, prob, seed, shape=shape, transpose=transpose, corder=corder, matrix_mode='mm',
+                             dtype=wdtype).astype(np.float64)
+    act = active(B).astype(np.float64)
+    return G @ act if corder else G.T @ act

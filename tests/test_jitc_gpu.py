@@ -1,0 +1,162 @@
+"""GPU parity for the JIT-connectivity ops against (i) the golden vectors generated from the reference's own
+numpy golden model and (ii) the numpy oracle.  Connectivity is integer work: scalar-weight results are exact
+(count * w); uniform / normal sums are compared at rtol = atol = 1e-5 (1e-4 for normal: logf/sqrtf ULPs),
+the tolerances the reference's own golden-model tests use (brainevent/_jit_uniform/binary_test.py:102-184)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_csr_gpu import spikes_of
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+COMBOS = [(t, c) for t in (False, True) for c in (False, True)]
+
+
+@pytest.mark.parametrize('transpose,corder', COMBOS)
+@pytest.mark.parametrize('shape', [(13, 17), (20, 30)])
+def test_jitumv_matches_reference_dense_golden(be, transpose, corder, shape):
+    dense = np.load(os.path.join(G, 'jitu_dense.npz'))
+    D = dense[f'{shape[0]}x{shape[1]}_t{int(transpose)}_c{int(corder)}_mv'].astype(np.float64)   # [out_len, in_len]
+    rng = np.random.default_rng(3)
+    for kind in ('bool', 'float'):
+        v = spikes_of(rng, D.shape[1], 0.5, kind)
+        got = be.binary_jitumv(np.float32(-1.5), np.float32(1.5), 0.2, v, 123, shape=shape, transpose=transpose, corder=corder)
+        act = (v > 0) if kind == 'float' else v
+        np.testing.assert_allclose(got, D @ act.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('transpose,corder', COMBOS)
+def test_jitumm_matches_reference_dense_golden(be, transpose, corder):
+    shape = (13, 17)
+    dense = np.load(os.path.join(G, 'jitu_dense.npz'))
+    D = dense[f'13x17_t{int(transpose)}_c{int(corder)}_mm'].astype(np.float64)
+    rng = np.random.default_rng(4)
+    B = rng.random((D.shape[1], 5)) < 0.5
+    got = be.binary_jitumm(np.float32(-1.5), np.float32(1.5), 0.2, B, 123, shape=shape, transpose=transpose, corder=corder)
+    np.testing.assert_allclose(got, D @ B.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('transpose,corder', COMBOS)
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+@pytest.mark.parametrize('shape,prob', [((40, 70), 0.1), ((100, 50), 0.3), ((3, 5), 0.5), ((64, 257), 1.0)])
+def test_jitmv_matches_oracle(be, oracle, family, transpose, corder, shape, prob):
+    rng = np.random.default_rng(shape[0] + int(prob * 10))
+    in_len = shape[0] if transpose else shape[1]
+    v = spikes_of(rng, in_len, 0.4, 'bool')
+    seed = 42
+    if family == 's':
+        got = be.binary_jitsmv(np.float32(0.5), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        ref = oracle.binary_jitmv('s', 0.5, 0.0, prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        np.testing.assert_array_equal(got, ref.astype(np.float32))          # integer counts * 0.5: exact
+    elif family == 'u':
+        got = be.binary_jitumv(np.float32(0.1), np.float32(0.9), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        ref = oracle.binary_jitmv('u', np.float32(0.1), np.float32(0.9), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    else:
+        got = be.binary_jitnmv(np.float32(0.2), np.float32(1.3), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        ref = oracle.binary_jitmv('n', np.float32(0.2), np.float32(1.3), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    assert got.dtype == np.float32 and got.shape == ((shape[1],) if transpose else (shape[0],))
+
+
+@pytest.mark.parametrize('transpose,corder', COMBOS)
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+def test_jitmm_matches_oracle(be, oracle, family, transpose, corder):
+    shape, prob, seed, n = (40, 70), 0.15, 7, 6
+    rng = np.random.default_rng(9)
+    in_len = shape[0] if transpose else shape[1]
+    B = np.stack([spikes_of(rng, in_len, 0.4, 'float') for _ in range(n)], axis=1)
+    f = {'s': be.binary_jitsmm, 'u': be.binary_jitumm, 'n': be.binary_jitnmm}[family]
+    args = {'s': (np.float32(0.5),), 'u': (np.float32(0.1), np.float32(0.9)), 'n': (np.float32(0.2), np.float32(1.3))}[family]
+    got = f(*args, prob, B, seed, shape=shape, transpose=transpose, corder=corder)
+    w0, w1 = (args + (0.0,))[:2]
+    ref = oracle.binary_jitmm(family, w0, w1, prob, B, seed, shape=shape, transpose=transpose, corder=corder)
+    tol = 1e-4 if family == 'n' else 1e-5
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol)
+
+
+def test_jit_small_prob_many_chunks(be, oracle):
+    # conn_prob 0.1 % on a 5000-wide walk: clen = 2000 as at config C3
+    shape, prob, seed = (6, 5000), 0.001, 42
+    rng = np.random.default_rng(0)
+    v = spikes_of(rng, 5000, 0.5, 'bool')
+    got = be.binary_jitsmv(np.float32(1.0), prob, v, seed, shape=shape, transpose=False, corder=True)
+    ref = oracle.binary_jitmv('s', 1.0, 0.0, prob, v, seed, shape=shape, transpose=False, corder=True)
+    np.testing.assert_array_equal(got, ref.astype(np.float32))
+    v2 = np.ones(6, bool)
+    got2 = be.binary_jitsmv(np.float32(1.0), prob, v2, seed, shape=shape, transpose=True, corder=False)
+    ref2 = oracle.binary_jitmv('s', 1.0, 0.0, prob, v2, seed, shape=shape, transpose=True, corder=False)
+    np.testing.assert_array_equal(got2, ref2.astype(np.float32))
+
+
+def test_jit_scatter_large_walk_pieces(be):
+    # a walk long enough to need several LDS pieces per residue class (uniform: 16384 accumulators per piece);
+    # gather and scatter over the same generator orientation must agree: M (corder=False rows=inputs) vs its transpose
+    n_in, n_out, prob, seed = 64, 3_000_000, 0.0005, 11
+    rng = np.random.default_rng(1)
+    v = spikes_of(rng, n_in, 0.5, 'bool')
+    # scatter: shape (n_in, n_out), transpose=True, corder=False -> out[n_out]
+    y_s = be.binary_jitsmv(np.float32(2.0), prob, v, seed, shape=(n_in, n_out), transpose=True, corder=False)
+    y_u = be.binary_jitumv(np.float32(0.5), np.float32(1.5), prob, v, seed, shape=(n_in, n_out), transpose=True, corder=False)
+    assert y_s.shape == (n_out,) and y_u.shape == (n_out,)
+    # every edge carries weight 2 (scalar) and a weight in [0.5, 1.5] (uniform) on the same connectivity
+    cnt = y_s / 2.0
+    assert np.all(cnt == np.round(cnt)) and cnt.sum() > 0
+    assert np.all(y_u >= 0.5 * cnt - 1e-4) and np.all(y_u <= 1.5 * cnt + 1e-4)
+    # expected number of edges: active rows * n_out * prob
+    exp = v.sum() * n_out * prob
+    assert abs(cnt.sum() - exp) < 6 * np.sqrt(exp)
+
+
+def test_jit_prob_zero_and_one(be):
+    v = np.ones(9, bool)
+    assert not be.binary_jitsmv(np.float32(1.0), 0.0, v, 1, shape=(4, 9), transpose=False, corder=True).any()
+    full = be.binary_jitsmv(np.float32(1.0), 1.0, v, 1, shape=(4, 9), transpose=False, corder=True)
+    np.testing.assert_array_equal(full, np.full(4, 9.0, np.float32))      # prob = 1 -> cl = 2 -> every column connected
+
+
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+def test_jitc_classes_are_consistent(be, oracle, family):
+    shape, prob, seed = (30, 45), 0.2, 5
+    rng = np.random.default_rng(2)
+    cls_r = {'s': be.JITCScalarR, 'u': be.JITCUniformR, 'n': be.JITCNormalR}[family]
+    params = {'s': (np.float32(0.5),), 'u': (np.float32(0.1), np.float32(0.9)), 'n': (np.float32(0.2), np.float32(1.3))}[family]
+    w0, w1 = (params + (0.0,))[:2]
+    tol = 1e-4 if family == 'n' else 1e-5
+    for corder in (False, True):
+        M = cls_r((*params, prob, seed), shape=shape, corder=corder)
+        v = spikes_of(rng, shape[1], 0.5, 'bool')
+        s = spikes_of(rng, shape[0], 0.5, 'bool')
+        # M @ v : (shape, transpose=False, corder);   s @ M : (shape, transpose=True, not corder)
+        np.testing.assert_allclose(M @ be.BinaryArray(v),
+                                   oracle.binary_jitmv(family, w0, w1, prob, v, seed, shape=shape, transpose=False, corder=corder),
+                                   rtol=tol, atol=tol)
+        np.testing.assert_allclose(be.BinaryArray(s) @ M,
+                                   oracle.binary_jitmv(family, w0, w1, prob, s, seed, shape=shape, transpose=True, corder=not corder),
+                                   rtol=tol, atol=tol)
+        # the two directions see the same matrix: s @ (M @ v) == (s @ M) @ v
+        lhs = float(np.dot(s.astype(np.float64), M @ be.BinaryArray(v)))
+        rhs = float(np.dot((be.BinaryArray(s) @ M).astype(np.float64), v))
+        assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs))
+        # transposed container
+        Mt = M.T
+        assert Mt.shape == shape[::-1] and Mt.corder == (not corder)
+        np.testing.assert_allclose(Mt @ be.BinaryArray(s), be.BinaryArray(s) @ M, rtol=tol, atol=tol)
+        np.testing.assert_allclose(be.BinaryArray(v) @ Mt, M @ be.BinaryArray(v), rtol=tol, atol=tol)
+    with pytest.raises(ValueError):
+        cls_r((*params, 1.5, seed), shape=shape)
+
+
+def test_jit_f64_and_f16_outputs(be, oracle):
+    shape, prob, seed = (25, 40), 0.25, 3
+    v = np.ones(40, bool)
+    ref = oracle.binary_jitmv('u', 0.25, 0.75, prob, v, seed, shape=shape, transpose=False, corder=True, wdtype=np.float64)
+    got64 = be.binary_jitumv(np.float64(0.25), np.float64(0.75), prob, v, seed, shape=shape, transpose=False, corder=True)
+    assert got64.dtype == np.float64
+    np.testing.assert_allclose(got64, ref, rtol=1e-6, atol=1e-6)
+    got16 = be.binary_jitumv(np.float16(0.25), np.float16(0.75), prob, v, seed, shape=shape, transpose=False, corder=True)
+    assert got16.dtype == np.float16
+    np.testing.assert_allclose(got16.astype(np.float64), ref, rtol=2e-3, atol=2e-3)

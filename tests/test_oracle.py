@@ -1,0 +1,117 @@
+"""CPU tests: the oracle (numpy + C restatements) is pinned against the golden vectors generated from the
+reference's own numpy golden model and against the reference's known-answer tests (tests/golden/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+from oracle import oracle_c
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def scalars():
+    return json.load(open(os.path.join(G, 'light_rng_scalars.json')))
+
+
+def test_light_rng_scalars(scalars):
+    for x, y in scalars['mix32']:
+        assert O.lr_mix32(x) == y
+    for x, y in scalars['next']:
+        assert O.lr_next(x) == y
+    for r, b, y in scalars['bounded']:
+        assert O.lr_bounded(r, b) == y
+    for s, r, c, l, y in scalars['init']:
+        assert O.lr_init(s, r, c, l) == y
+    for st, cl, q, s2 in scalars['initial_q']:
+        assert O.lr_initial_q(st, cl) == (q, s2)
+    for s, r, c, y in scalars['uniform01']:
+        assert float(O.lr_uniform01(s, r, c)) == y
+    for p, y in scalars['conn_length']:
+        assert O.conn_length(p) == y
+    for n, y in scalars['default_chunk_size']:
+        assert O.default_chunk_size(n) == y
+
+
+def test_light_rng_normal01_properties():
+    # brainevent/_numba_random_test.py:60-100 pins normal01 statistically; here: finite, symmetric-ish, N(0,1) moments
+    z = np.array([O.lr_normal01(7, r, c) for r in range(60) for c in range(60)], dtype=np.float64)
+    assert np.isfinite(z).all() and abs(z.mean()) < 0.06 and abs(z.std() - 1.0) < 0.06
+    assert O.lr_normal01(1, 2, 3) == O.lr_normal01(1, 2, 3)
+
+
+def test_edges_match_reference_golden_model():
+    edges = np.load(os.path.join(G, 'jitc_edges.npz'))
+    for key in edges.files:
+        parts = dict((p[0], p[1:]) for p in key.replace('st', 'T').split('_'))
+        seed, prob, n_rows, n_cols, stride = int(parts['s']), float(parts['p']), int(parts['r']), int(parts['c']), int(parts['T'])
+        cs = 1250 if n_cols == 5000 else O.default_chunk_size(n_cols)
+        got = np.array(list(O.jit_iter_edges(seed, O.conn_length(prob), n_rows, n_cols, stride, cs)), dtype=np.int32).reshape(-1, 2)
+        assert np.array_equal(got, edges[key]), key
+
+
+def test_uniform_dense_matches_reference_golden_model():
+    dense = np.load(os.path.join(G, 'jitu_dense.npz'))
+    for key in dense.files:
+        shp, t, c, mm = key.split('_')
+        shape = tuple(int(x) for x in shp.split('x'))
+        transpose, corder = bool(int(t[1])), bool(int(c[1]))
+        Gm = O.jit_generator_matrix('u', np.float32(-1.5), np.float32(1.5), 0.2, 123, shape=shape, transpose=transpose,
+                                    corder=corder, matrix_mode=mm, dtype=np.float32)
+        D = Gm if corder else Gm.T
+        assert D.shape == dense[key].shape
+        np.testing.assert_array_equal(D, dense[key], err_msg=key)
+
+
+def _run_kat(k, impl):
+    if k['op'] == 'csrmv':
+        return impl.binary_csrmv(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['indptr']),
+                                 np.array(k['v']), tuple(k['shape']), k['transpose'])
+    if k['op'] == 'csrmm':
+        return impl.binary_csrmm(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['indptr']),
+                                 np.array(k['B']), tuple(k['shape']), k['transpose'])
+    if k['op'] == 'densemv':
+        return impl.binary_densemv(np.array(k['W'], np.float32), np.array(k['s']), k['transpose'])
+    if k['op'] == 'fcnmv':
+        return impl.binary_fcnmv(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['s']),
+                                 tuple(k['shape']), k['transpose'])
+    if k['op'] == 'fcnmm':
+        return impl.binary_fcnmm(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['M']),
+                                 tuple(k['shape']), k['transpose'])
+    raise KeyError(k['op'])
+
+
+def test_known_answer_tests_numpy_oracle():
+    for k in json.load(open(os.path.join(G, 'kat.json'))):
+        np.testing.assert_allclose(_run_kat(k, O), np.array(k['expect']), rtol=0, atol=0, err_msg=k['src'])
+
+
+def test_c_oracle_matches_numpy_oracle():
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        m, k = rng.integers(5, 80, 2)
+        lens = rng.integers(0, 12, m)
+        ptr = np.concatenate([[0], np.cumsum(lens)])
+        idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+        homo = trial % 2 == 0
+        w = np.array([0.75], np.float32) if homo else rng.random(ptr[-1]).astype(np.float32)
+        for transpose in (True, False):
+            n = m if transpose else k
+            for v in (rng.random(n) < 0.4, np.where(rng.random(n) < 0.4, 1.5, -0.5).astype(np.float32)):
+                a = oracle_c.csrmv_f32(w, idx, ptr, v, (m, k), transpose)
+                b = O.binary_csrmv(w, idx, ptr, v, (m, k), transpose)
+                np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_c_oracle_known_answers():
+    for k in json.load(open(os.path.join(G, 'kat.json'))):
+        if k['op'] != 'csrmv':
+            continue
+        v = np.array(k['v'])
+        v = v.astype(np.float32) if v.dtype.kind == 'f' else v
+        got = oracle_c.csrmv_f32(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['indptr']), v,
+                                 tuple(k['shape']), k['transpose'])
+        np.testing.assert_array_equal(got, np.array(k['expect'], np.float32))
