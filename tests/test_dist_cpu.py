@@ -1,0 +1,106 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: post-slice partition + spike all-gather.
+The local product is done by the oracle here (no GPU in this container); on MI355X the same DistributedScatter
+runs the HIP scatter on every rank (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, packed, n_pre, n_post, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from brainevent_amd import _dist as D
+        from oracle import oracle_np as O
+        rng = np.random.default_rng(0)                      # same matrix on every rank
+        lens = rng.integers(0, 40, n_pre)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        indices = rng.integers(0, n_post, indptr[-1]).astype(np.int32)
+        w = rng.random(indptr[-1]).astype(np.float32)
+        sw, si, sp, sshape = D.shard_csr_by_post(torch.from_numpy(w), torch.from_numpy(indices), torch.from_numpy(indptr),
+                                                 (n_pre, n_post), world, rank)
+        lo, hi = D.post_slice_bounds(n_post, world, rank)
+        assert sshape == (n_pre, hi - lo) and int(sp[-1]) == si.numel()
+        assert si.numel() == 0 or (int(si.min()) >= 0 and int(si.max()) < hi - lo)
+
+        def matmul(full, shard):
+            d, i, p, shp = shard
+            return O.binary_csrmv(d.numpy(), i.numpy(), p.numpy(), full.numpy(), shp, True)
+
+        ds = D.DistributedScatter((sw, si, sp, sshape), n_pre, packed=packed, matmul=matmul)
+        outs = []
+        for step in range(3):
+            full_ref = np.random.default_rng(100 + step).random(n_pre) < 0.2     # what the gathered vector must be
+            plo, phi = D.pre_slice_bounds(n_pre, world, rank)
+            local = torch.from_numpy(full_ref[plo:phi].copy())
+            got_full = ds.exchange.gather(local)
+            assert np.array_equal(got_full.numpy(), full_ref)
+            outs.append(ds.step(local))
+        q.put((rank, lo, hi, np.stack(outs)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('packed,n_pre,n_post', [(False, 64, 50), (False, 67, 53), (True, 64, 53), (True, 67, 50)])
+def test_post_sliced_scatter_world2(packed, n_pre, n_post):
+    from oracle import oracle_np as O
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, packed, n_pre, n_post, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == 0 and res[-1][2] == n_post and res[0][2] == res[1][1]       # slices tile the post population
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 40, n_pre)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = rng.integers(0, n_post, indptr[-1]).astype(np.int32)
+    w = rng.random(indptr[-1]).astype(np.float32)
+    for step in range(3):
+        spk = np.random.default_rng(100 + step).random(n_pre) < 0.2
+        ref = O.binary_csrmv(w, indices, indptr, spk, (n_pre, n_post), True)
+        got = np.concatenate([r[3][step] for r in res])
+        np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_slice_bounds_and_fixed_num_shards():
+    from brainevent_amd import _dist as D
+    for n, w in ((10, 3), (1_000_000, 8), (7, 8)):
+        b = [D.post_slice_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(x[1] - x[0] for x in b) - min(x[1] - x[0] for x in b) <= 1
+    rng = np.random.default_rng(1)
+    n_pre, n_post, K = 20, 37, 6
+    idx = torch.from_numpy(rng.integers(0, n_post, (n_pre, K)).astype(np.int32))
+    data = torch.from_numpy(rng.random((n_pre, K)).astype(np.float32))
+    dense = np.zeros((n_pre, n_post), np.float32)
+    np.add.at(dense, (np.repeat(np.arange(n_pre), K), idx.numpy().reshape(-1)), data.numpy().reshape(-1))
+    cols = []
+    for r in range(3):
+        d, i, p, shp = D.shard_fixed_num_by_post(data, idx, (n_pre, n_post), 3, r)
+        blk = np.zeros(shp, np.float32)
+        np.add.at(blk, (np.repeat(np.arange(n_pre), np.diff(p.numpy())), i.numpy()), d.numpy())
+        cols.append(blk)
+    np.testing.assert_allclose(np.concatenate(cols, axis=1), dense, rtol=1e-6)
+    bits = torch.from_numpy(rng.random(29) < 0.5)
+    assert torch.equal(D._unpack_bits(D._pack_bits(bits), 29), bits)

@@ -1,0 +1,178 @@
+"""CPU tests of the host logic: C-ABI surface, validators, operator dispatch contract, loud failure
+without a GPU.  No compute calls are made (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'brainevent_amd.h')
+
+
+def declared_symbols():
+    """Every function the public header declares, after macro expansion (gcc -E)."""
+    src = subprocess.run(['gcc', '-E', '-P', HEADER], check=True, capture_output=True, text=True).stdout
+    names = set(re.findall(r'\b(be_[A-Za-z0-9_]+)\s*\(', src))
+    assert len(names) > 200, len(names)
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    from brainevent_amd import _lib
+    if _lib.needs_build():
+        _lib.build()
+    lib = ctypes.CDLL(str(_lib.lib_path()))
+    missing = [n for n in declared_symbols() if not hasattr(lib, n)]
+    assert not missing, missing[:10]
+    lib.be_build_arch.restype = ctypes.c_char_p
+    assert lib.be_build_arch() == b'gfx950' and lib.be_version() >= 100
+
+
+def test_declared_symbol_families_cover_the_hot_path():
+    names = set(declared_symbols())
+    for fam in ('be_binary_csrmv_t_hetero_f32_bool', 'be_binary_csrmv_nt_homo_bf16_float', 'be_binary_csrmm_t_hetero_f16_bool',
+                'be_binary_fcnmv_scatter_homo_f32_bool', 'be_binary_fcnmm_gather_hetero_f64_float',
+                'be_binary_densemv_transpose_f32_bool', 'be_binary_densemm_no_transpose_bf16_float',
+                'be_binary_jitsmv_notrans_f32', 'be_binary_jitumv_trans_f16', 'be_binary_jitnmm_trans_f64',
+                'be_scatter_plan_count', 'be_scatter_plan_fill', 'be_binary_csrmm_t_plan', 'be_pack_spikes',
+                'be_compact_spikes', 'be_last_error', 'be_profile_enable'):
+        assert fam in names, fam
+
+
+def test_ops_fail_loudly_without_gpu():
+    import brainevent_amd as be
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    w = np.ones(2, np.float32)
+    with pytest.raises(be.KernelNotAvailableError):
+        be.binary_csrmv(w, np.array([0, 1], np.int32), np.array([0, 2], np.int32), np.array([True]), shape=(1, 2), transpose=True)
+    with pytest.raises(be.KernelNotAvailableError):
+        be.BinaryArray(np.array([True, False])) @ np.ones((2, 3), np.float32)
+    with pytest.raises(be.KernelNotAvailableError):
+        be.binary_jitsmv(np.float32(1.0), 0.5, np.ones(4, bool), 1, shape=(3, 4))
+
+
+def test_missing_library_is_a_load_error(monkeypatch, tmp_path):
+    from brainevent_amd import _lib
+    import brainevent_amd as be
+    monkeypatch.setenv('BE_HIP_LIB', str(tmp_path / 'nope.so'))
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(be.KernelLoadError):
+        _lib.lib()
+
+
+def test_structure_validators():
+    from brainevent_amd import _misc as M
+    idx = torch.tensor([0, 2, 1], dtype=torch.int64)
+    out = M._as_int32_indices(idx, 3, 'ctx')
+    assert out.dtype == torch.int32
+    with pytest.raises(ValueError):
+        M._as_int32_indices(torch.tensor([0, 3]), 3, 'ctx')
+    with pytest.raises(ValueError):
+        M._as_int32_indices(torch.tensor([-1, 1]), 3, 'ctx')
+    with pytest.raises(TypeError):
+        M._as_int32_indices(torch.tensor([0.5]), 3, 'ctx')
+    assert M._resolve_indptr_dtype(10) == torch.int32
+    assert M._resolve_indptr_dtype(2 ** 31) == torch.int64
+    with pytest.raises(OverflowError):
+        M._resolve_indptr_dtype(2 ** 31, np.int32)
+    with pytest.raises(ValueError):
+        M._resolve_indptr_dtype(5, 'int32')
+    ptr = torch.tensor([0, 2, 3], dtype=torch.int32)
+    ind = torch.tensor([0, 1, 1], dtype=torch.int32)
+    M._check_compressed_structure(ind, ptr, (2, 2), 'csr')
+    with pytest.raises(ValueError):
+        M._check_compressed_structure(ind, torch.tensor([1, 2, 3], dtype=torch.int32), (2, 2), 'csr')     # indptr[0] != 0
+    with pytest.raises(ValueError):
+        M._check_compressed_structure(ind, torch.tensor([0, 3, 2], dtype=torch.int32), (2, 2), 'csr')     # not monotone
+    with pytest.raises(ValueError):
+        M._check_compressed_structure(ind, torch.tensor([0, 2, 4], dtype=torch.int32), (2, 2), 'csr')     # indptr[-1] != nse
+    with pytest.raises(ValueError):
+        M._check_compressed_structure(ind, ptr, (3, 2), 'csr')                                            # length
+    with pytest.raises(TypeError):
+        M._check_compressed_structure(ind.long(), ptr, (2, 2), 'csr')
+    assert M._normalize_chunk_size(17) == 5 and M._normalize_chunk_size(4_000_000) == 1_000_000
+    with pytest.raises(ValueError):
+        M._normalize_chunk_size(8, 0)
+    assert (M._MV_STRIDE, M._MM_STRIDE) == (32, 4)
+
+
+def test_operator_dispatch_contract():
+    import warnings
+    import brainevent_amd as be
+    from brainevent_amd._op import OpKernel
+    op = OpKernel('unit_test_op')
+    op.def_kernel('a', 'gpu', lambda x: ('a', x))
+    op.def_kernel('b', 'gpu', lambda x: ('b', x))
+    assert op.available_backends('gpu') == ['a', 'b'] and op(1) == ('a', 1)
+    assert op(1, backend='b') == ('b', 1)                            # per-call wins
+    be.config.set_backend('gpu', 'b')
+    try:
+        assert op(1) == ('b', 1)                                     # global beats the per-operator default
+        be.config.set_backend('gpu', 'zzz')
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter('always')
+            assert op(1) == ('a', 1)                                 # unknown global backend: warn + default
+        assert wlist
+    finally:
+        be.config.clear_backends()
+    with pytest.raises(be.KernelFallbackExhaustedError):
+        op(1, backend='zzz')                                         # unknown per-call backend: error
+    op.set_default('gpu', 'b')
+    assert op(1) == ('b', 1)
+    with pytest.raises(be.KernelFallbackExhaustedError):
+        op.set_default('gpu', 'zzz')
+    assert 'unit_test_op' in be.get_all_primitive_names()
+    op.def_tags('x', 'y')
+    assert 'unit_test_op' in be.get_primitives_by_tags({'x'})
+    for name in ('binary_csrmv', 'binary_csrmm', 'binary_densemv', 'binary_densemm', 'binary_fcnmv', 'binary_fcnmm',
+                 'binary_jitsmv', 'binary_jitsmm', 'binary_jitumv', 'binary_jitumm', 'binary_jitnmv', 'binary_jitnmm'):
+        assert be.get_registry()[name].available_backends('gpu') == ['hip']
+
+
+def test_config_backend_api():
+    import brainevent_amd as be
+    be.config.clear_backends()
+    assert be.config.get_backend('gpu') is None
+    be.config.set_backend('gpu', 'hip')
+    assert be.config.get_backend('gpu') == 'hip'
+    be.config.set_backend('gpu', None)
+    assert be.config.get_backend('gpu') is None
+    with pytest.raises(ValueError):
+        be.config.set_backend('tpu', 'x')
+    with pytest.raises(TypeError):
+        be.config.set_backend('gpu', 3)
+
+
+def test_binaryarray_container():
+    import brainevent_amd as be
+    s = be.BinaryArray([True, False, True])
+    assert s.shape == (3,) and s.ndim == 1 and s.size == 3 and s.dtype == np.bool_ and len(s) == 3
+    assert isinstance(s.with_value(np.zeros(2, bool)), be.BinaryArray)
+    assert s[0] and not s[1]
+    m = be.BinaryArray(np.zeros((2, 3), bool))
+    assert m.T.shape == (3, 2) and m.transpose().shape == (3, 2)
+    assert be.BinaryArray(s).value is s.value
+    with pytest.raises(be.MathError):
+        be.BinaryArray(np.zeros((2, 2, 2), bool)) @ np.ones((2, 2), np.float32)
+
+
+def test_jit_host_helpers():
+    from brainevent_amd import _jitc as J
+    assert J._initialize_conn_length(0.001) == 2000 and J._initialize_conn_length(1.0) == 2 and J._initialize_conn_length(0.0) == 0
+    assert J._initialize_conn_length(0.3) == 7
+    assert J._initialize_seed(np.array([5], np.int32)) == 5 and isinstance(J._initialize_seed(None), int)
+    # fixed-point exponent keeps |w| * 2^e * n below 2^62
+    for wmax, n in ((1.0, 10), (0.5, 10 ** 7), (123.0, 4_000_000), (1e-6, 100)):
+        e = J._fixed_scale_exp(wmax, n)
+        assert wmax * 2.0 ** e * n < 2.0 ** 62
+    with pytest.raises(ValueError):
+        J._validate_prob(1.5)
+    with pytest.raises(ValueError):
+        J._validate_prob(float('nan'))
+    with pytest.raises(ValueError):
+        J._validate_prob(np.array([0.1, 0.2]))
