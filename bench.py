@@ -47,6 +47,10 @@ def parse():
     ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
     ap.add_argument('--parts', type=int, default=0)
     ap.add_argument('--shift', type=int, default=0)
+    ap.add_argument('--workload', choices=['csr', 'jitc', 'fcn', 'dense'], default='csr',
+                    help='csr = the headline C2 config; the others are the secondary BASELINE.json configs (single GPU)')
+    ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
+    ap.add_argument('--batch', type=int, default=32, help='dense: batch rows')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
@@ -101,8 +105,103 @@ def cpu_baseline(args, n_post, n_conn):
     }
 
 
+def time_steps(step, steps, warmup):
+    import ctypes as ct
+    from brainevent_amd import _lib
+    for i in range(warmup):
+        out = step(i)
+    prof_enable = _lib.fn('be_profile_enable', ct.c_int, [ct.c_int])
+    prof_read = _lib.fn('be_profile_read', ct.c_int, [ct.c_void_p, ct.c_int])
+    _lib.check(prof_enable(steps), 'be_profile_enable')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = (ct.c_float * steps)()
+    n_rec = prof_read(ct.cast(ms, ct.c_void_p), steps)
+    prof_enable(0)
+    return elapsed, (float(np.mean(ms[:n_rec])) if n_rec > 0 else None), out
+
+
+def secondary(args):
+    """Secondary single-GPU workloads (BASELINE.json configs[2..4]); same JSON shape, own metric strings."""
+    import brainevent_amd as be
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    n_batch = 20
+    cfg, roof = {}, None
+    if args.workload == 'jitc':
+        n = args.n if args.n != 1_000_000 else 4_000_000
+        prob = args.conn if args.conn != 0.01 else 0.001
+        M = be.JITCScalarR((np.float32(1.0), prob, 42), shape=(n, n), corder=not args.jit_gather)
+        spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
+        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ M
+        elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
+        upd = float(out.double().sum().item())          # weight 1: the sum is the number of delivered edges
+        value = upd * args.steps / elapsed / 1e9 if not args.jit_gather else n * n * prob * args.steps / elapsed / 1e9
+        metric = 'synaptic updates/sec (Geff/s), BinaryArray @ JITCScalarR ' + ('gather: generated edges/s' if args.jit_gather else 'scatter')
+        cfg = {'workload': f'BinaryArray({args.fire:g}) @ JITCScalarR w=1 prob={prob:g} seed=42 {n}x{n}, '
+                           f"{'gather (corder=False matrix)' if args.jit_gather else 'scatter (corder=True matrix)'}",
+               'edges_last_step': upd}
+        if kern_ms:
+            # no stored matrix: HBM is not the bound; report the bandwidth a stored CSR would have needed (8 B/update)
+            roof = {'bound': 'valu+lds (no HBM matrix traffic)', 'achieved': None, 'peak': None, 'unit': 'GB/s', 'frac': None,
+                    'traffic': None, 'kernel_ms': round(kern_ms, 5),
+                    'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
+    elif args.workload == 'fcn':
+        n = args.n if args.n != 1_000_000 else 10_000_000
+        K = 1000
+        idx = torch.empty((n, K), dtype=torch.int32, device=dev)
+        for lo in range(0, n, 200_000):
+            hi = min(n, lo + 200_000)
+            idx[lo:hi] = torch.randint(0, n, (hi - lo, K), dtype=torch.int32, device=dev, generator=g)
+        w = torch.ones(1, device=dev) if args.homo else torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
+        conn = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False)
+        conn.prepare()
+        spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
+        act = spikes.sum(dim=1).cpu().numpy()
+        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ conn
+        elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
+        upd = sum(int(act[(args.warmup + i) % n_batch]) for i in range(args.steps)) * K
+        value = upd / elapsed / 1e9
+        metric = 'synaptic updates/sec (Geff/s), BinaryArray @ FixedNumPerPre scatter'
+        cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} N={n} {'homo' if args.homo else 'hetero'} f32, 1 GPU",
+               'route': 'plan' if conn.buffers.get('scatter_plan') is not None else 'direct (global atomics)'}
+        if kern_ms:
+            alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n
+            roof = {'bound': 'hbm', 'achieved': round(alg / (kern_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel_ms': round(kern_ms, 5)}
+    else:   # dense
+        n = args.n if args.n != 1_000_000 else 65536
+        W = torch.empty((n, n), dtype=torch.float16, device=dev).normal_(0, 1, generator=g)
+        spikes = torch.rand((n_batch, args.batch, n), device=dev, generator=g) < args.fire
+        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ W
+        elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
+        pairs = float(spikes.sum().item()) / n_batch
+        value = pairs * n * args.steps / elapsed / 1e9
+        metric = 'synaptic updates/sec (Geff/s), batched BinaryArray @ dense fp16'
+        union = float(spikes.any(dim=1).sum().item()) / n_batch
+        cfg = {'workload': f'BinaryArray({args.fire:g}) [{args.batch},{n}] @ dense fp16 [{n},{n}]', 'union_rows': union,
+               'active_pairs': pairs}
+        if kern_ms:
+            alg = union * n * 2 + args.batch * n * 2
+            roof = {'bound': 'hbm', 'achieved': round(alg / (kern_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel_ms': round(kern_ms, 5),
+                    'algorithmic_bytes_per_launch': int(alg)}
+    line = {'metric': metric, 'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16' if args.workload == 'dense' else 'f32', 'data': 'synthetic', 'config': cfg, 'roofline': roof}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload != 'csr':
+        return secondary(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
