@@ -43,23 +43,23 @@ class ScatterPlan:
     """Post-sliced row segments of a CSR / fixed-number-connectivity matrix (device resident).
 
     Built once per matrix (structure + weights), reused by every ``spk @ matrix`` call.  Fields:
-    ``seg_ptr`` uint32 ``[n_slices*m + 1]`` (units of 4 entries), ``idx16`` uint16 ``[total]``,
-    ``w32`` f32 ``[total]`` (hetero only), ``slice_shift``, ``scale_exp`` (fixed-point exponent).
+    ``seg`` int32 view of ``{uint32 block start / 128 B, uint32 n4}`` per (row, slice), ``blob`` uint8 (the
+    128-byte aligned blocks ``[f32 weights][uint16 local columns]``), ``slice_shift``, ``scale_exp``
+    (fixed-point exponent).  See ``include/brainevent_amd.h`` for the exact layout.
     """
 
     #: default slice widths: hetero accumulators are 8 B (2^14 * 8 = 128 KiB of LDS), homo are 4 B
     HETERO_SHIFT = 14
     HOMO_SHIFT = 15
 
-    def __init__(self, m, k, homo, slice_shift, seg_ptr, idx16, w32, total, scale_exp, weight_dtype):
+    def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
         self.slice_shift = int(slice_shift)
         self.n_slices = (self.k + (1 << self.slice_shift) - 1) >> self.slice_shift
-        self.seg_ptr, self.idx16, self.w32 = seg_ptr, idx16, w32
-        self.total = int(total)
+        self.seg, self.blob = seg, blob
         self.scale_exp = int(scale_exp)
         self.weight_dtype = weight_dtype
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Dict = {}
 
     # -- sizing ---------------------------------------------------------------------------------
     @staticmethod
@@ -73,10 +73,7 @@ class ScatterPlan:
         return int(max(1, min(64, 256 // max(self.n_slices, 1))))
 
     def nbytes(self) -> int:
-        n = self.seg_ptr.numel() * 4 + self.idx16.numel() * 2
-        if self.w32 is not None:
-            n += self.w32.numel() * 4
-        return n
+        return self.seg.numel() * 4 + self.blob.numel()
 
     def workspace(self, parts: int, n_batch: int = 1) -> torch.Tensor:
         key = (parts, n_batch)
@@ -105,23 +102,20 @@ class ScatterPlan:
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         if indptr is not None:
             indptr = A.to_device(indptr)
-        seg_ptr = torch.empty(n_slices * m + 1, dtype=torch.int32, device=dev)   # bit pattern = uint32
+        seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
         f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int])
         scratch = A.workspace(f_scr(m, k, slice_shift))
-        total = c_i64(0)
+        blob_bytes = c_i64(0)
         f_cnt = fn('be_scatter_plan_count', c_int,
-                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
-        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, A.ptr(seg_ptr), A.ptr(scratch),
-                    scratch.numel(), ctypes.byref(total), st), 'be_scatter_plan_count')
-        total = int(total.value)
-        idx16 = torch.empty(max(total, 4), dtype=torch.int16, device=dev)
-        w32 = None if homo else torch.empty(max(total, 4), dtype=torch.float32, device=dev)
+                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
+        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, int(homo), A.ptr(seg),
+                    A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
+        blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
         maxabs = torch.zeros(1, dtype=torch.int32, device=dev)
         f_fill = fn('be_scatter_plan_fill', c_int,
-                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp])
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp])
         check(f_fill(A.ptr(weights), int(homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, m, k,
-                     slice_shift, A.ptr(seg_ptr), total, A.ptr(idx16), A.ptr(w32), A.ptr(maxabs), st),
-              'be_scatter_plan_fill')
+                     slice_shift, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
         scale_exp = 0
         if not homo:
             bits = int(maxabs.item()) & 0xFFFFFFFF
@@ -132,7 +126,7 @@ class ScatterPlan:
             e = math.frexp(wmax)[1] if wmax > 0 else 0
             scale_exp = 62 - e - max(1, int(math.ceil(math.log2(m + 1))))
             scale_exp = max(-90, min(150, scale_exp))   # 2^(scale_exp-32) must be a normal f32
-        return cls(m, k, homo, slice_shift, seg_ptr, idx16, w32, total, scale_exp, weights.dtype)
+        return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype)
 
 
 def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor, sd: int, out_bm: torch.Tensor,
@@ -144,11 +138,10 @@ def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor
         parts = max(1, min(parts, 512 // (plan.n_slices * nb)))
     ws = plan.workspace(parts, nb)
     f = fn('be_binary_csrmm_t_plan', c_int,
-           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64,
-            c_vp])
-    check(f(A.ptr(weights), int(plan.homo), A.wcode(out_bm), A.ptr(plan.idx16), A.ptr(plan.w32), A.ptr(plan.seg_ptr),
-            A.ptr(spikes_bm), sd, A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, parts, plan.scale_exp, A.ptr(ws),
-            ws.numel(), A.stream_ptr()), 'be_binary_csrmm_t_plan')
+           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp])
+    check(f(A.ptr(weights), int(plan.homo), A.wcode(out_bm), A.ptr(plan.blob), A.ptr(plan.seg), A.ptr(spikes_bm), sd,
+            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, parts, plan.scale_exp, A.ptr(ws), ws.numel(),
+            A.stream_ptr()), 'be_binary_csrmm_t_plan')
 
 
 # =====================================================================================================

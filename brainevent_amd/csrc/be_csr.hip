@@ -183,12 +183,26 @@ __global__ void __launch_bounds__(256) k_csrmv_nt(const W* __restrict__ weights,
 
 // =================================================================================================
 // scatter plan: count -> scan -> fill
+//
+// Layout ("post-sliced row segments", row-major): for row r and output slice s the entries of row r whose
+// column falls in slice s form one *block*, 128-byte aligned, stored as
+//     [ f32 weight x 4*n4 ][ uint16 local column x 4*n4 ]        (hetero;  homo: the uint16 part only)
+// where n4 = ceil(count / 4) and pads are (local column = 2^slice_shift, weight = 0).
+// seg[r * n_slices + s] = { start of the block in 128-B units, n4 }.
+// Row-major order keeps the 60-odd blocks of one active row within one ~64 KB window (they are read at about
+// the same time by the workgroups of all slices), and 128-B alignment makes a block of b bytes cost
+// ceil(b / 128) cache lines instead of ~b/128 + 1.5.
 // =================================================================================================
 constexpr int kMaxSlices = 4096;   // LDS histogram capacity of the plan kernels
 
-// one workgroup per row (grid-stride): per-slice histogram of the row, rounded up to multiples of 4
+__host__ __device__ __forceinline__ uint32_t plan_block_units(uint32_t n4, bool homo) {
+  const uint32_t bytes = n4 * (homo ? 8u : 24u);
+  return (bytes + 127u) >> 7;
+}
+
+// one workgroup per row (grid-stride): per-slice histogram of the row -> seg[r][s] = { block units, n4 }
 __global__ void __launch_bounds__(256) k_plan_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
-                                                    int slice_shift, int n_slices, uint32_t* __restrict__ cnt4) {
+                                                    int slice_shift, int n_slices, int homo, uint2* __restrict__ seg) {
   __shared__ uint32_t hist[kMaxSlices];
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) hist[s] = 0;
@@ -196,21 +210,24 @@ __global__ void __launch_bounds__(256) k_plan_count(const int32_t* __restrict__ 
     const int64_t b = rp.at(r), e = rp.at(r + 1);
     for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[((uint32_t)indices[j]) >> slice_shift], 1u);
     __syncthreads();
-    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) cnt4[(int64_t)s * m + r] = (hist[s] + 3u) >> 2;
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
+      const uint32_t n4 = (hist[s] + 3u) >> 2;
+      seg[r * n_slices + s] = make_uint2(plan_block_units(n4, homo != 0), n4);
+    }
     __syncthreads();
   }
 }
 
-// three-pass exclusive scan of a uint32 array (sums carried in uint64 so overflow is detectable)
+// three-pass exclusive scan of the .x fields of a uint2 array (sums carried in uint64: overflow is detectable)
 constexpr int kScanChunk = 2048;   // elements per workgroup of 256 threads (8 each)
 
-__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t* __restrict__ a, int64_t n, uint64_t* __restrict__ sums) {
+__global__ void __launch_bounds__(256) k_scan_block_sums(const uint2* __restrict__ a, int64_t n, uint64_t* __restrict__ sums) {
   __shared__ uint64_t red[256];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk;
   uint64_t s = 0;
   for (int i = threadIdx.x; i < kScanChunk; i += 256) {
     const int64_t j = base + i;
-    if (j < n) s += a[j];
+    if (j < n) s += a[j].x;
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -247,14 +264,14 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint64_t* __restrict__ sums,
   if (threadIdx.x == 0) sums[n_blocks] = carry;
 }
 
-__global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ a, int64_t n, const uint64_t* __restrict__ sums) {
+__global__ void __launch_bounds__(256) k_scan_apply(uint2* __restrict__ a, int64_t n, const uint64_t* __restrict__ sums) {
   __shared__ uint32_t tsum[256];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
   uint32_t v[8];
   uint32_t s = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    v[i] = (base + i < n) ? a[base + i] : 0u;
+    v[i] = (base + i < n) ? a[base + i].x : 0u;
     s += v[i];
   }
   tsum[threadIdx.x] = s;
@@ -269,26 +286,27 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ a, in
   uint32_t run = (uint32_t)sums[blockIdx.x] + tsum[threadIdx.x] - s;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if (base + i < n) a[base + i] = run;
+    if (base + i < n) a[base + i].x = run;
     run += v[i];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a[n] = (uint32_t)sums[gridDim.x];
 }
 
-// one workgroup per row (grid-stride): place every entry of the row into its (slice, row) segment
+// one workgroup per row (grid-stride): place every entry of the row into its block, then write the pads
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
-                                                   int64_t m, int slice_shift, int n_slices,
-                                                   const uint32_t* __restrict__ seg_ptr, uint16_t* __restrict__ idx16,
-                                                   float* __restrict__ w32, uint32_t* __restrict__ maxabs_bits) {
+                                                   int64_t m, int slice_shift, int n_slices, const uint2* __restrict__ seg,
+                                                   unsigned char* __restrict__ blob, uint32_t* __restrict__ maxabs_bits) {
   __shared__ uint32_t cur[kMaxSlices];
-  __shared__ uint32_t seg_base[kMaxSlices];
+  __shared__ uint32_t seg_start[kMaxSlices];
+  __shared__ uint32_t seg_n4[kMaxSlices];
   const uint32_t mask = (1u << slice_shift) - 1u;
   uint32_t my_max = 0;
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
+      const uint2 sg = seg[r * n_slices + s];
       cur[s] = 0;
-      seg_base[s] = seg_ptr[(int64_t)s * m + r];
+      seg_start[s] = sg.x;
+      seg_n4[s] = sg.y;
     }
     __syncthreads();
     const int64_t b = rp.at(r), e = rp.at(r + 1);
@@ -296,13 +314,28 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
       const uint32_t c = (uint32_t)indices[j];
       const uint32_t s = c >> slice_shift;
       const uint32_t rank = atomicAdd(&cur[s], 1u);
-      const int64_t pos = (int64_t)seg_base[s] * 4 + rank;
-      idx16[pos] = (uint16_t)(c & mask);
-      if (!HOMO) {
+      unsigned char* blk = blob + ((int64_t)seg_start[s] << 7);
+      if (HOMO) {
+        reinterpret_cast<uint16_t*>(blk)[rank] = (uint16_t)(c & mask);
+      } else {
         const float w = (float)WTraits<W>::load(weights, j);
-        w32[pos] = w;
+        reinterpret_cast<float*>(blk)[rank] = w;
+        reinterpret_cast<uint16_t*>(blk + (size_t)seg_n4[s] * 16)[rank] = (uint16_t)(c & mask);
         const uint32_t ab = __float_as_uint(w) & 0x7fffffffu;
         my_max = ab > my_max ? ab : my_max;
+      }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {   // pads: dummy slot, zero weight
+      unsigned char* blk = blob + ((int64_t)seg_start[s] << 7);
+      const uint32_t n = seg_n4[s] * 4;
+      for (uint32_t i = cur[s]; i < n; ++i) {
+        if (HOMO) {
+          reinterpret_cast<uint16_t*>(blk)[i] = (uint16_t)(1u << slice_shift);
+        } else {
+          reinterpret_cast<float*>(blk)[i] = 0.f;
+          reinterpret_cast<uint16_t*>(blk + (size_t)seg_n4[s] * 16)[i] = (uint16_t)(1u << slice_shift);
+        }
       }
     }
     __syncthreads();
@@ -316,15 +349,6 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
     }
     if (lane_id() == 0 && my_max != 0) atomicMax(maxabs_bits, my_max);
   }
-}
-
-__global__ void __launch_bounds__(256) k_fill_u16(uint16_t* __restrict__ p, int64_t n, uint16_t v) {
-  // n is a multiple of 4 and p is 8-byte aligned: store 4 entries at a time
-  const uint32_t vv = (uint32_t)v | ((uint32_t)v << 16);
-  uint2* p4 = reinterpret_cast<uint2*>(p);
-  const int64_t n4 = n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p4[i] = make_uint2(vv, vv);
 }
 
 // =================================================================================================
@@ -372,40 +396,43 @@ typedef unsigned be_v4u __attribute__((ext_vector_type(4)));
 constexpr int kBufFlags = 0x00020000;   // raw buffer, 32-bit data format (guide T8)
 
 struct SegGroup {
-  uint32_t base[4], len[4];
+  uint32_t start[4], n4[4];   // block start (128-B units), number of 4-entry groups
   be_v2u iv[4];
   be_v4u wv[4];
 };
 
 template <bool HOMO>
-__device__ __forceinline__ void seg_issue(SegGroup& g, int i, int nvalid, uint32_t b4, uint32_t e4, int lane,
-                                          const uint2* __restrict__ idx4, const float4* __restrict__ w4) {
+__device__ __forceinline__ void seg_issue(SegGroup& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
+                                          const unsigned char* __restrict__ blob) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int src = (i + q) & 63;
-    g.base[q] = __builtin_amdgcn_readlane(b4, src);
-    g.len[q] = (i + q < nvalid) ? (__builtin_amdgcn_readlane(e4, src) - g.base[q]) : 0u;
+    g.start[q] = __builtin_amdgcn_readlane(st_v, src);
+    g.n4[q] = (i + q < nvalid) ? __builtin_amdgcn_readlane(n4_v, src) : 0u;
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    // a descriptor addresses < 4 GiB: segments longer than 2^26 units are clamped here and
-    // finished by the tail loop of seg_consume through plain global loads
-    const uint32_t l = g.len[q] < (1u << 26) ? g.len[q] : (1u << 26);
-    auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(idx4 + g.base[q]), 0, (int)(l * 8u), kBufFlags);
-    g.iv[q] = __builtin_amdgcn_raw_buffer_load_b64(ri, lane * 8, 0, 0);
-    if (!HOMO) {
-      auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(w4 + g.base[q]), 0, (int)(l * 16u), kBufFlags);
+    // a descriptor addresses < 4 GiB: longer segments are clamped here and finished by the tail loop
+    const uint32_t l = g.n4[q] < (1u << 26) ? g.n4[q] : (1u << 26);
+    unsigned char* blk = const_cast<unsigned char*>(blob) + ((uint64_t)g.start[q] << 7);
+    if (HOMO) {
+      auto ri = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(l * 8u), kBufFlags);
+      g.iv[q] = __builtin_amdgcn_raw_buffer_load_b64(ri, lane * 8, 0, 0);
+    } else {
+      auto rw = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(l * 16u), kBufFlags);
       g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, 0);
+      auto ri = __builtin_amdgcn_make_buffer_rsrc(blk + (uint64_t)g.n4[q] * 16u, 0, (int)(l * 8u), kBufFlags);
+      g.iv[q] = __builtin_amdgcn_raw_buffer_load_b64(ri, lane * 8, 0, 0);
     }
   }
 }
 
 template <bool HOMO>
 __device__ __forceinline__ void seg_consume(const SegGroup& g, typename PlanAcc<HOMO>::type* acc, int lane, float scale,
-                                            const uint2* __restrict__ idx4, const float4* __restrict__ w4) {
+                                            const unsigned char* __restrict__ blob) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if ((uint32_t)lane < g.len[q]) {
+    if ((uint32_t)lane < g.n4[q]) {
       const uint2 iv = make_uint2(g.iv[q].x, g.iv[q].y);
       float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!HOMO) wv = make_float4(__uint_as_float(g.wv[q].x), __uint_as_float(g.wv[q].y), __uint_as_float(g.wv[q].z),
@@ -414,29 +441,33 @@ __device__ __forceinline__ void seg_consume(const SegGroup& g, typename PlanAcc<
     }
   }
   // long segments (> 256 entries): remaining chunks, wave-uniform guard
-  if ((g.len[0] | g.len[1] | g.len[2] | g.len[3]) > 64u) {
+  if ((g.n4[0] | g.n4[1] | g.n4[2] | g.n4[3]) > 64u) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      for (uint32_t o = 64 + lane; o < g.len[q]; o += 64) {
-        const uint2 ivt = idx4[(uint64_t)g.base[q] + o];
+      const unsigned char* blk = blob + ((uint64_t)g.start[q] << 7);
+      const uint2* ip = reinterpret_cast<const uint2*>(HOMO ? blk : blk + (uint64_t)g.n4[q] * 16u);
+      const float4* wp = reinterpret_cast<const float4*>(blk);
+      for (uint32_t o = 64 + lane; o < g.n4[q]; o += 64) {
+        const uint2 ivt = ip[o];
         float4 wvt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!HOMO) wvt = w4[(uint64_t)g.base[q] + o];
+        if (!HOMO) wvt = wp[o];
         plan_add4<HOMO>(acc, ivt, wvt, scale);
       }
     }
   }
 }
 
-// grid = n_slices * parts workgroups of 1024 threads; workgroup (slice, part) owns 2^slice_shift (+1 pad)
-// accumulators in LDS and walks the active rows at list positions part, part+parts, ...
-// Memory-level parallelism is what this kernel lives on (one workgroup per CU, 16 waves): every wave
-// keeps two groups of 4 segments in flight (register double buffer) and prefetches the segment
+// Workgroup -> (part, slice).  Blocks b and b + 8 share an XCD (round-robin dispatch, a speed assumption only):
+// block b handles linear task L = (b % 8) * (gridDim.x / 8) + b / 8 with part = L / n_slices, slice = L % n_slices,
+// so the workgroups of one XCD work on the same part (same active rows) and neighbouring slices: the rows'
+// segment-pointer lines (n_slices x 8 B per row, contiguous) are fetched into that XCD's L2 once.
+// gridDim.x is a multiple of 8; tasks L >= n_slices * parts are idle.
+// Each wave keeps two groups of 4 segments in flight (register double buffer) and prefetches the segment
 // pointers of its next 64 rows and the row ids of the 64 after those.
 template <bool HOMO>
-__global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restrict__ idx4, const float4* __restrict__ w4,
-                                                          const uint32_t* __restrict__ seg_ptr,
+__global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                           const uint32_t* __restrict__ active,
-                                                          const uint32_t* __restrict__ n_active_p, int64_t m,
+                                                          const uint32_t* __restrict__ n_active_p, int n_slices,
                                                           int slice_shift, int parts, float scale,
                                                           typename PlanAcc<HOMO>::type* __restrict__ partial,
                                                           int64_t active_stride) {
@@ -444,10 +475,14 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   const int S = 1 << slice_shift;
-  const int slice = blockIdx.x / parts;
-  const int part = blockIdx.x - slice * parts;
+  const int per_xcd = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int n_tasks = n_slices * parts;
+  if (L >= n_tasks) return;
+  const int part = L / n_slices;
+  const int slice = L - part * n_slices;
   active += (int64_t)blockIdx.y * active_stride;
-  partial += (int64_t)blockIdx.y * gridDim.x * S;
+  partial += ((int64_t)blockIdx.y * n_tasks + L) * S;
   {
     uint4* z = reinterpret_cast<uint4*>(smem_raw);
     const int n16 = (int)(((size_t)(S + 1) * sizeof(acc_t) + 15) / 16);
@@ -456,7 +491,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
   __syncthreads();
 
   const uint32_t n_active = n_active_p[blockIdx.y];
-  const uint32_t* sp = seg_ptr + (int64_t)slice * m;
+  const uint2* sp = seg + slice;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   // list position of this lane's row in batch b of this wave
   const uint64_t a0 = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
@@ -470,9 +505,8 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
     bool v_n = a < n_active;
     uint32_t r_n = active[a < last ? a : last];
     a += a_step;
-    uint32_t b4 = sp[r_n], e4 = sp[r_n + 1];
-    b4 = v_n ? b4 : 0u;
-    e4 = v_n ? e4 : 0u;
+    uint2 sg = sp[(uint64_t)r_n * n_slices];
+    uint32_t st_v = sg.x, n4_v = v_n ? sg.y : 0u;
     bool v_c = v_n;
     v_n = a < n_active;
     r_n = active[a < last ? a : last];
@@ -481,21 +515,21 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
     while (__ballot(v_c) != 0ull) {
       const int nvalid = __popcll(__ballot(v_c));   // valid lanes form a prefix: a grows with the lane
       // issue next batch's bounds and the batch-after-next's row ids before touching this batch's data
-      uint32_t b4n = sp[r_n], e4n = sp[r_n + 1];
+      const uint2 sgn = sp[(uint64_t)r_n * n_slices];
       const bool v_nn = a < n_active;
       const uint32_t r_nn = active[a < last ? a : last];
       a += a_step;
 
       SegGroup gA, gB;
-      seg_issue<HOMO>(gA, 0, nvalid, b4, e4, lane, idx4, w4);
+      seg_issue<HOMO>(gA, 0, nvalid, st_v, n4_v, lane, blob);
       for (int i = 0; i < nvalid; i += 8) {
-        seg_issue<HOMO>(gB, i + 4, nvalid, b4, e4, lane, idx4, w4);
-        seg_consume<HOMO>(gA, acc, lane, scale, idx4, w4);
-        seg_issue<HOMO>(gA, i + 8, nvalid, b4, e4, lane, idx4, w4);
-        seg_consume<HOMO>(gB, acc, lane, scale, idx4, w4);
+        seg_issue<HOMO>(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
+        seg_consume<HOMO>(gA, acc, lane, scale, blob);
+        seg_issue<HOMO>(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
+        seg_consume<HOMO>(gB, acc, lane, scale, blob);
       }
-      b4 = v_n ? b4n : 0u;
-      e4 = v_n ? e4n : 0u;
+      st_v = sgn.x;
+      n4_v = v_n ? sgn.y : 0u;
       v_c = v_n;
       v_n = v_nn;
       r_n = r_nn;
@@ -505,16 +539,16 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const uint2* __restric
   {
     // S * sizeof(acc_t) is a multiple of 16 (slice_shift >= 4)
     const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
-    uint4* dst = reinterpret_cast<uint4*>(partial + (int64_t)blockIdx.x * S);
+    uint4* dst = reinterpret_cast<uint4*>(partial);
     const int n16 = (int)((size_t)S * sizeof(acc_t) / 16);
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
   }
 }
 
-// out[j] = sum over the parts of slice(j)
+// out[j] = sum over the parts of slice(j); partial is [batch][part][slice][S]
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO>::type* __restrict__ partial, int parts,
-                                                     int slice_shift, int64_t k, double inv_scale,
+                                                     int n_slices, int slice_shift, int64_t k, double inv_scale,
                                                      const W* __restrict__ weights, W* __restrict__ out, int64_t partial_stride) {
   partial += (int64_t)blockIdx.y * partial_stride;
   out += (int64_t)blockIdx.y * k;
@@ -522,17 +556,18 @@ __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO
   const int S = 1 << slice_shift;
   typename WTraits<W>::acc w0 = 0;
   if (HOMO) w0 = WTraits<W>::load(weights, 0);
+  const int64_t pstep = (int64_t)n_slices * S;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < k; j += stride) {
     const int64_t slice = j >> slice_shift;
     const int loc = (int)(j & (S - 1));
-    const typename PlanAcc<HOMO>::type* p = partial + (slice * parts) * S + loc;
+    const typename PlanAcc<HOMO>::type* p = partial + slice * S + loc;
     if (HOMO) {
       uint32_t c = 0;
-      for (int q = 0; q < parts; ++q) c += p[(int64_t)q * S];
+      for (int q = 0; q < parts; ++q) c += p[(int64_t)q * pstep];
       WTraits<W>::store(out, j, (typename WTraits<W>::acc)c * w0);
     } else {
       unsigned long long s = 0;
-      for (int q = 0; q < parts; ++q) s += p[(int64_t)q * S];
+      for (int q = 0; q < parts; ++q) s += p[(int64_t)q * pstep];
       WTraits<W>::store_d(out, j, (double)(long long)s * inv_scale);
     }
   }
@@ -765,61 +800,57 @@ int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift) {
 }
 
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
-                          int64_t k, int slice_shift, uint32_t* seg_ptr, void* scratch, int64_t scratch_bytes,
-                          int64_t* total_entries_host, be_stream_t stream) {
+                          int64_t k, int slice_shift, int homo, void* seg, void* scratch, int64_t scratch_bytes,
+                          int64_t* blob_bytes_host, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   const int n_slices = n_slices_of(k, slice_shift);
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
-  BE_REQUIRE(seg_ptr && scratch && total_entries_host, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(seg && scratch && blob_bytes_host, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift), BE_ERR_WORKSPACE, "scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
   const int64_t n = (int64_t)n_slices * m;
-  hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m, slice_shift, n_slices, seg_ptr);
+  uint2* sg = static_cast<uint2*>(seg);
+  hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m, slice_shift, n_slices,
+                     homo, sg);
   BE_LAUNCH_CHECK();
   uint64_t* sums = static_cast<uint64_t*>(scratch);
   const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
   BE_REQUIRE(n_blocks < (1ll << 31), BE_ERR_RANGE, "plan index too large");
-  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, st, seg_ptr, n, sums);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, st, sg, n, sums);
   BE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, n_blocks);
   BE_LAUNCH_CHECK();
-  uint64_t total4 = 0;
-  BE_HIP(hipMemcpyAsync(&total4, sums + n_blocks, 8, hipMemcpyDeviceToHost, st));
+  uint64_t total_units = 0;
+  BE_HIP(hipMemcpyAsync(&total_units, sums + n_blocks, 8, hipMemcpyDeviceToHost, st));
   BE_HIP(hipStreamSynchronize(st));
-  BE_REQUIRE(total4 < (1ull << 32), BE_ERR_RANGE, "matrix too large for a 32-bit segment index");
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_blocks), dim3(256), 0, st, seg_ptr, n, sums);
+  BE_REQUIRE(total_units < (1ull << 32), BE_ERR_RANGE, "matrix too large for a 32-bit block index (512 GiB)");
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_blocks), dim3(256), 0, st, sg, n, sums);
   BE_LAUNCH_CHECK();
-  *total_entries_host = (int64_t)(total4 * 4);
+  *blob_bytes_host = (int64_t)(total_units << 7);
   return BE_OK;
 }
 
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
-                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
-                         const uint32_t* seg_ptr, int64_t total_entries, uint16_t* idx16, float* w32,
-                         uint32_t* maxabs_bits, be_stream_t stream) {
+                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, const void* seg,
+                         void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
-  BE_REQUIRE(total_entries >= 0 && (total_entries & 3) == 0, BE_ERR_INVALID, "total_entries must be a multiple of 4");
-  BE_REQUIRE(seg_ptr && maxabs_bits && (total_entries == 0 || idx16), BE_ERR_INVALID, "null pointer");
-  BE_REQUIRE(homo || total_entries == 0 || (w32 && weights), BE_ERR_INVALID, "hetero plan needs weights and w32");
+  BE_REQUIRE(seg && maxabs_bits && blob, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(homo || weights, BE_ERR_INVALID, "hetero plan needs weights");
   const int n_slices = n_slices_of(k, slice_shift);
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
   BE_HIP(hipMemsetAsync(maxabs_bits, 0, 4, st));
-  if (total_entries == 0) return BE_OK;
-  hipLaunchKernelGGL(k_fill_u16, dim3(grid_for(total_entries / 4, 256, 4096)), dim3(256), 0, st, idx16, total_entries,
-                     (uint16_t)(1u << slice_shift));
-  BE_LAUNCH_CHECK();
-  if (!homo) BE_HIP(hipMemsetAsync(w32, 0, (size_t)total_entries * 4, st));
   const int grid = grid_for(m, 1, 256 * 16);
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_fill<W, HOMO>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),
-                                   indices, rp, m, slice_shift, n_slices, seg_ptr, idx16, w32, maxabs_bits));
+                                   indices, rp, m, slice_shift, n_slices, static_cast<const uint2*>(seg),
+                                   static_cast<unsigned char*>(blob), maxabs_bits));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
@@ -834,16 +865,16 @@ int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_s
   return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, parts, homo);
 }
 
-int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
-                           const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k,
-                           int64_t n_batch, int slice_shift, int parts, int scale_exp, void* workspace,
-                           int64_t workspace_bytes, be_stream_t stream) {
+int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
+                           const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int64_t n_batch,
+                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
   BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(parts >= 1 && parts <= 64, BE_ERR_INVALID, "parts must be in [1, 64]");
-  BE_REQUIRE(seg_ptr && spikes && out && idx16, BE_ERR_INVALID, "null pointer");
-  BE_REQUIRE(homo ? weights != nullptr : w32 != nullptr, BE_ERR_INVALID, "missing weights");
+  BE_REQUIRE(seg && spikes && out && blob, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(!homo || weights != nullptr, BE_ERR_INVALID, "missing weights");
   BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
   const int64_t S = 1ll << slice_shift;
   const size_t lds = ((size_t)(S + 1) * (homo ? 4 : 8) + 15) & ~(size_t)15;
@@ -862,39 +893,38 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const uint
   if (rc != BE_OK) return rc;
   const float scale = ldexpf(1.0f, scale_exp - 32);   // see fixed_from_f32
   const double inv_scale = ldexp(1.0, -scale_exp);
-  const dim3 grid((unsigned)(n_slices * parts), (unsigned)n_batch), block(1024);
+  const int n_tasks = n_slices * parts;
+  const dim3 grid((unsigned)((n_tasks + 7) / 8 * 8), (unsigned)n_batch), block(1024);
   const int prof = be_prof_begin(st);
   if (homo) {
     auto kern = k_plan_accumulate<true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const uint2*>(idx16),
-                       reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
-                       static_cast<uint32_t*>(partial), astride);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
+                       active, count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride);
   } else {
     auto kern = k_plan_accumulate<false>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const uint2*>(idx16),
-                       reinterpret_cast<const float4*>(w32), seg_ptr, active, count, m, slice_shift, parts, scale,
-                       static_cast<unsigned long long*>(partial), astride);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
+                       active, count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
+                       astride);
   }
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   const int rgrid = grid_for(k, 256, n_batch >= 8 ? 256 : 2048);
-  const int64_t pstride = (int64_t)n_slices * parts * S;
+  const int64_t pstride = (int64_t)n_tasks * S;
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid, (unsigned)n_batch), dim3(256), 0, st,
-                                   static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, slice_shift, k,
-                                   inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride));
+                                   static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, n_slices, slice_shift,
+                                   k, inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
-int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
-                           const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k,
-                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
-                           be_stream_t stream) {
-  return be_binary_csrmm_t_plan(weights, homo, wdtype, idx16, w32, seg_ptr, spikes, spike_dtype, out, m, k, 1, slice_shift,
-                                parts, scale_exp, workspace, workspace_bytes, stream);
+int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
+                           const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift, int parts,
+                           int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  return be_binary_csrmm_t_plan(weights, homo, wdtype, blob, seg, spikes, spike_dtype, out, m, k, 1, slice_shift, parts,
+                                scale_exp, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------- per-variant symbols

@@ -107,24 +107,24 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  * (brainevent/_csr/main.py:58-88, brainevent/_csr/hybrid_config.py:298-324): built once per matrix,
  * cached by the CSR object, passed to every call.
  *
- * Layout: output neurons are cut into slices of 2^slice_shift; for slice s and row r the entries of
- * row r whose column falls in slice s are stored contiguously as (uint16 local column, f32 weight),
- * padded to a multiple of 4 entries (pad: local column = 2^slice_shift, weight 0).
- *   seg_ptr[s*m + r] .. seg_ptr[s*m + r + 1]  delimit that segment in units of 4 entries.
+ * Layout: output neurons are cut into slices of 2^slice_shift.  For row r and slice s the entries of row r
+ * whose column falls in slice s form one 128-byte-aligned block inside `blob`:
+ *     [ f32 weight x 4*n4 ][ uint16 local column x 4*n4 ]      (homo: only the uint16 part)
+ * with n4 = ceil(count / 4); pads carry local column 2^slice_shift and weight 0.
+ *     seg[(r * n_slices + s)] = { uint32 block start in 128-B units, uint32 n4 }     (8 bytes per entry)
  *
- *   step 1  be_scatter_plan_count : fills seg_ptr (n_slices*m + 1 uint32) and returns the total number
- *           of stored entries (multiple of 4) in *total_entries_host.  SYNCHRONOUS (it reads the total back).
- *   step 2  caller allocates idx16[total] (uint16) and, for hetero weights, w32[total] (f32).
- *   step 3  be_scatter_plan_fill  : fills idx16 / w32; writes max |w| as f32 bits to *maxabs_bits (device uint32).
+ *   step 1  be_scatter_plan_count : fills seg (m * n_slices entries of 8 B) and returns the size of `blob`
+ *           in *blob_bytes_host.  SYNCHRONOUS (it reads the total back).
+ *   step 2  caller allocates blob (128-byte aligned, blob_bytes + 128).
+ *   step 3  be_scatter_plan_fill  : fills blob; writes max |w| as f32 bits to *maxabs_bits (device uint32).
  * ---------------------------------------------------------------------------------------------- */
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift);
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len,
-                          int64_t m, int64_t k, int slice_shift, uint32_t* seg_ptr, void* scratch,
-                          int64_t scratch_bytes, int64_t* total_entries_host, be_stream_t stream);
+                          int64_t m, int64_t k, int slice_shift, int homo, void* seg, void* scratch,
+                          int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream);
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                          int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
-                         const uint32_t* seg_ptr, int64_t total_entries, uint16_t* idx16, float* w32,
-                         uint32_t* maxabs_bits, be_stream_t stream);
+                         const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream);
 
 /* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
  *   weights : device pointer to weights[0] (homo only; may be NULL for hetero)
@@ -137,14 +137,13 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo);
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int parts,
                                                int homo);
-int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
-                           const uint32_t* seg_ptr, const void* spikes, int spike_dtype, void* out, int64_t m,
-                           int64_t k, int slice_shift, int parts, int scale_exp, void* workspace,
-                           int64_t workspace_bytes, be_stream_t stream);
-int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const uint16_t* idx16, const float* w32,
-                           const uint32_t* seg_ptr, const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m,
-                           int64_t k, int64_t n_batch, int slice_shift, int parts, int scale_exp, void* workspace,
-                           int64_t workspace_bytes, be_stream_t stream);
+int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
+                           const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
+                           int parts, int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
+                           const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m, int64_t k, int64_t n_batch,
+                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * binary_csrmv / binary_csrmm, transpose=False (gather):  out[i] = sum_j w[j] * e(spikes[indices[j]])

@@ -126,7 +126,7 @@ def test_csrmv_plan_matches_oracle(be, oracle, homo, kind, shift, parts):
     if not homo:
         w = rng.normal(0, 1, w.shape).astype(np.float32)   # mixed signs
     plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift)
-    assert plan.total % 4 == 0 and plan.total >= idx.size
+    assert plan.blob.numel() % 128 == 0 and plan.nbytes() > 0
     v = spikes_of(rng, m, 0.2, kind)
     spikes, sd = A.spikes_to_device(v)
     out = torch.empty(k, dtype=torch.float32, device='cuda')
