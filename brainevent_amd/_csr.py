@@ -81,6 +81,7 @@ class ScatterPlan:
         if ws is None:
             f = fn('be_binary_csrmm_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int])
             ws = A.workspace(f(self.m, self.k, n_batch, self.slice_shift, parts, int(self.homo)))
+            ws[:4 * max(n_batch, 64)].zero_()   # spike counters: zero on entry, re-armed by every call
             self._ws = {key: ws}
         return ws
 

@@ -195,8 +195,11 @@ __global__ void __launch_bounds__(256) k_csrmv_nt(const W* __restrict__ weights,
 // =================================================================================================
 constexpr int kMaxSlices = 4096;   // LDS histogram capacity of the plan kernels
 
-__host__ __device__ __forceinline__ uint32_t plan_block_units(uint32_t n4, bool homo) {
-  const uint32_t bytes = n4 * (homo ? 8u : 24u);
+// entries are stored in groups: 4 per group with weights (8 B of columns + 16 B of weights per lane),
+// 8 per group without (16 B of columns per lane) — one group is what one lane loads
+__host__ __device__ __forceinline__ uint32_t plan_group(bool homo) { return homo ? 8u : 4u; }
+__host__ __device__ __forceinline__ uint32_t plan_block_units(uint32_t n_groups, bool homo) {
+  const uint32_t bytes = n_groups * (homo ? 16u : 24u);
   return (bytes + 127u) >> 7;
 }
 
@@ -211,7 +214,8 @@ __global__ void __launch_bounds__(256) k_plan_count(const int32_t* __restrict__ 
     for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[((uint32_t)indices[j]) >> slice_shift], 1u);
     __syncthreads();
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
-      const uint32_t n4 = (hist[s] + 3u) >> 2;
+      const uint32_t gsz = plan_group(homo != 0);
+      const uint32_t n4 = (hist[s] + gsz - 1u) / gsz;
       seg[r * n_slices + s] = make_uint2(plan_block_units(n4, homo != 0), n4);
     }
     __syncthreads();
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
     __syncthreads();
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {   // pads: dummy slot, zero weight
       unsigned char* blk = blob + ((int64_t)seg_start[s] << 7);
-      const uint32_t n = seg_n4[s] * 4;
+      const uint32_t n = seg_n4[s] * plan_group(HOMO);
       for (uint32_t i = cur[s]; i < n; ++i) {
         if (HOMO) {
           reinterpret_cast<uint16_t*>(blk)[i] = (uint16_t)(1u << slice_shift);
@@ -386,7 +390,14 @@ __device__ __forceinline__ void plan_add4(typename PlanAcc<HOMO>::type* acc, uin
   }
 }
 
-// One group = up to 4 row segments whose first 64x4 entries are in flight together.
+__device__ __forceinline__ void plan_count8(uint32_t* acc, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  atomicAdd(&acc[a & 0xffffu], 1u); atomicAdd(&acc[a >> 16], 1u);
+  atomicAdd(&acc[b & 0xffffu], 1u); atomicAdd(&acc[b >> 16], 1u);
+  atomicAdd(&acc[c & 0xffffu], 1u); atomicAdd(&acc[c >> 16], 1u);
+  atomicAdd(&acc[d & 0xffffu], 1u); atomicAdd(&acc[d >> 16], 1u);
+}
+
+// One group = up to 4 row segments whose first 64 lane-groups are in flight together.
 // Loads go through raw buffer descriptors built per segment from wave-uniform (base, length): lanes
 // past the end of a segment are range-checked by the hardware (no traffic, zeros returned), so the
 // loads need no exec-mask branches and hipcc can keep *counted* vmcnt waits — with conditional
@@ -415,9 +426,9 @@ __device__ __forceinline__ void seg_issue(SegGroup& g, int i, int nvalid, uint32
     // a descriptor addresses < 4 GiB: longer segments are clamped here and finished by the tail loop
     const uint32_t l = g.n4[q] < (1u << 26) ? g.n4[q] : (1u << 26);
     unsigned char* blk = const_cast<unsigned char*>(blob) + ((uint64_t)g.start[q] << 7);
-    if (HOMO) {
-      auto ri = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(l * 8u), kBufFlags);
-      g.iv[q] = __builtin_amdgcn_raw_buffer_load_b64(ri, lane * 8, 0, 0);
+    if (HOMO) {   // 8 uint16 columns per lane; they travel in the wv registers
+      auto ri = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(l * 16u), kBufFlags);
+      g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, 0, 0);
     } else {
       auto rw = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(l * 16u), kBufFlags);
       g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, 0);
@@ -433,11 +444,14 @@ __device__ __forceinline__ void seg_consume(const SegGroup& g, typename PlanAcc<
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if ((uint32_t)lane < g.n4[q]) {
-      const uint2 iv = make_uint2(g.iv[q].x, g.iv[q].y);
-      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!HOMO) wv = make_float4(__uint_as_float(g.wv[q].x), __uint_as_float(g.wv[q].y), __uint_as_float(g.wv[q].z),
-                                  __uint_as_float(g.wv[q].w));
-      plan_add4<HOMO>(acc, iv, wv, scale);
+      if (HOMO) {
+        plan_count8(reinterpret_cast<uint32_t*>(acc), g.wv[q].x, g.wv[q].y, g.wv[q].z, g.wv[q].w);
+      } else {
+        const uint2 iv = make_uint2(g.iv[q].x, g.iv[q].y);
+        const float4 wv = make_float4(__uint_as_float(g.wv[q].x), __uint_as_float(g.wv[q].y), __uint_as_float(g.wv[q].z),
+                                      __uint_as_float(g.wv[q].w));
+        plan_add4<HOMO>(acc, iv, wv, scale);
+      }
     }
   }
   // long segments (> 256 entries): remaining chunks, wave-uniform guard
@@ -445,13 +459,15 @@ __device__ __forceinline__ void seg_consume(const SegGroup& g, typename PlanAcc<
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned char* blk = blob + ((uint64_t)g.start[q] << 7);
-      const uint2* ip = reinterpret_cast<const uint2*>(HOMO ? blk : blk + (uint64_t)g.n4[q] * 16u);
-      const float4* wp = reinterpret_cast<const float4*>(blk);
       for (uint32_t o = 64 + lane; o < g.n4[q]; o += 64) {
-        const uint2 ivt = ip[o];
-        float4 wvt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!HOMO) wvt = wp[o];
-        plan_add4<HOMO>(acc, ivt, wvt, scale);
+        if (HOMO) {
+          const uint4 c = reinterpret_cast<const uint4*>(blk)[o];
+          plan_count8(reinterpret_cast<uint32_t*>(acc), c.x, c.y, c.z, c.w);
+        } else {
+          const uint2 ivt = reinterpret_cast<const uint2*>(blk + (uint64_t)g.n4[q] * 16u)[o];
+          const float4 wvt = reinterpret_cast<const float4*>(blk)[o];
+          plan_add4<HOMO>(acc, ivt, wvt, scale);
+        }
       }
     }
   }
@@ -549,7 +565,9 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO>::type* __restrict__ partial, int parts,
                                                      int n_slices, int slice_shift, int64_t k, double inv_scale,
-                                                     const W* __restrict__ weights, W* __restrict__ out, int64_t partial_stride) {
+                                                     const W* __restrict__ weights, W* __restrict__ out, int64_t partial_stride,
+                                                     uint32_t* __restrict__ count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) count[blockIdx.y] = 0u;   // re-arm the spike counter for the next call
   partial += (int64_t)blockIdx.y * partial_stride;
   out += (int64_t)blockIdx.y * k;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -599,8 +617,8 @@ inline int64_t direct_ws_bytes(int64_t m, int64_t k, int wdtype, int64_t nb) {
 
 template <typename SP>
 int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, int64_t active_stride, uint32_t* count,
-                   hipStream_t st) {
-  BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
+                   hipStream_t st, bool zero_first) {
+  if (zero_first) BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
   if (n == 0 || nb == 0) return BE_OK;
   const int64_t tiles = (n + 256 * kCompactPerThread - 1) / (256 * kCompactPerThread);
   hipLaunchKernelGGL(k_compact_spikes<SP>, dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
@@ -610,9 +628,9 @@ int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, 
 }
 
 int compact_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* active, int64_t active_stride,
-                uint32_t* count, hipStream_t st) {
-  if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, nb, active, active_stride, count, st);
-  if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, nb, active, active_stride, count, st);
+                uint32_t* count, hipStream_t st, bool zero_first = true) {
+  if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, nb, active, active_stride, count, st, zero_first);
+  if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, nb, active, active_stride, count, st, zero_first);
   be_set_error("unknown spike dtype");
   return BE_ERR_INVALID;
 }
@@ -889,7 +907,9 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const int64_t astride = active_stride_of(m);
   void* partial = wsb + counts_bytes(n_batch) + n_batch * astride * 4;
   const int n_slices = n_slices_of(k, slice_shift);
-  int rc = compact_any(spikes, spike_dtype, m, n_batch, active, astride, count, st);
+  // the per-batch counters at the head of the workspace are zero on entry (caller contract) and are zeroed
+  // again by k_plan_reduce once the accumulate kernel has consumed them: saves a 5 us memset node per step
+  int rc = compact_any(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false);
   if (rc != BE_OK) return rc;
   const float scale = ldexpf(1.0f, scale_exp - 32);   // see fixed_from_f32
   const double inv_scale = ldexp(1.0, -scale_exp);
@@ -915,7 +935,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid, (unsigned)n_batch), dim3(256), 0, st,
                                    static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, n_slices, slice_shift,
-                                   k, inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride));
+                                   k, inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride, count));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }

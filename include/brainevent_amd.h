@@ -109,9 +109,10 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *
  * Layout: output neurons are cut into slices of 2^slice_shift.  For row r and slice s the entries of row r
  * whose column falls in slice s form one 128-byte-aligned block inside `blob`:
- *     [ f32 weight x 4*n4 ][ uint16 local column x 4*n4 ]      (homo: only the uint16 part)
- * with n4 = ceil(count / 4); pads carry local column 2^slice_shift and weight 0.
- *     seg[(r * n_slices + s)] = { uint32 block start in 128-B units, uint32 n4 }     (8 bytes per entry)
+ *     hetero: [ f32 weight x 4*ng ][ uint16 local column x 4*ng ]   with ng = ceil(count / 4) lane groups
+ *     homo  : [ uint16 local column x 8*ng ]                          with ng = ceil(count / 8)
+ * pads carry local column 2^slice_shift (a dummy accumulator) and weight 0.
+ *     seg[(r * n_slices + s)] = { uint32 block start in 128-B units, uint32 ng }     (8 bytes per entry)
  *
  *   step 1  be_scatter_plan_count : fills seg (m * n_slices entries of 8 B) and returns the size of `blob`
  *           in *blob_bytes_host.  SYNCHRONOUS (it reads the total back).
@@ -132,7 +133,9 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
  *               weight is accumulated as round(w * 2^scale_exp) in a 64-bit integer (order independent,
  *               bitwise reproducible); |w|max * 2^scale_exp * m must stay below 2^62.
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
- *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, parts, homo) bytes
+ *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, parts, homo) bytes.
+ *               Its first 4 * n_batch bytes (the spike counters) must be ZERO on entry; they are zero again when the
+ *               call has completed, so a workspace zero-filled once can be reused for every step.
  */
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo);
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int parts,
