@@ -331,7 +331,8 @@ inline int64_t dense_ws_bytes(int64_t rows_w, int64_t cols_w, int64_t nb, int tr
   b += 256;                                                              // counts
   if (transpose) {
     const int64_t acc = (wdtype == BE_F64) ? 8 : 4;
-    b += be_align_up((int64_t)16 * nb * cols_w * acc, 256);              // partial (<= 16 parts)
+    const int64_t rows_p = nb < 32 ? 32 : nb;                            // the MFMA path keeps 32 batch rows per part
+    b += be_align_up((int64_t)16 * rows_p * cols_w * acc, 256);          // partial (<= 16 parts)
   }
   return b;
 }
@@ -445,6 +446,209 @@ int densemm_nt_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
   return BE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA path (f16 / bf16 weights, transpose=True, batched):  out[b, n] = sum_k S[b, k] * W[k, n]
+//
+//   v_mfma_f32_32x32x16_{f16,bf16}:  M = 32 batch rows, N = 32 weight columns, K = 16 weight rows per step.
+//   K runs over the *union list* of rows that carry a spike in any batch row (rows without spikes are never
+//   read); A (the 0/1 spike tile) is rebuilt in registers from the 16 row masks of the step; B (the weight
+//   tile) is loaded row-major with 16-B loads, staged in LDS with a 64-B row pad, and read back through
+//   ds_read_b64_tr_b16 — the hardware transpose read — which is conflict-free at that pad
+//   (row stride 576 B = 144 dwords = 16 mod 64 banks; the two 16-column groups of a half-wave sit 8 banks apart).
+//   Workgroup = 4 waves = 256 columns x one K range; each wave owns 64 columns (two 32x32 accumulators).
+//   K is split over gridDim.y parts; f32 partials are reduced in fixed order.
+// NOTE: 0 * inf = NaN inside an MFMA, so a non-finite weight in an active row reaches every batch row;
+//       the vector path (which only ever adds selected rows) is used when that matters (n_batch < 8).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 be_v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 be_v8bf __attribute__((ext_vector_type(8)));
+typedef short be_v8s __attribute__((ext_vector_type(8)));
+typedef short be_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+typedef float be_v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kMfmaCols = 256;                       // columns per workgroup
+constexpr int kMfmaRowBytes = kMfmaCols * 2 + 64;    // LDS row stride (padded)
+constexpr int kMfmaTileBytes = 16 * kMfmaRowBytes;   // one K-step tile
+
+template <typename W> struct MfmaOne;
+template <> struct MfmaOne<__half> { static constexpr uint32_t one = 0x3C00u; };
+template <> struct MfmaOne<__hip_bfloat16> { static constexpr uint32_t one = 0x3F80u; };
+
+template <typename W>
+__device__ __forceinline__ be_v16f mfma_32x32x16(be_v8s a, be_v8s b, be_v16f c) {
+  if (std::is_same<W, __half>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(be_v8h, a), __builtin_bit_cast(be_v8h, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(be_v8bf, a), __builtin_bit_cast(be_v8bf, b), c, 0, 0, 0);
+}
+
+constexpr int kMfmaChunk = 64;   // K-steps whose row ids / masks are staged in LDS at a time
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. every global
+// load in flight — which would serialise the register ring of the MFMA kernel to one HBM round trip per step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weights, int64_t n,
+                                                      const uint32_t* __restrict__ mask, const uint32_t* __restrict__ ulist,
+                                                      const uint32_t* __restrict__ ucount, float* __restrict__ partial) {
+  __shared__ __align__(16) unsigned char tile[2][kMfmaTileBytes];
+  constexpr int D = 4;     // K-steps of weight rows in flight per thread (register ring); even
+  // D extra all-zero steps behind every chunk: the ring runs past the chunk end without any branch
+  __shared__ uint32_t rows_s[(kMfmaChunk + D) * 16];
+  __shared__ uint32_t masks_s[(kMfmaChunk + D) * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t col0 = (int64_t)blockIdx.x * kMfmaCols;
+  const uint32_t n_union = ucount[0];
+  const uint32_t steps_total = (n_union + 15u) >> 4;
+  const uint32_t per_part = (steps_total + gridDim.y - 1) / gridDim.y;
+  const uint32_t t_begin = blockIdx.y * per_part;
+  const uint32_t t_end = t_begin + per_part < steps_total ? t_begin + per_part : steps_total;
+
+  // staging role: thread loads 16-B chunk `ch` of tile rows `r0` and `r0 + 8`.  Loads are unconditional
+  // (clamped address, result zeroed by a select) so that hipcc keeps counted vmcnt waits across the ring.
+  const int ch = tid & 31, r0 = tid >> 5;
+  const bool col_ok = col0 + (int64_t)ch * 8 < n;     // n % 8 == 0: a chunk is all-in or all-out
+  const W* wcol = weights + (col_ok ? col0 + (int64_t)ch * 8 : 0);
+
+  // MFMA role
+  const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pq = gi & 3;
+  const int b_row = lane & 31, h = lane >> 5;
+  const int tr_off = ((grp >> 1) * 8 + q) * kMfmaRowBytes + (wave * 64 + (grp & 1) * 16 + 4 * pq) * 2;
+
+  be_v16f acc0 = {}, acc1 = {};
+  uint4 ra[D], rb[D];
+  uint32_t rk[D];
+
+  for (uint32_t c0 = t_begin; c0 < t_end; c0 += kMfmaChunk) {
+    const uint32_t c_end = c0 + kMfmaChunk < t_end ? c0 + kMfmaChunk : t_end;
+    __syncthreads();                                   // previous chunk fully consumed
+    for (int j = tid; j < (kMfmaChunk + D) * 16; j += 256) {
+      const uint32_t i = c0 * 16u + j;
+      const bool v = i < n_union && (c0 + (j >> 4)) < c_end;
+      const uint32_t rid = v ? (ulist[i] & 0x0fffffffu) : 0u;
+      rows_s[j] = rid;
+      masks_s[j] = v ? mask[rid] : 0u;               // mask 0 => the row contributes nothing
+    }
+    __syncthreads();
+
+    // fetch only issues the loads (nothing may consume a loaded register here, or the wait lands right
+    // behind the load); padded rows / columns are turned into exact zeros when the slot is stashed
+    auto fetch = [&](uint32_t t, uint4& a, uint4& b, uint32_t& ok) {     // steps past c_end are zero steps
+      const uint32_t s = (t - c0) < (uint32_t)(kMfmaChunk + D - 1) ? (t - c0) : (uint32_t)(kMfmaChunk + D - 1);
+      a = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[s * 16 + r0] * n);
+      b = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[s * 16 + r0 + 8] * n);
+      ok = (col_ok && masks_s[s * 16 + r0] != 0u ? 1u : 0u) | (col_ok && masks_s[s * 16 + r0 + 8] != 0u ? 2u : 0u);
+    };
+    auto stash = [&](int buf, const uint4& a, const uint4& b, uint32_t ok) {        // registers -> LDS
+      *reinterpret_cast<uint4*>(&tile[buf][r0 * kMfmaRowBytes + ch * 16]) = (ok & 1u) ? a : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(&tile[buf][(r0 + 8) * kMfmaRowBytes + ch * 16]) = (ok & 2u) ? b : make_uint4(0, 0, 0, 0);
+    };
+
+    // prologue: step c0 -> LDS[0]; steps c0+1 .. c0+D -> ring slots 1 .. D-1, 0
+    fetch(c0, ra[0], rb[0], rk[0]);
+    stash(0, ra[0], rb[0], rk[0]);
+#pragma unroll
+    for (int s = 1; s <= D; ++s) fetch(c0 + s, ra[s % D], rb[s % D], rk[s % D]);
+    lds_barrier();
+    for (uint32_t t0 = c0; t0 < c_end; t0 += D) {
+#pragma unroll
+      for (int ii = 0; ii < D; ++ii) {
+        const uint32_t t = t0 + ii;
+        {                     // no branch here: steps in [c_end, c_end + D) multiply zeros (see rows_s / masks_s)
+          const int buf = ii & 1;            // D is even and chunks start at ring position 0
+          const uint32_t* mk = &masks_s[(t - c0) * 16 + 8 * h];
+          // A operand: element j of this lane = spike bit of batch row b_row at tile row 8h + j
+          be_v8s a;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] = (short)(((mk[j] >> b_row) & 1u) * MfmaOne<W>::one);
+          // B operands through the hardware transpose read (all 64 lanes active here: EXEC is full)
+          const unsigned char* tb = &tile[buf][0] + tr_off;
+          typedef __attribute__((address_space(3))) be_v4s* lds_v4s;
+          const be_v4s b0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb));
+          const be_v4s b0hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 4 * kMfmaRowBytes));
+          const be_v4s b1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 64));
+          const be_v4s b1hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 64 + 4 * kMfmaRowBytes));
+          const be_v8s b0 = {b0lo[0], b0lo[1], b0lo[2], b0lo[3], b0hi[0], b0hi[1], b0hi[2], b0hi[3]};
+          const be_v8s b1 = {b1lo[0], b1lo[1], b1lo[2], b1lo[3], b1hi[0], b1hi[1], b1hi[2], b1hi[3]};
+          acc0 = mfma_32x32x16<W>(a, b0, acc0);
+          acc1 = mfma_32x32x16<W>(a, b1, acc1);
+          // next step's rows go to the other LDS buffer; their ring slot is refilled D steps ahead
+          stash(buf ^ 1, ra[(ii + 1) % D], rb[(ii + 1) % D], rk[(ii + 1) % D]);
+          fetch(t + 1 + D, ra[(ii + 1) % D], rb[(ii + 1) % D], rk[(ii + 1) % D]);
+          lds_barrier();
+        }
+      }
+    }
+  }
+  // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* pbase = partial + (int64_t)blockIdx.y * 32 * n;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int64_t c0 = col0 + wave * 64 + (lane & 31);
+    if (c0 < n) pbase[(int64_t)row * n + c0] = acc0[r];
+    if (c0 + 32 < n) pbase[(int64_t)row * n + c0 + 32] = acc1[r];
+  }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_mfma_reduce(const float* __restrict__ partial, int parts, int64_t part_stride,
+                                                     int64_t total, W* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * part_stride + i];
+    WTraits<W>::store(out, i, s);
+  }
+}
+
+inline int mfma_parts(int64_t n) {
+  const int64_t tiles = (n + kMfmaCols - 1) / kMfmaCols;
+  int64_t p = 1536 / (tiles > 0 ? tiles : 1);
+  return (int)(p < 1 ? 1 : (p > 16 ? 16 : p));
+}
+
+template <typename W>
+int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t k, int64_t n, int64_t nb, void* ws,
+                   hipStream_t st) {
+  DenseWs d = carve(ws, k);
+  float* partial = static_cast<float*>(d.partial);     // sized for 16 * nb * n floats >= parts * 32 * n when nb >= 8 ... see ws
+  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
+  const int64_t nt = n_tiles_of(k);
+  uint32_t* flag = d.lists;
+  uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;
+  uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
+  const int parts = mfma_parts(n);
+  const int prof = be_prof_begin(st);
+  for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
+    const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    if (sd == BE_SPIKE_FLOAT)
+      hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const float*>(chunk), k, nc, d.mask);
+    else
+      hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const uint8_t*>(chunk), k, nc, d.mask);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_union_flags, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st, d.mask, k, flag);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gl_count, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile, ulist, k);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_densemm_mfma<W>, dim3((unsigned)((n + kMfmaCols - 1) / kMfmaCols), parts), dim3(256), 0, st, weights,
+                       n, d.mask, ulist, d.count + kMaxGroups, partial);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mfma_reduce<W>, dim3(grid_cap((int64_t)nc * n, 256, 2048)), dim3(256), 0, st, partial, parts,
+                       (int64_t)32 * n, (int64_t)nc * n, out_bm + b0 * n);
+    BE_LAUNCH_CHECK();
+  }
+  be_prof_end(prof, st);
+  return BE_OK;
+}
+
 template <typename W>
 int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm, int64_t rows_w, int64_t cols_w,
                 int64_t nb, int transpose, void* ws, hipStream_t st) {
@@ -453,6 +657,9 @@ int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm
   constexpr int V = Vec16<W>::n;
   const bool vec_ok = (cols_w % V == 0) && ((reinterpret_cast<uintptr_t>(weights) & 15) == 0);
   if (transpose) {
+    if constexpr (std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value) {
+      if (vec_ok && nb >= 8) return densemm_t_mfma<W>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+    }
     if (vec_ok) return densemm_t_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
     return densemm_t_vec<W, 1>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
   }
