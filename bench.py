@@ -212,9 +212,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, all-gather, max-reduce) with a single rank:
+    # the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     import brainevent_amd as be
@@ -246,26 +252,26 @@ def main():
     g.manual_seed(999 + rank)
     n_local = n_pre // world
     local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
-    full = torch.empty(n_pre, dtype=torch.bool, device=dev)
-    if world > 1:
+    if use_dist:
+        from brainevent_amd._dist import SpikeExchange
+        exchange = SpikeExchange(n_pre, packed=False, device=dev)     # one all-gather per step (RCCL over xGMI)
+        assert exchange.hi - exchange.lo == n_local, 'n must be divisible by the number of GPUs'
         counts = torch.empty(n_batch, dtype=torch.int64, device=dev)
         for b in range(n_batch):
-            dist.all_gather_into_tensor(full.view(torch.uint8), local_spikes[b].view(torch.uint8))
-            counts[b] = full.sum()
+            counts[b] = exchange.gather(local_spikes[b]).sum()
         active_per_vec = counts.cpu().numpy()
     else:
         active_per_vec = local_spikes.sum(dim=1).cpu().numpy()
 
     def step(i):
         s = local_spikes[i % n_batch]
-        if world > 1:
-            dist.all_gather_into_tensor(full.view(torch.uint8), s.view(torch.uint8))
-            s = full
+        if use_dist:
+            s = exchange.gather(s)
         return be.BinaryArray(s) @ csr
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -285,7 +291,7 @@ def main():
     prof_enable(0)
     kern_ms = float(np.mean(ms[:n_rec])) if n_rec > 0 else None
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -336,7 +342,7 @@ def main():
             except Exception as e:   # the CPU leg must never sink the GPU number
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

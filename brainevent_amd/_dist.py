@@ -101,7 +101,12 @@ class SpikeExchange:
     def gather(self, local_spikes: torch.Tensor) -> torch.Tensor:
         """``local_spikes``: bool / uint8 ``[hi - lo]`` of this rank -> bool ``[n_pre]`` on every rank."""
         assert local_spikes.numel() == self.hi - self.lo
-        payload = _pack_bits(local_spikes != 0) if self.packed else (local_spikes != 0).to(torch.uint8)
+        if self.packed:
+            payload = _pack_bits(local_spikes != 0)
+        elif local_spikes.dtype == torch.bool:
+            payload = local_spikes.view(torch.uint8)            # zero-copy: bool storage is one 0/1 byte per spike
+        else:
+            payload = (local_spikes != 0).to(torch.uint8)
         if self.uniform:
             self.dist.all_gather_into_tensor(self._full, payload.contiguous(), group=self.group)
             if not self.packed:

@@ -45,3 +45,36 @@ def csrmv_f32(w, indices, indptr, v, shape, transpose):
     f.restype = None
     f(_p(w), int(w.size == 1), _p(indices), _p(indptr), _p(v), is_float, m, k, _p(out))
     return out
+
+
+def densemv_f32(w, s, transpose):
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    s = np.ascontiguousarray(s)
+    is_float = int(s.dtype == np.float32)
+    if not is_float:
+        s = s.astype(np.uint8)
+    out = np.empty(w.shape[1] if transpose else w.shape[0], dtype=np.float32)
+    f = lib().oracle_densemv_f32
+    f.argtypes = [_vp, _i64, _i64, _vp, _int, _int, _vp]
+    f.restype = None
+    f(_p(w), w.shape[0], w.shape[1], _p(s), is_float, int(transpose), _p(out))
+    return out
+
+
+def jitmv(mode, w0, w1, prob, vector, seed, *, shape, transpose, corder, stride=32):
+    """binary_jit{s,u,n}mv in C: mode 's' | 'u' | 'n'; w1 = high for 'u' (span formed here), scale for 'n'."""
+    import math
+    v = np.asarray(vector)
+    act = np.ascontiguousarray(((v != 0) if v.dtype.kind in 'biu' else (v > 0)).astype(np.uint8))
+    in_len = shape[0] if transpose else shape[1]
+    out_len = shape[1] if transpose else shape[0]
+    clen = 0 if float(prob) == 0.0 else max(2, int(math.ceil(2.0 / float(prob))))
+    m = {'s': 0, 'u': 1, 'n': 2}[mode]
+    a = np.float32(w0)
+    b = np.float32(np.float32(w1) - np.float32(w0)) if mode == 'u' else np.float32(w1)
+    out = np.empty(out_len, dtype=np.float64)
+    f = lib().oracle_jitmv
+    f.argtypes = [_int, ctypes.c_float, ctypes.c_float, _i64, ctypes.c_uint32, _vp, _i64, _i64, _i64, _int, _int, _vp]
+    f.restype = None
+    f(m, a, b, clen, int(seed) & 0xFFFFFFFF, _p(act), int(shape[1]), in_len, out_len, int(bool(corder)), int(stride), _p(out))
+    return out

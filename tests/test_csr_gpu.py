@@ -178,3 +178,24 @@ def test_csr_class_uses_plan_and_matches(be, oracle, monkeypatch):
     np.testing.assert_allclose(csc @ be.BinaryArray(v), ref, rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(be.BinaryArray(v2) @ csc, oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v2, (m, k), False),
                                rtol=RTOL, atol=ATOL)
+
+
+def test_coba_4k_plumbing_config(be, oracle):
+    """BASELINE.json configs[0] (COBA_2005: 4000 neurons = 3200 E + 800 I, 80 synapses per neuron, weights 0.6 / 6.7,
+    examples/COBA_2005.py:38-58): both projections through CSR + `@` for a few time steps against the oracle."""
+    rng = np.random.default_rng(2005)
+    n, n_exc, n_conn = 4000, 3200, 80
+    def proj(n_pre, w):
+        indptr = (np.arange(n_pre + 1) * n_conn).astype(np.int32)
+        indices = rng.integers(0, n, n_pre * n_conn).astype(np.int32)
+        return be.CSR((np.asarray([w], np.float32), indices, indptr), shape=(n_pre, n)), indices, indptr
+    exc, ei, ep = proj(n_exc, 0.6)
+    inh, ii, ip = proj(n - n_exc, 6.7)
+    for step in range(5):
+        spk = rng.random(n) < 0.05
+        ge = be.BinaryArray(spk[:n_exc]) @ exc
+        gi = be.BinaryArray(spk[n_exc:]) @ inh
+        np.testing.assert_allclose(ge, oracle.binary_csrmv(np.asarray([0.6], np.float32), ei, ep, spk[:n_exc], (n_exc, n), True),
+                                   rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gi, oracle.binary_csrmv(np.asarray([6.7], np.float32), ii, ip, spk[n_exc:], (n - n_exc, n), True),
+                                   rtol=1e-5, atol=1e-5)

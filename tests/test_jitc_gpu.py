@@ -160,3 +160,26 @@ def test_jit_f64_and_f16_outputs(be, oracle):
     got16 = be.binary_jitumv(np.float16(0.25), np.float16(0.75), prob, v, seed, shape=shape, transpose=False, corder=True)
     assert got16.dtype == np.float16
     np.testing.assert_allclose(got16.astype(np.float64), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+@pytest.mark.parametrize('corder', [True, False])
+def test_jitmv_mid_size_matches_c_oracle(be, family, corder):
+    """Mid-size parity (many chunks per residue class, several workgroups) against the C restatement of the walk."""
+    from oracle import oracle_c
+    shape, prob, seed = (3000, 5003), 0.02, 77
+    rng = np.random.default_rng(8)
+    for transpose in (False, True):
+        in_len = shape[0] if transpose else shape[1]
+        v = spikes_of(rng, in_len, 0.1, 'bool')
+        params = {'s': (0.5, 0.0), 'u': (0.1, 0.9), 'n': (0.2, 1.3)}[family]
+        ref = oracle_c.jitmv(family, *params, prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+        if family == 's':
+            got = be.binary_jitsmv(np.float32(0.5), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+            np.testing.assert_array_equal(got, ref.astype(np.float32))
+        elif family == 'u':
+            got = be.binary_jitumv(np.float32(0.1), np.float32(0.9), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+        else:
+            got = be.binary_jitnmv(np.float32(0.2), np.float32(1.3), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)

@@ -115,3 +115,23 @@ def test_c_oracle_known_answers():
         got = oracle_c.csrmv_f32(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['indptr']), v,
                                  tuple(k['shape']), k['transpose'])
         np.testing.assert_array_equal(got, np.array(k['expect'], np.float32))
+
+
+def test_c_oracle_jit_and_dense_match_numpy_oracle():
+    rng = np.random.default_rng(5)
+    for mode, (w0, w1) in {'s': (0.5, 0.0), 'u': (0.1, 0.9), 'n': (0.2, 1.3)}.items():
+        for transpose in (False, True):
+            for corder in (False, True):
+                for stride in (32, 4):
+                    shape, prob, seed = (19, 37), 0.25, 11
+                    v = rng.random(shape[0] if transpose else shape[1]) < 0.5
+                    a = oracle_c.jitmv(mode, w0, w1, prob, v, seed, shape=shape, transpose=transpose, corder=corder, stride=stride)
+                    f = O.binary_jitmv if stride == 32 else (lambda *args, **kw: O.binary_jitmm(args[0], args[1], args[2], args[3],
+                                                                                               np.asarray(args[4])[:, None], args[5], **kw)[:, 0])
+                    b = f(mode, np.float32(w0), np.float32(w1), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+                    tol = 1e-5 if mode == 'n' else 0.0      # logf (libm) vs numpy log differ by ULPs in the tails
+                    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+    W = rng.normal(size=(11, 13)).astype(np.float32)
+    for transpose in (True, False):
+        s = rng.random(11 if transpose else 13) < 0.5
+        np.testing.assert_allclose(oracle_c.densemv_f32(W, s, transpose), O.binary_densemv(W, s, transpose), rtol=1e-6, atol=1e-6)
