@@ -170,7 +170,8 @@ def secondary(args):
         value = upd / elapsed / 1e9
         metric = 'synaptic updates/sec (Geff/s), BinaryArray @ FixedNumPerPre scatter'
         cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} N={n} {'homo' if args.homo else 'hetero'} f32, 1 GPU",
-               'route': 'plan' if conn.buffers.get('scatter_plan') is not None else 'direct (global atomics)'}
+               'route': type(conn.buffers.get('scatter_plan')).__name__ if conn.buffers.get('scatter_plan') is not None
+               else 'direct (global atomics)'}
         if kern_ms:
             alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n
             roof = {'bound': 'hbm', 'achieved': round(alg / (kern_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

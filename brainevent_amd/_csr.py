@@ -30,7 +30,7 @@ from ._lib import check, fn
 from ._misc import _as_indptr, _as_int32_indices, _check_compressed_structure
 from ._op import OpKernel
 
-__all__ = ['CSR', 'CSC', 'ScatterPlan', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p', 'binary_csrmm_p',
+__all__ = ['CSR', 'CSC', 'ScatterPlan', 'BinnedScatter', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p', 'binary_csrmm_p',
            'binary_csrmv_p_call', 'binary_csrmm_p_call']
 
 c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
@@ -130,6 +130,51 @@ class ScatterPlan:
         return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype)
 
 
+class BinnedScatter:
+    """Workspace of the *binned* scatter route: no per-matrix layout, only per-slice bins that are refilled every call
+    (``be_binary_csrmv_t_binned``).  Used when a matrix is large but a :class:`ScatterPlan` does not pay — fewer than
+    ``PLAN_MIN_SEGMENT`` entries per (row, slice), e.g. ``FixedNumPerPre`` with K = 1000 over 10M outputs.
+
+    ``bin_capacity`` (entries per slice bin) is a tuning knob: bins that overflow are delivered through global atomics
+    (correct, slower).  It is sized for ``max_active_fraction`` of the rows firing in one step.
+    """
+
+    def __init__(self, weights: torch.Tensor, m: int, k: int, nnz: int, *, max_active_fraction: float = 0.05,
+                 slice_shift: Optional[int] = None):
+        self.m, self.k = int(m), int(k)
+        self.homo = weights.numel() == 1
+        self.slice_shift = ScatterPlan.default_shift(k, self.homo) if slice_shift is None else int(slice_shift)
+        self.n_slices = (self.k + (1 << self.slice_shift) - 1) >> self.slice_shift
+        expect = max_active_fraction * nnz / max(self.n_slices, 1)
+        self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
+        self.scale_exp = 0
+        if not self.homo:
+            wmax = float(weights.abs().max().item())
+            if not math.isfinite(wmax):
+                raise MathError("BinnedScatter: weights contain inf/nan; use the direct route (workspace=None).")
+            e = math.frexp(wmax)[1] if wmax > 0 else 0
+            self.scale_exp = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(m + 1))))))
+        f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
+        self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))
+
+    @staticmethod
+    def applicable(weights: torch.Tensor, k: int) -> bool:
+        if weights.dtype != torch.float32:
+            return False
+        shift = ScatterPlan.default_shift(k, weights.numel() == 1)
+        return ((k + (1 << shift) - 1) >> shift) <= 2048
+
+
+def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes, sd, out) -> None:
+    f = fn('be_binary_csrmv_t_binned', c_int,
+           [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp, c_i64,
+            c_vp])
+    is64 = int(indptr is not None and indptr.dtype == torch.int64)
+    check(f(A.ptr(weights), int(ws.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes), sd,
+            A.ptr(out), ws.m, ws.k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(),
+            A.stream_ptr()), 'be_binary_csrmv_t_binned')
+
+
 def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor, sd: int, out_bm: torch.Tensor,
                parts: Optional[int] = None) -> None:
     """Planned scatter for a batch: ``spikes_bm`` is ``[n_batch, m]`` (or ``[m]``), ``out_bm`` ``[n_batch, k]``."""
@@ -171,6 +216,10 @@ def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, w
         if isinstance(workspace, ScatterPlan):
             assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
             _plan_call(workspace, weights, spikes_bm, sd, out)
+            return out
+        if isinstance(workspace, BinnedScatter) and nb == 1:
+            assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
+            _binned_call(workspace, weights, indices, indptr, -1, spikes_bm, sd, out)
             return out
         f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
         ws = A.workspace(f_ws(m, k, nb, A.wcode(weights)))
@@ -382,6 +431,8 @@ class CompressedSparseData:
             if self.nse / (m * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096 and \
                     self.data.dtype != torch.float64:
                 plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
+            elif BinnedScatter.applicable(self.data, k):
+                plan = BinnedScatter(self.data, m, k, self.nse)
         self.buffers['scatter_plan'] = plan
         return plan
 

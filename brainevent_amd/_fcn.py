@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _array as A
-from ._csr import ScatterPlan, _plan_call, PLAN_MIN_SEGMENT
+from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, PLAN_MIN_SEGMENT
 from . import _csr as _csr_mod
 from ._event import BinaryArray
 from ._lib import check, fn
@@ -54,6 +54,9 @@ def _fcn_batched(weights, indices, spikes_bm, sd, *, shape, transpose, workspace
     if transpose:
         if isinstance(workspace, ScatterPlan):
             _plan_call(workspace, weights, spikes_bm, sd, out)
+            return out
+        if isinstance(workspace, BinnedScatter) and nb == 1:
+            _binned_call(workspace, weights, indices, None, n_conn, spikes_bm, sd, out)
             return out
         f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
         ws = A.workspace(f_ws(n_rows, n_cols, nb, A.wcode(weights)))
@@ -199,7 +202,7 @@ class FixedNumConn:
     ndim = property(lambda self: 2)
 
     # -- per-matrix workspace -----------------------------------------------------------------------
-    def _scatter_workspace(self) -> Optional[ScatterPlan]:
+    def _scatter_workspace(self):
         if 'scatter_plan' in self.buffers:
             return self.buffers['scatter_plan']
         n_rows, n_cols = self._a_shape
@@ -211,6 +214,8 @@ class FixedNumConn:
             if self.num_conn / n_slices >= PLAN_MIN_SEGMENT and n_slices <= 4096:
                 plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols), row_len=self.num_conn,
                                          slice_shift=shift)
+            elif BinnedScatter.applicable(self.data, n_cols):
+                plan = BinnedScatter(self.data, n_rows, n_cols, self.nse)
         self.buffers['scatter_plan'] = plan
         return plan
 

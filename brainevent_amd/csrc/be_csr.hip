@@ -726,6 +726,227 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
 
 inline bool check_rows(const void* indptr, int64_t row_len) { return indptr != nullptr || row_len >= 0; }
 
+// =================================================================================================
+// binned route: event-driven scatter for matrices WITHOUT a plan (or whose rows put too few entries into
+// one output slice for the plan to pay: FixedNumPerPre K=1000 over 10M outputs has 1.6 entries per (row, slice)).
+//
+//   pass B (k_bin_rows)   : persistent workgroups take active rows round-robin, fill an LDS batch of <= kBinBatch
+//                           entries, counting-sort it by output slice ("bin") in LDS, reserve one range per
+//                           (workgroup, bin) in that bin's global region (one returning atomic each) and copy the
+//                           runs out coalesced as (uint16 local column, f32 weight).
+//   pass C (k_bin_accumulate): one workgroup per (bin, part) streams the bin and accumulates in LDS with integer
+//                           atomics exactly like the planned route, then adds its slice to the output.
+//   A bin region that overflows its capacity never corrupts anything: that run is delivered with global float
+//   atomics instead (slow path, still correct).
+// HBM traffic per update (hetero): 8 B read (pass B) + 6 B write + 6 B read = 20 B  vs  8 B algorithmic.
+// =================================================================================================
+constexpr int kBinBatch = 12288;     // entries per LDS batch (6 B each = 72 KiB)
+constexpr int kMaxBins = 2048;       // 4 x 4 B x 2048 = 32 KiB of LDS bookkeeping
+
+template <typename W, bool HOMO>
+__global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
+                                                   const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
+                                                   int slice_shift, int n_bins, uint32_t cap, uint32_t* __restrict__ bin_cursor,
+                                                   uint32_t* __restrict__ bin_valid, uint16_t* __restrict__ bin_idx,
+                                                   float* __restrict__ bin_w, float* __restrict__ out) {
+  __shared__ uint32_t hist[kMaxBins], offs[kMaxBins], fill[kMaxBins], gpos[kMaxBins];
+  __shared__ uint16_t s_idx[kBinBatch];
+  __shared__ float s_w[HOMO ? 1 : kBinBatch];
+  __shared__ uint32_t s_rows[1024];       // batch: row id
+  __shared__ uint32_t s_lens[1024];       //        piece length
+  __shared__ int64_t s_begin[1024];       //        first entry of the piece
+  __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_nrows, s_total;
+  __shared__ uint64_t s_next;             // next list position of this workgroup
+  __shared__ int64_t s_carry_begin;       // unfinished tail of a long row
+  __shared__ uint32_t s_carry_row, s_carry_len;
+
+  const uint32_t n_active = *n_active_p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const uint32_t mask = (1u << slice_shift) - 1u;
+  float w0 = 0.f;
+  if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
+  if (tid == 0) { s_next = blockIdx.x; s_carry_len = 0; }
+  __syncthreads();
+
+  for (;;) {
+    // ---- form a batch: thread t looks at this workgroup's t-th next row (loads in parallel), a block scan of
+    //      the row lengths picks the longest prefix that fits kBinBatch entries; a row longer than a batch is
+    //      processed alone, one batch-sized piece at a time (carry)
+    for (int b = tid; b < n_bins; b += blockDim.x) { hist[b] = 0; fill[b] = 0; }
+    if (s_carry_len) {               // uniform: shared state
+      __syncthreads();
+      if (tid == 0) {
+        const uint32_t take = s_carry_len < (uint32_t)kBinBatch ? s_carry_len : (uint32_t)kBinBatch;
+        s_rows[0] = s_carry_row; s_begin[0] = s_carry_begin; s_lens[0] = take;
+        s_carry_begin += take; s_carry_len -= take;
+        s_nrows = 1; s_total = take;
+      }
+      __syncthreads();
+    } else {
+      const uint64_t a = s_next + (uint64_t)tid * gridDim.x;
+      uint32_t r = 0; int64_t rb = 0; uint64_t len = 0;
+      if (a < n_active) {
+        r = active[a];
+        rb = rp.at(r);
+        len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
+      }
+      const uint32_t len32 = len > 0xfffffffeull ? 0xfffffffeu : (uint32_t)len;
+      // inclusive scan of the (saturating) lengths
+      s_scan[tid] = len32 > (uint32_t)kBinBatch ? (uint32_t)kBinBatch + 1u : len32;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t t = 0;
+        if (tid >= off) t = s_scan[tid - off];
+        __syncthreads();
+        const uint32_t sum = s_scan[tid] + t;
+        s_scan[tid] = sum > (uint32_t)kBinBatch ? (uint32_t)kBinBatch + 1u : sum;   // saturate: no overflow
+        __syncthreads();
+      }
+      const bool in_list = a < n_active;
+      const bool fits = in_list && s_scan[tid] <= (uint32_t)kBinBatch;
+      const int nfit = __syncthreads_count(fits);          // rows 0 .. nfit-1 (a prefix: the scan is monotone)
+      if (fits) { s_rows[tid] = r; s_begin[tid] = rb; s_lens[tid] = len32; }
+      if (tid == 0) {
+        if (nfit > 0) {
+          s_nrows = nfit; s_total = s_scan[nfit - 1];
+          s_next += (uint64_t)nfit * gridDim.x;
+        } else if (in_list) {                               // the first row alone exceeds a batch: start carrying it
+          s_rows[0] = r; s_begin[0] = rb; s_lens[0] = (uint32_t)kBinBatch;
+          s_carry_row = r; s_carry_begin = rb + kBinBatch;
+          s_carry_len = (len - kBinBatch) > 0xffffffffull ? 0xffffffffu : (uint32_t)(len - kBinBatch);
+          s_nrows = 1; s_total = (uint32_t)kBinBatch;
+          s_next += gridDim.x;
+        } else {
+          s_nrows = 0; s_total = 0;
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t nrows = s_nrows;
+    if (nrows == 0) break;
+
+    // ---- phase 1: histogram of the batch over the bins (wave per row piece)
+    for (uint32_t i = wave; i < nrows; i += nw) {
+      const int64_t b = s_begin[i];
+      const uint32_t len = s_lens[i];
+      for (uint32_t j = lane; j < len; j += 64) atomicAdd(&hist[((uint32_t)indices[b + j]) >> slice_shift], 1u);
+    }
+    __syncthreads();
+    // ---- phase 2: exclusive scan of hist (n_bins <= 2048: two per thread) + one range reservation per bin
+    {
+      const uint32_t v0 = (2 * tid < n_bins) ? hist[2 * tid] : 0u, v1 = (2 * tid + 1 < n_bins) ? hist[2 * tid + 1] : 0u;
+      s_scan[tid] = v0 + v1;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t t = 0;
+        if (tid >= off) t = s_scan[tid - off];
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+      }
+      const uint32_t excl = s_scan[tid] - (v0 + v1);
+      if (2 * tid < n_bins) {
+        offs[2 * tid] = excl;
+        gpos[2 * tid] = v0 ? atomicAdd(&bin_cursor[2 * tid], v0) : 0u;
+      }
+      if (2 * tid + 1 < n_bins) {
+        offs[2 * tid + 1] = excl + v0;
+        gpos[2 * tid + 1] = v1 ? atomicAdd(&bin_cursor[2 * tid + 1], v1) : 0u;
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: place the entries into the LDS batch sorted by bin (second read of the rows comes from L2)
+    for (uint32_t i = wave; i < nrows; i += nw) {
+      const int64_t b = s_begin[i];
+      const uint32_t len = s_lens[i];
+      for (uint32_t j = lane; j < len; j += 64) {
+        const uint32_t c = (uint32_t)indices[b + j];
+        const uint32_t bin = c >> slice_shift;
+        const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
+        s_idx[pos] = (uint16_t)(c & mask);
+        if (!HOMO) s_w[pos] = (float)WTraits<W>::load(weights, b + j);
+      }
+    }
+    __syncthreads();
+    // ---- phase 4: copy the runs out, one wave per bin; runs that do not fit go through global atomics
+    for (int bin = wave; bin < n_bins; bin += nw) {
+      const uint32_t cnt = hist[bin];
+      if (cnt == 0) continue;
+      const uint32_t o = offs[bin], g = gpos[bin];
+      if ((uint64_t)g + cnt <= cap) {
+        uint16_t* di = bin_idx + (int64_t)bin * cap + g;
+        float* dw = bin_w + (int64_t)bin * cap + g;
+        for (uint32_t j = lane; j < cnt; j += 64) {
+          di[j] = s_idx[o + j];
+          if (!HOMO) dw[j] = s_w[o + j];
+        }
+      } else {
+        // the bin is full: everything from position g on is NOT in the bin (later reservations start even higher)
+        if (lane == 0) atomicMin(&bin_valid[bin], g);
+        float* dst = out + ((int64_t)bin << slice_shift);
+        for (uint32_t j = lane; j < cnt; j += 64) atomicAdd(dst + s_idx[o + j], HOMO ? w0 : s_w[o + j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <bool HOMO>
+__global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restrict__ bin_idx, const float* __restrict__ bin_w,
+                                                         const uint32_t* __restrict__ bin_cursor,
+                                                         const uint32_t* __restrict__ bin_valid, uint32_t cap, int slice_shift,
+                                                         int parts, int64_t k, float scale, double inv_scale,
+                                                         const float* __restrict__ w0p, float* __restrict__ out) {
+  using acc_t = typename PlanAcc<HOMO>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
+  const int S = 1 << slice_shift;
+  const int bin = blockIdx.x / parts, part = blockIdx.x - bin * parts;
+  uint32_t cnt = bin_cursor[bin];
+  const uint32_t valid = bin_valid[bin];         // first position that was NOT written (cap if the bin never overflowed)
+  cnt = cnt < valid ? cnt : valid;
+  cnt = cnt < cap ? cnt : cap;
+  const float w0 = HOMO ? w0p[0] : 0.f;
+  if (cnt == 0) return;                     // nothing was binned here (out already holds zeros / overflow adds)
+  for (int i = threadIdx.x; i < S; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  // this part's share, in units of 8 entries
+  const uint32_t n8 = (cnt + 7u) >> 3;
+  const uint32_t per = (n8 + parts - 1) / parts;
+  const uint32_t g_begin = part * per, g_end = g_begin + per < n8 ? g_begin + per : n8;
+  const uint16_t* bi = bin_idx + (int64_t)bin * cap;
+  const float* bw = bin_w + (int64_t)bin * cap;
+  for (uint32_t g = g_begin + threadIdx.x; g < g_end; g += blockDim.x) {
+    const uint32_t e0 = g * 8u;
+    if (e0 + 8u <= cnt) {        // cap is a multiple of 8: bin regions are 16-byte aligned
+      const uint4 iv = *reinterpret_cast<const uint4*>(bi + e0);
+      if (HOMO) {
+        plan_count8(reinterpret_cast<uint32_t*>(acc), iv.x, iv.y, iv.z, iv.w);
+      } else {
+        const float4 wa = *reinterpret_cast<const float4*>(bw + e0), wb = *reinterpret_cast<const float4*>(bw + e0 + 4);
+        plan_add4<HOMO>(acc, make_uint2(iv.x, iv.y), wa, scale);
+        plan_add4<HOMO>(acc, make_uint2(iv.z, iv.w), wb, scale);
+      }
+    } else {
+      for (uint32_t e = e0; e < cnt; ++e) {
+        if (HOMO) atomicAdd(reinterpret_cast<uint32_t*>(acc) + bi[e], 1u);
+        else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + bi[e], fixed_from_f32(bw[e], scale));
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t j0 = (int64_t)bin << slice_shift;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    if (j0 + i >= k) break;
+    float v;
+    if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
+    else v = (float)((double)(long long)reinterpret_cast<unsigned long long*>(acc)[i] * inv_scale);
+    if (v != 0.f) atomicAdd(out + j0 + i, v);     // contiguous float atomics; one add per output unless parts > 1
+  }
+}
+
+
 }  // namespace
 
 // =================================================================================================
@@ -945,6 +1166,79 @@ int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void
                            int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   return be_binary_csrmm_t_plan(weights, homo, wdtype, blob, seg, spikes, spike_dtype, out, m, k, 1, slice_shift, parts,
                                 scale_exp, workspace, workspace_bytes, stream);
+}
+
+
+// ---------------------------------------------------------------- binned route (no plan)
+static inline int64_t binned_cap_align(int64_t cap) { return (cap + 7) & ~7ll; }
+
+int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity) {
+  const int64_t n_bins = n_slices_of(k, slice_shift);
+  const int64_t cap = binned_cap_align(bin_capacity);
+  return 256 + be_align_up(m * 4, 256) + 2 * be_align_up(n_bins * 4, 256) + be_align_up(n_bins * cap * 2, 256) +
+         be_align_up(n_bins * cap * 4, 256);
+}
+
+int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                             int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                             int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
+                             int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(wdtype == BE_F32, BE_ERR_UNSUPPORTED, "the binned route supports f32 weights / outputs");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights && indices && spikes && out, BE_ERR_INVALID, "null pointer");
+  const int n_bins = n_slices_of(k, slice_shift);
+  BE_REQUIRE(n_bins <= kMaxBins, BE_ERR_RANGE, "too many bins for the binned route");
+  const int64_t cap = binned_cap_align(bin_capacity);
+  BE_REQUIRE(cap >= 8 && cap < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
+  BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
+  const int64_t S = 1ll << slice_shift;
+  const size_t lds = (size_t)S * (homo ? 4 : 8);
+  BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
+  BE_REQUIRE(workspace != nullptr &&
+                 workspace_bytes >= be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity),
+             BE_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned char* wsb = static_cast<unsigned char*>(workspace);
+  uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(wsb + 256 + be_align_up(m * 4, 256));
+  uint32_t* valid = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cursor) + be_align_up((int64_t)n_bins * 4, 256));
+  uint16_t* bin_idx = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(valid) + be_align_up((int64_t)n_bins * 4, 256));
+  float* bin_w = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_idx) + be_align_up((int64_t)n_bins * cap * 2, 256));
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  BE_HIP(hipMemsetAsync(out, 0, (size_t)k * 4, st));
+  BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_bins * 4, st));
+  BE_HIP(hipMemsetAsync(valid, 0xff, (size_t)n_bins * 4, st));
+  int rc = compact_any(spikes, spike_dtype, m, 1, active, 0, count, st);
+  if (rc != BE_OK) return rc;
+  const int prof = be_prof_begin(st);
+  if (homo)
+    hipLaunchKernelGGL((k_bin_rows<float, true>), dim3(512), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
+                       active, count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
+  else
+    hipLaunchKernelGGL((k_bin_rows<float, false>), dim3(512), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
+                       active, count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
+  BE_LAUNCH_CHECK();
+  int parts = 512 / (n_bins > 0 ? n_bins : 1);
+  parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+  const float scale = ldexpf(1.0f, scale_exp - 32);
+  const double inv_scale = ldexp(1.0, -scale_exp);
+  if (homo) {
+    auto kern = k_bin_accumulate<true>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap,
+                       slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(weights), static_cast<float*>(out));
+  } else {
+    auto kern = k_bin_accumulate<false>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap,
+                       slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(nullptr), static_cast<float*>(out));
+  }
+  be_prof_end(prof, st);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
 }
 
 // ---------------------------------------------------------------- per-variant symbols

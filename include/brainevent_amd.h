@@ -149,6 +149,20 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
                            be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * binned scatter: the event-driven transpose=True product for a matrix WITHOUT a plan (raw CSR / fixed-length rows),
+ * f32 only.  The active rows' entries are counting-sorted by output slice in LDS, written to per-slice bins of
+ * `bin_capacity` entries each, and accumulated per bin in LDS (integer atomics, like the planned route).  A bin that
+ * overflows is delivered through global atomics instead (slower, still correct), so `bin_capacity` is a tuning
+ * parameter, not a correctness one: about 1.5 x expected_active_rows x mean_row_length / n_slices.
+ * Same role as binary_csrmv_wat_hybrid_* (brainevent/_csr/binary_csrmv_hybrid.cu:619-632): no preprocessing.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity);
+int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                             int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out,
+                             int64_t m, int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
+                             int64_t workspace_bytes, be_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * binary_csrmv / binary_csrmm, transpose=False (gather):  out[i] = sum_j w[j] * e(spikes[indices[j]])
  * replaces: binary_csrmv_nt_auto_{homo,hetero}_{…}_{bool,float} (brainevent/_csr/binary_csrmv.cu:437-486),
  *           binary_csrmm_nt_auto_{…} (brainevent/_csr/binary_csrmm.cu:328-392) and, with indptr == NULL,

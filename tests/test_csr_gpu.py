@@ -199,3 +199,65 @@ def test_coba_4k_plumbing_config(be, oracle):
                                    rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(gi, oracle.binary_csrmv(np.asarray([6.7], np.float32), ii, ip, spk[n_exc:], (n - n_exc, n), True),
                                    rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# binned route (no plan): LDS counting sort into per-slice bins, then LDS accumulate
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('kind', ['bool', 'float'])
+@pytest.mark.parametrize('shift,lens', [(6, 'ragged'), (10, 'ragged'), (14, 'fixed'), (8, 'long')])
+def test_csrmv_binned_matches_oracle(be, oracle, homo, kind, shift, lens):
+    from brainevent_amd._csr import BinnedScatter, _binned_call
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(7 + shift)
+    m, k = 3000, 50000
+    if lens == 'ragged':
+        row_lens = rng.integers(0, 200, m); row_lens[::5] = 0
+    elif lens == 'fixed':
+        row_lens = np.full(m, 100)
+    else:
+        row_lens = rng.integers(0, 50, m); row_lens[[3, 1500]] = 40000      # rows longer than one LDS batch (carry)
+    w, idx, ptr = rand_csr(rng, m, k, row_lens, homo=homo)
+    if not homo:
+        w = rng.normal(0, 1, w.shape).astype(np.float32)
+    v = spikes_of(rng, m, 0.3, kind)
+    v[[3, 1500]] = 1 if kind != 'float' else 1.0
+    wd, idd, ptd = A.to_device(w), A.to_device(idx), A.to_device(ptr)
+    spikes, sd = A.spikes_to_device(v)
+    ws = BinnedScatter(wd, m, k, idx.size, max_active_fraction=0.6, slice_shift=shift)
+    out = torch.empty(k, dtype=torch.float32, device='cuda')
+    _binned_call(ws, wd, idd, ptd, -1, spikes, sd, out)
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_csrmv_binned_overflow_falls_back_correctly(be, oracle):
+    """Bins sized far too small: the overflowing runs go through global atomics; the result must still be right."""
+    from brainevent_amd._csr import BinnedScatter, _binned_call
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(3)
+    m, k = 4000, 40000
+    w, idx, ptr = rand_csr(rng, m, k, np.full(m, 150))
+    v = spikes_of(rng, m, 0.5, 'bool')
+    wd, idd, ptd = A.to_device(w), A.to_device(idx), A.to_device(ptr)
+    spikes, sd = A.spikes_to_device(v)
+    ws = BinnedScatter(wd, m, k, idx.size, max_active_fraction=0.001, slice_shift=12)    # ~1/500 of what is needed
+    out = torch.empty(k, dtype=torch.float32, device='cuda')
+    _binned_call(ws, wd, idd, ptd, -1, spikes, sd, out)
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_fixed_num_uses_binned_route_when_rows_are_sparse_per_slice(be, oracle, monkeypatch):
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(12)
+    n_pre, n_post, K = 2000, 200000, 20            # 20 entries per row over 13 slices: < 8 per (row, slice)
+    idx = rng.integers(0, n_post, (n_pre, K)).astype(np.int32)
+    w = rng.uniform(0.1, 1, (n_pre, K)).astype(np.float32)
+    conn = be.FixedNumPerPre((w, idx), shape=(n_pre, n_post))
+    s = spikes_of(rng, n_pre, 0.05, 'bool')
+    got = be.BinaryArray(s) @ conn
+    assert isinstance(conn.buffers['scatter_plan'], C.BinnedScatter)
+    np.testing.assert_allclose(got, oracle.binary_fcnmv(w.astype(np.float64), idx, s, (n_pre, n_post), True), rtol=RTOL, atol=ATOL)
