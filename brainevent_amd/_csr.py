@@ -436,10 +436,58 @@ class CompressedSparseData:
         self.buffers['scatter_plan'] = plan
         return plan
 
-    def prepare(self):
-        """Build the scatter workspace now (otherwise it is built by the first ``spk @ matrix``)."""
+    def prepare(self, mirror: bool = False):
+        """Build the scatter workspace now (otherwise it is built by the first ``spk @ matrix``).
+        ``mirror=True`` also builds the transposed mirror so that the *gather* direction runs event-driven too."""
         self._scatter_workspace()
+        if mirror:
+            self.build_mirror()
         return self
+
+    # -- transposed mirror: makes the unfavourable (gather) direction event-driven -----------------------------
+    def build_mirror(self):
+        """Materialise the transposed structure once (the reference's ``_weight_indices`` / ``csr_to_csc_index`` route,
+        ``brainevent/_csr/main.py:1321-1357``, ``brainevent/_misc.py:1516``) and plan it: afterwards ``CSR @ spk`` /
+        ``spk @ CSC`` scatter over the *active columns* instead of reading the whole matrix.  Costs a second copy of
+        the matrix; built with device sorts (one-off plumbing), so it is limited to matrices whose sort fits in HBM."""
+        if 'mirror' in self.buffers:
+            return self.buffers['mirror']
+        m, k = self._plan_shape()                      # stored structure: m rows, k secondary ids
+        nse = self.nse
+        if nse > (1 << 31):
+            raise MemoryError("build_mirror: the device sort of > 2^31 entries is not supported; "
+                              "the gather kernel is used instead")
+        rows = torch.repeat_interleave(torch.arange(m, dtype=torch.int32, device=self.indices.device),
+                                       (self.indptr[1:] - self.indptr[:-1]).to(torch.int64))
+        order = torch.argsort(self.indices, stable=True)
+        t_indices = rows[order].contiguous()           # secondary ids of the mirror = primary ids here
+        counts = torch.bincount(self.indices.to(torch.int64), minlength=k)
+        t_indptr = torch.zeros(k + 1, dtype=torch.int64, device=self.indices.device)
+        torch.cumsum(counts, 0, out=t_indptr[1:])
+        t_indptr = t_indptr.to(self.indptr.dtype)
+        t_data = self.data if self.data.numel() == 1 else self.data[order].contiguous()
+        mirror = {'data': t_data, 'indices': t_indices, 'indptr': t_indptr, 'shape': (k, m), 'plan': None}
+        homo = t_data.numel() == 1
+        if nse >= PLAN_MIN_NNZ and t_data.dtype != torch.float64:
+            shift = ScatterPlan.default_shift(m, homo)
+            n_slices = (m + (1 << shift) - 1) >> shift
+            if nse / (k * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096:
+                mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift)
+            elif BinnedScatter.applicable(t_data, m):
+                mirror['plan'] = BinnedScatter(t_data, k, m, nse)
+        self.buffers['mirror'] = mirror
+        return mirror
+
+    def _gather_via_mirror(self, v):
+        """Event-driven evaluation of the gather direction through the mirror, or ``None`` if there is no mirror."""
+        mr = self.buffers.get('mirror')
+        if mr is None:
+            return None
+        if v.ndim == 1:
+            return binary_csrmv_p_call(mr['data'], mr['indices'], mr['indptr'], v, mr['plan'], shape=mr['shape'],
+                                       transpose=True, backend=self.backend)[0]
+        return binary_csrmm_p_call(mr['data'], mr['indices'], mr['indptr'], v, mr['plan'], shape=mr['shape'],
+                                   transpose=True, backend=self.backend)[0]
 
     def _res(self, t):
         return A.to_result(t, self._numpy_result)
@@ -456,7 +504,10 @@ class CSR(CompressedSparseData):
     def __matmul__(self, other):      # csr @ other
         if isinstance(other, BinaryArray):
             v = _event_value(other)
-            if v.ndim == 1:
+            r = self._gather_via_mirror(v) if v.ndim in (1, 2) else None
+            if r is not None:
+                pass
+            elif v.ndim == 1:
                 r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, None, shape=self.shape,
                                         transpose=False, backend=self.backend)[0]
             elif v.ndim == 2:
@@ -515,7 +566,14 @@ class CSC(CompressedSparseData):
     def __rmatmul__(self, other):     # other @ csc : gather
         if isinstance(other, BinaryArray):
             v = _event_value(other)
+            r = None
             if v.ndim == 1:
+                r = self._gather_via_mirror(v)
+            elif v.ndim == 2 and 'mirror' in self.buffers:
+                r = self._gather_via_mirror(v.T).T
+            if r is not None:
+                pass
+            elif v.ndim == 1:
                 r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, None, shape=self.shape[::-1],
                                         transpose=False, backend=self.backend)[0]
             elif v.ndim == 2:

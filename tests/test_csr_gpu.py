@@ -261,3 +261,29 @@ def test_fixed_num_uses_binned_route_when_rows_are_sparse_per_slice(be, oracle, 
     got = be.BinaryArray(s) @ conn
     assert isinstance(conn.buffers['scatter_plan'], C.BinnedScatter)
     np.testing.assert_allclose(got, oracle.binary_fcnmv(w.astype(np.float64), idx, s, (n_pre, n_post), True), rtol=RTOL, atol=ATOL)
+
+
+def test_mirror_makes_gather_direction_event_driven(be, oracle, monkeypatch):
+    """with the transposed mirror built, `CSR @ spk` / `spk @ CSC` scatter over the active columns."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(31)
+    m, k = 3000, 2500
+    lens = rng.integers(100, 400, m)
+    w, idx, ptr = rand_csr(rng, m, k, lens)
+    csr = be.CSR((w, idx, ptr), shape=(m, k)).prepare(mirror=True)
+    assert isinstance(csr.buffers['mirror']['plan'], (C.ScatterPlan, C.BinnedScatter))
+    v = spikes_of(rng, k, 0.05, 'bool')
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), False)
+    np.testing.assert_allclose(csr @ be.BinaryArray(v), ref, rtol=RTOL, atol=ATOL)
+    B = np.stack([spikes_of(rng, k, 0.05, 'bool') for _ in range(3)], axis=1)
+    np.testing.assert_allclose(csr @ be.BinaryArray(B), oracle.binary_csrmm(w.astype(np.float64), idx, ptr, B, (m, k), False),
+                               rtol=RTOL, atol=ATOL)
+    csc = be.CSC((w, idx, ptr), shape=(k, m)).prepare(mirror=True)       # same arrays seen as CSC of the transpose
+    np.testing.assert_allclose(be.BinaryArray(v) @ csc, ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(be.BinaryArray(B.T) @ csc, oracle.binary_csrmm(w.astype(np.float64), idx, ptr, B, (m, k), False).T,
+                               rtol=RTOL, atol=ATOL)
+    # the mirror is the exact transpose
+    mr = csr.buffers['mirror']
+    d = np.zeros((k, m)); np.add.at(d, (np.repeat(np.arange(k), np.diff(mr['indptr'].cpu().numpy())), mr['indices'].cpu().numpy()), mr['data'].cpu().numpy())
+    np.testing.assert_allclose(d.T, csr.todense(), rtol=1e-6)
