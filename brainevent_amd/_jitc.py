@@ -363,6 +363,51 @@ class JITCMatrix:
     def _params(self):
         return (*self._weights, self.prob, self.seed)
 
+    # -- materialisation (reference: ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``, ``_jit_scalar/main.py`` mode views) ----
+    def tocsr(self, matrix_mode: str = 'mv'):
+        """Materialise the drawn connectivity on the device.  ``matrix_mode`` picks the matrix of the ``mv`` ops
+        (lane stride 32) or of the ``mm`` ops (stride 4) — they differ, as in the reference.
+
+        The generator matrix has the walk owners as rows; for a logical matrix it is the CSR form when the walk
+        owners are the logical rows and the CSC form otherwise, so this returns a :class:`CSR` or a :class:`CSC`
+        of ``self.shape`` (both multiply identically).  f32 weights.
+        """
+        from ._csr import CSR, CSC
+        if matrix_mode not in ('mv', 'mm'):
+            raise ValueError(f"matrix_mode must be 'mv' or 'mm', got {matrix_mode!r}.")
+        stride = 32 if matrix_mode == 'mv' else 4
+        # orientation of ``M @ v`` for this class (see __matmul__)
+        if self._is_row:
+            gshape, transpose, corder = self.shape, False, self.corder
+        else:
+            gshape, transpose, corder = self.shape[::-1], True, self.corder
+        in_len = gshape[0] if transpose else gshape[1]
+        out_len = gshape[1] if transpose else gshape[0]
+        n_rows, walk = (out_len, in_len) if corder else (in_len, out_len)
+        dev = A.device()
+        clen = _initialize_conn_length(self.prob)
+        w0, w1, _ = _jit_params(self._family, *(self._weights + (None,))[:2])
+        counts = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+        f_cnt = fn('be_jitc_csr_count', c_int, [c_i64, c_u32, c_i64, c_i64, c_i64, c_int, c_vp, c_vp])
+        check(f_cnt(clen, self.seed & 0xFFFFFFFF, int(gshape[1]), n_rows, walk, stride, A.ptr(counts), A.stream_ptr()),
+              'be_jitc_csr_count')
+        indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts[:n_rows].to(torch.int64), 0, out=indptr[1:])
+        nnz = int(indptr[-1].item())
+        indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        mode = _FAMILY[self._family]
+        weights = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev) if mode else None
+        f_fill = fn('be_jitc_csr_fill', c_int, [c_int, c_dbl, c_dbl, c_i64, c_u32, c_i64, c_i64, c_i64, c_int, c_vp, c_vp,
+                                               c_vp, c_vp, c_vp])
+        check(f_fill(mode, w0, w1, clen, self.seed & 0xFFFFFFFF, int(gshape[1]), n_rows, walk, stride, A.ptr(indptr),
+                     A.ptr(counts), A.ptr(indices), A.ptr(weights), A.stream_ptr()), 'be_jitc_csr_fill')
+        data = weights[:nnz] if mode else torch.full((1,), float(w0), dtype=torch.float32, device=dev)
+        # generator rows are the outputs of ``M @ v`` iff corder: then G is M row-wise (CSR), else column-wise (CSC)
+        cls = CSR if corder else CSC
+        out = cls._from_parts(data, indices[:nnz], indptr, shape=self.shape if self._is_row else self.shape,
+                              numpy_result=not any(isinstance(w, torch.Tensor) for w in self._weights))
+        return out
+
     def transpose(self, axes=None):
         assert axes is None, "transpose does not support axes argument."
         return self._transposed_cls(self._params(), shape=self.shape[::-1], corder=not self.corder,

@@ -349,6 +349,79 @@ __global__ void __launch_bounds__(256) k_jit_convert(const A* __restrict__ src, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) WTraits<W>::store_d(dst, i, (double)src[i]);
 }
 
+// ------------------------------------------------------------------------------------------------ materialise
+// Generator matrix -> CSR (rows = walk owners).  One thread per (row, chunk, lane) task: count its edges, then
+// reserve a contiguous range of the row with one atomic and re-walk writing (column [, weight]).
+// Within a row the order of the tasks is unspecified; columns inside one task are increasing.
+__global__ void __launch_bounds__(256) k_jit_csr_count(JitP p, int64_t n_rows, uint32_t* __restrict__ row_counts) {
+  const int64_t tasks_per_row = (int64_t)p.n_chunks * p.stride;
+  const int64_t n_tasks = n_rows * tasks_per_row;
+  const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += stride_t) {
+    const int64_t row = t / tasks_per_row;
+    const int rem = (int)(t - row * tasks_per_row);
+    const int chunk = rem / p.stride;
+    const uint32_t l = (uint32_t)(rem - chunk * p.stride);
+    const int64_t cs = (int64_t)chunk * p.chunk_size;
+    const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+    const int64_t width = ce - cs;
+    uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+    uint32_t q = lr_initial_q(state, p.cl);
+    uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
+    uint32_t cnt = 0;
+    while ((int64_t)lj < width) {
+      ++cnt;
+      state = lr_next(state);
+      q = q + 1u + lr_bounded(state, p.cl - 1u);
+      lj = (uint64_t)l + (uint64_t)p.stride * q;
+    }
+    if (cnt) atomicAdd(&row_counts[row], cnt);
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jit_csr_fill(JitP p, int64_t n_rows, const int64_t* __restrict__ indptr,
+                                                      uint32_t* __restrict__ cursor, int32_t* __restrict__ indices,
+                                                      float* __restrict__ weights) {
+  const int64_t tasks_per_row = (int64_t)p.n_chunks * p.stride;
+  const int64_t n_tasks = n_rows * tasks_per_row;
+  const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += stride_t) {
+    const int64_t row = t / tasks_per_row;
+    const int rem = (int)(t - row * tasks_per_row);
+    const int chunk = rem / p.stride;
+    const uint32_t l = (uint32_t)(rem - chunk * p.stride);
+    const int64_t cs = (int64_t)chunk * p.chunk_size;
+    const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+    const int64_t width = ce - cs;
+    const uint32_t state0 = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+    uint32_t state = state0;
+    const uint32_t q0 = lr_initial_q(state, p.cl);
+    const uint32_t state1 = state;
+    uint32_t q = q0, cnt = 0;
+    uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
+    while ((int64_t)lj < width) {
+      ++cnt;
+      state = lr_next(state);
+      q = q + 1u + lr_bounded(state, p.cl - 1u);
+      lj = (uint64_t)l + (uint64_t)p.stride * q;
+    }
+    if (cnt == 0) continue;
+    int64_t pos = indptr[row] + atomicAdd(&cursor[row], cnt);
+    state = state1; q = q0;
+    lj = (uint64_t)l + (uint64_t)p.stride * q;
+    while ((int64_t)lj < width) {
+      const int64_t j = cs + (int64_t)lj;
+      indices[pos] = (int32_t)j;
+      if (MODE != MODE_SCALAR) weights[pos] = edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)j);
+      ++pos;
+      state = lr_next(state);
+      q = q + 1u + lr_bounded(state, p.cl - 1u);
+      lj = (uint64_t)l + (uint64_t)p.stride * q;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 inline int gcap(int64_t n, int block, int cap) {
   int64_t g = (n + block - 1) / block;
@@ -589,6 +662,47 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
                          static_cast<const float*>(scratch), static_cast<__hip_bfloat16*>(out_bm), n);
     BE_LAUNCH_CHECK();
   }
+  return BE_OK;
+}
+
+
+// ---------------------------------------------------------------- materialisation (generator matrix -> CSR)
+// replaces: brainevent/_jit_scalar/csr.cu count + fill (and the uniform / normal twins).
+// rows = walk owners: n_rows generator rows, walk over walk_len columns; stride 32 (mv matrix) or 4 (mm matrix).
+int be_jitc_csr_count(int64_t clen, uint32_t seed, int64_t shape1, int64_t n_rows, int64_t walk_len, int stride,
+                      uint32_t* row_counts, be_stream_t stream) {
+  BE_REQUIRE(n_rows >= 0 && walk_len >= 0 && shape1 >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(stride == 32 || stride == 4, BE_ERR_INVALID, "stride must be 32 (mv) or 4 (mm)");
+  BE_REQUIRE(n_rows < (1ll << 32) && walk_len < (1ll << 31), BE_ERR_RANGE, "dimensions out of range");
+  if (n_rows == 0) return BE_OK;
+  BE_REQUIRE(row_counts != nullptr, BE_ERR_INVALID, "null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BE_HIP(hipMemsetAsync(row_counts, 0, (size_t)n_rows * 4, st));
+  if (walk_len == 0 || clen <= 0) return BE_OK;
+  const JitP p = make_params(shape1, walk_len, seed, clen, stride, 0, 0);
+  hipLaunchKernelGGL(k_jit_csr_count, dim3(gcap(n_rows * p.n_chunks * stride, 256, 8192)), dim3(256), 0, st, p, n_rows,
+                     row_counts);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+int be_jitc_csr_fill(int mode, double w0, double w1, int64_t clen, uint32_t seed, int64_t shape1, int64_t n_rows,
+                     int64_t walk_len, int stride, const int64_t* indptr, uint32_t* cursor, int32_t* indices,
+                     float* weights, be_stream_t stream) {
+  BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
+  BE_REQUIRE(n_rows >= 0 && walk_len >= 0 && shape1 >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(stride == 32 || stride == 4, BE_ERR_INVALID, "stride must be 32 (mv) or 4 (mm)");
+  BE_REQUIRE(n_rows < (1ll << 32) && walk_len < (1ll << 31), BE_ERR_RANGE, "dimensions out of range");
+  if (n_rows == 0 || walk_len == 0 || clen <= 0) return BE_OK;
+  BE_REQUIRE(indptr && cursor && indices && (mode == MODE_SCALAR || weights), BE_ERR_INVALID, "null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_rows * 4, st));
+  const JitP p = make_params(shape1, walk_len, seed, clen, stride, w0, w1);
+  const dim3 grid(gcap(n_rows * p.n_chunks * stride, 256, 8192));
+  if (mode == MODE_SCALAR) hipLaunchKernelGGL(k_jit_csr_fill<MODE_SCALAR>, grid, dim3(256), 0, st, p, n_rows, indptr, cursor, indices, weights);
+  else if (mode == MODE_UNIFORM) hipLaunchKernelGGL(k_jit_csr_fill<MODE_UNIFORM>, grid, dim3(256), 0, st, p, n_rows, indptr, cursor, indices, weights);
+  else hipLaunchKernelGGL(k_jit_csr_fill<MODE_NORMAL>, grid, dim3(256), 0, st, p, n_rows, indptr, cursor, indices, weights);
+  BE_LAUNCH_CHECK();
   return BE_OK;
 }
 

@@ -223,6 +223,17 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
                     int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,
                     int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream);
 
+/* materialisation of the generator matrix as CSR (rows = walk owners; stride 32 = the mv matrix, 4 = the mm matrix)
+ * replaces: the count + fill kernels of brainevent/_jit_scalar/csr.cu (and the uniform / normal twins).
+ *   count: row_counts[n_rows] (uint32) <- number of generated edges per row
+ *   fill : caller scans the counts into indptr (int64, n_rows + 1) and allocates indices[nnz] (+ weights[nnz] f32 for
+ *          modes 1 / 2); cursor[n_rows] is scratch.  Order inside a row is unspecified. */
+int be_jitc_csr_count(int64_t clen, uint32_t seed, int64_t shape1, int64_t n_rows, int64_t walk_len, int stride,
+                      uint32_t* row_counts, be_stream_t stream);
+int be_jitc_csr_fill(int mode, double w0, double w1, int64_t clen, uint32_t seed, int64_t shape1, int64_t n_rows,
+                     int64_t walk_len, int stride, const int64_t* indptr, uint32_t* cursor, int32_t* indices,
+                     float* weights, be_stream_t stream);
+
 /* named per-family / per-dtype symbols: be_binary_jit{s,u,n}{mv,mm}_{notrans,trans}_{f32,f64,f16,bf16} */
 #define BE_JIT_MV_ARGS double w0, double w1, int64_t clen, uint32_t seed, const void *spikes, int spike_dtype,    \
                        void *out, int64_t shape1, int64_t in_len, int64_t out_len, int scale_exp,                 \

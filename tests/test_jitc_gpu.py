@@ -183,3 +183,46 @@ def test_jitmv_mid_size_matches_c_oracle(be, family, corder):
         else:
             got = be.binary_jitnmv(np.float32(0.2), np.float32(1.3), prob, v, seed, shape=shape, transpose=transpose, corder=corder)
             np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+@pytest.mark.parametrize('cls_kind', ['R', 'C'])
+@pytest.mark.parametrize('corder', [False, True])
+def test_jitc_materialisation_matches_ops_and_oracle(be, oracle, family, cls_kind, corder):
+    """the materialised matrix (CSR or CSC) is the matrix the on-the-fly ops multiply with."""
+    shape, prob, seed = (37, 52), 0.2, 13
+    cls = getattr(be, {'s': 'JITCScalar', 'u': 'JITCUniform', 'n': 'JITCNormal'}[family] + cls_kind)
+    params = {'s': (np.float32(0.5),), 'u': (np.float32(0.1), np.float32(0.9)), 'n': (np.float32(0.2), np.float32(1.3))}[family]
+    w0, w1 = (params + (0.0,))[:2]
+    M = cls((*params, prob, seed), shape=shape, corder=corder)
+    tol = 1e-4 if family == 'n' else 1e-6
+    rng = np.random.default_rng(0)
+    for mode in ('mv', 'mm'):
+        S = M.tocsr(mode)
+        assert S.shape == shape
+        D = S.todense()
+        # oracle: D[out, in] of `M @ v`
+        if cls_kind == 'R':
+            gshape, transpose = shape, False
+        else:
+            gshape, transpose = shape[::-1], True
+        G = oracle.jit_generator_matrix(family, w0, w1, prob, seed, shape=gshape, transpose=transpose, corder=corder,
+                                        matrix_mode=mode, dtype=np.float32)
+        Dref = G if corder else G.T
+        np.testing.assert_allclose(D, Dref, rtol=tol, atol=tol)
+    # the stored matrix and the on-the-fly ops agree in both directions (mv matrix)
+    S = M.tocsr('mv')
+    v = spikes_of(rng, shape[1], 0.5, 'bool')
+    s = spikes_of(rng, shape[0], 0.5, 'bool')
+    np.testing.assert_allclose(S @ be.BinaryArray(v), M @ be.BinaryArray(v), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(be.BinaryArray(s) @ S, be.BinaryArray(s) @ M, rtol=1e-5, atol=1e-5)
+
+
+def test_jitc_materialised_scatter_matches_on_the_fly_mid_size(be):
+    n, prob, seed = 20000, 0.01, 42
+    M = be.JITCScalarR((np.float32(1.0), prob, seed), shape=(n, n), corder=True)
+    S = M.tocsr('mv')
+    assert abs(S.nse - n * n * prob) < 6 * np.sqrt(n * n * prob)
+    rng = np.random.default_rng(4)
+    s = spikes_of(rng, n, 0.02, 'bool')
+    np.testing.assert_array_equal(be.BinaryArray(s) @ S, be.BinaryArray(s) @ M)      # integer counts: exact
