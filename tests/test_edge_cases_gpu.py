@@ -1,0 +1,103 @@
+"""GPU edge cases across the operators: empty operands, all-zero / all-one spikes, NaN and negative float spikes,
+integer spike dtypes, large batches, torch-tensor operands on the device, dtype preservation."""
+import numpy as np
+import pytest
+import torch
+
+from test_csr_gpu import rand_csr, spikes_of
+
+pytestmark = pytest.mark.gpu
+
+
+def test_float_spikes_threshold_semantics(be, oracle):
+    # active iff > 0: zeros, negatives and NaN are inactive (NaN > 0 is False), +inf is active
+    rng = np.random.default_rng(0)
+    m, k = 64, 80
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(1, 10, m))
+    v = rng.normal(0, 1, m).astype(np.float32)
+    v[0], v[1], v[2], v[3] = np.nan, np.inf, -np.inf, 0.0
+    got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True)
+    act = np.nan_to_num(v, nan=-1.0) > 0
+    np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, act, (m, k), True), rtol=1e-5, atol=1e-5)
+    W = rng.normal(0, 1, (m, k)).astype(np.float32)
+    np.testing.assert_allclose(be.binary_densemv(W, v, transpose=True), oracle.binary_densemv(W.astype(np.float64), act, True), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', [np.int8, np.uint8, np.int32, np.int64, np.float64, np.float16])
+def test_spike_dtypes_are_normalised(be, oracle, dtype):
+    rng = np.random.default_rng(1)
+    m, k = 50, 60
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(0, 8, m))
+    s = (rng.random(m) < 0.5)
+    v = (s * 3).astype(dtype)
+    np.testing.assert_allclose(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True),
+                               oracle.binary_csrmv(w, idx, ptr, s, (m, k), True), rtol=1e-5, atol=1e-5)
+    W = rng.normal(0, 1, (m, k)).astype(np.float32)
+    np.testing.assert_allclose(be.BinaryArray(v) @ W, oracle.binary_densemv(W.astype(np.float64), s, True), rtol=1e-5, atol=1e-4)
+
+
+def test_no_spikes_and_all_spikes(be, oracle):
+    rng = np.random.default_rng(2)
+    m, k = 300, 70000
+    w, idx, ptr = rand_csr(rng, m, k, np.full(m, 300))
+    import brainevent_amd._csr as C
+    old = C.PLAN_MIN_NNZ
+    C.PLAN_MIN_NNZ = 1
+    try:
+        csr = be.CSR((w, idx, ptr), shape=(m, k))
+        z = be.BinaryArray(np.zeros(m, bool)) @ csr
+        assert z.shape == (k,) and not z.any()
+        o = be.BinaryArray(np.ones(m, bool)) @ csr
+        np.testing.assert_allclose(o, oracle.binary_csrmv(w.astype(np.float64), idx, ptr, np.ones(m, bool), (m, k), True), rtol=1e-5, atol=1e-5)
+        z2 = be.BinaryArray(np.zeros(m, bool)) @ csr          # the re-armed counter survives an empty call
+        assert not z2.any()
+    finally:
+        C.PLAN_MIN_NNZ = old
+    assert not be.binary_jitsmv(np.float32(1.0), 0.1, np.zeros(k, bool), 3, shape=(m, k), transpose=False, corder=True).any()
+    assert not be.binary_jitsmv(np.float32(1.0), 0.1, np.zeros(m, bool), 3, shape=(m, k), transpose=True, corder=False).any()
+
+
+def test_empty_shapes(be):
+    w1 = np.ones(1, np.float32)
+    e_i, e_p = np.zeros(0, np.int32), np.zeros(1, np.int32)
+    assert be.binary_csrmv(w1, e_i, e_p, np.zeros(0, bool), shape=(0, 5), transpose=True).shape == (5,)
+    assert be.binary_csrmv(w1, e_i, np.zeros(4, np.int32), np.zeros(0, bool), shape=(3, 0), transpose=False).shape == (3,)
+    assert be.binary_densemv(np.zeros((0, 4), np.float32), np.zeros(0, bool), transpose=True).tolist() == [0, 0, 0, 0]
+    assert be.binary_densemm(np.zeros((3, 4), np.float32), np.zeros((4, 0), bool), transpose=False).shape == (3, 0)
+    assert be.binary_fcnmv(w1, np.zeros((0, 3), np.int32), np.zeros(0, bool), shape=(0, 7), transpose=True).shape == (7,)
+    assert be.binary_jitsmv(np.float32(1.0), 0.5, np.zeros(0, bool), 1, shape=(4, 0), transpose=False, corder=True).tolist() == [0, 0, 0, 0]
+
+
+def test_large_batch_and_torch_operands(be, oracle):
+    rng = np.random.default_rng(3)
+    m, k, n = 90, 120, 70          # n > 64: several batch passes for dense (32 per pass)
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(0, 20, m))
+    B = rng.random((m, n)) < 0.3
+    wt, it, pt, Bt = (torch.tensor(x, device='cuda') for x in (w, idx, ptr, B))
+    got = be.binary_csrmm(wt, it, pt, Bt, shape=(m, k), transpose=True)
+    assert isinstance(got, torch.Tensor) and got.is_cuda and tuple(got.shape) == (k, n)
+    np.testing.assert_allclose(got.cpu().numpy(), oracle.binary_csrmm(w.astype(np.float64), idx, ptr, B, (m, k), True), rtol=1e-5, atol=1e-5)
+    W = rng.normal(0, 1, (m, k)).astype(np.float32)
+    gd = be.binary_densemm(torch.tensor(W, device='cuda'), Bt, transpose=True)
+    np.testing.assert_allclose(gd.cpu().numpy(), oracle.binary_densemm(W.astype(np.float64), B, True), rtol=1e-5, atol=1e-4)
+    Wh = torch.tensor(W, device='cuda').half()
+    gh = be.BinaryArray(Bt.T.contiguous()) @ Wh          # [n, m] @ [m, k]: MFMA path (70 batch rows = 3 passes)
+    assert gh.dtype == torch.float16 and tuple(gh.shape) == (n, k)
+    np.testing.assert_allclose(gh.float().cpu().numpy(), oracle.binary_densemm(Wh.float().cpu().numpy().astype(np.float64), B, True).T,
+                               rtol=2e-3, atol=2e-2)
+
+
+def test_backend_keyword_contract(be):
+    w, idx, ptr = np.ones(2, np.float32), np.array([0, 1], np.int32), np.array([0, 2], np.int32)
+    v = np.array([True])
+    assert be.binary_csrmv(w, idx, ptr, v, shape=(1, 2), transpose=True, backend='hip').tolist() == [1.0, 1.0]
+    with pytest.raises(be.KernelFallbackExhaustedError):
+        be.binary_csrmv(w, idx, ptr, v, shape=(1, 2), transpose=True, backend='numba')
+    with pytest.raises(AssertionError):
+        be.binary_csrmv(w, idx, ptr, np.array([True, False]), shape=(1, 2), transpose=True)       # shape mismatch
+    with pytest.raises(AssertionError):
+        be.binary_csrmv(np.array([1, 2]), idx, ptr, v, shape=(1, 2), transpose=True)               # integer weights
+    with pytest.raises(ValueError):
+        be.CSR((w, np.array([0, 5], np.int32), ptr), shape=(1, 2))                                 # column out of range
+    with pytest.raises(ValueError):
+        be.CSR((w, idx, np.array([0, 3], np.int32)), shape=(1, 2))                                 # indptr[-1] != nse
