@@ -29,9 +29,7 @@ namespace {
 // 256 * kCompactPerThread elements: per-thread activity bits stay in registers, one LDS scan gives the
 // offsets and ONE global atomic per workgroup reserves the output range (a returning atomic per wave
 // serialises at ~11 ns each on one address: 85 us for 1M spikes at 1 % firing, measured).
-constexpr int kCompactPerThread = 16;
-
-template <typename SP>
+template <typename SP, int kCompactPerThread>
 __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
                                                         uint32_t* __restrict__ active, uint32_t* __restrict__ count,
                                                         int64_t active_stride) {
@@ -42,21 +40,31 @@ __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type*
   __shared__ uint32_t block_base;
   const int64_t tile = (int64_t)blockIdx.x * (256 * kCompactPerThread);
   const int64_t first = tile + (int64_t)threadIdx.x * kCompactPerThread;
-  uint32_t bits = 0;
-  if (sizeof(typename SP::type) == 1 && first + kCompactPerThread <= n &&
-      (reinterpret_cast<uintptr_t>(spikes) & 15) == 0) {
-    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(spikes) + first);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  // activity bits of this thread's kCompactPerThread consecutive elements (16 per word)
+  constexpr int NW = kCompactPerThread / 16;
+  uint32_t bits[NW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+  for (int u = 0; u < NW; ++u) {
+    const int64_t f = first + 16 * u;
+    uint32_t bw = 0;
+    if (sizeof(typename SP::type) == 1 && f + 16 <= n && (reinterpret_cast<uintptr_t>(spikes) & 15) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(spikes) + f);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bits |= (((w[q] >> (8 * b)) & 0xffu) != 0u ? 1u : 0u) << (4 * q + b);
-  } else {
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int i = 0; i < kCompactPerThread; ++i)
-      if (first + i < n && SP::active(spikes[first + i])) bits |= 1u << i;
+        for (int b = 0; b < 4; ++b) bw |= (((w[q] >> (8 * b)) & 0xffu) != 0u ? 1u : 0u) << (4 * q + b);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (f + i < n && SP::active(spikes[f + i])) bw |= 1u << i;
+    }
+    bits[u] = bw;
   }
-  const uint32_t cnt = __popc(bits);
+  uint32_t cnt_all = 0;
+#pragma unroll
+  for (int u = 0; u < NW; ++u) cnt_all += __popc(bits[u]);
+  const uint32_t cnt = cnt_all;
   // inclusive scan over the wave, then over the 4 waves
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   uint32_t incl = cnt;
@@ -76,10 +84,14 @@ __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type*
   if (threadIdx.x == 0) block_base = total ? atomicAdd(count, total) : 0u;
   __syncthreads();
   uint32_t pos = block_base + wave_off + incl - cnt;
-  while (bits) {
-    const int b = __ffs(bits) - 1;
-    bits &= bits - 1;
-    active[pos++] = (uint32_t)(first + b);
+#pragma unroll
+  for (int u = 0; u < NW; ++u) {
+    uint32_t bw = bits[u];
+    while (bw) {
+      const int b = __ffs(bw) - 1;
+      bw &= bw - 1;
+      active[pos++] = (uint32_t)(first + 16 * u + b);
+    }
   }
 }
 
@@ -620,9 +632,17 @@ int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, 
                    hipStream_t st, bool zero_first) {
   if (zero_first) BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
   if (n == 0 || nb == 0) return BE_OK;
-  const int64_t tiles = (n + 256 * kCompactPerThread - 1) / (256 * kCompactPerThread);
-  hipLaunchKernelGGL(k_compact_spikes<SP>, dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
-                     static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
+  // one returning atomic per workgroup serialises at ~11 ns each on one address: keep the number of workgroups
+  // per spike vector in the hundreds (4096 elements per workgroup up to 4M spikes, 16384 beyond)
+  if (n <= (4ll << 20)) {
+    const int64_t tiles = (n + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL((k_compact_spikes<SP, 16>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
+                       static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
+  } else {
+    const int64_t tiles = (n + 256 * 64 - 1) / (256 * 64);
+    hipLaunchKernelGGL((k_compact_spikes<SP, 64>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
+                       static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
+  }
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
@@ -740,8 +760,28 @@ inline bool check_rows(const void* indptr, int64_t row_len) { return indptr != n
 //   atomics instead (slow path, still correct).
 // HBM traffic per update (hetero): 8 B read (pass B) + 6 B write + 6 B read = 20 B  vs  8 B algorithmic.
 // =================================================================================================
-constexpr int kBinBatch = 12288;     // entries per LDS batch (6 B each = 72 KiB)
 constexpr int kMaxBins = 2048;       // 4 x 4 B x 2048 = 32 KiB of LDS bookkeeping
+// entries per LDS batch of (uint16 column [, f32 weight]) payload
+template <bool HOMO> struct BinBatch { static constexpr int n = HOMO ? 49152 : 16384; };   // 96 KiB of payload
+
+// block-wide inclusive scan over 1024 threads (wave shuffles + one LDS hop): 2 barriers instead of 20
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wave_tot /* [16] in LDS */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w)
+    if (w < wave) base += wave_tot[w];
+  __syncthreads();
+  return base + incl;
+}
 
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
@@ -749,14 +789,15 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
                                                    int slice_shift, int n_bins, uint32_t cap, uint32_t* __restrict__ bin_cursor,
                                                    uint32_t* __restrict__ bin_valid, uint16_t* __restrict__ bin_idx,
                                                    float* __restrict__ bin_w, float* __restrict__ out) {
+  constexpr uint32_t kBatch = BinBatch<HOMO>::n;
   __shared__ uint32_t hist[kMaxBins], offs[kMaxBins], fill[kMaxBins], gpos[kMaxBins];
-  __shared__ uint16_t s_idx[kBinBatch];
-  __shared__ float s_w[HOMO ? 1 : kBinBatch];
+  __shared__ uint16_t s_idx[kBatch];
+  __shared__ float s_w[HOMO ? 1 : kBatch];
   __shared__ uint32_t s_rows[1024];       // batch: row id
   __shared__ uint32_t s_lens[1024];       //        piece length
   __shared__ int64_t s_begin[1024];       //        first entry of the piece
-  __shared__ uint32_t s_scan[1024];
-  __shared__ uint32_t s_nrows, s_total;
+  __shared__ uint32_t s_wtot[16];
+  __shared__ uint32_t s_nrows;
   __shared__ uint64_t s_next;             // next list position of this workgroup
   __shared__ int64_t s_carry_begin;       // unfinished tail of a long row
   __shared__ uint32_t s_carry_row, s_carry_len;
@@ -771,16 +812,16 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
 
   for (;;) {
     // ---- form a batch: thread t looks at this workgroup's t-th next row (loads in parallel), a block scan of
-    //      the row lengths picks the longest prefix that fits kBinBatch entries; a row longer than a batch is
-    //      processed alone, one batch-sized piece at a time (carry)
+    //      the row lengths picks the longest prefix that fits one batch; a row longer than a batch is processed
+    //      alone, one batch-sized piece at a time (carry)
     for (int b = tid; b < n_bins; b += blockDim.x) { hist[b] = 0; fill[b] = 0; }
     if (s_carry_len) {               // uniform: shared state
       __syncthreads();
       if (tid == 0) {
-        const uint32_t take = s_carry_len < (uint32_t)kBinBatch ? s_carry_len : (uint32_t)kBinBatch;
+        const uint32_t take = s_carry_len < kBatch ? s_carry_len : kBatch;
         s_rows[0] = s_carry_row; s_begin[0] = s_carry_begin; s_lens[0] = take;
         s_carry_begin += take; s_carry_len -= take;
-        s_nrows = 1; s_total = take;
+        s_nrows = 1;
       }
       __syncthreads();
     } else {
@@ -792,33 +833,24 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
         len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
       }
       const uint32_t len32 = len > 0xfffffffeull ? 0xfffffffeu : (uint32_t)len;
-      // inclusive scan of the (saturating) lengths
-      s_scan[tid] = len32 > (uint32_t)kBinBatch ? (uint32_t)kBinBatch + 1u : len32;
-      __syncthreads();
-      for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t t = 0;
-        if (tid >= off) t = s_scan[tid - off];
-        __syncthreads();
-        const uint32_t sum = s_scan[tid] + t;
-        s_scan[tid] = sum > (uint32_t)kBinBatch ? (uint32_t)kBinBatch + 1u : sum;   // saturate: no overflow
-        __syncthreads();
-      }
+      // lengths saturate at kBatch + 1 per row; 1024 of them cannot overflow 32 bits
+      const uint32_t incl = block_scan_1024(len32 > kBatch ? kBatch + 1u : len32, s_wtot);
       const bool in_list = a < n_active;
-      const bool fits = in_list && s_scan[tid] <= (uint32_t)kBinBatch;
+      const bool fits = in_list && incl <= kBatch;
       const int nfit = __syncthreads_count(fits);          // rows 0 .. nfit-1 (a prefix: the scan is monotone)
       if (fits) { s_rows[tid] = r; s_begin[tid] = rb; s_lens[tid] = len32; }
       if (tid == 0) {
         if (nfit > 0) {
-          s_nrows = nfit; s_total = s_scan[nfit - 1];
+          s_nrows = nfit;
           s_next += (uint64_t)nfit * gridDim.x;
         } else if (in_list) {                               // the first row alone exceeds a batch: start carrying it
-          s_rows[0] = r; s_begin[0] = rb; s_lens[0] = (uint32_t)kBinBatch;
-          s_carry_row = r; s_carry_begin = rb + kBinBatch;
-          s_carry_len = (len - kBinBatch) > 0xffffffffull ? 0xffffffffu : (uint32_t)(len - kBinBatch);
-          s_nrows = 1; s_total = (uint32_t)kBinBatch;
+          s_rows[0] = r; s_begin[0] = rb; s_lens[0] = kBatch;
+          s_carry_row = r; s_carry_begin = rb + kBatch;
+          s_carry_len = (len - kBatch) > 0xffffffffull ? 0xffffffffu : (uint32_t)(len - kBatch);
+          s_nrows = 1;
           s_next += gridDim.x;
         } else {
-          s_nrows = 0; s_total = 0;
+          s_nrows = 0;
         }
       }
       __syncthreads();
@@ -826,26 +858,28 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
     const uint32_t nrows = s_nrows;
     if (nrows == 0) break;
 
-    // ---- phase 1: histogram of the batch over the bins (wave per row piece)
+    // ---- phase 1: histogram of the batch over the bins (wave per row piece, 4 independent loads in flight:
+    //      clamped index + predicate instead of a conditional load)
     for (uint32_t i = wave; i < nrows; i += nw) {
       const int64_t b = s_begin[i];
       const uint32_t len = s_lens[i];
-      for (uint32_t j = lane; j < len; j += 64) atomicAdd(&hist[((uint32_t)indices[b + j]) >> slice_shift], 1u);
+      for (uint32_t j0 = 0; j0 < len; j0 += 256) {
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t j = j0 + 64 * u + lane;
+          c[u] = (uint32_t)indices[b + (j < len ? j : len - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + 64 * u + lane < len) atomicAdd(&hist[c[u] >> slice_shift], 1u);
+      }
     }
     __syncthreads();
     // ---- phase 2: exclusive scan of hist (n_bins <= 2048: two per thread) + one range reservation per bin
     {
       const uint32_t v0 = (2 * tid < n_bins) ? hist[2 * tid] : 0u, v1 = (2 * tid + 1 < n_bins) ? hist[2 * tid + 1] : 0u;
-      s_scan[tid] = v0 + v1;
-      __syncthreads();
-      for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t t = 0;
-        if (tid >= off) t = s_scan[tid - off];
-        __syncthreads();
-        s_scan[tid] += t;
-        __syncthreads();
-      }
-      const uint32_t excl = s_scan[tid] - (v0 + v1);
+      const uint32_t excl = block_scan_1024(v0 + v1, s_wtot) - (v0 + v1);
       if (2 * tid < n_bins) {
         offs[2 * tid] = excl;
         gpos[2 * tid] = v0 ? atomicAdd(&bin_cursor[2 * tid], v0) : 0u;
@@ -860,12 +894,25 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
     for (uint32_t i = wave; i < nrows; i += nw) {
       const int64_t b = s_begin[i];
       const uint32_t len = s_lens[i];
-      for (uint32_t j = lane; j < len; j += 64) {
-        const uint32_t c = (uint32_t)indices[b + j];
-        const uint32_t bin = c >> slice_shift;
-        const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
-        s_idx[pos] = (uint16_t)(c & mask);
-        if (!HOMO) s_w[pos] = (float)WTraits<W>::load(weights, b + j);
+      for (uint32_t j0 = 0; j0 < len; j0 += 256) {
+        uint32_t c[4];
+        float wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t j = j0 + 64 * u + lane;
+          const int64_t e = b + (j < len ? j : len - 1);
+          c[u] = (uint32_t)indices[e];
+          wv[u] = HOMO ? 0.f : (float)WTraits<W>::load(weights, e);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j0 + 64 * u + lane < len) {
+            const uint32_t bin = c[u] >> slice_shift;
+            const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
+            s_idx[pos] = (uint16_t)(c[u] & mask);
+            if (!HOMO) s_w[pos] = wv[u];
+          }
+        }
       }
     }
     __syncthreads();
@@ -1215,10 +1262,10 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   if (rc != BE_OK) return rc;
   const int prof = be_prof_begin(st);
   if (homo)
-    hipLaunchKernelGGL((k_bin_rows<float, true>), dim3(512), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
+    hipLaunchKernelGGL((k_bin_rows<float, true>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
                        active, count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
   else
-    hipLaunchKernelGGL((k_bin_rows<float, false>), dim3(512), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
+    hipLaunchKernelGGL((k_bin_rows<float, false>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
                        active, count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
   BE_LAUNCH_CHECK();
   int parts = 512 / (n_bins > 0 ? n_bins : 1);
