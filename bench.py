@@ -51,6 +51,9 @@ def parse():
                     help='csr = the headline C2 config; the others are the secondary BASELINE.json configs (single GPU)')
     ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
     ap.add_argument('--batch', type=int, default=32, help='dense: batch rows')
+    ap.add_argument('--k', type=int, default=1000, help='fcn: synapses per pre neuron (stored on this GPU)')
+    ap.add_argument('--n-post', type=int, default=0, help='fcn: post population on this GPU (default: n); with --k 125 '
+                    '--n-post 1250000 this is one rank of the 8-way post-sliced N=10M, K=1000 config')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
@@ -154,13 +157,14 @@ def secondary(args):
                     'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
     elif args.workload == 'fcn':
         n = args.n if args.n != 1_000_000 else 10_000_000
-        K = 1000
+        K = args.k
+        n_post = args.n_post or n
         idx = torch.empty((n, K), dtype=torch.int32, device=dev)
         for lo in range(0, n, 200_000):
             hi = min(n, lo + 200_000)
-            idx[lo:hi] = torch.randint(0, n, (hi - lo, K), dtype=torch.int32, device=dev, generator=g)
+            idx[lo:hi] = torch.randint(0, n_post, (hi - lo, K), dtype=torch.int32, device=dev, generator=g)
         w = torch.ones(1, device=dev) if args.homo else torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
-        conn = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False)
+        conn = be.FixedNumPerPre((w, idx), shape=(n, n_post), check_indices=False)
         conn.prepare()
         spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
         act = spikes.sum(dim=1).cpu().numpy()
@@ -169,11 +173,12 @@ def secondary(args):
         upd = sum(int(act[(args.warmup + i) % n_batch]) for i in range(args.steps)) * K
         value = upd / elapsed / 1e9
         metric = 'synaptic updates/sec (Geff/s), BinaryArray @ FixedNumPerPre scatter'
-        cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} N={n} {'homo' if args.homo else 'hetero'} f32, 1 GPU",
+        cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} {n} pre x {n_post} post "
+                           f"{'homo' if args.homo else 'hetero'} f32, 1 GPU",
                'route': type(conn.buffers.get('scatter_plan')).__name__ if conn.buffers.get('scatter_plan') is not None
                else 'direct (global atomics)'}
         if kern_ms:
-            alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n
+            alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n_post
             roof = {'bound': 'hbm', 'achieved': round(alg / (kern_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel_ms': round(kern_ms, 5)}
     else:   # dense
