@@ -378,6 +378,24 @@ class CompressedSparseData:
             obj._numpy_result = numpy_result
         return obj
 
+    @classmethod
+    def fromdense(cls, mat, *, nse: Optional[int] = None, backend: Optional[str] = None):
+        """Build from a dense matrix (host-side helper; non-zeros in row-major order for ``CSR``, column-major for
+        ``CSC`` — reference ``CSR.fromdense`` / ``CSC.fromdense``, ``brainevent/_csr/main.py``)."""
+        dense = mat.cpu().numpy() if isinstance(mat, torch.Tensor) else np.asarray(mat)
+        if dense.ndim != 2:
+            raise ValueError(f"{cls.__name__}.fromdense expects a 2-D matrix; got {dense.ndim}-D.")
+        view = dense if cls._compressed_format == 'csr' else dense.T
+        rows, cols = np.nonzero(view)
+        if nse is not None:
+            rows, cols = rows[:nse], cols[:nse]
+        data = view[rows, cols]
+        indptr = np.zeros(view.shape[0] + 1, dtype=np.int32)
+        np.cumsum(np.bincount(rows, minlength=view.shape[0]), out=indptr[1:])
+        obj = cls((data, cols.astype(np.int32), indptr), shape=dense.shape, backend=backend)
+        obj._numpy_result = not isinstance(mat, torch.Tensor)
+        return obj
+
     # -- properties ------------------------------------------------------------------------------
     @property
     def nse(self) -> int:

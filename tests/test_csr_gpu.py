@@ -287,3 +287,75 @@ def test_mirror_makes_gather_direction_event_driven(be, oracle, monkeypatch):
     mr = csr.buffers['mirror']
     d = np.zeros((k, m)); np.add.at(d, (np.repeat(np.arange(k), np.diff(mr['indptr'].cpu().numpy())), mr['indices'].cpu().numpy()), mr['data'].cpu().numpy())
     np.testing.assert_allclose(d.T, csr.todense(), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's seeded-numpy operator tests (brainevent/_csr/main_test.py:1289-1358): same generator,
+# same seeds, same shapes, same dense-equivalence assertion (atol 1e-5)
+# ---------------------------------------------------------------------------------------------------
+def _rand_dense(rng, m, n, p=0.4):
+    return ((rng.random((m, n)) < p) * rng.random((m, n))).astype(np.float32)
+
+
+def test_reference_seeded_operator_cases(be):
+    rng = np.random.default_rng(3)                                   # main_test.py:1296-1307  csr @ ev
+    csr = be.CSR.fromdense(_rand_dense(rng, 5, 7))
+    ev = rng.random(7) > 0.5
+    got = csr @ be.BinaryArray(ev)
+    assert got.shape == (5,)
+    np.testing.assert_allclose(got, csr.todense() @ ev.astype(np.float32), atol=1e-5)
+
+    rng = np.random.default_rng(4)                                   # :1310-1320  ev @ csr
+    csr = be.CSR.fromdense(_rand_dense(rng, 5, 7))
+    ev = rng.random(5) > 0.5
+    got = be.BinaryArray(ev) @ csr
+    assert got.shape == (7,)
+    np.testing.assert_allclose(got, ev.astype(np.float32) @ csr.todense(), atol=1e-5)
+
+    rng = np.random.default_rng(5)                                   # :1323-1334  ev @ csc
+    csc = be.CSC.fromdense(_rand_dense(rng, 6, 4))
+    ev = rng.random(6) > 0.5
+    got = be.BinaryArray(ev) @ csc
+    assert got.shape == (4,)
+    np.testing.assert_allclose(got, ev.astype(np.float32) @ csc.todense(), atol=1e-5)
+
+    rng = np.random.default_rng(6)                                   # :1337-1347  csc @ ev
+    csc = be.CSC.fromdense(_rand_dense(rng, 6, 4))
+    ev = rng.random(4) > 0.5
+    got = csc @ be.BinaryArray(ev)
+    assert got.shape == (6,)
+    np.testing.assert_allclose(got, csc.todense() @ ev.astype(np.float32), atol=1e-5)
+
+    rng = np.random.default_rng(7)                                   # :1350-1358  with_data round trip
+    csr = be.CSR.fromdense(_rand_dense(rng, 5, 7))
+    ev = rng.random(7) > 0.5
+    got = csr.with_data(csr.data) @ be.BinaryArray(ev)
+    np.testing.assert_allclose(got, csr.todense() @ ev.astype(np.float32), atol=1e-5)
+
+
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('float_events', [True, False])
+def test_reference_binary_operator_matrix(be, homo, float_events):
+    """Test_CSR_BinaryOperator-style sweep (brainevent/_csr/main_test.py:83-140): homo / hetero weights x bool /
+    float-as-bool events, all four operator forms against the dense product."""
+    rng = np.random.default_rng(11)
+    m, k = 20, 40
+    dense = _rand_dense(rng, m, k, p=0.1)
+    if homo:
+        dense = (dense != 0) * np.float32(1.5)
+    csr = be.CSR.fromdense(dense)
+    if homo:
+        csr = be.CSR((np.asarray([1.5], np.float32), csr.indices.cpu().numpy(), csr.indptr.cpu().numpy()), shape=(m, k))
+    x = rng.random(m) < 0.5
+    y = rng.random(k) < 0.5
+    xe = x.astype(np.float32) if float_events else x
+    ye = y.astype(np.float32) if float_events else y
+    np.testing.assert_allclose(be.BinaryArray(xe) @ csr, x.astype(np.float32) @ dense, atol=1e-5)
+    np.testing.assert_allclose(csr @ be.BinaryArray(ye), dense @ y.astype(np.float32), atol=1e-5)
+    csc = csr.T
+    np.testing.assert_allclose(be.BinaryArray(ye) @ csc, y.astype(np.float32) @ dense.T, atol=1e-5)
+    np.testing.assert_allclose(csc @ be.BinaryArray(xe), dense.T @ x.astype(np.float32), atol=1e-5)
+    X = rng.random((3, m)) < 0.5
+    np.testing.assert_allclose(be.BinaryArray(X) @ csr, X.astype(np.float32) @ dense, atol=1e-5)
+    Y = rng.random((k, 3)) < 0.5
+    np.testing.assert_allclose(csr @ be.BinaryArray(Y), dense @ Y.astype(np.float32), atol=1e-5)
