@@ -110,8 +110,10 @@ __device__ __forceinline__ A edge_weight(const JitP& p, uint32_t row, uint32_t c
 template <int MODE> struct GatherAcc { using type = double; };
 template <> struct GatherAcc<MODE_SCALAR> { using type = uint32_t; };
 
+// 1024 threads per workgroup: the staged bitmap takes most of the LDS (one workgroup per CU), so the 16 waves of
+// that one workgroup are all the latency hiding the CU gets for the dependent LDS lookups of the walk.
 template <int MODE, bool BITS_IN_LDS>
-__global__ void __launch_bounds__(256) k_jit_mv_gather(JitP p, const uint32_t* __restrict__ bits, int64_t m,
+__global__ void __launch_bounds__(1024) k_jit_mv_gather(JitP p, const uint32_t* __restrict__ bits, int64_t m,
                                                        typename GatherAcc<MODE>::type* __restrict__ partial) {
   using AccT = typename GatherAcc<MODE>::type;
   extern __shared__ uint32_t bits_s[];
@@ -131,24 +133,28 @@ __global__ void __launch_bounds__(256) k_jit_mv_gather(JitP p, const uint32_t* _
   }
   const uint32_t l = threadIdx.x & 31u;
   const int64_t half = threadIdx.x >> 5;
-  const int64_t rows_per_iter = (int64_t)gridDim.x * 8;
+  const int64_t halves = blockDim.x >> 5;
+  const int64_t rows_per_iter = (int64_t)gridDim.x * halves;
   const int64_t m_round = (m + rows_per_iter - 1) / rows_per_iter * rows_per_iter;
-  for (int64_t row = (int64_t)blockIdx.x * 8 + half; row < m_round; row += rows_per_iter) {
+  for (int64_t row = (int64_t)blockIdx.x * halves + half; row < m_round; row += rows_per_iter) {
     AccT acc = AccT(0);
     if (row < m) {
+      // the walk in the q domain: lane l visits chunk-local columns l + 32 q, i.e. always bit ((cs + l) & 31) of
+      // consecutive 32-bit words of the packed spike vector — one LDS word per step, no 64-bit arithmetic
       uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
       uint32_t q = lr_initial_q(state, p.cl);
-      uint64_t lj = (uint64_t)l + 32ull * q;
-      while ((int64_t)lj < width) {
-        const int64_t j = cs + (int64_t)lj;
-        const bool on = (bsrc[(j >> 5) - w_off] >> (j & 31)) & 1u;
+      const uint32_t qmax = width > (int64_t)l ? (uint32_t)((width - l + 31) >> 5) : 0u;   // l + 32 q < width
+      const int64_t bit0 = cs + l;
+      const uint32_t sh = (uint32_t)(bit0 & 31);
+      const uint32_t* wp = bsrc + ((bit0 >> 5) - w_off);
+      while (q < qmax) {
+        const bool on = (wp[q] >> sh) & 1u;
         if (on) {
           if (MODE == MODE_SCALAR) acc += 1;
-          else acc += (AccT)edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)j);
+          else acc += (AccT)edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)(bit0 + 32ll * q));
         }
         state = lr_next(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
-        lj = (uint64_t)l + 32ull * q;
       }
     }
 #pragma unroll
@@ -476,14 +482,14 @@ int jit_mv_gather(const JitP& p, const void* spikes, int sd, void* out, int64_t 
   int rc = be_pack_spikes(spikes, sd, p.walk_len, bits, st);
   if (rc != BE_OK) return rc;
   const size_t lds = (size_t)(((std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32) + 2) * 4;
-  const dim3 grid(gcap(m, 8, 1024), p.n_chunks);
+  const dim3 grid(gcap(m, 32, 512), p.n_chunks);
   const int prof = be_prof_begin(st);
   if (lds <= 150 * 1024) {
     auto kern = k_jit_mv_gather<MODE, true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, bits, m, partial);
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, p, bits, m, partial);
   } else {
-    hipLaunchKernelGGL((k_jit_mv_gather<MODE, false>), grid, dim3(256), 0, st, p, bits, m, partial);
+    hipLaunchKernelGGL((k_jit_mv_gather<MODE, false>), grid, dim3(1024), 0, st, p, bits, m, partial);
   }
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
