@@ -633,8 +633,8 @@ int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, 
   if (zero_first) BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
   if (n == 0 || nb == 0) return BE_OK;
   // one returning atomic per workgroup serialises at ~11 ns each on one address: keep the number of workgroups
-  // per spike vector in the hundreds (4096 elements per workgroup up to 4M spikes, 16384 beyond)
-  if (n <= (4ll << 20)) {
+  // per spike vector in the hundreds (4096 elements per workgroup up to 2M spikes, 16384 beyond)
+  if (n <= (2ll << 20)) {
     const int64_t tiles = (n + 256 * 16 - 1) / (256 * 16);
     hipLaunchKernelGGL((k_compact_spikes<SP, 16>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
                        static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);

@@ -24,6 +24,7 @@
 #include "be_common.h"
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -217,18 +218,16 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
   __syncthreads();
   const uint32_t n_active = n_active_p[0];
   if (q_begin < q_end) {
+    const uint32_t qb = (uint32_t)q_begin, qe = (uint32_t)q_end;      // Q < 2^27: 32-bit walk arithmetic
+    const uint32_t j0 = (uint32_t)(cs + l);
     for (uint64_t a = (uint64_t)part * blockDim.x + threadIdx.x; a < n_active; a += (uint64_t)parts * blockDim.x) {
       const uint32_t row = active[a];
       uint32_t state = lr_init(p.seed, row, chunk, l);
       uint32_t q = lr_initial_q(state, p.cl);
-      while ((int64_t)q < q_end) {
-        if ((int64_t)q >= q_begin) {
-          if (MODE == MODE_SCALAR) {
-            atomicAdd(&acc[q - (uint32_t)q_begin], (AccT)1);
-          } else {
-            const uint32_t j = (uint32_t)(cs + l + 32ll * q);
-            atomicAdd(&acc[q - (uint32_t)q_begin], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j), fx_scale));
-          }
+      while (q < qe) {
+        if (q >= qb) {
+          if (MODE == MODE_SCALAR) atomicAdd(&acc[q - qb], (AccT)1);
+          else atomicAdd(&acc[q - qb], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + 32u * q), fx_scale));
         }
         state = lr_next(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
@@ -240,27 +239,53 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
   for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) dst[i] = acc[i];
 }
 
+// partial is class-major ([class][piece][part][piece_len], class = chunk * 32 + lane residue) while the output is
+// column-major in (q, lane): out[chunk_start + 32 q + l].  One workgroup transposes a tile of 32 classes x 256 q
+// through LDS: coalesced reads per class row, coalesced writes of 8192 consecutive outputs.  piece_len is a
+// multiple of 256, so a tile never straddles two pieces.
 template <int MODE, typename W>
 __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename ScatterAcc<MODE>::type* __restrict__ partial,
                                                             JitP p, int pieces, int parts, uint32_t piece_len,
                                                             double inv_scale, W* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.walk_len; j += stride) {
-    const int64_t chunk = j / p.chunk_size;
-    const int64_t local = j - chunk * p.chunk_size;
-    const int64_t l = local & 31, q = local >> 5;
-    const int64_t piece = q / piece_len, i = q - piece * piece_len;
-    const int64_t cls = chunk * 32 + l;
-    const typename ScatterAcc<MODE>::type* src = partial + ((cls * pieces + piece) * parts) * (int64_t)piece_len + i;
-    if (MODE == MODE_SCALAR) {
-      uint64_t c = 0;
-      for (int q2 = 0; q2 < parts; ++q2) c += src[(int64_t)q2 * piece_len];
-      WTraits<W>::store_d(out, j, (double)c * p.w0);
-    } else {
-      unsigned long long s = 0;
-      for (int q2 = 0; q2 < parts; ++q2) s += src[(int64_t)q2 * piece_len];
-      WTraits<W>::store_d(out, j, (double)(long long)s * inv_scale);
+  using TileT = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
+  __shared__ TileT tile[32][257];
+  const int chunk = blockIdx.y;
+  const int64_t cs = (int64_t)chunk * p.chunk_size;
+  const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+  const int64_t width = ce - cs;
+  const int64_t q0 = (int64_t)blockIdx.x * 256;
+  if (q0 * 32 >= width) return;
+  const int64_t piece = q0 / piece_len, i0 = q0 - piece * piece_len;
+  const int t = threadIdx.x;
+  using AccT = typename ScatterAcc<MODE>::type;
+  const int64_t cls_stride = (int64_t)pieces * parts * piece_len;      // between consecutive classes
+  const AccT* base = partial + (((int64_t)chunk * 32 * pieces + piece) * parts) * (int64_t)piece_len + i0 + t;
+  // 8 class rows x parts loads in flight per thread
+  for (int l0 = 0; l0 < 32; l0 += 8) {
+    unsigned long long sum[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum[u] = 0;
+    for (int q2 = 0; q2 < parts; ++q2) {
+      AccT v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(l0 + u) * cls_stride + (int64_t)q2 * piece_len];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum[u] += (unsigned long long)v[u];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = l0 + u;
+      double val = 0.0;
+      if ((q0 + t) * 32 + l < width)
+        val = (MODE == MODE_SCALAR) ? (double)sum[u] * p.w0 : (double)(long long)sum[u] * inv_scale;
+      tile[l][t] = (TileT)val;
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < 32; ++r) {
+    const int jl = r * 256 + t;                 // tile-local output index: 32 * (q - q0) + l
+    const int64_t j_local = q0 * 32 + jl;
+    if (j_local < width) WTraits<W>::store_d(out, cs + j_local, (double)tile[jl & 31][jl >> 5]);
   }
 }
 
@@ -447,7 +472,7 @@ inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t
   return p;
 }
 
-constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators per scatter workgroup (128 KiB)
+constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators per scatter workgroup (128 KiB); multiples of 256
 
 struct ScatterGeom { int n_classes, pieces, parts; uint32_t piece_len; };
 inline ScatterGeom scatter_geom(const JitP& p, bool scalar) {
@@ -457,7 +482,7 @@ inline ScatterGeom scatter_geom(const JitP& p, bool scalar) {
   const uint32_t cap = scalar ? kPieceU32 : kPieceU64;
   g.pieces = (int)std::max<int64_t>(1, (Qmax + cap - 1) / cap);
   const int64_t per_piece = (Qmax + g.pieces - 1) / g.pieces;
-  g.piece_len = (uint32_t)std::max<int64_t>(4, (per_piece + 3) & ~3ll);
+  g.piece_len = (uint32_t)std::max<int64_t>(256, (per_piece + 255) & ~255ll);   // multiple of the reduce tile
   int parts = 512 / std::max(1, g.n_classes * g.pieces);
   g.parts = std::max(1, std::min(parts, 16));
   return g;
@@ -519,8 +544,12 @@ int jit_mv_scatter(const JitP& p, const void* spikes, int sd, void* out, int64_t
                      g.pieces, g.parts, g.piece_len, fx_scale, partial);
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_jit_scatter_reduce<MODE, W>), dim3(gcap(p.walk_len, 256, 2048)), dim3(256), 0, st, partial, p,
-                     g.pieces, g.parts, g.piece_len, ldexp(1.0, -scale_exp), static_cast<W*>(out));
+  {
+    const int64_t q_per_chunk = (std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32;
+    const dim3 rgrid((unsigned)((q_per_chunk + 255) / 256), (unsigned)p.n_chunks);
+    hipLaunchKernelGGL((k_jit_scatter_reduce<MODE, W>), rgrid, dim3(256), 0, st, partial, p, g.pieces, g.parts, g.piece_len,
+                       ldexp(1.0, -scale_exp), static_cast<W*>(out));
+  }
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
