@@ -195,7 +195,7 @@ __device__ __forceinline__ unsigned long long jit_fixed_from_f32(float w, float 
 }
 
 // grid.x = n_classes * pieces * parts.  class = chunk * 32 + lane residue.
-template <int MODE>
+template <int MODE, bool ONE_PIECE>
 __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t* __restrict__ active,
                                                          const uint32_t* __restrict__ n_active_p, int pieces, int parts,
                                                          uint32_t piece_len, float fx_scale,
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
       uint32_t state = lr_init(p.seed, row, chunk, l);
       uint32_t q = lr_initial_q(state, p.cl);
       while (q < qe) {
-        if (q >= qb) {
+        if (ONE_PIECE || q >= qb) {        // one piece per class: qb == 0, no test in the loop
           if (MODE == MODE_SCALAR) atomicAdd(&acc[q - qb], (AccT)1);
           else atomicAdd(&acc[q - qb], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + 32u * q), fx_scale));
         }
@@ -536,12 +536,18 @@ int jit_mv_scatter(const JitP& p, const void* spikes, int sd, void* out, int64_t
   if (rc != BE_OK) return rc;
   const ScatterGeom g = scatter_geom(p, MODE == MODE_SCALAR);
   const size_t lds = (size_t)g.piece_len * sizeof(AccT);
-  auto kern = k_jit_mv_scatter<MODE>;
-  BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float fx_scale = ldexpf(1.0f, scale_exp - 32);
+  const dim3 sgrid((unsigned)(g.n_classes * g.pieces * g.parts));
   const int prof = be_prof_begin(st);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g.n_classes * g.pieces * g.parts)), dim3(1024), lds, st, p, active, count,
-                     g.pieces, g.parts, g.piece_len, fx_scale, partial);
+  if (g.pieces == 1) {
+    auto kern = k_jit_mv_scatter<MODE, true>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial);
+  } else {
+    auto kern = k_jit_mv_scatter<MODE, false>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial);
+  }
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   {
