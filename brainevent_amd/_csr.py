@@ -51,6 +51,8 @@ class ScatterPlan:
     #: default slice widths: hetero accumulators are 8 B (2^14 * 8 = 128 KiB of LDS), homo are 4 B
     HETERO_SHIFT = 14
     HOMO_SHIFT = 15
+    #: a plan is refused when its smallest non-zero weight would be represented with fewer bits than this
+    MIN_WEIGHT_BITS = 16
 
     def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
@@ -112,21 +114,25 @@ class ScatterPlan:
         check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, int(homo), A.ptr(seg),
                     A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
         blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
-        maxabs = torch.zeros(1, dtype=torch.int32, device=dev)
+        maxabs = torch.zeros(2, dtype=torch.int32, device=dev)      # f32 bits of max |w| and of the smallest non-zero |w|
         f_fill = fn('be_scatter_plan_fill', c_int,
                     [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp])
         check(f_fill(A.ptr(weights), int(homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, m, k,
                      slice_shift, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
         scale_exp = 0
         if not homo:
-            bits = int(maxabs.item()) & 0xFFFFFFFF
-            if bits >= 0x7F800000:
+            mm = maxabs.cpu().numpy().view(np.uint32)
+            if int(mm[0]) >= 0x7F800000:
                 raise MathError("ScatterPlan: weights contain inf/nan; use the direct route (workspace=None).")
-            wmax = float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+            wmax, wmin = (float(x) for x in mm.view(np.float32))
             # |w| <= wmax < 2^e ;  sums of at most m terms must stay below 2^62
             e = math.frexp(wmax)[1] if wmax > 0 else 0
             scale_exp = 62 - e - max(1, int(math.ceil(math.log2(m + 1))))
             scale_exp = max(-90, min(150, scale_exp))   # 2^(scale_exp-32) must be a normal f32
+            # the smallest non-zero weight must keep at least MIN_WEIGHT_BITS bits in the fixed-point sum
+            if int(mm[1]) != 0xFFFFFFFF and wmin * 2.0 ** scale_exp < 2.0 ** cls.MIN_WEIGHT_BITS:
+                raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
+                                f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
         return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype)
 
 
@@ -154,6 +160,10 @@ class BinnedScatter:
                 raise MathError("BinnedScatter: weights contain inf/nan; use the direct route (workspace=None).")
             e = math.frexp(wmax)[1] if wmax > 0 else 0
             self.scale_exp = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(m + 1))))))
+            nz = weights.abs()
+            nz = nz[nz > 0]
+            if nz.numel() and float(nz.min().item()) * 2.0 ** self.scale_exp < 2.0 ** ScatterPlan.MIN_WEIGHT_BITS:
+                raise MathError("BinnedScatter: dynamic range of the weights exceeds what the fixed-point sums resolve.")
         f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
         self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))
 
@@ -448,9 +458,15 @@ class CompressedSparseData:
             n_slices = (k + (1 << shift) - 1) >> shift
             if self.nse / (m * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096 and \
                     self.data.dtype != torch.float64:
-                plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
+                try:
+                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
+                except MathError:
+                    plan = None       # inf / nan / extreme dynamic range: float atomics (direct route) handle those
             elif BinnedScatter.applicable(self.data, k):
-                plan = BinnedScatter(self.data, m, k, self.nse)
+                try:
+                    plan = BinnedScatter(self.data, m, k, self.nse)
+                except MathError:
+                    plan = None
         self.buffers['scatter_plan'] = plan
         return plan
 

@@ -212,10 +212,16 @@ class FixedNumConn:
             shift = ScatterPlan.default_shift(n_cols, homo)
             n_slices = (n_cols + (1 << shift) - 1) >> shift
             if self.num_conn / n_slices >= PLAN_MIN_SEGMENT and n_slices <= 4096:
-                plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols), row_len=self.num_conn,
-                                         slice_shift=shift)
+                try:
+                    plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols),
+                                             row_len=self.num_conn, slice_shift=shift)
+                except _csr_mod.MathError:
+                    plan = None
             elif BinnedScatter.applicable(self.data, n_cols):
-                plan = BinnedScatter(self.data, n_rows, n_cols, self.nse)
+                try:
+                    plan = BinnedScatter(self.data, n_rows, n_cols, self.nse)
+                except _csr_mod.MathError:
+                    plan = None
         self.buffers['scatter_plan'] = plan
         return plan
 

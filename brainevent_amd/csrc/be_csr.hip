@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
   __shared__ uint32_t seg_start[kMaxSlices];
   __shared__ uint32_t seg_n4[kMaxSlices];
   const uint32_t mask = (1u << slice_shift) - 1u;
-  uint32_t my_max = 0;
+  uint32_t my_max = 0, my_min = 0xffffffffu;
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
       const uint2 sg = seg[r * n_slices + s];
@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
         reinterpret_cast<uint16_t*>(blk + (size_t)seg_n4[s] * 16)[rank] = (uint16_t)(c & mask);
         const uint32_t ab = __float_as_uint(w) & 0x7fffffffu;
         my_max = ab > my_max ? ab : my_max;
+        if (ab != 0u) my_min = ab < my_min ? ab : my_min;
       }
     }
     __syncthreads();
@@ -364,6 +365,12 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
       my_max = o > my_max ? o : my_max;
     }
     if (lane_id() == 0 && my_max != 0) atomicMax(maxabs_bits, my_max);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = __shfl_down(my_min, off, 64);
+      my_min = o < my_min ? o : my_min;
+    }
+    if (lane_id() == 0 && my_min != 0xffffffffu) atomicMin(maxabs_bits + 1, my_min);   // smallest non-zero |w|
   }
 }
 
@@ -1132,6 +1139,7 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
   BE_HIP(hipMemsetAsync(maxabs_bits, 0, 4, st));
+  BE_HIP(hipMemsetAsync(maxabs_bits + 1, 0xff, 4, st));
   const int grid = grid_for(m, 1, 256 * 16);
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_fill<W, HOMO>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),

@@ -117,7 +117,9 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *   step 1  be_scatter_plan_count : fills seg (m * n_slices entries of 8 B) and returns the size of `blob`
  *           in *blob_bytes_host.  SYNCHRONOUS (it reads the total back).
  *   step 2  caller allocates blob (128-byte aligned, blob_bytes + 128).
- *   step 3  be_scatter_plan_fill  : fills blob; writes max |w| as f32 bits to *maxabs_bits (device uint32).
+ *   step 3  be_scatter_plan_fill  : fills blob; writes the f32 bit patterns of max |w| and of the smallest non-zero |w|
+ *           to maxabs_bits[0] and maxabs_bits[1] (device uint32[2]) so that the caller can pick the fixed-point exponent
+ *           and refuse matrices whose dynamic range the 64-bit fixed-point sums cannot resolve.
  * ---------------------------------------------------------------------------------------------- */
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift);
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len,

@@ -359,3 +359,26 @@ def test_reference_binary_operator_matrix(be, homo, float_events):
     np.testing.assert_allclose(be.BinaryArray(X) @ csr, X.astype(np.float32) @ dense, atol=1e-5)
     Y = rng.random((k, 3)) < 0.5
     np.testing.assert_allclose(csr @ be.BinaryArray(Y), dense @ Y.astype(np.float32), atol=1e-5)
+
+
+def test_plan_refuses_weights_it_cannot_resolve_and_class_falls_back(be, oracle, monkeypatch):
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(17)
+    m, k = 400, 40000
+    w, idx, ptr = rand_csr(rng, m, k, [200] * m)
+    v = spikes_of(rng, m, 0.2, 'bool')
+    # (a) extreme dynamic range: one weight 1e30, the rest ~1e-12 -> fixed point cannot hold both
+    w_dr = (w * 1e-12).astype(np.float32); w_dr[5] = 1e30
+    with pytest.raises(be.MathError):
+        C.ScatterPlan.build(w_dr, idx, torch.tensor(ptr), shape=(m, k))
+    csr = be.CSR((w_dr, idx, ptr), shape=(m, k))
+    got = be.BinaryArray(v) @ csr                      # falls back to the direct route (float atomics)
+    assert csr.buffers['scatter_plan'] is None
+    ref = oracle.binary_csrmv(w_dr.astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-20)
+    # (b) inf weights
+    w_inf = w.copy(); w_inf[7] = np.inf
+    csr = be.CSR((w_inf, idx, ptr), shape=(m, k))
+    got = be.BinaryArray(np.ones(m, bool)) @ csr
+    assert csr.buffers['scatter_plan'] is None and np.isinf(got[idx[7]])
