@@ -125,8 +125,8 @@ def _jitmm_hip(family, a, b, clen, B, seed, *, shape, transpose, corder, out_dty
     if out_len == 0 or n == 0:
         return out_bm.T
     w0, w1, _ = _jit_params(family, a, b)
-    f_ws = fn('be_binary_jitmm_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
-    ws = A.workspace(f_ws(in_len, out_len, n))
+    f_ws = fn('be_binary_jitmm_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_i64, c_int])
+    ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, n, 1 if corder else 0))
     name = f"be_binary_jit{family}mm_{'notrans' if corder else 'trans'}_{A.wsuffix(out_bm)}"
     f = fn(name, c_int, _MM_ARGS)
     check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(Bt.T.contiguous()), sd, A.ptr(out_bm), int(shape[1]), in_len,

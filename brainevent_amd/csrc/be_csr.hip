@@ -1021,6 +1021,14 @@ int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* 
   return compact_any(spikes, spike_dtype, n, 1, active_ids, 0, count, static_cast<hipStream_t>(stream));
 }
 
+// batched compaction for the other translation units (be_jitc.hip): spikes_bm [nb, n] -> active[b * stride ...], count[b]
+int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch, uint32_t* active_ids,
+                              int64_t active_stride, uint32_t* counts, be_stream_t stream) {
+  BE_REQUIRE(n >= 0 && n <= 0xffffffffll && n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "shape out of range");
+  BE_REQUIRE(counts && (n == 0 || n_batch == 0 || (spikes_bm && active_ids)), BE_ERR_INVALID, "null pointer");
+  return compact_any(spikes_bm, spike_dtype, n, n_batch, active_ids, active_stride, counts, static_cast<hipStream_t>(stream));
+}
+
 int64_t be_binary_csrmm_t_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int wdtype) {
   return direct_ws_bytes(m, k, wdtype, n_batch);
 }

@@ -194,29 +194,34 @@ __device__ __forceinline__ unsigned long long jit_fixed_from_f32(float w, float 
   return ((unsigned long long)(unsigned)hi << 32) | lo;
 }
 
-// grid.x = n_classes * pieces * parts.  class = chunk * 32 + lane residue.
+// grid.x = n_classes * pieces * parts.  class = chunk * stride + lane residue (stride 32 for the mv matrix, 4 for mm).
+// gridDim.y = batch column: active lists / counters / partials of column b live at b * (their stride).
 template <int MODE, bool ONE_PIECE>
 __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t* __restrict__ active,
                                                          const uint32_t* __restrict__ n_active_p, int pieces, int parts,
                                                          uint32_t piece_len, float fx_scale,
-                                                         typename ScatterAcc<MODE>::type* __restrict__ partial) {
+                                                         typename ScatterAcc<MODE>::type* __restrict__ partial,
+                                                         int64_t active_stride) {
   using AccT = typename ScatterAcc<MODE>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   AccT* acc = reinterpret_cast<AccT*>(smem_raw);
   const int part = blockIdx.x % parts;
   const int piece = (blockIdx.x / parts) % pieces;
   const int cls = blockIdx.x / (parts * pieces);
-  const uint32_t chunk = cls >> 5, l = cls & 31u;
+  const uint32_t S = (uint32_t)p.stride;
+  const uint32_t chunk = (uint32_t)cls / S, l = (uint32_t)cls - chunk * S;
+  active += (int64_t)blockIdx.y * active_stride;
+  partial += (int64_t)blockIdx.y * gridDim.x * piece_len;
   const int64_t cs = (int64_t)chunk * p.chunk_size;
   const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
   const int64_t width = ce - cs;
-  // positions q with l + 32 q < width
-  const int64_t Q = width > (int64_t)l ? (width - l + 31) / 32 : 0;
+  // positions q with l + stride * q < width
+  const int64_t Q = width > (int64_t)l ? (width - l + S - 1) / S : 0;
   const int64_t q_begin = (int64_t)piece * piece_len;
   const int64_t q_end = q_begin + piece_len < Q ? q_begin + piece_len : Q;
   for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) acc[i] = 0;
   __syncthreads();
-  const uint32_t n_active = n_active_p[0];
+  const uint32_t n_active = n_active_p[blockIdx.y];
   if (q_begin < q_end) {
     const uint32_t qb = (uint32_t)q_begin, qe = (uint32_t)q_end;      // Q < 2^27: 32-bit walk arithmetic
     const uint32_t j0 = (uint32_t)(cs + l);
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
       while (q < qe) {
         if (ONE_PIECE || q >= qb) {        // one piece per class: qb == 0, no test in the loop
           if (MODE == MODE_SCALAR) atomicAdd(&acc[q - qb], (AccT)1);
-          else atomicAdd(&acc[q - qb], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + 32u * q), fx_scale));
+          else atomicAdd(&acc[q - qb], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + S * q), fx_scale));
         }
         state = lr_next(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
@@ -239,60 +244,64 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
   for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) dst[i] = acc[i];
 }
 
-// partial is class-major ([class][piece][part][piece_len], class = chunk * 32 + lane residue) while the output is
-// column-major in (q, lane): out[chunk_start + 32 q + l].  One workgroup transposes a tile of 32 classes x 256 q
-// through LDS: coalesced reads per class row, coalesced writes of 8192 consecutive outputs.  piece_len is a
-// multiple of 256, so a tile never straddles two pieces.
+// partial is class-major ([class][piece][part][piece_len], class = chunk * stride + lane residue) while the output is
+// column-major in (q, lane): out[chunk_start + stride * q + l].  One workgroup transposes a tile of `stride` classes x
+// 256 q through LDS: coalesced reads per class row, coalesced writes of stride * 256 consecutive outputs.
+// piece_len is a multiple of 256, so a tile never straddles two pieces.  gridDim.z = batch column.
 template <int MODE, typename W>
 __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename ScatterAcc<MODE>::type* __restrict__ partial,
                                                             JitP p, int pieces, int parts, uint32_t piece_len,
-                                                            double inv_scale, W* __restrict__ out) {
+                                                            double inv_scale, W* __restrict__ out, int64_t partial_stride) {
   using TileT = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
   __shared__ TileT tile[32][257];
+  partial += (int64_t)blockIdx.z * partial_stride;
+  out += (int64_t)blockIdx.z * p.walk_len;
+  const int S = p.stride;
   const int chunk = blockIdx.y;
   const int64_t cs = (int64_t)chunk * p.chunk_size;
   const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
   const int64_t width = ce - cs;
   const int64_t q0 = (int64_t)blockIdx.x * 256;
-  if (q0 * 32 >= width) return;
+  if (q0 * S >= width) return;
   const int64_t piece = q0 / piece_len, i0 = q0 - piece * piece_len;
   const int t = threadIdx.x;
   using AccT = typename ScatterAcc<MODE>::type;
   const int64_t cls_stride = (int64_t)pieces * parts * piece_len;      // between consecutive classes
-  const AccT* base = partial + (((int64_t)chunk * 32 * pieces + piece) * parts) * (int64_t)piece_len + i0 + t;
-  // 8 class rows x parts loads in flight per thread
-  for (int l0 = 0; l0 < 32; l0 += 8) {
+  const AccT* base = partial + (((int64_t)chunk * S * pieces + piece) * parts) * (int64_t)piece_len + i0 + t;
+  // up to 8 class rows x parts loads in flight per thread
+  for (int l0 = 0; l0 < S; l0 += 8) {
     unsigned long long sum[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) sum[u] = 0;
     for (int q2 = 0; q2 < parts; ++q2) {
       AccT v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(l0 + u) * cls_stride + (int64_t)q2 * piece_len];
+      for (int u = 0; u < 8; ++u) v[u] = (l0 + u < S) ? base[(int64_t)(l0 + u) * cls_stride + (int64_t)q2 * piece_len] : AccT(0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) sum[u] += (unsigned long long)v[u];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int l = l0 + u;
+      if (l >= S) break;
       double val = 0.0;
-      if ((q0 + t) * 32 + l < width)
+      if ((q0 + t) * S + l < width)
         val = (MODE == MODE_SCALAR) ? (double)sum[u] * p.w0 : (double)(long long)sum[u] * inv_scale;
       tile[l][t] = (TileT)val;
     }
   }
   __syncthreads();
-  for (int r = 0; r < 32; ++r) {
-    const int jl = r * 256 + t;                 // tile-local output index: 32 * (q - q0) + l
-    const int64_t j_local = q0 * 32 + jl;
-    if (j_local < width) WTraits<W>::store_d(out, cs + j_local, (double)tile[jl & 31][jl >> 5]);
+  for (int r = 0; r < S; ++r) {
+    const int jl = r * 256 + t;                 // tile-local output index: stride * (q - q0) + l
+    const int64_t j_local = q0 * S + jl;
+    if (j_local < width) WTraits<W>::store_d(out, cs + j_local, (double)tile[jl % S][jl / S]);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ mm (stride 4)
-// one thread per generator row; spike matrix as per-row column masks (<= 32 columns per pass).
-// gather : out_bm[c, row] = sum over edges j of row with bit c of mask[j] set
-// scatter: for rows with mask != 0: out_bm[c, j] += w for every edge j and every set bit c (global atomics)
+// gather : one thread per generator row; spike matrix as per-column masks (<= 32 batch columns per pass):
+//          out_bm[c, row] = sum over edges j of row with bit c of mask[j] set
+// scatter: the residue-class kernel above with lane stride 4 and gridDim.y = batch column (jit_scatter_batched)
 template <int MODE, typename A>
 __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
                                                        A* __restrict__ out_bm) {
@@ -326,40 +335,6 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
 #pragma unroll
     for (int c = 0; c < 32; ++c)
       if (c < nc) out_bm[(int64_t)c * m + row] = (MODE == MODE_SCALAR) ? (A)(acc[c] * (A)p.w0) : acc[c];
-  }
-}
-
-template <int MODE, typename A>
-__global__ void __launch_bounds__(256) k_jit_mm_scatter(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
-                                                        A* __restrict__ out_bm) {
-  const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
-  const int64_t k = p.walk_len;
-  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < m; row += stride_t) {
-    const uint32_t mk = mask[row];
-    if (!mk) continue;
-    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-      const int64_t cs = (int64_t)chunk * p.chunk_size;
-      const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
-      const int64_t width = ce - cs;
-      for (uint32_t l = 0; l < (uint32_t)p.stride; ++l) {
-        uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
-        uint32_t q = lr_initial_q(state, p.cl);
-        uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
-        while ((int64_t)lj < width) {
-          const int64_t j = cs + (int64_t)lj;
-          const A w = edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)j);
-          uint32_t mm = mk;
-          while (mm) {
-            const int c = __ffs(mm) - 1;
-            mm &= mm - 1;
-            if (c < nc) atomicAdd(out_bm + (int64_t)c * k + j, w);
-          }
-          state = lr_next(state);
-          q = q + 1u + lr_bounded(state, p.cl - 1u);
-          lj = (uint64_t)l + (uint64_t)p.stride * q;
-        }
-      }
-    }
   }
 }
 
@@ -475,15 +450,15 @@ inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t
 constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators per scatter workgroup (128 KiB); multiples of 256
 
 struct ScatterGeom { int n_classes, pieces, parts; uint32_t piece_len; };
-inline ScatterGeom scatter_geom(const JitP& p, bool scalar) {
+inline ScatterGeom scatter_geom(const JitP& p, bool scalar, int64_t n_batch = 1) {
   ScatterGeom g;
-  g.n_classes = p.n_chunks * 32;
-  const int64_t Qmax = (std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32;
+  g.n_classes = p.n_chunks * p.stride;
+  const int64_t Qmax = (std::min<int64_t>(p.chunk_size, p.walk_len) + p.stride - 1) / p.stride;
   const uint32_t cap = scalar ? kPieceU32 : kPieceU64;
   g.pieces = (int)std::max<int64_t>(1, (Qmax + cap - 1) / cap);
   const int64_t per_piece = (Qmax + g.pieces - 1) / g.pieces;
   g.piece_len = (uint32_t)std::max<int64_t>(256, (per_piece + 255) & ~255ll);   // multiple of the reduce tile
-  int parts = 512 / std::max(1, g.n_classes * g.pieces);
+  int parts = (int)(512 / std::max<int64_t>(1, (int64_t)g.n_classes * g.pieces * n_batch));
   g.parts = std::max(1, std::min(parts, 16));
   return g;
 }
@@ -494,6 +469,8 @@ inline ScatterGeom scatter_geom(const JitP& p, bool scalar) {
 extern "C" int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,
                                  be_stream_t stream);
 extern "C" int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
+extern "C" int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch,
+                                         uint32_t* active_ids, int64_t active_stride, uint32_t* counts, be_stream_t stream);
 
 namespace {
 
@@ -524,40 +501,61 @@ int jit_mv_gather(const JitP& p, const void* spikes, int sd, void* out, int64_t 
   return BE_OK;
 }
 
+inline int64_t jit_counts_bytes(int64_t nb) { return be_align_up(nb * 4, 256); }
+inline int64_t jit_active_stride(int64_t m) { return be_align_up(m * 4, 256) / 4; }
+
+inline int64_t jit_scatter_ws_bytes(const JitP& p, int64_t m, int64_t nb) {
+  const ScatterGeom g = scatter_geom(p, false, nb), gs = scatter_geom(p, true, nb);
+  const int64_t a = (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len * 8;
+  const int64_t b = (int64_t)gs.n_classes * gs.pieces * gs.parts * gs.piece_len * 4;
+  return jit_counts_bytes(nb) + nb * jit_active_stride(m) * 4 + be_align_up(nb * std::max(a, b), 256);
+}
+
+// scatter ("trans" kernel) for a batch: spikes_bm [nb, m] -> out_bm [nb, walk_len]; stride 32 (mv) or 4 (mm)
 template <int MODE, typename W>
-int jit_mv_scatter(const JitP& p, const void* spikes, int sd, void* out, int64_t m, int scale_exp, void* ws,
-                   hipStream_t st) {
+int jit_scatter_batched(const JitP& p, const void* spikes_bm, int sd, void* out_bm, int64_t m, int64_t nb, int scale_exp,
+                        void* ws, hipStream_t st) {
   using AccT = typename ScatterAcc<MODE>::type;
   unsigned char* wsb = static_cast<unsigned char*>(ws);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
-  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
-  AccT* partial = reinterpret_cast<AccT*>(wsb + 256 + be_align_up(m * 4, 256));
-  int rc = be_compact_spikes(spikes, sd, m, active, count, st);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + jit_counts_bytes(nb));
+  const int64_t astride = jit_active_stride(m);
+  AccT* partial = reinterpret_cast<AccT*>(wsb + jit_counts_bytes(nb) + nb * astride * 4);
+  int rc = be_compact_spikes_batched(spikes_bm, sd, m, nb, active, astride, count, st);
   if (rc != BE_OK) return rc;
-  const ScatterGeom g = scatter_geom(p, MODE == MODE_SCALAR);
+  const ScatterGeom g = scatter_geom(p, MODE == MODE_SCALAR, nb);
   const size_t lds = (size_t)g.piece_len * sizeof(AccT);
   const float fx_scale = ldexpf(1.0f, scale_exp - 32);
-  const dim3 sgrid((unsigned)(g.n_classes * g.pieces * g.parts));
+  const dim3 sgrid((unsigned)(g.n_classes * g.pieces * g.parts), (unsigned)nb);
   const int prof = be_prof_begin(st);
   if (g.pieces == 1) {
     auto kern = k_jit_mv_scatter<MODE, true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial);
+    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial,
+                       astride);
   } else {
     auto kern = k_jit_mv_scatter<MODE, false>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial);
+    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial,
+                       astride);
   }
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   {
-    const int64_t q_per_chunk = (std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32;
-    const dim3 rgrid((unsigned)((q_per_chunk + 255) / 256), (unsigned)p.n_chunks);
+    const int64_t q_per_chunk = (std::min<int64_t>(p.chunk_size, p.walk_len) + p.stride - 1) / p.stride;
+    const dim3 rgrid((unsigned)((q_per_chunk + 255) / 256), (unsigned)p.n_chunks, (unsigned)nb);
+    const int64_t pstride = (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len;
     hipLaunchKernelGGL((k_jit_scatter_reduce<MODE, W>), rgrid, dim3(256), 0, st, partial, p, g.pieces, g.parts, g.piece_len,
-                       ldexp(1.0, -scale_exp), static_cast<W*>(out));
+                       ldexp(1.0, -scale_exp), static_cast<W*>(out_bm), pstride);
   }
   BE_LAUNCH_CHECK();
   return BE_OK;
+}
+
+template <int MODE, typename W>
+int jit_mv_scatter(const JitP& p, const void* spikes, int sd, void* out, int64_t m, int scale_exp, void* ws,
+                   hipStream_t st) {
+  return jit_scatter_batched<MODE, W>(p, spikes, sd, out, m, 1, scale_exp, ws, st);
 }
 
 inline int64_t jit_mv_ws_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int gather) {
@@ -567,12 +565,20 @@ inline int64_t jit_mv_ws_bytes(int64_t shape1, int64_t in_len, int64_t out_len, 
     const int64_t n_chunks = (in_len + chunk - 1) / chunk;
     return be_align_up((n_words + 2) * 4, 256) + be_align_up(std::max<int64_t>(1, n_chunks) * out_len * 8, 256);
   }
-  JitP p = make_params(shape1, out_len, 0, 2, 32, 0, 0);
-  const ScatterGeom g = scatter_geom(p, false);
-  const ScatterGeom gs = scatter_geom(p, true);
-  const int64_t a = (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len * 8;
-  const int64_t b = (int64_t)gs.n_classes * gs.pieces * gs.parts * gs.piece_len * 4;
-  return 256 + be_align_up(in_len * 4, 256) + be_align_up(std::max(a, b), 256);
+  const JitP p = make_params(shape1, out_len, 0, 2, 32, 0, 0);
+  return jit_scatter_ws_bytes(p, in_len, 1);
+}
+
+// fixed-point exponent from the weight bound of a family: |w| * 2^e * n_rows < 2^62
+inline int jit_scale_exp(int mode, double w0, double w1, int64_t n_rows) {
+  double wmax = std::fabs(w0);
+  if (mode == MODE_UNIFORM) wmax = std::max(std::fabs(w0), std::fabs(w0 + w1));
+  if (mode == MODE_NORMAL) wmax = std::fabs(w0) + 6.5 * std::fabs(w1);     // |normal01| <= 6.37 after the 1e-10 clamp
+  int e = 0;
+  if (wmax > 0) std::frexp(wmax, &e);
+  int lg = 1;
+  while ((1ll << lg) < n_rows + 1) ++lg;
+  return std::max(-90, std::min(150, 62 - e - lg));
 }
 
 template <int MODE>
@@ -593,10 +599,8 @@ int jit_mv_dispatch(const JitP& p, int wdtype, const void* spikes, int sd, void*
 
 template <int MODE, typename A>
 int jit_mm_run(const JitP& p, const uint32_t* mask, int64_t rows, int nc, int gather, A* out_bm, hipStream_t st) {
-  if (gather)
-    hipLaunchKernelGGL((k_jit_mm_gather<MODE, A>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
-  else
-    hipLaunchKernelGGL((k_jit_mm_scatter<MODE, A>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
+  (void)gather;   // only the gather ("notrans") direction comes here; the scatter runs jit_scatter_batched
+  hipLaunchKernelGGL((k_jit_mm_gather<MODE, A>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
@@ -636,8 +640,11 @@ int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, ui
   }
 }
 
-int64_t be_binary_jitmm_workspace_bytes(int64_t in_len, int64_t out_len, int64_t n_batch) {
-  return be_align_up(in_len * 4, 256) + be_align_up(std::max<int64_t>(1, n_batch) * out_len * 8, 256);
+int64_t be_binary_jitmm_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch, int gather) {
+  const int64_t nb = std::max<int64_t>(1, n_batch);
+  if (gather) return be_align_up(in_len * 4, 256) + be_align_up(nb * out_len * 8, 256);
+  const JitP p = make_params(shape1, out_len, 0, 2, 4, 0, 0);
+  return jit_scatter_ws_bytes(p, in_len, nb);
 }
 
 // spikes_bm [n_batch, in_len] -> out_bm [n_batch, out_len]; gather: generator rows = out_len, walk over in_len;
@@ -657,8 +664,26 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
     return BE_OK;
   }
   BE_REQUIRE(spikes_bm != nullptr, BE_ERR_INVALID, "spikes is NULL");
-  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_binary_jitmm_workspace_bytes(in_len, out_len, n_batch),
+  BE_REQUIRE(workspace != nullptr &&
+                 workspace_bytes >= be_binary_jitmm_workspace_bytes(shape1, in_len, out_len, n_batch, gather),
              BE_ERR_WORKSPACE, "workspace too small");
+  if (!gather) {
+    // scatter: the batched residue-class kernel of the mv path with lane stride 4 (gridDim.y = batch column)
+    const JitP ps = make_params(shape1, out_len, seed, clen, 4, w0, w1);
+    const int se = jit_scale_exp(mode, w0, w1, in_len);
+#define BE_JITMM_SC(MODE_)                                                                                              \
+    switch (wdtype) {                                                                                                   \
+      case BE_F32: return jit_scatter_batched<MODE_, float>(ps, spikes_bm, spike_dtype, out_bm, in_len, n_batch, se, workspace, st);          \
+      case BE_F64: return jit_scatter_batched<MODE_, double>(ps, spikes_bm, spike_dtype, out_bm, in_len, n_batch, se, workspace, st);         \
+      case BE_F16: return jit_scatter_batched<MODE_, __half>(ps, spikes_bm, spike_dtype, out_bm, in_len, n_batch, se, workspace, st);         \
+      case BE_BF16: return jit_scatter_batched<MODE_, __hip_bfloat16>(ps, spikes_bm, spike_dtype, out_bm, in_len, n_batch, se, workspace, st); \
+      default: be_set_error("unknown weight dtype"); return BE_ERR_INVALID;                                             \
+    }
+    if (mode == MODE_SCALAR) { BE_JITMM_SC(MODE_SCALAR) }
+    else if (mode == MODE_UNIFORM) { BE_JITMM_SC(MODE_UNIFORM) }
+    else { BE_JITMM_SC(MODE_NORMAL) }
+#undef BE_JITMM_SC
+  }
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* mask = reinterpret_cast<uint32_t*>(wsb);
   void* scratch = wsb + be_align_up(in_len * 4, 256);

@@ -71,6 +71,9 @@ int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bit
 /* spikes[n] -> active_ids[<=n] (unordered) and *count (device uint32) */
 int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,
                       be_stream_t stream);
+/* batch-major spikes_bm[n_batch, n] -> active_ids[b * active_stride + ...] and counts[b] */
+int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch, uint32_t* active_ids,
+                              int64_t active_stride, uint32_t* counts, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch convention (all *mm entry points): spikes_bm is batch-major [n_batch, len] and out_bm is
@@ -220,7 +223,7 @@ int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t 
 int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                     int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather,
                     int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
-int64_t be_binary_jitmm_workspace_bytes(int64_t in_len, int64_t out_len, int64_t n_batch);
+int64_t be_binary_jitmm_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch, int gather);
 int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes_bm,
                     int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,
                     int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream);
