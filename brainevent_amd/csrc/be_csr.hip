@@ -193,6 +193,133 @@ __global__ void __launch_bounds__(256) k_csrmv_nt(const W* __restrict__ weights,
   }
 }
 
+// long rows: one wave per row, 16 waves per workgroup (they share the LDS bitmap, which takes most of the LDS, so
+// these 16 waves are all the latency hiding a CU gets), 4 consecutive entries per lane per load through raw buffer
+// descriptors (range-checked: no tail branches), two iterations (2 KB of indices [+ 2 KB of f32 weights]) in flight.
+// f32 weights are streamed unconditionally with the same vector loads — a dependent load per active entry would
+// serialise the row at one HBM round trip per hit; other weight dtypes keep the conditional scalar load.
+typedef unsigned be_nt_v4u __attribute__((ext_vector_type(4)));
+
+template <typename W, bool HOMO, bool BITS_IN_LDS>
+__global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                        RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
+                                                        W* __restrict__ out, int64_t m) {
+  bits_g += (int64_t)blockIdx.y * n_words;
+  out += (int64_t)blockIdx.y * m;
+  extern __shared__ uint32_t bits_s[];
+  const uint32_t* bits = bits_g;
+  if (BITS_IN_LDS) {
+    for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) bits_s[i] = bits_g[i];
+    __syncthreads();
+    bits = bits_s;
+  }
+  using ACC = typename WTraits<W>::acc;
+  constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
+  const int lane = lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  ACC w0 = ACC(0);
+  if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
+
+  // one row: entries [j_begin, len) of the row starting at b, through descriptors of at most 2^30 entries
+  auto row_tail = [&](int64_t b, int64_t len, int64_t j_begin, ACC& acc, int& cnt) {
+    for (int64_t p0 = (j_begin >> 30) << 30; p0 < len; p0 += (1ll << 30)) {
+      const int64_t plen = len - p0 < (1ll << 30) ? len - p0 : (1ll << 30);
+      auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(indices + b + p0), 0, (int)(plen * 4), 0x00020000);
+      auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(VECW ? weights + b + p0 : weights), 0,
+                                                  VECW ? (int)(plen * 4) : 0, 0x00020000);
+      for (int64_t j0 = (p0 == ((j_begin >> 30) << 30)) ? (j_begin - p0) : 0; j0 < plen; j0 += 512) {
+        be_nt_v4u c[2], wv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int off = (int)(j0 + 256 * u + 4 * lane) * 4;
+          c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0);
+          if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + 256 * u + 4 * lane + q;
+            if (j < plen) {
+              const uint32_t col = c[u][q];
+              const bool on = (bits[col >> 5] >> (col & 31)) & 1u;
+              if (HOMO) cnt += on ? 1 : 0;
+              else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
+              else if (on) acc += (ACC)WTraits<W>::load(weights, b + p0 + j);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // rows of this wave: wave, wave + n_waves, ...; their bounds are fetched 64 at a time (lane l -> l-th next row) and
+  // four rows' first 256 entries are in flight together; longer rows continue in row_tail
+  for (int64_t t0 = 0;; t0 += 64) {
+    const int64_t my_r = wave + n_waves * (t0 + lane);
+    const bool valid = my_r < m;
+    const unsigned long long vmask = __ballot(valid);
+    if (vmask == 0ull) break;
+    const int64_t rc = valid ? my_r : 0;
+    int64_t rb = rp.at(rc), re = rp.at(rc + 1);
+    if (!valid) { rb = 0; re = 0; }
+    const uint32_t b_lo = (uint32_t)rb, b_hi = (uint32_t)((uint64_t)rb >> 32);
+    const uint64_t rl = (uint64_t)(re - rb);
+    const uint32_t l_lo = (uint32_t)rl, l_hi = (uint32_t)(rl >> 32);
+    const int nvalid = __popcll(vmask);
+    for (int i = 0; i < nvalid; i += 4) {
+      int64_t gb[4], gl[4];
+      be_nt_v4u c[4], wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int src = (i + q) & 63;
+        gb[q] = (int64_t)(((uint64_t)__builtin_amdgcn_readlane(b_hi, src) << 32) | __builtin_amdgcn_readlane(b_lo, src));
+        gl[q] = (i + q < nvalid)
+                    ? (int64_t)(((uint64_t)__builtin_amdgcn_readlane(l_hi, src) << 32) | __builtin_amdgcn_readlane(l_lo, src))
+                    : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t hl = gl[q] < 256 ? gl[q] : 256;       // head: first 256 entries
+        auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(indices + gb[q]), 0, (int)(hl * 4), 0x00020000);
+        c[q] = __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, 0, 0);
+        if (VECW) {
+          auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(weights + gb[q]), 0, (int)(hl * 4), 0x00020000);
+          wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i + q >= nvalid) break;                           // uniform
+        ACC acc = ACC(0);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t j = 4 * lane + e;
+          if (j < gl[q] && j < 256) {
+            const uint32_t col = c[q][e];
+            const bool on = (bits[col >> 5] >> (col & 31)) & 1u;
+            if (HOMO) cnt += on ? 1 : 0;
+            else if (VECW) acc += on ? (ACC)__uint_as_float(wv[q][e]) : ACC(0);
+            else if (on) acc += (ACC)WTraits<W>::load(weights, gb[q] + j);
+          }
+        }
+        if (gl[q] > 256) row_tail(gb[q], gl[q], 256, acc, cnt);   // uniform
+        if (HOMO) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+          acc = (ACC)cnt * w0;
+        } else {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        }
+        if (lane == 0) WTraits<W>::store(out, wave + n_waves * (t0 + i + q), acc);
+      }
+    }
+  }
+}
+
 // =================================================================================================
 // scatter plan: count -> scan -> fill
 //
@@ -739,7 +866,23 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
   const int64_t avg = nnz_hint / (m > 0 ? m : 1);
   if (avg <= 8) return csrmv_nt_launch<W, HOMO, 4>(weights, indices, rp, bits, n_words, out, m, nb, st);
   if (avg <= 48) return csrmv_nt_launch<W, HOMO, 16>(weights, indices, rp, bits, n_words, out, m, nb, st);
-  return csrmv_nt_launch<W, HOMO, 64>(weights, indices, rp, bits, n_words, out, m, nb, st);
+  {
+    const size_t lds = (size_t)n_words * 4;
+    const int grid = grid_for(m, 16, nb >= 8 ? 256 : 512);
+    const int prof = be_prof_begin(st);
+    if (lds <= 150 * 1024) {
+      auto kern = k_csrmv_nt_wave<W, HOMO, true>;
+      BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
+                         bits, n_words, static_cast<W*>(out), m);
+    } else {
+      hipLaunchKernelGGL((k_csrmv_nt_wave<W, HOMO, false>), dim3(grid, (unsigned)nb), dim3(1024), 0, st,
+                         static_cast<const W*>(weights), indices, rp, bits, n_words, static_cast<W*>(out), m);
+    }
+    be_prof_end(prof, st);
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
 }
 
 #define BE_DISPATCH_W(wdtype, HOMO_FLAG, CALL)                                  \
