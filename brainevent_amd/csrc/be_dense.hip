@@ -591,6 +591,75 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA path, transpose=False (batched):  out[i, b] = sum_k W[i, k] * S[k, b]
+//   A = 32 weight rows x 16 k: exactly the MFMA A-operand layout (lane: row = lane & 31, 8 consecutive k at
+//   8 * (lane >> 5)), so a lane loads its fragment with ONE 16-byte global load — no LDS, no transpose.
+//   B = the 0/1 spike tile (16 k x 32 batch rows), rebuilt in registers from 16 masks staged in LDS per K chunk.
+//   One wave = 32 weight rows over the whole K range, 8 K-steps of weight rows in flight (register ring).
+//   The whole matrix is streamed (this direction cannot skip rows), so the bound is k * m * sizeof(W) / HBM.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNtChunk = 4096;   // k per mask chunk staged in LDS (256 steps)
+constexpr int kNtRing = 8;
+
+template <typename W>
+__global__ void __launch_bounds__(256) k_densemm_nt_mfma(const W* __restrict__ weights, int64_t m, int64_t k,
+                                                         const uint32_t* __restrict__ mask, W* __restrict__ out_bm, int nc,
+                                                         int b0) {
+  __shared__ uint32_t masks_s[kNtChunk + 16 * kNtRing];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int r_lane = lane & 31, h = lane >> 5;
+  const int64_t row = m0 + r_lane < m ? m0 + r_lane : m - 1;            // clamped: results of rows >= m are dropped
+  const W* wrow = weights + row * k + 8 * h;
+  be_v16f acc = {};
+  uint4 ring[kNtRing];
+  for (int64_t c0 = 0; c0 < k; c0 += kNtChunk) {
+    const int64_t clen = k - c0 < kNtChunk ? k - c0 : kNtChunk;          // multiple of 8 (k % 8 == 0)
+    const int steps = (int)((clen + 15) >> 4);
+    __syncthreads();
+    for (int j = tid; j < kNtChunk + 16 * kNtRing; j += 256) masks_s[j] = (j < clen) ? mask[c0 + j] : 0u;
+    __syncthreads();
+    // fetch only issues the load (address clamped into the row); a half-step past the end of k is zeroed at use
+    auto fetch = [&](int t, uint4& a) {
+      int64_t kpos = c0 + 16 * (int64_t)t;
+      kpos = kpos + 8 * h + 8 <= k ? kpos : (k - 8 - 8 * h > 0 ? k - 8 - 8 * h : 0);
+      a = *reinterpret_cast<const uint4*>(wrow + kpos);
+    };
+#pragma unroll
+    for (int s = 0; s < kNtRing; ++s) {
+      fetch(s, ring[s]);
+      __builtin_amdgcn_sched_barrier(0);      // keep the issue order = the consume order (counted vmcnt needs it)
+    }
+    for (int t0 = 0; t0 < steps; t0 += kNtRing) {
+#pragma unroll
+      for (int ii = 0; ii < kNtRing; ++ii) {
+        const int t = t0 + ii;            // steps beyond `steps` multiply zero masks (padding of masks_s)
+        const uint32_t* mk = &masks_s[16 * t + 8 * h];
+        be_v8s bfrag;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bfrag[j] = (short)(((mk[j] >> r_lane) & 1u) * MfmaOne<W>::one);
+        const bool in_k = c0 + 16 * (int64_t)t + 8 * h + 8 <= k;
+        const uint4 av = in_k ? ring[ii] : make_uint4(0, 0, 0, 0);
+        const be_v8s afrag = __builtin_bit_cast(be_v8s, av);
+        acc = mfma_32x32x16<W>(afrag, bfrag, acc);
+        fetch(t + kNtRing, ring[ii]);
+        // pin the refill here: hipcc otherwise sinks the loads next to their uses and the ring collapses to depth 2
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // C layout: col (batch) = lane & 31, row (weight row) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int b = lane & 31;
+  if (b < nc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[r]);
+    }
+  }
+}
+
 template <typename W>
 __global__ void __launch_bounds__(256) k_mfma_reduce(const float* __restrict__ partial, int parts, int64_t part_stride,
                                                      int64_t total, W* __restrict__ out) {
@@ -650,6 +719,30 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
 }
 
 template <typename W>
+int densemm_nt_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t m, int64_t k, int64_t nb, void* ws,
+                    hipStream_t st) {
+  DenseWs d = carve(ws, k);
+  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
+  const int prof = be_prof_begin(st);
+  for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
+    const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    if (sd == BE_SPIKE_FLOAT)
+      hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const float*>(chunk), k, nc, d.mask);
+    else
+      hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
+                         static_cast<const uint8_t*>(chunk), k, nc, d.mask);
+    BE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_densemm_nt_mfma<W>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
+                       out_bm, nc, (int)b0);
+    BE_LAUNCH_CHECK();
+  }
+  be_prof_end(prof, st);
+  return BE_OK;
+}
+
+template <typename W>
 int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm, int64_t rows_w, int64_t cols_w,
                 int64_t nb, int transpose, void* ws, hipStream_t st) {
   const W* w = static_cast<const W*>(weights);
@@ -662,6 +755,11 @@ int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm
     }
     if (vec_ok) return densemm_t_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
     return densemm_t_vec<W, 1>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+  }
+  if constexpr (std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value) {
+    // enough rows to fill the chip with 32-row waves; k >= 16 so that the clamped tail load stays inside the row
+    if (vec_ok && nb >= 8 && rows_w >= 4096 && cols_w >= 16)
+      return densemm_nt_mfma<W>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
   }
   if (vec_ok) return densemm_nt_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
   return densemm_nt_vec<W, 1>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);

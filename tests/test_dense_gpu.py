@@ -82,3 +82,24 @@ def test_binaryarray_dense_errors(be):
         be.BinaryArray(np.asarray(1, np.uint8)) @ W                # 0-D
     with pytest.raises(be.MathError):
         be.BinaryArray(np.ones((2, 2, 3), np.uint8)) @ W           # 3-D
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape,nb', [((4096, 1024), 8), ((4200, 1048), 33), ((8192, 72), 16)])
+def test_densemm_mfma_both_directions(be, oracle, dtype, shape, nb):
+    """Shapes that take the MFMA kernels (>= 8 batch rows; no-transpose additionally needs >= 4096 weight rows),
+    including row / column counts that are not tile multiples and a k that is 8 (not 16) aligned."""
+    rng = np.random.default_rng(shape[1] + nb)
+    W = torch.tensor(rng.normal(0, 1, shape), dtype=dtype, device='cuda')
+    Wd = W.float().cpu().numpy().astype(np.float64)
+    tol = 2e-3 if dtype == torch.float16 else 2e-2
+    S_nt = torch.tensor(rng.random((shape[1], nb)) < 0.3, device='cuda')           # W[m,k] @ S[k,nb]
+    got = be.binary_densemm(W, S_nt, transpose=False)
+    ref = oracle.binary_densemm(Wd, S_nt.cpu().numpy(), False)
+    assert tuple(got.shape) == (shape[0], nb) and got.dtype == dtype
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+    S_t = torch.tensor(rng.random((shape[0], nb)) < 0.3, device='cuda')            # W[k,n].T @ S[k,nb]
+    got = be.binary_densemm(W, S_t, transpose=True)
+    ref = oracle.binary_densemm(Wd, S_t.cpu().numpy(), True)
+    assert tuple(got.shape) == (shape[1], nb)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
