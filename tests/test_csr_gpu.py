@@ -382,3 +382,42 @@ def test_plan_refuses_weights_it_cannot_resolve_and_class_falls_back(be, oracle,
     csr = be.CSR((w_inf, idx, ptr), shape=(m, k))
     got = be.BinaryArray(np.ones(m, bool)) @ csr
     assert csr.buffers['scatter_plan'] is None and np.isinf(got[idx[7]])
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_scatter_plan_preserves_structure_bit_exactly(be, homo):
+    """Decode the planned layout (seg table + 128-byte aligned blocks) back to (row, column, weight) triples on the
+    host: it must be exactly the CSR's multiset — integer structure and weight bit patterns."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(99)
+    m, k, shift = 300, 5000, 9
+    lens = rng.integers(0, 120, m); lens[::11] = 0
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift)
+    seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
+    blob = plan.blob.cpu().numpy()
+    S = 1 << shift
+    got = []
+    for r in range(m):
+        for s in range(plan.n_slices):
+            start, ng = int(seg[r, s, 0]), int(seg[r, s, 1])
+            if ng == 0:
+                continue
+            assert (start * 128) % 128 == 0
+            base = start * 128
+            if homo:
+                cols = blob[base:base + ng * 16].view(np.uint16)
+                ws = np.zeros(cols.size, np.uint32)
+            else:
+                ws = blob[base:base + ng * 16].view(np.uint32)
+                cols = blob[base + ng * 16:base + ng * 24].view(np.uint16)
+            for c, wb in zip(cols, ws):
+                if c == S:                       # pad entry
+                    assert wb == 0
+                    continue
+                assert c < S
+                got.append((r, s * S + int(c), int(wb)))
+    wbits = np.zeros(idx.size, np.uint32) if homo else w.view(np.uint32)
+    rows = np.repeat(np.arange(m), np.diff(ptr))
+    ref = sorted(zip(rows.tolist(), idx.tolist(), wbits.tolist()))
+    assert sorted(got) == ref
