@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--fire', type=float, default=0.01)
     ap.add_argument('--homo', action='store_true', help='homogeneous weight (4 B/update) instead of hetero f32')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--exchange', choices=['bits', 'bytes'], default='bits', help='payload of the per-step spike all-gather (N > 1)')
     ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
     ap.add_argument('--parts', type=int, default=0)
     ap.add_argument('--shift', type=int, default=0)
@@ -257,11 +258,13 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(999 + rank)
     n_local = n_pre // world
-    local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
     if use_dist:
         from brainevent_amd._dist import SpikeExchange
-        exchange = SpikeExchange(n_pre, packed=False, device=dev)     # one all-gather per step (RCCL over xGMI)
-        assert exchange.hi - exchange.lo == n_local, 'n must be divisible by the number of GPUs'
+        # one all-gather per step (RCCL over xGMI); bit-packed by default: 1/8 of the bytes, consumed packed
+        exchange = SpikeExchange(n_pre, packed=(args.exchange == 'bits'), device=dev)
+        n_local = exchange.hi - exchange.lo
+    local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
+    if use_dist:
         counts = torch.empty(n_batch, dtype=torch.int64, device=dev)
         for b in range(n_batch):
             counts[b] = exchange.gather(local_spikes[b]).sum()
@@ -272,7 +275,7 @@ def main():
     def step(i):
         s = local_spikes[i % n_batch]
         if use_dist:
-            s = exchange.gather(s)
+            return exchange.gather_events(s) @ csr
         return be.BinaryArray(s) @ csr
 
     def fence():
@@ -337,7 +340,7 @@ def main():
                                    f"{n_pre} pre x {n_post_total} post, {args.conn:g} density "
                                    f"({n_conn} synapses/row/shard), route={args.route}",
                        'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
-                       'parallelism': f'post-slice x{world}' + (' + spike all-gather' if world > 1 else ''),
+                       'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange})' if use_dist else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
                        'mean_active_rows': mean_active, 'checksum': checksum},
             'roofline': roof,

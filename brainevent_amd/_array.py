@@ -11,7 +11,7 @@ import torch
 from ._lib import require_device
 
 BE_F32, BE_F64, BE_F16, BE_BF16 = 0, 1, 2, 3
-BE_SPIKE_BOOL, BE_SPIKE_FLOAT = 0, 1
+BE_SPIKE_BOOL, BE_SPIKE_FLOAT, BE_SPIKE_BITS = 0, 1, 2
 
 _W_CODE = {torch.float32: BE_F32, torch.float64: BE_F64, torch.float16: BE_F16, torch.bfloat16: BE_BF16}
 _W_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16', torch.bfloat16: 'bf16'}
@@ -21,9 +21,26 @@ def is_array(x: Any) -> bool:
     return isinstance(x, (np.ndarray, torch.Tensor, np.generic, list, tuple, int, float, bool))
 
 
+class PackedSpikes:
+    """1-D event vector held bit-packed on the device: ``bits`` is ``uint32[ceil(n/32)]`` (stored as an int32
+    tensor), bit ``i % 32`` of word ``i // 32`` (the layout of the reference's ``bitpack``,
+    ``brainevent/_event/bitpack_binary.py:32-75``).  Quacks like a 1-D bool array for the shape validators."""
+    __slots__ = ('bits', 'n', 'numpy_result')
+
+    def __init__(self, bits: torch.Tensor, n: int, numpy_result: bool = False):
+        assert bits.ndim == 1 and bits.dtype in (torch.int32, torch.uint32), "bits must be a 1-D 32-bit word tensor"
+        assert bits.numel() >= (int(n) + 31) // 32, "bits too short for n"
+        self.bits, self.n, self.numpy_result = bits, int(n), bool(numpy_result)
+
+    shape = property(lambda self: (self.n,))
+    ndim = property(lambda self: 1)
+    dtype = property(lambda self: torch.bool)
+    size = property(lambda self: self.n)
+
+
 def wants_numpy(*xs) -> bool:
     """Result type follows the inputs: torch tensor if any operand is one, else numpy."""
-    return not any(isinstance(x, torch.Tensor) for x in xs)
+    return not any(isinstance(x, torch.Tensor) or (isinstance(x, PackedSpikes) and not x.numpy_result) for x in xs)
 
 
 def device() -> torch.device:
@@ -74,6 +91,8 @@ def spikes_to_device(v) -> Tuple[torch.Tensor, int]:
     other float widths are thresholded to bool first, other integers are cast to bool
     (reference ``brainevent/_dense/binary.py:162-163``, ``brainevent/_fcn/binary.py:285``).
     """
+    if isinstance(v, PackedSpikes):
+        return to_device(v.bits), BE_SPIKE_BITS
     t = to_device(v)
     if t.dtype in (torch.bool, torch.uint8, torch.int8):
         return t, BE_SPIKE_BOOL

@@ -25,7 +25,7 @@ import torch
 
 from . import _array as A
 from ._error import MathError
-from ._event import BinaryArray
+from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
 from ._misc import _as_indptr, _as_int32_indices, _check_compressed_structure
 from ._op import OpKernel
@@ -129,11 +129,33 @@ class ScatterPlan:
             e = math.frexp(wmax)[1] if wmax > 0 else 0
             scale_exp = 62 - e - max(1, int(math.ceil(math.log2(m + 1))))
             scale_exp = max(-90, min(150, scale_exp))   # 2^(scale_exp-32) must be a normal f32
-            # the smallest non-zero weight must keep at least MIN_WEIGHT_BITS bits in the fixed-point sum
-            if int(mm[1]) != 0xFFFFFFFF and wmin * 2.0 ** scale_exp < 2.0 ** cls.MIN_WEIGHT_BITS:
+            if int(mm[1]) != 0xFFFFFFFF and not _fixed_point_resolves(weights, indices, k, scale_exp, wmin):
                 raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
                                 f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
         return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype)
+
+
+def _fixed_point_resolves(weights: torch.Tensor, indices: Optional[torch.Tensor], k: int, scale_exp: int,
+                          wmin: float) -> bool:
+    """Accuracy gate of the fixed-point routes.  A sum of ``n`` weights carries an absolute error below
+    ``n * 2^-scale_exp``; the routes are used when that is below ``2^-MIN_WEIGHT_BITS`` of the largest weight
+    *of every output column* (so each output is good to ~1e-5 of its column's weight scale, the tolerance of the
+    path).  Cheap sufficient test first: the globally smallest non-zero ``|w|`` keeps ``MIN_WEIGHT_BITS`` bits.
+    Otherwise (e.g. U[0,1) weights: 1e10 samples contain values down to 2^-32) the per-column maxima decide:
+    one chunked scatter-max over the entries, build time only."""
+    thr = 2.0 ** (ScatterPlan.MIN_WEIGHT_BITS - scale_exp)
+    if wmin >= thr:
+        return True
+    if indices is None:
+        return False
+    flat_w, flat_i = weights.reshape(-1), indices.reshape(-1)
+    colmax = torch.zeros(int(k), dtype=torch.float32, device=flat_w.device)
+    chunk = 1 << 26
+    for lo in range(0, flat_i.numel(), chunk):
+        colmax.scatter_reduce_(0, flat_i[lo:lo + chunk].long(), flat_w[lo:lo + chunk].abs().float(), 'amax',
+                               include_self=True)
+    live = colmax[colmax > 0]              # columns without a non-zero weight are exact zeros
+    return bool((live >= thr).all().item()) if live.numel() else True
 
 
 class BinnedScatter:
@@ -146,7 +168,7 @@ class BinnedScatter:
     """
 
     def __init__(self, weights: torch.Tensor, m: int, k: int, nnz: int, *, max_active_fraction: float = 0.05,
-                 slice_shift: Optional[int] = None):
+                 slice_shift: Optional[int] = None, indices: Optional[torch.Tensor] = None):
         self.m, self.k = int(m), int(k)
         self.homo = weights.numel() == 1
         self.slice_shift = ScatterPlan.default_shift(k, self.homo) if slice_shift is None else int(slice_shift)
@@ -162,7 +184,7 @@ class BinnedScatter:
             self.scale_exp = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(m + 1))))))
             nz = weights.abs()
             nz = nz[nz > 0]
-            if nz.numel() and float(nz.min().item()) * 2.0 ** self.scale_exp < 2.0 ** ScatterPlan.MIN_WEIGHT_BITS:
+            if nz.numel() and not _fixed_point_resolves(weights, indices, k, self.scale_exp, float(nz.min().item())):
                 raise MathError("BinnedScatter: dynamic range of the weights exceeds what the fixed-point sums resolve.")
         f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
         self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))
@@ -210,6 +232,18 @@ def _variant(homo: bool, w: torch.Tensor, sd: int) -> str:
 _CSRMM_ARGS = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]
 
 
+_CSRMM_GENERIC_ARGS = [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]
+
+
+def _csrmm_generic(weights, indices, indptr, row_len, spikes_bm, sd, out, m, k, nb, ws, transpose) -> None:
+    """``be_binary_csrmm_{t,nt}`` with explicit dtype codes (any spike encoding; ``indptr=None`` = fixed row length)."""
+    name = 'be_binary_csrmm_t' if transpose else 'be_binary_csrmm_nt'
+    f = fn(name, c_int, _CSRMM_GENERIC_ARGS)
+    is64 = int(indptr is not None and indptr.dtype == torch.int64)
+    check(f(A.ptr(weights), int(weights.numel() == 1), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len,
+            A.ptr(spikes_bm), sd, A.ptr(out), m, k, nb, A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+
+
 def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, workspace=None):
     """Run the CSR kernels on a batch-major spike matrix ``[n_batch, len]`` -> ``[n_batch, out_len]``."""
     m, k = int(shape[0]), int(shape[1])
@@ -233,11 +267,14 @@ def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, w
             return out
         f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
         ws = A.workspace(f_ws(m, k, nb, A.wcode(weights)))
-        f = fn('be_binary_csrmm_t_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
+        f = None if sd == A.BE_SPIKE_BITS else fn('be_binary_csrmm_t_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
     else:
         f_ws = fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
         ws = A.workspace(f_ws(m, k, nb))
-        f = fn('be_binary_csrmm_nt_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
+        f = None if sd == A.BE_SPIKE_BITS else fn('be_binary_csrmm_nt_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
+    if f is None:     # bit-packed events go through the generic entry point (the per-variant names cover bool / float)
+        _csrmm_generic(weights, indices, indptr, -1, spikes_bm, sd, out, m, k, nb, ws, transpose)
+        return out
     check(f(A.ptr(weights), A.ptr(indices), A.ptr(indptr), is64, A.ptr(spikes_bm), A.ptr(out), m, k, nb, A.ptr(ws),
             ws.numel(), A.stream_ptr()), f.__name__)
     return out
@@ -464,7 +501,7 @@ class CompressedSparseData:
                     plan = None       # inf / nan / extreme dynamic range: float atomics (direct route) handle those
             elif BinnedScatter.applicable(self.data, k):
                 try:
-                    plan = BinnedScatter(self.data, m, k, self.nse)
+                    plan = BinnedScatter(self.data, m, k, self.nse, indices=self.indices)
                 except MathError:
                     plan = None
         self.buffers['scatter_plan'] = plan
@@ -505,10 +542,13 @@ class CompressedSparseData:
         if nse >= PLAN_MIN_NNZ and t_data.dtype != torch.float64:
             shift = ScatterPlan.default_shift(m, homo)
             n_slices = (m + (1 << shift) - 1) >> shift
-            if nse / (k * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096:
-                mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift)
-            elif BinnedScatter.applicable(t_data, m):
-                mirror['plan'] = BinnedScatter(t_data, k, m, nse)
+            try:
+                if nse / (k * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096:
+                    mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift)
+                elif BinnedScatter.applicable(t_data, m):
+                    mirror['plan'] = BinnedScatter(t_data, k, m, nse, indices=t_indices)
+            except MathError:        # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel
+                mirror['plan'] = None
         self.buffers['mirror'] = mirror
         return mirror
 
@@ -527,8 +567,9 @@ class CompressedSparseData:
         return A.to_result(t, self._numpy_result)
 
 
-def _event_value(other: BinaryArray):
-    return other.value
+def _event_value(other):
+    """Kernel operand of an event container: packed words for 1-D bit-packed containers, else the value."""
+    return event_operand(other)
 
 
 class CSR(CompressedSparseData):
@@ -536,7 +577,7 @@ class CSR(CompressedSparseData):
     _compressed_format = 'csr'
 
     def __matmul__(self, other):      # csr @ other
-        if isinstance(other, BinaryArray):
+        if is_event(other):
             v = _event_value(other)
             r = self._gather_via_mirror(v) if v.ndim in (1, 2) else None
             if r is not None:
@@ -553,7 +594,7 @@ class CSR(CompressedSparseData):
         raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
 
     def __rmatmul__(self, other):     # other @ csr
-        if isinstance(other, BinaryArray):
+        if is_event(other):
             v = _event_value(other)
             ws = self._scatter_workspace()
             if v.ndim == 1:
@@ -583,7 +624,7 @@ class CSC(CompressedSparseData):
     _compressed_format = 'csc'
 
     def __matmul__(self, other):      # csc @ other : scatter over the active columns
-        if isinstance(other, BinaryArray):
+        if is_event(other):
             v = _event_value(other)
             ws = self._scatter_workspace()
             if v.ndim == 1:
@@ -598,7 +639,7 @@ class CSC(CompressedSparseData):
         raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
 
     def __rmatmul__(self, other):     # other @ csc : gather
-        if isinstance(other, BinaryArray):
+        if is_event(other):
             v = _event_value(other)
             r = None
             if v.ndim == 1:

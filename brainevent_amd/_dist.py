@@ -8,14 +8,15 @@ population; one ``all_gather`` rebuilds the full spike vector everywhere; the sc
 outputs are disjoint (no reduction, no halo).
 
 The exchange carries the spike vector bit-packed (1 bit per neuron: 125 KB instead of 1 MB at N = 1M) when
-``packed=True``; xGMI is point-to-point, so the payload per link is what matters.
+``packed=True``; xGMI is point-to-point, so the payload per link is what matters, and the kernels consume the
+gathered words as they are (no unpack).
 """
 from typing import Callable, Optional, Tuple
 
 import numpy as np
 import torch
 
-__all__ = ['post_slice_bounds', 'pre_slice_bounds', 'shard_csr_by_post', 'shard_fixed_num_by_post', 'SpikeExchange',
+__all__ = ['post_slice_bounds', 'pre_slice_bounds', 'word_aligned_bounds', 'shard_csr_by_post', 'shard_fixed_num_by_post', 'SpikeExchange',
            'DistributedScatter']
 
 
@@ -73,8 +74,23 @@ def _unpack_bits(packed: torch.Tensor, n: int) -> torch.Tensor:
     return ((packed.view(-1, 1) & w) != 0).view(-1)[:n]
 
 
+def word_aligned_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Slice ``[lo, hi)`` of an ``n``-long vector for ``rank`` when every rank owns the same whole number of 32-bit
+    words (the last owners may hold fewer — or no — elements).  Used by the bit-packed exchange so the gathered words
+    are the packed full vector with no re-alignment."""
+    wpr = (((int(n) + 31) // 32) + world - 1) // world
+    lo = min(int(n), rank * wpr * 32)
+    return lo, min(int(n), (rank + 1) * wpr * 32)
+
+
 class SpikeExchange:
-    """All-gather of the per-rank spike slices into the full spike vector (the only collective of the path)."""
+    """All-gather of the per-rank spike slices into the full spike vector (the only collective of the path).
+
+    ``packed=False``: one byte per neuron, balanced slices (``pre_slice_bounds``).
+    ``packed=True`` : one bit per neuron, word-aligned slices (``word_aligned_bounds``).  On the GPU the local slice is
+    packed by ``be_pack_spikes``, the words are gathered, and the result is handed to the kernels still packed
+    (``BitPackedBinary.from_packed`` -> ``BE_SPIKE_BITS``): 1/8 of the bytes on every xGMI link and no unpack kernel.
+    """
 
     def __init__(self, n_pre: int, group=None, packed: bool = False, device=None):
         import torch.distributed as dist
@@ -84,60 +100,91 @@ class SpikeExchange:
         self.rank = dist.get_rank(group)
         self.n_pre = int(n_pre)
         self.packed = bool(packed)
-        self.bounds = [pre_slice_bounds(n_pre, self.world, r) for r in range(self.world)]
+        self.device = device
+        bounds_of = word_aligned_bounds if self.packed else pre_slice_bounds
+        self.bounds = [bounds_of(self.n_pre, self.world, r) for r in range(self.world)]
         self.lo, self.hi = self.bounds[self.rank]
         sizes = [b[1] - b[0] for b in self.bounds]
-        self.uniform = len(set(sizes)) == 1 and (not packed or sizes[0] % 8 == 0)
-        self.device = device
-        n_local = sizes[0]
-        if self.uniform:
-            per = n_local // 8 if packed else n_local
-            self._full = torch.empty(per * self.world, dtype=torch.uint8, device=device)
+        if self.packed:
+            self.words_per_rank = (((self.n_pre + 31) // 32) + self.world - 1) // self.world
+            self._local_words = torch.zeros(max(self.words_per_rank, 1), dtype=torch.int32, device=device)
+            self._full_words = torch.zeros(max(self.words_per_rank, 1) * self.world, dtype=torch.int32, device=device)
+            self.uniform = True
         else:
-            # ragged slices: every rank pads its payload to the largest slice (collectives need equal sizes)
-            self._pad = max((s + 7) // 8 if packed else s for s in sizes)
-            self._chunks = [torch.empty(self._pad, dtype=torch.uint8, device=device) for _ in sizes]
+            self.uniform = len(set(sizes)) == 1
+            if self.uniform:
+                self._full = torch.empty(sizes[0] * self.world, dtype=torch.uint8, device=device)
+            else:
+                # ragged slices: every rank pads its payload to the largest slice (collectives need equal sizes)
+                self._pad = max(sizes)
+                self._chunks = [torch.empty(self._pad, dtype=torch.uint8, device=device) for _ in sizes]
+
+    # -- packed path ------------------------------------------------------------------------------------
+    def _gather_words(self, local_spikes: torch.Tensor) -> torch.Tensor:
+        n_local = self.hi - self.lo
+        if local_spikes.is_cuda:
+            import ctypes
+            from . import _array as A
+            from ._lib import fn, check
+            sp, sd = A.spikes_to_device(local_spikes)
+            if n_local:
+                f = fn('be_pack_spikes', ctypes.c_int,
+                       [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p])
+                check(f(A.ptr(sp), sd, n_local, A.ptr(self._local_words), A.stream_ptr()), 'be_pack_spikes')
+        else:           # CPU tensors (gloo tests): same words through tensor arithmetic
+            by = _pack_bits(local_spikes != 0)
+            buf = self._local_words.view(torch.uint8)
+            buf.zero_()
+            buf[:by.numel()] = by
+        self.dist.all_gather_into_tensor(self._full_words, self._local_words, group=self.group)
+        return self._full_words
+
+    def gather_events(self, local_spikes: torch.Tensor):
+        """This rank's spikes ``[hi - lo]`` -> the full spike vector as an event container usable as ``ev @ shard``."""
+        from ._event import BinaryArray, BitPackedBinary
+        assert local_spikes.numel() == self.hi - self.lo
+        if self.packed:
+            words = self._gather_words(local_spikes)
+            if words.is_cuda:
+                return BitPackedBinary.from_packed(words, self.n_pre)
+            return BinaryArray(_unpack_bits(words.view(torch.uint8), self.n_pre))
+        return BinaryArray(self._gather_bytes(local_spikes))
 
     def gather(self, local_spikes: torch.Tensor) -> torch.Tensor:
         """``local_spikes``: bool / uint8 ``[hi - lo]`` of this rank -> bool ``[n_pre]`` on every rank."""
-        assert local_spikes.numel() == self.hi - self.lo
-        if self.packed:
-            payload = _pack_bits(local_spikes != 0)
-        elif local_spikes.dtype == torch.bool:
+        return self.gather_events(local_spikes).value
+
+    # -- one byte per neuron ---------------------------------------------------------------------------
+    def _gather_bytes(self, local_spikes: torch.Tensor) -> torch.Tensor:
+        if local_spikes.dtype == torch.bool:
             payload = local_spikes.view(torch.uint8)            # zero-copy: bool storage is one 0/1 byte per spike
         else:
             payload = (local_spikes != 0).to(torch.uint8)
         if self.uniform:
             self.dist.all_gather_into_tensor(self._full, payload.contiguous(), group=self.group)
-            if not self.packed:
-                return self._full.view(torch.bool)
-            return _unpack_bits(self._full, self.n_pre)
+            return self._full.view(torch.bool)
         if payload.numel() < self._pad:
             payload = torch.cat([payload, torch.zeros(self._pad - payload.numel(), dtype=torch.uint8, device=payload.device)])
         self.dist.all_gather(self._chunks, payload.contiguous(), group=self.group)
-        parts = [(_unpack_bits(c, b[1] - b[0]) if self.packed else c[:b[1] - b[0]].view(torch.bool))
-                 for c, b in zip(self._chunks, self.bounds)]
-        return torch.cat(parts)
+        return torch.cat([c[:b[1] - b[0]].view(torch.bool) for c, b in zip(self._chunks, self.bounds)])
 
 
 class DistributedScatter:
     """``spikes @ M`` with ``M`` post-sliced over the ranks of a process group.
 
-    ``matmul(full_spikes, shard) -> local_out`` defaults to the event-driven GPU product; tests inject a CPU
-    checker there to exercise the partition + exchange logic under ``gloo``.
+    The local product defaults to the event-driven GPU kernels (``events @ shard``); tests inject a CPU checker
+    ``matmul(full_spikes, shard)`` there to exercise the partition + exchange logic under ``gloo``.
     """
 
     def __init__(self, shard, n_pre: int, group=None, packed: bool = False, device=None,
                  matmul: Optional[Callable] = None):
         self.shard = shard
         self.exchange = SpikeExchange(n_pre, group=group, packed=packed, device=device)
-        self.matmul = matmul if matmul is not None else self._gpu_matmul
-
-    @staticmethod
-    def _gpu_matmul(full_spikes, shard):
-        from ._event import BinaryArray
-        return BinaryArray(full_spikes) @ shard
+        self.matmul = matmul
 
     def step(self, local_spikes: torch.Tensor):
         """One time step: exchange, then the local scatter.  Returns this rank's output slice."""
-        return self.matmul(self.exchange.gather(local_spikes), self.shard)
+        events = self.exchange.gather_events(local_spikes)
+        if self.matmul is not None:
+            return self.matmul(events.value, self.shard)
+        return events @ self.shard

@@ -21,9 +21,9 @@ import numpy as np
 import torch
 
 from . import _array as A
-from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, PLAN_MIN_SEGMENT
+from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, _csrmm_generic, PLAN_MIN_SEGMENT
 from . import _csr as _csr_mod
-from ._event import BinaryArray
+from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
 from ._misc import _as_int32_indices, check_fixed_conn_num_shape
 from ._op import OpKernel
@@ -65,6 +65,9 @@ def _fcn_batched(weights, indices, spikes_bm, sd, *, shape, transpose, workspace
         f_ws = fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
         ws = A.workspace(f_ws(n_rows, n_cols, nb))
         f = fn('be_binary_fcnmm_gather_' + _variant(homo, weights, sd), c_int, _FCN_MM_ARGS)
+    if sd == A.BE_SPIKE_BITS:
+        _csrmm_generic(weights, indices, None, n_conn, spikes_bm, sd, out, n_rows, n_cols, nb, ws, transpose)
+        return out
     check(f(A.ptr(weights), A.ptr(indices), A.ptr(spikes_bm), A.ptr(out), n_rows, n_cols, n_conn, nb, A.ptr(ws),
             ws.numel(), A.stream_ptr()), f.__name__)
     return out
@@ -219,7 +222,7 @@ class FixedNumConn:
                     plan = None
             elif BinnedScatter.applicable(self.data, n_cols):
                 try:
-                    plan = BinnedScatter(self.data, n_rows, n_cols, self.nse)
+                    plan = BinnedScatter(self.data, n_rows, n_cols, self.nse, indices=self.indices)
                 except _csr_mod.MathError:
                     plan = None
         self.buffers['scatter_plan'] = plan
@@ -243,10 +246,10 @@ class FixedNumConn:
                                    backend=self.backend, workspace=ws)[0]
 
     def _dispatch(self, other, transpose_W: bool):
-        if not isinstance(other, BinaryArray):
+        if not is_event(other):
             raise NotImplementedError("only BinaryArray operands are on the accelerated path "
                                       "(float fcnmv is out of scope).")
-        value = other.value
+        value = event_operand(other)
         if value.ndim == 1:
             r = self._binary_matvec(value, transpose_W)
         elif value.ndim == 2:

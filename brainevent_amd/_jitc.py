@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _array as A
-from ._event import BinaryArray
+from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
 from ._op import OpKernel
 
@@ -333,9 +333,9 @@ class JITCMatrix:
 
     # -- dispatch (reference _jit_scalar/main.py:885-1065 for R, :1069+ for C) ---------------------
     def __matmul__(self, other):
-        if not isinstance(other, BinaryArray):
+        if not is_event(other):
             raise NotImplementedError("only BinaryArray operands are on the accelerated path (float jit ops are out of scope).")
-        v = other.value
+        v = event_operand(other, allow_packed=False)
         if self._is_row:
             shape, transpose, corder = self.shape, False, self.corder
         else:
@@ -347,9 +347,9 @@ class JITCMatrix:
         raise NotImplementedError(f"matmul with object of shape {v.shape}")
 
     def __rmatmul__(self, other):
-        if not isinstance(other, BinaryArray):
+        if not is_event(other):
             raise NotImplementedError("only BinaryArray operands are on the accelerated path (float jit ops are out of scope).")
-        v = other.value
+        v = event_operand(other, allow_packed=False)
         if self._is_row:
             shape, transpose, corder = self.shape, True, not self.corder
         else:

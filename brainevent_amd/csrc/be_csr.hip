@@ -95,6 +95,66 @@ __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type*
   }
 }
 
+// Compaction straight from a bit-packed spike vector (BE_SPIKE_BITS: bit i%32 of word i/32, rows of
+// ceil(n/32) words in a batch).  Same block-aggregated reservation as above; a thread owns kWords words.
+template <int kWords>
+__global__ void __launch_bounds__(256) k_compact_bits(const uint32_t* __restrict__ words, int64_t n, int64_t n_words,
+                                                      uint32_t* __restrict__ active, uint32_t* __restrict__ count,
+                                                      int64_t active_stride) {
+  words += (int64_t)blockIdx.y * n_words;
+  active += (int64_t)blockIdx.y * active_stride;
+  count += blockIdx.y;
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t block_base;
+  const int64_t first_word = ((int64_t)blockIdx.x * 256 + threadIdx.x) * kWords;
+  uint32_t bits[kWords];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int u = 0; u < kWords; ++u) {
+    const int64_t w = first_word + u;
+    uint32_t bw = (w < n_words) ? words[w] : 0u;
+    const int64_t left = n - w * 32;                      // bits of this word that are inside the vector
+    if (left < 32) bw &= (left <= 0) ? 0u : ((1u << left) - 1u);
+    bits[u] = bw;
+    cnt += __popc(bw);
+  }
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) wave_off += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (threadIdx.x == 0) block_base = total ? atomicAdd(count, total) : 0u;
+  __syncthreads();
+  uint32_t pos = block_base + wave_off + incl - cnt;
+#pragma unroll
+  for (int u = 0; u < kWords; ++u) {
+    uint32_t bw = bits[u];
+    while (bw) {
+      const int b = __ffs(bw) - 1;
+      bw &= bw - 1;
+      active[pos++] = (uint32_t)((first_word + u) * 32 + b);
+    }
+  }
+}
+
+// bits -> one 0/1 byte per spike (for the consumers that index spikes by position)
+__global__ void __launch_bounds__(256) k_unpack_spikes(const uint32_t* __restrict__ words, int64_t n,
+                                                       uint8_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (uint8_t)((words[i >> 5] >> (i & 31)) & 1u);
+}
+
 template <typename SP>
 __global__ void __launch_bounds__(256) k_pack_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
                                                      uint32_t* __restrict__ bits, int64_t words_stride) {
@@ -785,6 +845,20 @@ int compact_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* act
                 uint32_t* count, hipStream_t st, bool zero_first = true) {
   if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, nb, active, active_stride, count, st, zero_first);
   if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, nb, active, active_stride, count, st, zero_first);
+  if (sd == BE_SPIKE_BITS) {
+    if (zero_first) BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
+    if (n == 0 || nb == 0) return BE_OK;
+    const int64_t n_words = (n + 31) / 32;
+    if (n <= (2ll << 20)) {
+      hipLaunchKernelGGL((k_compact_bits<1>), dim3((unsigned)((n_words + 255) / 256), (unsigned)nb), dim3(256), 0, st,
+                         static_cast<const uint32_t*>(spikes), n, n_words, active, count, active_stride);
+    } else {
+      hipLaunchKernelGGL((k_compact_bits<4>), dim3((unsigned)((n_words + 1023) / 1024), (unsigned)nb), dim3(256), 0, st,
+                         static_cast<const uint32_t*>(spikes), n, n_words, active, count, active_stride);
+    }
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
   be_set_error("unknown spike dtype");
   return BE_ERR_INVALID;
 }
@@ -858,10 +932,13 @@ int csrmv_nt_launch(const void* weights, const int32_t* indices, RowPtr rp, cons
 template <typename W, bool HOMO>
 int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
              void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
-  uint32_t* bits = static_cast<uint32_t*>(ws);
   const int64_t n_words = (k + 31) / 32;
-  int rc = pack_any(spikes, sd, k, nb, bits, n_words, st);
-  if (rc != BE_OK) return rc;
+  const uint32_t* bits = static_cast<const uint32_t*>(spikes);   // BE_SPIKE_BITS: already in the kernels' format
+  if (sd != BE_SPIKE_BITS) {
+    int rc = pack_any(spikes, sd, k, nb, static_cast<uint32_t*>(ws), n_words, st);
+    if (rc != BE_OK) return rc;
+    bits = static_cast<const uint32_t*>(ws);
+  }
   if (m == 0 || nb == 0) return BE_OK;
   const int64_t avg = nnz_hint / (m > 0 ? m : 1);
   if (avg <= 8) return csrmv_nt_launch<W, HOMO, 4>(weights, indices, rp, bits, n_words, out, m, nb, st);
@@ -1155,6 +1232,23 @@ int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bit
   BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
   BE_REQUIRE(n == 0 || (spikes && bits), BE_ERR_INVALID, "null pointer");
   return pack_any(spikes, spike_dtype, n, 1, bits, (n + 31) / 32, static_cast<hipStream_t>(stream));
+}
+
+int be_pack_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch, uint32_t* bits,
+                           be_stream_t stream) {
+  BE_REQUIRE(n >= 0 && n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "bad n / n_batch");
+  BE_REQUIRE(n == 0 || n_batch == 0 || (spikes_bm && bits), BE_ERR_INVALID, "null buffer");
+  return pack_any(spikes_bm, spike_dtype, n, n_batch, bits, (n + 31) / 32, static_cast<hipStream_t>(stream));
+}
+
+int be_unpack_spikes(const uint32_t* bits, int64_t n, uint8_t* spikes_out, be_stream_t stream) {
+  BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n must be >= 0");
+  BE_REQUIRE(n == 0 || (bits && spikes_out), BE_ERR_INVALID, "null buffer");
+  if (n == 0) return BE_OK;
+  hipLaunchKernelGGL(k_unpack_spikes, dim3(grid_for(n, 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream), bits, n,
+                     spikes_out);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
 }
 
 int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,

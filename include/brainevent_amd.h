@@ -46,6 +46,10 @@ extern "C" {
 #define BE_BF16 3
 #define BE_SPIKE_BOOL 0
 #define BE_SPIKE_FLOAT 1
+/* bit-packed events: uint32 words, bit i%32 of word i/32 (rows of ceil(n/32) words in a batch); the layout of the
+ * reference's `bitpack` (brainevent/_event/bitpack_binary.py:32-75).  Accepted by be_compact_spikes* and by the
+ * scatter entry points that start with a compaction (be_binary_csrmv/mm_t, *_t_plan, *_t_binned). */
+#define BE_SPIKE_BITS 2
 
 typedef void* be_stream_t; /* hipStream_t */
 
@@ -68,6 +72,11 @@ int be_profile_read(float* ms_host, int capacity);
  * ---------------------------------------------------------------------------------------------- */
 /* spikes[n] -> bits[ceil(n/32)] (bit i%32 of word i/32 set iff spike i active) */
 int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
+/* batch-major spikes_bm[n_batch, n] -> bits[n_batch, ceil(n/32)] */
+int be_pack_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch, uint32_t* bits,
+                           be_stream_t stream);
+/* bits[ceil(n/32)] -> spikes_out[n] (one 0/1 byte per spike) */
+int be_unpack_spikes(const uint32_t* bits, int64_t n, uint8_t* spikes_out, be_stream_t stream);
 /* spikes[n] -> active_ids[<=n] (unordered) and *count (device uint32) */
 int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count,
                       be_stream_t stream);

@@ -267,3 +267,38 @@ def binary_jitmm(mode, w0, w1, prob, B, seed, *, shape, transpose, corder, wdtyp
                              dtype=wdtype).astype(np.float64)
     act = active(B).astype(np.float64)
     return G @ act if corder else G.T @ act
+
+
+# =====================================================================================================
+# event encodings
+# =====================================================================================================
+def bitpack(arr, axis):
+    """uint32 words along ``axis``; bit b of word w = element 32 w + b; non-zero is True
+    (reference brainevent/_event/bitpack_binary.py:32-75)."""
+    a = np.asarray(arr) != 0
+    axis = axis % a.ndim
+    n = a.shape[axis]
+    nw = (n + 31) // 32
+    pad = [(0, 0)] * a.ndim
+    pad[axis] = (0, nw * 32 - n)
+    a = np.pad(a, pad).astype(np.uint64)
+    shp = list(a.shape)
+    shp[axis] = nw
+    shp.insert(axis + 1, 32)
+    a = a.reshape(shp)
+    sh = [1] * a.ndim
+    sh[axis + 1] = 32
+    shifts = np.arange(32, dtype=np.uint64).reshape(sh)
+    return (a << shifts).sum(axis=axis + 1).astype(np.uint32)
+
+
+def compact_1d(x):
+    """(sorted active positions, count) of a 1-D array; active = non-zero (reference brainevent/_event/compact.py:81-92)."""
+    ids = np.flatnonzero(np.asarray(x) != 0).astype(np.int32)
+    return ids, ids.size
+
+
+def compact_2d(x):
+    """Rows of ``x (n, batch)`` active in any batch column (reference brainevent/_event/compact.py:115-126)."""
+    ids = np.flatnonzero((np.asarray(x) != 0).any(axis=1)).astype(np.int32)
+    return ids, ids.size

@@ -421,3 +421,29 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo):
     rows = np.repeat(np.arange(m), np.diff(ptr))
     ref = sorted(zip(rows.tolist(), idx.tolist(), wbits.tolist()))
     assert sorted(got) == ref
+
+
+def test_fixed_point_gate_accepts_wide_uniform_weights(be, oracle):
+    """U[0,1) weights with a few values far below the fixed-point resolution (what 1e10 samples contain at C2 scale): the global-minimum test alone would
+    refuse the plan; the per-column maxima accept it, and the result is within tolerance."""
+    from brainevent_amd._csr import ScatterPlan, BinnedScatter
+    rng = np.random.default_rng(23)
+    m, k = 2000, 3000
+    w, idx, ptr = rand_csr(rng, m, k, [100] * m)
+    w[rng.integers(0, w.size, 50)] = np.float32(2.0 ** -38)      # < 2^(16 - scale_exp) = 2^-35 for 2000 rows
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k))
+    v = spikes_of(rng, m, 0.3, 'bool')
+    ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), True)
+    got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    wd, idd = torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda()
+    with pytest.raises(be.MathError):            # without the structure only the global test is available
+        BinnedScatter(wd, m, k, idx.size)
+    ws = BinnedScatter(wd, m, k, idx.size, indices=idd)
+    got = be.binary_csrmv(wd, idd, torch.from_numpy(ptr).cuda(), torch.from_numpy(v).cuda(), shape=(m, k), transpose=True,
+                          workspace=ws)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+    # a column made only of unresolvable weights is still refused
+    w2 = w.copy(); col = idx[0]; w2[idx == col] = np.float32(2.0 ** -45)
+    with pytest.raises(be.MathError):
+        ScatterPlan.build(w2, idx, torch.tensor(ptr), shape=(m, k))

@@ -45,7 +45,7 @@ def _worker(rank, world, port, packed, n_pre, n_post, q):
         outs = []
         for step in range(3):
             full_ref = np.random.default_rng(100 + step).random(n_pre) < 0.2     # what the gathered vector must be
-            plo, phi = D.pre_slice_bounds(n_pre, world, rank)
+            plo, phi = ds.exchange.lo, ds.exchange.hi
             local = torch.from_numpy(full_ref[plo:phi].copy())
             got_full = ds.exchange.gather(local)
             assert np.array_equal(got_full.numpy(), full_ref)
@@ -55,7 +55,8 @@ def _worker(rank, world, port, packed, n_pre, n_post, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('packed,n_pre,n_post', [(False, 64, 50), (False, 67, 53), (True, 64, 53), (True, 67, 50)])
+@pytest.mark.parametrize('packed,n_pre,n_post', [(False, 64, 50), (False, 67, 53), (True, 64, 53), (True, 67, 50), (True, 20, 9),
+                                                 (True, 200, 31)])
 def test_post_sliced_scatter_world2(packed, n_pre, n_post):
     from oracle import oracle_np as O
     world = 2
@@ -85,6 +86,10 @@ def test_post_sliced_scatter_world2(packed, n_pre, n_post):
 
 def test_slice_bounds_and_fixed_num_shards():
     from brainevent_amd import _dist as D
+    for n, w in ((10, 3), (1_000_000, 8), (7, 8), (64, 2), (65, 2), (1, 4)):
+        b = [D.word_aligned_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert all(x[0] % 32 == 0 or x[0] == n for x in b) and len({(x[1] - x[0] + 31) // 32 for x in b if x[1] - x[0] == b[0][1]}) == 1
     for n, w in ((10, 3), (1_000_000, 8), (7, 8)):
         b = [D.post_slice_bounds(n, w, r) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))

@@ -1,0 +1,214 @@
+"""Bit-packed / compacted event encodings against the oracle, and as operands of the
+scatter / gather kernels.  Construction cases mirror the reference's own
+``brainevent/_event/compact_binary_test.py`` (shapes, dtypes, counts, sorted active ids)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    import brainevent_amd as be
+    return be
+
+
+@pytest.mark.parametrize('shape,axis', [((100,), 0), ((1,), 0), ((32,), 0), ((33,), 0), ((64,), 0), ((7, 100), 1),
+                                        ((7, 100), 0), ((50, 8), 1), ((3, 5, 70), 2), ((3, 5, 70), 1), ((0,), 0)])
+def test_bitpack_matches_oracle(be, shape, axis):
+    rng = np.random.default_rng(sum(shape) + axis)
+    x = rng.random(shape) > 0.6
+    got = be.bitpack(x, axis)
+    assert got.dtype == np.uint32
+    np.testing.assert_array_equal(got, O.bitpack(x, axis))
+    got_t = be.bitpack(torch.from_numpy(x).cuda(), axis)
+    assert isinstance(got_t, torch.Tensor) and got_t.dtype == torch.int32
+    np.testing.assert_array_equal(got_t.cpu().numpy().view(np.uint32), O.bitpack(x, axis))
+
+
+def test_bitpack_many_short_rows_and_nonbool(be):
+    rng = np.random.default_rng(5)
+    x = (rng.random((70000, 40)) > 0.5)
+    np.testing.assert_array_equal(be.bitpack(x, 1), O.bitpack(x, 1))
+    f = np.array([0.0, 1.0, -2.0, 0.0, 3.5], np.float32)          # encoders: non-zero is True (negatives too)
+    np.testing.assert_array_equal(be.bitpack(f, 0), O.bitpack(f, 0))
+    assert int(be.bitpack(f, 0)[0]) == 0b10110
+
+
+class TestCompactBinaryConstruction:
+    def test_1d_basic(self, be):
+        x = np.random.RandomState(0).rand(100) > 0.7
+        cb = be.CompactBinary.from_array(x)
+        assert cb.packed.dtype == np.uint32 and cb.packed.shape == ((100 + 31) // 32,)
+        assert cb.active_ids.shape == (100,) and cb.active_ids.dtype == np.int32
+        ids, n = O.compact_1d(x)
+        assert int(cb.n_active[0]) == n == int(x.sum())
+        np.testing.assert_array_equal(np.sort(cb.active_ids[:n]), ids)
+        np.testing.assert_array_equal(cb.packed, O.bitpack(x, 0))
+        np.testing.assert_array_equal(cb.value, x)
+        assert cb.shape == (100,) and cb.ndim == 1 and cb.size == 100 and cb.n_orig == 100 and cb.batch_size is None
+
+    def test_float_input(self, be):
+        cb = be.CompactBinary.from_array(np.array([0.0, 1.0, 0.0, 2.0, 0.0], np.float32))
+        assert int(cb.n_active[0]) == 2
+
+    def test_light_skips_compaction(self, be):
+        x = np.array([False, True, True, False])
+        cb = be.CompactBinary.from_array_light(x)
+        assert cb.packed.shape == (1,)
+        np.testing.assert_array_equal(cb.active_ids, np.zeros(4, np.int32))
+        np.testing.assert_array_equal(cb.n_active, np.zeros(1, np.int32))
+
+    def test_compact_only_vector(self, be):
+        x = np.array([0.0, 1.0, 0.0, 1.0, 0.0, 1.0], np.float32)
+        cb = be.CompactBinary.compacy_only_vector(x)
+        assert cb.packed.shape == (0,)
+        assert int(cb.n_active[0]) == 3
+        np.testing.assert_array_equal(np.sort(cb.active_ids[:3]), [1, 3, 5])
+        with pytest.raises(ValueError, match="only supports 1D arrays"):
+            be.CompactBinary.compacy_only_vector(np.zeros((2, 3), bool))
+
+    def test_2d(self, be):
+        x = np.random.RandomState(1).rand(50, 8) > 0.7
+        cb = be.CompactBinary.from_array(x)
+        assert cb.packed.dtype == np.uint32 and cb.packed.shape == (50, 1)
+        ids, n = O.compact_2d(x)
+        assert int(cb.n_active[0]) == n
+        np.testing.assert_array_equal(np.sort(cb.active_ids[:n]), ids)
+        np.testing.assert_array_equal(cb.packed, O.bitpack(x, 1))
+        x2 = np.random.RandomState(2).rand(20, 100) > 0.8
+        assert be.CompactBinary.from_array(x2).packed.shape == (20, 4)
+        assert be.CompactBinary.from_array(x2).shape == (20, 100)
+
+    def test_zeros_ones_and_errors(self, be):
+        assert int(be.CompactBinary.from_array(np.zeros(64, bool)).n_active[0]) == 0
+        assert int(be.CompactBinary.from_array(np.zeros((32, 8), bool)).n_active[0]) == 0
+        cb = be.CompactBinary.from_array(np.ones(64, bool))
+        np.testing.assert_array_equal(np.sort(cb.active_ids[:64]), np.arange(64))
+        cb = be.CompactBinary.from_array(np.ones((32, 8), bool))
+        np.testing.assert_array_equal(np.sort(cb.active_ids[:32]), np.arange(32))
+        with pytest.raises(ValueError):
+            be.CompactBinary.from_array(np.zeros((2, 2, 2), bool))
+        with pytest.raises(ValueError):
+            be.CompactBinary.from_array(np.zeros(4, bool), bit_width=16)
+
+    def test_from_packed_roundtrip_and_device(self, be):
+        x = torch.tensor([False, True, False, True], device='cuda')
+        cb = be.CompactBinary.from_array(x)
+        assert isinstance(cb.packed, torch.Tensor) and cb.packed.is_cuda
+        rb = be.CompactBinary.from_packed(cb.packed, cb.active_ids, cb.n_active, cb.value, n_orig=cb.n_orig,
+                                          batch_size=cb.batch_size, bit_width=cb.bit_width)
+        assert rb.packed is cb.packed and rb.n_orig == 4 and int(rb.n_active[0]) == 2
+
+
+def test_bitpacked_binary_container(be):
+    x = np.random.default_rng(3).random((6, 70)) > 0.5
+    bp = be.BinaryArray(x).bitpack()
+    assert isinstance(bp, be.BitPackedBinary)
+    assert bp.shape == (6, 70) and bp.ndim == 2 and bp.original_shape == (6, 70)
+    assert len(bp.packed) == 2
+    np.testing.assert_array_equal(bp.packed[0], O.bitpack(x, 0))
+    np.testing.assert_array_equal(bp.packed[1], O.bitpack(x, 1))
+    t = bp.T
+    assert t.shape == (70, 6)
+    np.testing.assert_array_equal(t.packed[0], O.bitpack(x.T, 0))
+    np.testing.assert_array_equal(t.packed[1], O.bitpack(x.T, 1))
+    np.testing.assert_array_equal(t.value, x.T)
+    W = np.random.default_rng(4).standard_normal((70, 9)).astype(np.float32)
+    np.testing.assert_allclose(bp @ W, O.binary_densemm(W, x.T, transpose=True).T, rtol=1e-5, atol=1e-5)
+    with pytest.raises(be.MathError):
+        be.BitPackedBinary(np.zeros((2, 2, 2), bool)) @ W[:2]
+
+
+def _rand_csr(rng, m, k, max_len, homo):
+    lens = rng.integers(0, max_len, m)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    w = np.array([1.5], np.float32) if homo else rng.random(ptr[-1]).astype(np.float32)
+    return w, idx, ptr
+
+
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('m,k', [(257, 300), (4000, 70001), (31, 5)])
+def test_packed_operands_on_csr(be, homo, m, k):
+    """BitPackedBinary / CompactBinary as the event operand: all four operator forms, direct and planned routes."""
+    rng = np.random.default_rng(m + k)
+    w, idx, ptr = _rand_csr(rng, m, k, 40, homo)
+    csr = be.CSR((w, idx, ptr), shape=(m, k))
+    s_m = rng.random(m) < 0.2
+    s_k = rng.random(k) < 0.2
+    for make in (lambda s: be.BinaryArray(s).bitpack(), be.CompactBinary.from_array):
+        ref_t = O.binary_csrmv(w, idx, ptr, s_m, shape=(m, k), transpose=True)
+        ref_nt = O.binary_csrmv(w, idx, ptr, s_k, shape=(m, k), transpose=False)
+        np.testing.assert_allclose(make(s_m) @ csr, ref_t, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(csr @ make(s_k), ref_nt, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(csr.T @ make(s_m), ref_t, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(make(s_k) @ csr.T, ref_nt, rtol=1e-5, atol=1e-5)
+    # planned route + packed-only vector (what the spike exchange delivers)
+    from brainevent_amd._csr import ScatterPlan
+    csr.buffers['scatter_plan'] = ScatterPlan.build(csr.data, csr.indices, csr.indptr, shape=(m, k), slice_shift=9)
+    words = be.bitpack(torch.from_numpy(s_m).cuda(), 0)
+    got = be.BitPackedBinary.from_packed(words, m) @ csr
+    assert isinstance(got, torch.Tensor)
+    np.testing.assert_allclose(got.cpu().numpy(), ref_t, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(be.BitPackedBinary.from_packed(words, m).value.cpu().numpy(), s_m)
+
+
+def test_packed_operands_bitwise_equal_to_plain(be):
+    """Same kernels after the compaction => bitwise identical results on the integer-accumulating routes."""
+    rng = np.random.default_rng(77)
+    m, k = 3000, 50000
+    w, idx, ptr = _rand_csr(rng, m, k, 200, homo=False)
+    from brainevent_amd._csr import ScatterPlan, BinnedScatter
+    s = torch.from_numpy(rng.random(m) < 0.1).cuda()
+    for ws in ('plan', 'binned'):
+        csr = be.CSR((torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(ptr).cuda()), shape=(m, k))
+        csr.buffers['scatter_plan'] = (ScatterPlan.build(csr.data, csr.indices, csr.indptr, shape=(m, k)) if ws == 'plan'
+                                       else BinnedScatter(csr.data, m, k, idx.size))
+        a = be.BinaryArray(s) @ csr
+        b = be.BinaryArray(s).bitpack() @ csr
+        if ws == 'plan':      # fixed-order integer sums: bitwise reproducible whatever the order of the active list
+            assert torch.equal(a, b), ws
+        else:                 # the binned route merges its per-part sums with float atomics
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_packed_operands_on_fixed_num(be, homo):
+    rng = np.random.default_rng(9)
+    n_pre, n_post, nc = 500, 777, 12
+    idx = rng.integers(0, n_post, (n_pre, nc)).astype(np.int32)
+    w = np.array([0.5], np.float32) if homo else rng.random((n_pre, nc)).astype(np.float32)
+    M = be.FixedNumPerPre((w, idx), shape=(n_pre, n_post))
+    s_pre = rng.random(n_pre) < 0.3
+    s_post = rng.random(n_post) < 0.3
+    np.testing.assert_allclose(be.BinaryArray(s_pre).bitpack() @ M,
+                               O.binary_fcnmv(w, idx, s_pre, shape=(n_pre, n_post), transpose=True), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(M @ be.CompactBinary.from_array(s_post),
+                               O.binary_fcnmv(w, idx, s_post, shape=(n_pre, n_post), transpose=False), rtol=1e-5, atol=1e-5)
+
+
+def test_float_payload_keeps_op_semantics(be):
+    """Negative floats are set bits for the encoder (non-zero) but inactive for the product (> 0): the containers
+    must not feed packed words to the kernels for float payloads."""
+    w = np.array([1.0, 2.0, 3.0, 4.0], np.float32)
+    idx = np.array([0, 2, 1, 2], np.int32)
+    ptr = np.array([0, 2, 4], np.int32)
+    csr = be.CSR((w, idx, ptr), shape=(2, 3))
+    v = np.array([1.0, -1.0], np.float32)
+    np.testing.assert_allclose(be.BinaryArray(v).bitpack() @ csr, [1, 0, 2])      # reference KAT _csr/binary_test.py:370-393
+    np.testing.assert_allclose(be.CompactBinary.from_array(v) @ csr, [1, 0, 2])
+
+
+def test_packed_on_jitc_and_dense(be):
+    rng = np.random.default_rng(2)
+    s = rng.random(64) < 0.3
+    M = be.JITCScalarR((1.5, 0.2, 123), shape=(64, 48))
+    ref = be.BinaryArray(s) @ M
+    np.testing.assert_array_equal(be.BinaryArray(s).bitpack() @ M, ref)
+    np.testing.assert_array_equal(be.CompactBinary.from_array(s) @ M, ref)
+    W = rng.standard_normal((64, 5)).astype(np.float32)
+    np.testing.assert_allclose(be.CompactBinary.from_array(s) @ W, O.binary_densemv(W, s, transpose=True), rtol=1e-5, atol=1e-5)
