@@ -11,7 +11,7 @@ import torch
 from ._lib import require_device
 
 BE_F32, BE_F64, BE_F16, BE_BF16 = 0, 1, 2, 3
-BE_SPIKE_BOOL, BE_SPIKE_FLOAT, BE_SPIKE_BITS = 0, 1, 2
+BE_SPIKE_BOOL, BE_SPIKE_FLOAT, BE_SPIKE_BITS, BE_SPIKE_IDS = 0, 1, 2, 3
 
 _W_CODE = {torch.float32: BE_F32, torch.float64: BE_F64, torch.float16: BE_F16, torch.bfloat16: BE_BF16}
 _W_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16', torch.bfloat16: 'bf16'}
@@ -38,9 +38,50 @@ class PackedSpikes:
     size = property(lambda self: self.n)
 
 
+class _SpikeIdsStruct(ctypes.Structure):      # be_spike_ids_t of include/brainevent_amd.h
+    _fields_ = [('active_ids', ctypes.c_void_p), ('n_active', ctypes.c_void_p)]
+
+
+class ActiveIds:
+    """1-D event vector given as the device list of its active positions: the first ``count[0]`` entries of ``ids``
+    (int32, each ``< n``, listed once) — C ABI code ``BE_SPIKE_IDS``; scatter entry points only.  ``data_ptr()`` is the
+    host address of the ``be_spike_ids_t`` the C side reads."""
+    __slots__ = ('ids', 'count', 'n', 'numpy_result', '_c')
+
+    def __init__(self, ids: torch.Tensor, count: torch.Tensor, n: int, numpy_result: bool = False):
+        assert ids.dtype == torch.int32 and count.dtype == torch.int32 and ids.is_cuda and count.is_cuda
+        self.ids, self.count, self.n, self.numpy_result = ids, count, int(n), bool(numpy_result)
+        self._c = _SpikeIdsStruct(ids.data_ptr(), count.data_ptr())
+
+    shape = property(lambda self: (self.n,))
+    ndim = property(lambda self: 1)
+    dtype = property(lambda self: torch.bool)
+    size = property(lambda self: self.n)
+
+    def data_ptr(self) -> int:
+        return ctypes.addressof(self._c)
+
+    def reshape(self, *shape):
+        return _IdsRow(self)
+
+
+class _IdsRow:
+    """``ActiveIds`` seen as a one-row batch (what the batched launchers take)."""
+    __slots__ = ('src',)
+
+    def __init__(self, src: ActiveIds):
+        self.src = src
+
+    shape = property(lambda self: (1, self.src.n))
+    ndim = property(lambda self: 2)
+
+    def data_ptr(self) -> int:
+        return self.src.data_ptr()
+
+
 def wants_numpy(*xs) -> bool:
     """Result type follows the inputs: torch tensor if any operand is one, else numpy."""
-    return not any(isinstance(x, torch.Tensor) or (isinstance(x, PackedSpikes) and not x.numpy_result) for x in xs)
+    return not any(isinstance(x, torch.Tensor) or (isinstance(x, (PackedSpikes, ActiveIds)) and not x.numpy_result) for x in xs)
 
 
 def device() -> torch.device:
@@ -93,6 +134,8 @@ def spikes_to_device(v) -> Tuple[torch.Tensor, int]:
     """
     if isinstance(v, PackedSpikes):
         return to_device(v.bits), BE_SPIKE_BITS
+    if isinstance(v, ActiveIds):
+        return v, BE_SPIKE_IDS
     t = to_device(v)
     if t.dtype in (torch.bool, torch.uint8, torch.int8):
         return t, BE_SPIKE_BOOL

@@ -267,7 +267,7 @@ def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, w
             return out
         f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
         ws = A.workspace(f_ws(m, k, nb, A.wcode(weights)))
-        f = None if sd == A.BE_SPIKE_BITS else fn('be_binary_csrmm_t_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
+        f = None if sd >= A.BE_SPIKE_BITS else fn('be_binary_csrmm_t_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
     else:
         f_ws = fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
         ws = A.workspace(f_ws(m, k, nb))
@@ -567,9 +567,10 @@ class CompressedSparseData:
         return A.to_result(t, self._numpy_result)
 
 
-def _event_value(other):
-    """Kernel operand of an event container: packed words for 1-D bit-packed containers, else the value."""
-    return event_operand(other)
+def _event_value(other, scatter: bool = False):
+    """Kernel operand of an event container: id list / packed words for 1-D compacted / bit-packed containers, else
+    the value."""
+    return event_operand(other, scatter=scatter)
 
 
 class CSR(CompressedSparseData):
@@ -595,7 +596,7 @@ class CSR(CompressedSparseData):
 
     def __rmatmul__(self, other):     # other @ csr
         if is_event(other):
-            v = _event_value(other)
+            v = _event_value(other, scatter=True)
             ws = self._scatter_workspace()
             if v.ndim == 1:
                 r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, ws, shape=self.shape, transpose=True,
@@ -625,7 +626,7 @@ class CSC(CompressedSparseData):
 
     def __matmul__(self, other):      # csc @ other : scatter over the active columns
         if is_event(other):
-            v = _event_value(other)
+            v = _event_value(other, scatter=True)
             ws = self._scatter_workspace()
             if v.ndim == 1:
                 r = binary_csrmv_p_call(self.data, self.indices, self.indptr, v, ws, shape=self.shape[::-1],

@@ -287,12 +287,13 @@ class CompactBinary:
     1-D ``(n,)``: ``packed (ceil(n/32),)``, ``active_ids (n,)`` int32 whose first ``n_active[0]`` entries are the
     active positions (in no particular order).  2-D ``(n, batch)``: ``packed (n, ceil(batch/32))`` packs the batch
     axis and ``active_ids`` lists the rows active in any batch column."""
-    __slots__ = ('_packed', '_active_ids', '_n_active', '_value', '_n_orig', '_batch_size', '_bit_width')
+    __slots__ = ('_packed', '_active_ids', '_n_active', '_value', '_n_orig', '_batch_size', '_bit_width', '_own_ids')
     __array_priority__ = 100
 
     def __init__(self, packed, active_ids, n_active, value, n_orig, batch_size=None, bit_width=32):
         self._packed, self._active_ids, self._n_active, self._value = packed, active_ids, n_active, value
         self._n_orig, self._batch_size, self._bit_width = n_orig, batch_size, bit_width
+        self._own_ids = False      # True when active_ids came out of this library's compaction (in range, listed once)
 
     @staticmethod
     def _compact(mask_source):
@@ -325,8 +326,10 @@ class CompactBinary:
                 ids = torch.zeros(n, dtype=torch.int32, device=t.device)
                 cnt = torch.zeros(1, dtype=torch.int32, device=t.device)
             pk = conv(packed)
-            return cls(pk.view(np.uint32) if as_np else pk, conv(ids), conv(cnt), x if not as_np else np.asarray(x),
-                       n_orig=n, batch_size=None, bit_width=32)
+            obj = cls(pk.view(np.uint32) if as_np else pk, conv(ids), conv(cnt), x if not as_np else np.asarray(x),
+                      n_orig=n, batch_size=None, bit_width=32)
+            obj._own_ids = compact_1d and not as_np
+            return obj
         if t.ndim == 2:
             packed = bitpack(t, 1)
             ids, cnt = cls._compact(_nonzero_mask(t).any(dim=1))
@@ -393,6 +396,14 @@ class CompactBinary:
             return A.PackedSpikes(A.to_device(np.ascontiguousarray(w).view(np.int32)), self._n_orig, numpy_result=True)
         return A.PackedSpikes(w, self._n_orig)
 
+    def _ids_operand(self):
+        """The compacted list as a kernel operand (scatter direction): only for lists this library produced on the
+        device — user-supplied lists (``from_packed``) are not trusted to be in range."""
+        from . import _array as A
+        if self.ndim != 1 or not self._own_ids or _is_float_payload(self._value):
+            return None
+        return A.ActiveIds(self._active_ids, self._n_active, self._n_orig)
+
     def __matmul__(self, oc):
         if _is_known_type(oc):
             return BinaryArray(self._value) @ oc
@@ -413,9 +424,14 @@ def is_event(x) -> bool:
     return isinstance(x, (BinaryArray, BitPackedBinary, CompactBinary))
 
 
-def event_operand(x, allow_packed: bool = True):
-    """The array a kernel call receives for event container ``x``: packed words for 1-D bit-packed containers
-    (when the op takes them), otherwise the plain value."""
+def event_operand(x, allow_packed: bool = True, scatter: bool = False):
+    """The array a kernel call receives for event container ``x``: the compacted id list (scatter ops, 1-D
+    ``CompactBinary`` built on the device), packed words for 1-D bit-packed containers (when the op takes them),
+    otherwise the plain value."""
+    if allow_packed and scatter and isinstance(x, CompactBinary):
+        p = x._ids_operand()
+        if p is not None:
+            return p
     if allow_packed and isinstance(x, (BitPackedBinary, CompactBinary)):
         p = x._packed_operand()
         if p is not None:

@@ -65,7 +65,7 @@ def _fcn_batched(weights, indices, spikes_bm, sd, *, shape, transpose, workspace
         f_ws = fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
         ws = A.workspace(f_ws(n_rows, n_cols, nb))
         f = fn('be_binary_fcnmm_gather_' + _variant(homo, weights, sd), c_int, _FCN_MM_ARGS)
-    if sd == A.BE_SPIKE_BITS:
+    if sd >= A.BE_SPIKE_BITS:
         _csrmm_generic(weights, indices, None, n_conn, spikes_bm, sd, out, n_rows, n_cols, nb, ws, transpose)
         return out
     check(f(A.ptr(weights), A.ptr(indices), A.ptr(spikes_bm), A.ptr(out), n_rows, n_cols, n_conn, nb, A.ptr(ws),
@@ -249,7 +249,7 @@ class FixedNumConn:
         if not is_event(other):
             raise NotImplementedError("only BinaryArray operands are on the accelerated path "
                                       "(float fcnmv is out of scope).")
-        value = event_operand(other)
+        value = event_operand(other, scatter=other.ndim == 1 and self._ell_transpose(transpose_W))
         if value.ndim == 1:
             r = self._binary_matvec(value, transpose_W)
         elif value.ndim == 2:

@@ -863,6 +863,28 @@ int compact_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* act
   return BE_ERR_INVALID;
 }
 
+// Active-row list of a scatter call: the spikes compacted into the workspace, or (BE_SPIKE_IDS, n_batch = 1) the
+// caller's own list — `spikes` is then a HOST pointer to a be_spike_ids_t holding two device pointers.
+struct ActiveList {
+  const uint32_t* ids;
+  const uint32_t* count;
+};
+int resolve_active(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* ws_active, int64_t astride,
+                   uint32_t* ws_count, hipStream_t st, bool zero_first, ActiveList* al) {
+  if (sd == BE_SPIKE_IDS) {
+    BE_REQUIRE(nb == 1, BE_ERR_UNSUPPORTED, "BE_SPIKE_IDS takes a single event vector (n_batch = 1)");
+    const be_spike_ids_t* s = static_cast<const be_spike_ids_t*>(spikes);
+    BE_REQUIRE(s->active_ids != nullptr && s->n_active != nullptr, BE_ERR_INVALID, "null id list");
+    al->ids = s->active_ids;
+    al->count = s->n_active;
+    if (zero_first) BE_HIP(hipMemsetAsync(ws_count, 0, 4, st));
+    return BE_OK;
+  }
+  al->ids = ws_active;
+  al->count = ws_count;
+  return compact_any(spikes, sd, n, nb, ws_active, astride, ws_count, st, zero_first);
+}
+
 template <typename SP>
 int launch_pack(const void* spikes, int64_t n, int64_t nb, uint32_t* bits, int64_t words_stride, hipStream_t st) {
   if (n == 0 || nb == 0) return BE_OK;
@@ -890,13 +912,14 @@ int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const
   using ACC = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
   ACC* acc = via_f32 ? reinterpret_cast<ACC*>(wsb + counts_bytes(nb) + nb * astride * 4) : static_cast<ACC*>(out);
   if (k > 0 && nb > 0) BE_HIP(hipMemsetAsync(acc, 0, (size_t)k * nb * sizeof(ACC), st));
-  int rc = compact_any(spikes, sd, m, nb, active, astride, count, st);
+  ActiveList al;
+  int rc = resolve_active(spikes, sd, m, nb, active, astride, count, st, true, &al);
   if (rc != BE_OK) return rc;
   if (m > 0 && k > 0 && nb > 0) {
     const int gx = nb >= 8 ? 512 : 2048;
     const int prof = be_prof_begin(st);
     hipLaunchKernelGGL((k_csrmv_t_direct<W, HOMO, ACC>), dim3(gx, (unsigned)nb), dim3(256), 0, st,
-                       static_cast<const W*>(weights), indices, rp, active, count, acc, astride, k);
+                       static_cast<const W*>(weights), indices, rp, al.ids, al.count, acc, astride, k);
     be_prof_end(prof, st);
     BE_LAUNCH_CHECK();
   }
@@ -1430,7 +1453,8 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const int n_slices = n_slices_of(k, slice_shift);
   // the per-batch counters at the head of the workspace are zero on entry (caller contract) and are zeroed
   // again by k_plan_reduce once the accumulate kernel has consumed them: saves a 5 us memset node per step
-  int rc = compact_any(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false);
+  ActiveList al;
+  int rc = resolve_active(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false, &al);
   if (rc != BE_OK) return rc;
   const float scale = ldexpf(1.0f, scale_exp - 32);   // see fixed_from_f32
   const double inv_scale = ldexp(1.0, -scale_exp);
@@ -1441,12 +1465,12 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     auto kern = k_plan_accumulate<true>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       active, count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride);
+                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride);
   } else {
     auto kern = k_plan_accumulate<false>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       active, count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
+                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
                        astride);
   }
   be_prof_end(prof, st);
@@ -1511,15 +1535,16 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   BE_HIP(hipMemsetAsync(out, 0, (size_t)k * 4, st));
   BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_bins * 4, st));
   BE_HIP(hipMemsetAsync(valid, 0xff, (size_t)n_bins * 4, st));
-  int rc = compact_any(spikes, spike_dtype, m, 1, active, 0, count, st);
+  ActiveList al;
+  int rc = resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, true, &al);
   if (rc != BE_OK) return rc;
   const int prof = be_prof_begin(st);
   if (homo)
     hipLaunchKernelGGL((k_bin_rows<float, true>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
-                       active, count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
+                       al.ids, al.count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
   else
     hipLaunchKernelGGL((k_bin_rows<float, false>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
-                       active, count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
+                       al.ids, al.count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
   BE_LAUNCH_CHECK();
   int parts = 512 / (n_bins > 0 ? n_bins : 1);
   parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);

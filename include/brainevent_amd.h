@@ -50,6 +50,14 @@ extern "C" {
  * reference's `bitpack` (brainevent/_event/bitpack_binary.py:32-75).  Accepted by be_compact_spikes* and by the
  * scatter entry points that start with a compaction (be_binary_csrmv/mm_t, *_t_plan, *_t_binned). */
 #define BE_SPIKE_BITS 2
+/* already-compacted events (single vector, scatter entry points only): `spikes` is a HOST pointer to a be_spike_ids_t
+ * whose two fields are DEVICE pointers — the first *n_active entries of active_ids are the active positions, each
+ * < m and listed once (caller contract; what be_compact_spikes produces).  The call skips its compaction kernel. */
+#define BE_SPIKE_IDS 3
+typedef struct be_spike_ids {
+  const uint32_t* active_ids;
+  const uint32_t* n_active;
+} be_spike_ids_t;
 
 typedef void* be_stream_t; /* hipStream_t */
 

@@ -212,3 +212,60 @@ def test_packed_on_jitc_and_dense(be):
     np.testing.assert_array_equal(be.CompactBinary.from_array(s) @ M, ref)
     W = rng.standard_normal((64, 5)).astype(np.float32)
     np.testing.assert_allclose(be.CompactBinary.from_array(s) @ W, O.binary_densemv(W, s, transpose=True), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('route', ['direct', 'plan', 'binned'])
+@pytest.mark.parametrize('homo', [True, False])
+def test_compacted_ids_as_scatter_operand(be, route, homo):
+    """A CompactBinary built on the device hands its id list to the scatter kernels (BE_SPIKE_IDS): no second compaction."""
+    from brainevent_amd import _array as A
+    from brainevent_amd._event import event_operand
+    from brainevent_amd._csr import ScatterPlan, BinnedScatter
+    rng = np.random.default_rng(31)
+    m, k = 5000, 40000
+    w, idx, ptr = _rand_csr(rng, m, k, 120, homo)
+    s = rng.random(m) < 0.15
+    cb = be.CompactBinary.from_array(torch.from_numpy(s).cuda())
+    assert isinstance(event_operand(cb, scatter=True), A.ActiveIds)
+    assert isinstance(event_operand(cb, scatter=False), A.PackedSpikes)
+    assert not isinstance(event_operand(be.CompactBinary.from_array(s), scatter=True), A.ActiveIds)   # host-built: not trusted
+    csr = be.CSR((torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(ptr).cuda()), shape=(m, k))
+    csr.buffers['scatter_plan'] = {'direct': None,
+                                   'plan': ScatterPlan.build(csr.data, csr.indices, csr.indptr, shape=(m, k)),
+                                   'binned': BinnedScatter(csr.data, m, k, idx.size, indices=csr.indices)}[route]
+    ref = O.binary_csrmv(w, idx, ptr, s, shape=(m, k), transpose=True)
+    got = cb @ csr
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose((csr.T @ cb).cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    if route == 'plan':
+        assert torch.equal(got, be.BinaryArray(torch.from_numpy(s).cuda()) @ csr)
+    # empty list and full list
+    for sv in (np.zeros(m, bool), np.ones(m, bool)):
+        cbe = be.CompactBinary.from_array(torch.from_numpy(sv).cuda())
+        np.testing.assert_allclose((cbe @ csr).cpu().numpy(), O.binary_csrmv(w, idx, ptr, sv, shape=(m, k), transpose=True),
+                                   rtol=1e-5, atol=1e-4)
+
+
+def test_compacted_ids_on_fixed_num_and_abi_contract(be):
+    import ctypes
+    from brainevent_amd import _array as A, _lib
+    rng = np.random.default_rng(8)
+    n_pre, n_post, nc = 600, 900, 10
+    idx = rng.integers(0, n_post, (n_pre, nc)).astype(np.int32)
+    w = rng.random((n_pre, nc)).astype(np.float32)
+    s = rng.random(n_pre) < 0.3
+    M = be.FixedNumPerPre((torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda()), shape=(n_pre, n_post))
+    cb = be.CompactBinary.from_array(torch.from_numpy(s).cuda())
+    np.testing.assert_allclose((cb @ M).cpu().numpy(), O.binary_fcnmv(w, idx, s, shape=(n_pre, n_post), transpose=True),
+                               rtol=1e-5, atol=1e-5)
+    # the id list is a single-vector encoding: a batch is refused with BE_ERR_UNSUPPORTED, never guessed at
+    ids = A.ActiveIds(cb.active_ids, cb.n_active, n_pre)
+    f = _lib.fn('be_binary_csrmm_t', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p])
+    out = torch.empty((2, n_post), dtype=torch.float32, device='cuda')
+    ws = A.workspace(1 << 20)
+    rc = f(A.ptr(M.data), 0, A.BE_F32, A.ptr(M.indices), None, 0, nc, ctypes.c_void_p(ids.data_ptr()), A.BE_SPIKE_IDS,
+           A.ptr(out), n_pre, n_post, 2, A.ptr(ws), ws.numel(), A.stream_ptr())
+    assert rc == -5
