@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--fire', type=float, default=0.01)
     ap.add_argument('--homo', action='store_true', help='homogeneous weight (4 B/update) instead of hetero f32')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--jit-shard', type=int, default=1, help='jitc workload: run rank 0 of an N-way walk-class partition')
     ap.add_argument('--exchange', choices=['bits', 'bytes'], default='bits', help='payload of the per-step spike all-gather (N > 1)')
     ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
     ap.add_argument('--parts', type=int, default=0)
@@ -143,7 +144,8 @@ def secondary(args):
         prob = args.conn if args.conn != 0.01 else 0.001
         M = be.JITCScalarR((np.float32(1.0), prob, 42), shape=(n, n), corder=not args.jit_gather)
         spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
-        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ M
+        target = M.scatter_shard(args.jit_shard, 0) if args.jit_shard > 1 else M     # rank 0's walk classes of an N-way split
+        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ target
         elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
         upd = float(out.double().sum().item())          # weight 1: the sum is the number of delivered edges
         value = upd * args.steps / elapsed / 1e9 if not args.jit_gather else n * n * prob * args.steps / elapsed / 1e9
@@ -151,6 +153,8 @@ def secondary(args):
         cfg = {'workload': f'BinaryArray({args.fire:g}) @ JITCScalarR w=1 prob={prob:g} seed=42 {n}x{n}, '
                            f"{'gather (corder=False matrix)' if args.jit_gather else 'scatter (corder=True matrix)'}",
                'edges_last_step': upd}
+        if args.jit_shard > 1:
+            cfg['shard'] = f'walk classes of rank 0 of {args.jit_shard} (no stored state; outputs of the ranks are disjoint)'
         if kern_ms:
             # no stored matrix: HBM is not the bound; report the bandwidth a stored CSR would have needed (8 B/update)
             roof = {'bound': 'valu+lds (no HBM matrix traffic)', 'achieved': None, 'peak': None, 'unit': 'GB/s', 'frac': None,

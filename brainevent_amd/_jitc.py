@@ -31,7 +31,7 @@ __all__ = [
     'binary_jitsmv', 'binary_jitsmm', 'binary_jitumv', 'binary_jitumm', 'binary_jitnmv', 'binary_jitnmm',
     'binary_jitsmv_p', 'binary_jitsmm_p', 'binary_jitumv_p', 'binary_jitumm_p', 'binary_jitnmv_p', 'binary_jitnmm_p',
     'binary_jitsmv_p_call', 'binary_jitsmm_p_call', 'binary_jitumv_p_call', 'binary_jitumm_p_call',
-    'binary_jitnmv_p_call', 'binary_jitnmm_p_call',
+    'binary_jitnmv_p_call', 'binary_jitnmm_p_call', 'JITCScatterShard', 'jit_scatter_class_columns',
 ]
 
 c_i64, c_int, c_vp, c_dbl, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_uint32
@@ -363,6 +363,10 @@ class JITCMatrix:
     def _params(self):
         return (*self._weights, self.prob, self.seed)
 
+    def scatter_shard(self, world: int, rank: int) -> 'JITCScatterShard':
+        """This rank's share of ``events @ self`` for a multi-GPU run (nothing is stored; see :class:`JITCScatterShard`)."""
+        return JITCScatterShard(self, world, rank)
+
     # -- materialisation (reference: ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``, ``_jit_scalar/main.py`` mode views) ----
     def tocsr(self, matrix_mode: str = 'mv'):
         """Materialise the drawn connectivity on the device.  ``matrix_mode`` picks the matrix of the ``mv`` ops
@@ -494,3 +498,80 @@ class JITCNormalC(_NormalInit):
 JITCScalarR._transposed_cls, JITCScalarC._transposed_cls = JITCScalarC, JITCScalarR
 JITCUniformR._transposed_cls, JITCUniformC._transposed_cls = JITCUniformC, JITCUniformR
 JITCNormalR._transposed_cls, JITCNormalC._transposed_cls = JITCNormalC, JITCNormalR
+
+
+# =====================================================================================================
+# multi-GPU partition of the scatter orientation ("JITC needs no storage — each GPU walks only its
+# chunk range / its rows, since the stream is keyed by (seed, row, chunk, lane)")
+# =====================================================================================================
+def jit_scatter_class_columns(shape1: int, out_len: int, class_begin: int, class_end: int, stride: int = 32) -> np.ndarray:
+    """Output columns touched by the walk classes ``[class_begin, class_end)`` (class = chunk * stride + lane):
+    ``chunk_start + lane + stride * q`` inside the chunk.  Ascending int64."""
+    chunk_size = max(1, (int(shape1) + 3) // 4)
+    cols = []
+    for c in range(int(class_begin), int(class_end)):
+        chunk, lane = divmod(c, stride)
+        cs = chunk * chunk_size
+        ce = min(cs + chunk_size, int(out_len))
+        if cs + lane < ce:
+            cols.append(np.arange(cs + lane, ce, stride, dtype=np.int64))
+    return np.sort(np.concatenate(cols)) if cols else np.zeros(0, np.int64)
+
+
+class JITCScatterShard:
+    """Rank ``rank`` of ``world``'s share of ``events @ M`` for a JIT-connectivity matrix in its scatter orientation.
+
+    The (chunk, lane) walk classes are dealt to the ranks in contiguous ranges; a class owns its output columns
+    outright, so the ranks' outputs are disjoint (no reduction) and nothing but the spike vector is exchanged.
+    ``events @ shard`` returns the full-length output with this rank's columns filled and zeros elsewhere;
+    ``owned_columns`` lists them.  Only 1-D events (the mv matrix, lane stride 32)."""
+
+    def __init__(self, mat: JITCMatrix, world: int, rank: int):
+        from ._dist import post_slice_bounds
+        if mat._is_row:       # same (shape, transpose, corder) mapping as JITCMatrix.__rmatmul__
+            shape, transpose, corder = mat.shape, True, not mat.corder
+        else:
+            shape, transpose, corder = mat.shape[::-1], False, not mat.corder
+        if corder:
+            raise ValueError("events @ M runs the gather kernel for this corder; only the scatter orientation shards by "
+                             "walk class (shard the gather orientation by output rows instead).")
+        self.mat, self.world, self.rank = mat, int(world), int(rank)
+        self.in_len = int(shape[0] if transpose else shape[1])
+        self.out_len = int(shape[1] if transpose else shape[0])
+        self.shape1 = int(shape[1])                  # keys the chunk width, as in the ops (reference _misc.py:74-122)
+        chunk_size = max(1, (self.shape1 + 3) // 4)
+        self.n_classes = ((self.out_len + chunk_size - 1) // chunk_size) * 32
+        self.class_begin, self.class_end = post_slice_bounds(self.n_classes, self.world, self.rank)
+        self._cols = None
+
+    @property
+    def owned_columns(self) -> np.ndarray:
+        if self._cols is None:
+            self._cols = jit_scatter_class_columns(self.shape1, self.out_len, self.class_begin, self.class_end)
+        return self._cols
+
+    def __rmatmul__(self, other):
+        if not is_event(other):
+            raise NotImplementedError("only event operands are on the accelerated path.")
+        v = event_operand(other, allow_packed=False)
+        if v.ndim != 1:
+            raise NotImplementedError("JITCScatterShard takes 1-D events.")
+        m = self.mat
+        in_len, out_len = self.in_len, self.out_len
+        assert v.shape[0] == in_len, f"vector length {v.shape[0]} != {in_len}"
+        spikes, sd = A.spikes_to_device(v)
+        out = torch.empty(out_len, dtype=m.dtype, device=A.device())
+        if out_len == 0:
+            return m._out(out, v)
+        a = m._weights[0]
+        b = m._weights[1] if m._family != 's' else 0.0
+        w0, w1, wmax = _jit_params(m._family, a, b)
+        f_ws = fn('be_binary_jitmv_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
+        ws = A.workspace(f_ws(self.shape1, in_len, out_len, 0))
+        f = fn('be_binary_jitmv_sharded', c_int,
+               [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
+                c_i64, c_vp])
+        check(f(_FAMILY[m._family], w0, w1, A.wcode(out), _initialize_conn_length(m.prob), m.seed & 0xFFFFFFFF, A.ptr(spikes),
+                sd, A.ptr(out), self.shape1, in_len, out_len, self.class_begin, self.class_end - self.class_begin,
+                _fixed_scale_exp(wmax, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()), 'be_binary_jitmv_sharded')
+        return m._out(out, v)

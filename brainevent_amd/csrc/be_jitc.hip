@@ -95,6 +95,7 @@ struct JitP {
   int n_chunks;             // ceil(walk_len / chunk_size)
   int stride;               // 32 (mv) or 4 (mm)
   double w0, w1;            // scalar: weight, -- | uniform: low, span | normal: loc, scale
+  int cls_begin, cls_count; // scatter: the (chunk, lane) classes [cls_begin, cls_begin + cls_count) this call owns
 };
 
 // edge weight in the arithmetic type A (float or double); (row, col) are the RNG-orientation coordinates
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
   AccT* acc = reinterpret_cast<AccT*>(smem_raw);
   const int part = blockIdx.x % parts;
   const int piece = (blockIdx.x / parts) % pieces;
-  const int cls = blockIdx.x / (parts * pieces);
+  const int cls = p.cls_begin + blockIdx.x / (parts * pieces);
   const uint32_t S = (uint32_t)p.stride;
   const uint32_t chunk = (uint32_t)cls / S, l = (uint32_t)cls - chunk * S;
   active += (int64_t)blockIdx.y * active_stride;
@@ -267,7 +268,9 @@ __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename Scatt
   const int t = threadIdx.x;
   using AccT = typename ScatterAcc<MODE>::type;
   const int64_t cls_stride = (int64_t)pieces * parts * piece_len;      // between consecutive classes
-  const AccT* base = partial + (((int64_t)chunk * S * pieces + piece) * parts) * (int64_t)piece_len + i0 + t;
+  // class c = chunk * S + l lives at local index c - cls_begin; classes outside the owned range read as zero
+  const int c0 = chunk * S - p.cls_begin;
+  const AccT* base = partial + ((int64_t)piece * parts) * (int64_t)piece_len + i0 + t;
   // up to 8 class rows x parts loads in flight per thread
   for (int l0 = 0; l0 < S; l0 += 8) {
     unsigned long long sum[8];
@@ -276,9 +279,16 @@ __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename Scatt
     for (int q2 = 0; q2 < parts; ++q2) {
       AccT v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (l0 + u < S) ? base[(int64_t)(l0 + u) * cls_stride + (int64_t)q2 * piece_len] : AccT(0);
+      for (int u = 0; u < 8; ++u) {      // unconditional loads from a clamped class row; the select happens at the add
+        const int c = c0 + l0 + u;
+        const int cc = c < 0 ? 0 : (c >= p.cls_count ? p.cls_count - 1 : c);
+        v[u] = base[(int64_t)cc * cls_stride + (int64_t)q2 * piece_len];
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sum[u] += (unsigned long long)v[u];
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + l0 + u;
+        sum[u] += (l0 + u < S && c >= 0 && c < p.cls_count) ? (unsigned long long)v[u] : 0ull;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -444,6 +454,8 @@ inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t
   p.stride = stride;
   p.w0 = w0;
   p.w1 = w1;
+  p.cls_begin = 0;
+  p.cls_count = p.n_chunks * stride;
   return p;
 }
 
@@ -452,7 +464,7 @@ constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators p
 struct ScatterGeom { int n_classes, pieces, parts; uint32_t piece_len; };
 inline ScatterGeom scatter_geom(const JitP& p, bool scalar, int64_t n_batch = 1) {
   ScatterGeom g;
-  g.n_classes = p.n_chunks * p.stride;
+  g.n_classes = p.cls_count;
   const int64_t Qmax = (std::min<int64_t>(p.chunk_size, p.walk_len) + p.stride - 1) / p.stride;
   const uint32_t cap = scalar ? kPieceU32 : kPieceU64;
   g.pieces = (int)std::max<int64_t>(1, (Qmax + cap - 1) / cap);
@@ -613,9 +625,34 @@ int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t 
   return jit_mv_ws_bytes(shape1, in_len, out_len, gather);
 }
 
+static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                      int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
+                      int class_begin, int class_count, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+
 int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                     int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
                     void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  return jitmv_impl(mode, w0, w1, wdtype, clen, seed, spikes, spike_dtype, out, shape1, in_len, out_len, gather, scale_exp, 0,
+                    -1, workspace, workspace_bytes, stream);
+}
+
+int be_jit_scatter_classes(int64_t shape1, int64_t out_len, int stride) {
+  BE_REQUIRE(shape1 >= 0 && out_len >= 0 && (stride == 32 || stride == 4), BE_ERR_INVALID, "bad arguments");
+  const JitP p = make_params(shape1, out_len, 0, 2, stride, 0, 0);
+  return p.n_chunks * stride;
+}
+
+int be_binary_jitmv_sharded(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                            int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int class_begin,
+                            int class_count, int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(class_begin >= 0 && class_count >= 0, BE_ERR_INVALID, "bad class range");
+  return jitmv_impl(mode, w0, w1, wdtype, clen, seed, spikes, spike_dtype, out, shape1, in_len, out_len, /*gather=*/0,
+                    scale_exp, class_begin, class_count, workspace, workspace_bytes, stream);
+}
+
+static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                      int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
+                      int class_begin, int class_count, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
   BE_REQUIRE(in_len >= 0 && out_len >= 0 && shape1 >= 0, BE_ERR_INVALID, "bad shape");
   BE_REQUIRE(in_len < (1ll << 32) && out_len < (1ll << 32), BE_ERR_RANGE, "dimensions must fit uint32 for the RNG keys");
@@ -632,7 +669,16 @@ int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, ui
              BE_ERR_WORKSPACE, "workspace too small");
   BE_REQUIRE(gather || mode == MODE_SCALAR || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID,
              "scale_exp out of range");
-  const JitP p = make_params(shape1, gather ? in_len : out_len, seed, clen, 32, w0, w1);
+  JitP p = make_params(shape1, gather ? in_len : out_len, seed, clen, 32, w0, w1);
+  if (class_count >= 0) {      // sharded scatter: only the classes [class_begin, class_begin + class_count)
+    BE_REQUIRE(class_begin + class_count <= p.cls_count, BE_ERR_RANGE, "class range exceeds be_jit_scatter_classes()");
+    p.cls_begin = class_begin;
+    p.cls_count = class_count;
+    if (class_count == 0) {
+      BE_HIP(hipMemsetAsync(out, 0, (size_t)out_len * esz, st));
+      return BE_OK;
+    }
+  }
   switch (mode) {
     case MODE_SCALAR: return jit_mv_dispatch<MODE_SCALAR>(p, wdtype, spikes, spike_dtype, out, in_len, out_len, gather, scale_exp, workspace, st);
     case MODE_UNIFORM: return jit_mv_dispatch<MODE_UNIFORM>(p, wdtype, spikes, spike_dtype, out, in_len, out_len, gather, scale_exp, workspace, st);

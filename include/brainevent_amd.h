@@ -240,6 +240,16 @@ int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t 
 int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                     int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather,
                     int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+/* Multi-GPU partition of the scatter ("trans") orientation with no stored state: the walk of a generator row is a
+ * set of independent streams keyed by (chunk, lane) (brainevent/_jit_scalar/binary_jitsmv.cu:54-66), and stream
+ * (chunk, lane) only ever touches the output columns chunk_start + lane + stride * q.  A rank that owns the classes
+ * [class_begin, class_begin + class_count) (class = chunk * stride + lane; be_jit_scatter_classes() of them in all)
+ * therefore owns those columns outright: `out` (full length out_len) receives the owned columns and zeros elsewhere,
+ * the outputs of the ranks are disjoint and their sum is the unsharded result.  Workspace: the unsharded query. */
+int be_jit_scatter_classes(int64_t shape1, int64_t out_len, int stride);
+int be_binary_jitmv_sharded(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                            int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int class_begin,
+                            int class_count, int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
 int64_t be_binary_jitmm_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch, int gather);
 int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes_bm,
                     int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,

@@ -109,3 +109,36 @@ def test_slice_bounds_and_fixed_num_shards():
     np.testing.assert_allclose(np.concatenate(cols, axis=1), dense, rtol=1e-6)
     bits = torch.from_numpy(rng.random(29) < 0.5)
     assert torch.equal(D._unpack_bits(D._pack_bits(bits), 29), bits)
+
+
+def test_jit_walk_class_columns_tile_the_output():
+    """Geometry of the JITC multi-GPU partition: the columns of the (chunk, lane) classes tile the output, and the
+    oracle's edge stream of a class stays inside that class's columns."""
+    from brainevent_amd._jitc import jit_scatter_class_columns
+    from brainevent_amd._dist import post_slice_bounds
+    from oracle import oracle_np as O
+    for shape1, out_len in ((17, 17), (1000, 1000), (30, 100), (4_000, 1_003), (3, 50)):
+        chunk = max(1, (shape1 + 3) // 4)
+        n_cls = ((out_len + chunk - 1) // chunk) * 32
+        for world in (1, 2, 8):
+            seen = np.zeros(out_len, np.int32)
+            for r in range(world):
+                lo, hi = post_slice_bounds(n_cls, world, r)
+                cols = jit_scatter_class_columns(shape1, out_len, lo, hi)
+                assert cols.size == 0 or (cols.min() >= 0 and cols.max() < out_len)
+                seen[cols] += 1
+            assert (seen == 1).all()
+    seed, clen, n_cols = 123, 10, 100
+    chunk = max(1, (n_cols + 3) // 4)
+    n_edges = 0
+    for c in range(((n_cols + chunk - 1) // chunk) * 32):
+        ch, lane = divmod(c, 32)
+        cs, ce = ch * chunk, min((ch + 1) * chunk, n_cols)
+        cols = set(jit_scatter_class_columns(n_cols, n_cols, c, c + 1).tolist())
+        q, state = O.lr_initial_q(O.lr_init(seed, 5, ch, lane), clen)
+        while cs + lane + 32 * q < ce:           # the whole stream of (row 5, chunk, lane) stays inside the class's columns
+            assert cs + lane + 32 * q in cols
+            n_edges += 1
+            state = O.lr_next(state)
+            q = q + 1 + O.lr_bounded(state, clen - 1)
+    assert n_edges > 0

@@ -226,3 +226,41 @@ def test_jitc_materialised_scatter_matches_on_the_fly_mid_size(be):
     rng = np.random.default_rng(4)
     s = spikes_of(rng, n, 0.02, 'bool')
     np.testing.assert_array_equal(be.BinaryArray(s) @ S, be.BinaryArray(s) @ M)      # integer counts: exact
+
+
+@pytest.mark.parametrize('cls_name,params', [('JITCScalarR', (1.5,)), ('JITCUniformR', (-1.0, 2.0)), ('JITCNormalC', (0.5, 0.3))])
+@pytest.mark.parametrize('world', [1, 2, 3, 8])
+def test_scatter_shards_tile_the_output(cls_name, params, world):
+    """Multi-GPU partition by walk class: every rank's output is the full result on its own columns and zero
+    elsewhere (bitwise), the column sets tile the output, nothing is stored."""
+    import ctypes
+    import brainevent_amd as be
+    from brainevent_amd import _lib
+    rng = np.random.default_rng(world)
+    n_in, n_out = 3000, 5003
+    cls = getattr(be, cls_name)
+    is_row = cls_name.endswith('R')
+    M = cls((*params, 0.02, 77), shape=(n_in, n_out) if is_row else (n_in, n_out), corder=True if is_row else False)
+    # pick the operand order that runs the scatter kernel for this class
+    s = rng.random(n_in) < 0.2
+    try:
+        shards = [M.scatter_shard(world, r) for r in range(world)]
+    except ValueError:
+        M = cls((*params, 0.02, 77), shape=(n_in, n_out), corder=not M.corder)
+        shards = [M.scatter_shard(world, r) for r in range(world)]
+    full = be.BinaryArray(s) @ M
+    n_cls = _lib.fn('be_jit_scatter_classes', ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int])(
+        shards[0].shape1, shards[0].out_len, 32)
+    assert shards[0].n_classes == n_cls and shards[0].out_len == n_out
+    seen = np.zeros(n_out, np.int32)
+    total = np.zeros(n_out, full.dtype)
+    for sh in shards:
+        out = be.BinaryArray(s) @ sh
+        cols = sh.owned_columns
+        seen[cols] += 1
+        mask = np.zeros(n_out, bool); mask[cols] = True
+        np.testing.assert_array_equal(out[mask], full[mask])
+        assert not out[~mask].any()
+        total += out
+    assert (seen == 1).all()
+    np.testing.assert_array_equal(total, full)
