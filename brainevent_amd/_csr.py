@@ -271,9 +271,10 @@ def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, w
     else:
         f_ws = fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])
         ws = A.workspace(f_ws(m, k, nb))
-        f = None if sd == A.BE_SPIKE_BITS else fn('be_binary_csrmm_nt_' + _variant(homo, weights, sd), c_int, _CSRMM_ARGS)
-    if f is None:     # bit-packed events go through the generic entry point (the per-variant names cover bool / float)
-        _csrmm_generic(weights, indices, indptr, -1, spikes_bm, sd, out, m, k, nb, ws, transpose)
+        f = None    # generic entry point: it takes the average row length as a hint for the kernel choice
+    if f is None:     # (also: bit-packed events / id lists — the per-variant names cover bool / float only)
+        hint = -1 if transpose else int(indices.numel() // max(m, 1))
+        _csrmm_generic(weights, indices, indptr, hint, spikes_bm, sd, out, m, k, nb, ws, transpose)
         return out
     check(f(A.ptr(weights), A.ptr(indices), A.ptr(indptr), is64, A.ptr(spikes_bm), A.ptr(out), m, k, nb, A.ptr(ws),
             ws.numel(), A.stream_ptr()), f.__name__)

@@ -381,6 +381,110 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
 }
 
 // =================================================================================================
+// batched gather fused over the batch (binary_csrmm, transpose=False, long rows): ONE pass over the matrix for up to 32
+// spike columns instead of one pass per column.  mask[j] holds the 32 columns' spikes of neuron j as one word (global /
+// L2: k words do not fit LDS); a lane keeps its 32 per-column partial sums in private LDS slots and visits only the set
+// bits of each entry's mask (at 1 % firing three entries in four have none), so the per-entry cost does not grow with
+// the batch.  One wave per row; at the row end the wave folds its 64 x 32 slots and writes out_bm[c, row].
+// =================================================================================================
+template <typename SP>
+__global__ void __launch_bounds__(256) k_batch_masks(const typename SP::type* __restrict__ spikes_bm, int64_t len, int nc,
+                                                     uint32_t* __restrict__ mask) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    uint32_t mk = 0;
+    for (int b = 0; b < nc; ++b) mk |= (SP::active(spikes_bm[(int64_t)b * len + i]) ? 1u : 0u) << b;
+    mask[i] = mk;
+  }
+}
+
+constexpr int kFusedSlots = 33;      // 32 columns + 1 pad word: lane l's slots start at bank l
+
+template <typename W, bool HOMO>
+__global__ void __launch_bounds__(1024) k_csrmm_nt_fused(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                         RowPtr rp, const uint32_t* __restrict__ mask, int nc,
+                                                         W* __restrict__ out_bm, int64_t m) {
+  extern __shared__ float fused_s[];                 // [1024][kFusedSlots]; uint32 counts when HOMO
+  constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
+  float* my = fused_s + threadIdx.x * kFusedSlots;
+  uint32_t* my_u = reinterpret_cast<uint32_t*>(my);
+#pragma unroll
+  for (int b = 0; b < 32; ++b) my[b] = 0.0f;
+  const int lane = lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const float* wave_slots = fused_s + (threadIdx.x & ~63) * kFusedSlots;
+  float w0 = 0.0f;
+  if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
+  for (int64_t r = wave; r < m; r += n_waves) {
+    const int64_t rb = rp.at(r), len = rp.at(r + 1) - rb;
+    for (int64_t p0 = 0; p0 < len; p0 += (1ll << 28)) {
+      const int64_t plen = len - p0 < (1ll << 28) ? len - p0 : (1ll << 28);
+      auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(indices + rb + p0), 0, (int)(plen * 4), 0x00020000);
+      auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(VECW ? weights + rb + p0 : weights), 0,
+                                                  VECW ? (int)(plen * 4) : 0, 0x00020000);
+      for (int64_t j0 = 0; j0 < plen; j0 += 512) {
+        be_nt_v4u c[2], wv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int off = (int)(j0 + 256 * u + 4 * lane) * 4;
+          c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0);       // out-of-range lanes read 0
+          if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+        }
+        uint32_t mk[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mk[4 * u + q] = mask[c[u][q]];          // unconditional gathers (column 0 for the tail)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + 256 * u + 4 * lane + q;
+            uint32_t bits = j < plen ? mk[4 * u + q] : 0u;
+            if (bits) {
+              float w = 0.0f;
+              if (!HOMO) w = VECW ? __uint_as_float(wv[u][q]) : (float)WTraits<W>::load(weights, rb + p0 + j);
+              do {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                if (HOMO) my_u[b] += 1u;
+                else my[b] += w;
+              } while (bits);
+            }
+          }
+        }
+      }
+    }
+    // fold the wave's 64 x 32 slots: lane l sums column (l & 31) over lanes [32 * (l >> 5), +32)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int col = lane & 31, half = lane >> 5;
+      const float* src = wave_slots + (half * 32) * kFusedSlots + col;
+      float sum = 0.0f;
+      uint32_t cnt = 0;
+#pragma unroll 8
+      for (int t = 0; t < 32; ++t) {
+        if (HOMO) cnt += reinterpret_cast<const uint32_t*>(src)[t * kFusedSlots];
+        else sum += src[t * kFusedSlots];
+      }
+      if (HOMO) {
+        cnt += __shfl_xor(cnt, 32, 64);
+        sum = (float)cnt * w0;
+      } else {
+        sum += __shfl_xor(sum, 32, 64);
+      }
+      if (lane < nc) WTraits<W>::store(out_bm, (int64_t)lane * m + r, sum);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 32; ++b) my[b] = 0.0f;
+  }
+}
+
+// =================================================================================================
 // scatter plan: count -> scan -> fill
 //
 // Layout ("post-sliced row segments", row-major): for row r and output slice s the entries of row r whose
@@ -811,6 +915,8 @@ inline int grid_for(int64_t n, int block, int cap) {
 }
 
 constexpr int kMaxBatch = 65535;
+constexpr int kFusedMinBatch = 4;      // batched gather: fuse over the batch from this many columns ...
+constexpr int64_t kFusedMinRow = 256;  // ... when rows average at least this many entries
 
 inline int64_t counts_bytes(int64_t nb) { return be_align_up(nb * 4, 256); }
 inline int64_t active_stride_of(int64_t m) { return be_align_up(m * 4, 256) / 4; }   // in uint32 elements
@@ -956,6 +1062,31 @@ template <typename W, bool HOMO>
 int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
              void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
   const int64_t n_words = (k + 31) / 32;
+  if (nb >= kFusedMinBatch && m > 0 && nnz_hint / m >= kFusedMinRow && !std::is_same<W, double>::value &&
+      (sd == BE_SPIKE_BOOL || sd == BE_SPIKE_FLOAT)) {
+    // long rows, several columns: one pass over the matrix per 32 columns (k_csrmm_nt_fused)
+    uint32_t* mask = static_cast<uint32_t*>(ws);
+    const size_t lds = (size_t)1024 * kFusedSlots * 4;
+    auto kern = k_csrmm_nt_fused<W, HOMO>;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t ssz = sd == BE_SPIKE_FLOAT ? 4 : 1;
+    for (int64_t c0 = 0; c0 < nb; c0 += 32) {
+      const int nc = (int)std::min<int64_t>(32, nb - c0);
+      const unsigned char* sp = static_cast<const unsigned char*>(spikes) + (size_t)c0 * k * ssz;
+      if (sd == BE_SPIKE_FLOAT)
+        hipLaunchKernelGGL(k_batch_masks<SpikeFloat>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(sp), k, nc, mask);
+      else
+        hipLaunchKernelGGL(k_batch_masks<SpikeBool>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st, sp, k, nc, mask);
+      BE_LAUNCH_CHECK();
+      const int prof = be_prof_begin(st);
+      hipLaunchKernelGGL(kern, dim3(grid_for(m, 16, 256)), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
+                         mask, nc, static_cast<W*>(out) + c0 * m, m);
+      be_prof_end(prof, st);
+      BE_LAUNCH_CHECK();
+    }
+    return BE_OK;
+  }
   const uint32_t* bits = static_cast<const uint32_t*>(spikes);   // BE_SPIKE_BITS: already in the kernels' format
   if (sd != BE_SPIKE_BITS) {
     int rc = pack_any(spikes, sd, k, nb, static_cast<uint32_t*>(ws), n_words, st);
@@ -1320,7 +1451,9 @@ int be_binary_csrmv_t(const void* weights, int homo, int wdtype, const int32_t* 
 
 int64_t be_binary_csrmm_nt_workspace_bytes(int64_t m, int64_t k, int64_t n_batch) {
   (void)m;
-  return be_align_up((((k + 31) / 32) * n_batch + 2) * 4, 256);
+  const int64_t bits = (((k + 31) / 32) * n_batch + 2) * 4;            // per-column bitmaps
+  const int64_t masks = n_batch >= kFusedMinBatch ? (k + 2) * 4 : 0;   // per-neuron column masks of the fused kernel
+  return be_align_up(std::max(bits, masks), 256);
 }
 int64_t be_binary_csrmv_nt_workspace_bytes(int64_t m, int64_t k) { return be_binary_csrmm_nt_workspace_bytes(m, k, 1); }
 

@@ -104,3 +104,28 @@ def test_fixed_num_classes(be, oracle, monkeypatch):
     np.testing.assert_allclose(be.BinaryArray(S) @ conn, S.astype(np.float32) @ conn.todense(), rtol=1e-4, atol=1e-4)
     with pytest.raises(ValueError):
         be.FixedNumPerPre((w, idx + n_post), shape=(n_pre, n_post))
+
+
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('wdtype', ['float32', 'float16'])
+@pytest.mark.parametrize('nb,spike_kind', [(4, 'bool'), (32, 'bool'), (37, 'float'), (70, 'bool')])
+def test_csrmm_gather_fused_over_batch_long_rows(homo, wdtype, nb, spike_kind):
+    """binary_csrmm transpose=False with long rows runs the kernel that is fused over the batch (one pass over the
+    matrix per 32 columns); rows of very different lengths, empty rows, more than 32 columns."""
+    import brainevent_amd as be
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(nb + homo)
+    m, k = 37, 9000
+    lens = rng.integers(300, 2500, m); lens[3] = 0; lens[10] = 1; lens[20] = 5000
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    w = (np.array([0.75]) if homo else rng.random(ptr[-1])).astype(wdtype)
+    B = rng.random((k, nb)) < 0.05
+    Bv = B if spike_kind == 'bool' else np.where(B, 1.5, -0.5).astype(np.float32)
+    got = be.binary_csrmm(w, idx, ptr, Bv, shape=(m, k), transpose=False)
+    ref = O.binary_csrmm(w.astype(np.float32), idx, ptr, B, (m, k), False)
+    tol = 1e-5 if wdtype == 'float32' else 2e-2
+    np.testing.assert_allclose(np.asarray(got, np.float32), ref, rtol=tol, atol=tol * 10)
+    # the class route (CSR @ B) gives the same numbers
+    got2 = be.CSR((w, idx, ptr), shape=(m, k)) @ be.BinaryArray(Bv)
+    np.testing.assert_allclose(np.asarray(got2, np.float32), np.asarray(got, np.float32), rtol=1e-6, atol=1e-6)
