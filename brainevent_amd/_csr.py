@@ -135,6 +135,20 @@ class ScatterPlan:
         return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype)
 
 
+def _abs_range(weights: torch.Tensor, chunk: int = 1 << 27):
+    """``(max |w|, smallest non-zero |w| or inf)`` in chunks (1e10 weights: no 40 GB temporaries; nan -> max is nan)."""
+    flat = weights.reshape(-1)
+    wmax, wmin = 0.0, math.inf
+    for lo in range(0, flat.numel(), chunk):
+        a = flat[lo:lo + chunk].abs().float()
+        mx = float(a.max().item())
+        wmax = mx if (mx != mx or mx > wmax) else wmax
+        if wmax != wmax:
+            return wmax, wmin
+        wmin = min(wmin, float(torch.where(a > 0, a, torch.full_like(a, math.inf)).min().item()))
+    return wmax, wmin
+
+
 def _fixed_point_resolves(weights: torch.Tensor, indices: Optional[torch.Tensor], k: int, scale_exp: int,
                           wmin: float) -> bool:
     """Accuracy gate of the fixed-point routes.  A sum of ``n`` weights carries an absolute error below
@@ -177,14 +191,12 @@ class BinnedScatter:
         self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
         self.scale_exp = 0
         if not self.homo:
-            wmax = float(weights.abs().max().item())
+            wmax, wmin = _abs_range(weights)
             if not math.isfinite(wmax):
                 raise MathError("BinnedScatter: weights contain inf/nan; use the direct route (workspace=None).")
             e = math.frexp(wmax)[1] if wmax > 0 else 0
             self.scale_exp = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(m + 1))))))
-            nz = weights.abs()
-            nz = nz[nz > 0]
-            if nz.numel() and not _fixed_point_resolves(weights, indices, k, self.scale_exp, float(nz.min().item())):
+            if math.isfinite(wmin) and not _fixed_point_resolves(weights, indices, k, self.scale_exp, wmin):
                 raise MathError("BinnedScatter: dynamic range of the weights exceeds what the fixed-point sums resolve.")
         f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
         self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))

@@ -103,6 +103,12 @@ def test_slice_bounds_and_fixed_num_shards():
     cols = []
     for r in range(3):
         d, i, p, shp = D.shard_fixed_num_by_post(data, idx, (n_pre, n_post), 3, r)
+        # the blocked implementation gives the same shard whatever the block size (here: 1, 2 and many rows per block)
+        for be_ in (1, 13, 50):
+            flat_ptr = torch.arange(n_pre + 1, dtype=torch.int64) * K
+            d2, i2, p2, shp2 = D.shard_csr_by_post(data.reshape(-1), idx.reshape(-1), flat_ptr, (n_pre, n_post), 3, r,
+                                                   block_entries=be_)
+            assert shp2 == shp and torch.equal(i2, i) and torch.equal(p2.long(), p.long()) and torch.equal(d2, d)
         blk = np.zeros(shp, np.float32)
         np.add.at(blk, (np.repeat(np.arange(n_pre), np.diff(p.numpy())), i.numpy()), d.numpy())
         cols.append(blk)
