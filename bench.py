@@ -246,8 +246,9 @@ def main():
     csr = be.CSR((weights, indices, indptr), shape=(n_pre, n_post), check_structure=False)
     plan_bytes = 0
     if args.route == 'plan':
-        shift = args.shift or C.ScatterPlan.default_shift(n_post, args.homo)
-        csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post), slice_shift=shift)
+        # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
+        csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post),
+                                                          slice_shift=args.shift or None)
         plan = csr.buffers['scatter_plan']
         plan_bytes = plan.nbytes()
         if args.parts:
@@ -346,6 +347,7 @@ def main():
                        'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
                        'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange})' if use_dist else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
+                       'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts' if args.route == 'plan' else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},
             'roofline': roof,
         }

@@ -54,10 +54,11 @@ class ScatterPlan:
     #: a plan is refused when its smallest non-zero weight would be represented with fewer bits than this
     MIN_WEIGHT_BITS = 16
 
-    def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype):
+    def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype, slice_width=0):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
         self.slice_shift = int(slice_shift)
-        self.n_slices = (self.k + (1 << self.slice_shift) - 1) >> self.slice_shift
+        self.slice_width = int(slice_width) if slice_width else (1 << self.slice_shift)   # columns per slice
+        self.n_slices = (self.k + self.slice_width - 1) // self.slice_width
         self.seg, self.blob = seg, blob
         self.scale_exp = int(scale_exp)
         self.weight_dtype = weight_dtype
@@ -70,6 +71,20 @@ class ScatterPlan:
         need = max(4, int(math.ceil(math.log2(max(int(k), 2)))))
         return min(cap, need)
 
+    @staticmethod
+    def balanced_width(k: int, slice_shift: int) -> int:
+        """Slice width that fills the chip evenly: as many slices as the capacity ``2^slice_shift`` needs, rounded up
+        so that ``n_slices * parts`` lands on a multiple of the 256 CUs (k = 1M, shift 14: 62 -> 64 slices of 15625,
+        4 workgroups each = 256 equal workgroups instead of 244 full ones and 4 nearly empty)."""
+        cap = 1 << slice_shift
+        n_min = (int(k) + cap - 1) // cap
+        if n_min >= 256:
+            n = (n_min + 7) // 8 * 8
+        else:
+            parts = max(1, 256 // n_min)
+            n = max(n_min, 256 // parts)
+        return max(1, min(cap, (int(k) + n - 1) // n))
+
     def default_parts(self) -> int:
         # one 1024-thread workgroup per CU: aim for ~256 workgroups in total
         return int(max(1, min(64, 256 // max(self.n_slices, 1))))
@@ -81,8 +96,8 @@ class ScatterPlan:
         key = (parts, n_batch)
         ws = self._ws.get(key)
         if ws is None:
-            f = fn('be_binary_csrmm_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int])
-            ws = A.workspace(f(self.m, self.k, n_batch, self.slice_shift, parts, int(self.homo)))
+            f = fn('be_binary_csrmm_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int])
+            ws = A.workspace(f(self.m, self.k, n_batch, self.slice_shift, self.slice_width, parts, int(self.homo)))
             ws[:4 * max(n_batch, 64)].zero_()   # spike counters: zero on entry, re-armed by every call
             self._ws = {key: ws}
         return ws
@@ -90,8 +105,10 @@ class ScatterPlan:
     # -- construction ---------------------------------------------------------------------------
     @classmethod
     def build(cls, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], *, shape,
-              row_len: int = -1, slice_shift: Optional[int] = None) -> 'ScatterPlan':
-        """Build the plan on the device.  ``indptr=None`` + ``row_len`` describes fixed-length rows."""
+              row_len: int = -1, slice_shift: Optional[int] = None, slice_width: Optional[int] = None) -> 'ScatterPlan':
+        """Build the plan on the device.  ``indptr=None`` + ``row_len`` describes fixed-length rows.  ``slice_shift``
+        (accumulator capacity) and ``slice_width`` (columns per slice) default to the LDS-filling capacity and the
+        balanced width; an explicit ``slice_shift`` alone means full-capacity slices."""
         m, k = int(shape[0]), int(shape[1])
         weights = A.to_device(weights).reshape(-1)
         indices = A.to_device(indices).reshape(-1)
@@ -99,26 +116,31 @@ class ScatterPlan:
         homo = weights.numel() == 1
         if slice_shift is None:
             slice_shift = cls.default_shift(k, homo)
-        n_slices = (k + (1 << slice_shift) - 1) >> slice_shift
+            if slice_width is None:
+                slice_width = cls.balanced_width(k, slice_shift)
+        if slice_width is None:
+            slice_width = 1 << slice_shift
+        assert 0 < slice_width <= (1 << slice_shift)
+        n_slices = (k + slice_width - 1) // slice_width
         dev = A.device()
         st = A.stream_ptr()
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         if indptr is not None:
             indptr = A.to_device(indptr)
         seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
-        f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int])
-        scratch = A.workspace(f_scr(m, k, slice_shift))
+        f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
+        scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
         blob_bytes = c_i64(0)
         f_cnt = fn('be_scatter_plan_count', c_int,
-                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
-        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, int(homo), A.ptr(seg),
+                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
+        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, slice_width, int(homo), A.ptr(seg),
                     A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
         blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
         maxabs = torch.zeros(2, dtype=torch.int32, device=dev)      # f32 bits of max |w| and of the smallest non-zero |w|
         f_fill = fn('be_scatter_plan_fill', c_int,
-                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp])
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp])
         check(f_fill(A.ptr(weights), int(homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, m, k,
-                     slice_shift, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
+                     slice_shift, slice_width, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
         scale_exp = 0
         if not homo:
             mm = maxabs.cpu().numpy().view(np.uint32)
@@ -132,7 +154,7 @@ class ScatterPlan:
             if int(mm[1]) != 0xFFFFFFFF and not _fixed_point_resolves(weights, indices, k, scale_exp, wmin):
                 raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
                                 f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
-        return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype)
+        return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width)
 
 
 def _abs_range(weights: torch.Tensor, chunk: int = 1 << 27):
@@ -228,9 +250,9 @@ def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor
         parts = max(1, min(parts, 512 // (plan.n_slices * nb)))
     ws = plan.workspace(parts, nb)
     f = fn('be_binary_csrmm_t_plan', c_int,
-           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp])
+           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp])
     check(f(A.ptr(weights), int(plan.homo), A.wcode(out_bm), A.ptr(plan.blob), A.ptr(plan.seg), A.ptr(spikes_bm), sd,
-            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, parts, plan.scale_exp, A.ptr(ws), ws.numel(),
+            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, plan.slice_width, parts, plan.scale_exp, A.ptr(ws), ws.numel(),
             A.stream_ptr()), 'be_binary_csrmm_t_plan')
 
 
@@ -509,7 +531,8 @@ class CompressedSparseData:
             if self.nse / (m * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096 and \
                     self.data.dtype != torch.float64:
                 try:
-                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
+                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift,
+                                             slice_width=ScatterPlan.balanced_width(k, shift))
                 except MathError:
                     plan = None       # inf / nan / extreme dynamic range: float atomics (direct route) handle those
             elif BinnedScatter.applicable(self.data, k):
@@ -557,7 +580,8 @@ class CompressedSparseData:
             n_slices = (m + (1 << shift) - 1) >> shift
             try:
                 if nse / (k * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096:
-                    mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift)
+                    mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift,
+                                                       slice_width=ScatterPlan.balanced_width(m, shift))
                 elif BinnedScatter.applicable(t_data, m):
                     mirror['plan'] = BinnedScatter(t_data, k, m, nse, indices=t_indices)
             except MathError:        # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel

@@ -217,7 +217,8 @@ class FixedNumConn:
             if self.num_conn / n_slices >= PLAN_MIN_SEGMENT and n_slices <= 4096:
                 try:
                     plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols),
-                                             row_len=self.num_conn, slice_shift=shift)
+                                             row_len=self.num_conn, slice_shift=shift,
+                                             slice_width=ScatterPlan.balanced_width(n_cols, shift))
                 except _csr_mod.MathError:
                     plan = None
             elif BinnedScatter.applicable(self.data, n_cols):

@@ -508,13 +508,13 @@ __host__ __device__ __forceinline__ uint32_t plan_block_units(uint32_t n_groups,
 
 // one workgroup per row (grid-stride): per-slice histogram of the row -> seg[r][s] = { block units, n4 }
 __global__ void __launch_bounds__(256) k_plan_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
-                                                    int slice_shift, int n_slices, int homo, uint2* __restrict__ seg) {
+                                                    uint32_t slice_width, int n_slices, int homo, uint2* __restrict__ seg) {
   __shared__ uint32_t hist[kMaxSlices];
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) hist[s] = 0;
     __syncthreads();
     const int64_t b = rp.at(r), e = rp.at(r + 1);
-    for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[((uint32_t)indices[j]) >> slice_shift], 1u);
+    for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[((uint32_t)indices[j]) / slice_width], 1u);
     __syncthreads();
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
       const uint32_t gsz = plan_group(homo != 0);
@@ -601,12 +601,12 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint2* __restrict__ a, int64
 // one workgroup per row (grid-stride): place every entry of the row into its block, then write the pads
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
-                                                   int64_t m, int slice_shift, int n_slices, const uint2* __restrict__ seg,
-                                                   unsigned char* __restrict__ blob, uint32_t* __restrict__ maxabs_bits) {
+                                                   int64_t m, int slice_shift, uint32_t slice_width, int n_slices,
+                                                   const uint2* __restrict__ seg, unsigned char* __restrict__ blob,
+                                                   uint32_t* __restrict__ maxabs_bits) {
   __shared__ uint32_t cur[kMaxSlices];
   __shared__ uint32_t seg_start[kMaxSlices];
   __shared__ uint32_t seg_n4[kMaxSlices];
-  const uint32_t mask = (1u << slice_shift) - 1u;
   uint32_t my_max = 0, my_min = 0xffffffffu;
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
@@ -619,15 +619,16 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
     const int64_t b = rp.at(r), e = rp.at(r + 1);
     for (int64_t j = b + threadIdx.x; j < e; j += blockDim.x) {
       const uint32_t c = (uint32_t)indices[j];
-      const uint32_t s = c >> slice_shift;
+      const uint32_t s = c / slice_width;
+      const uint32_t loc = c - s * slice_width;
       const uint32_t rank = atomicAdd(&cur[s], 1u);
       unsigned char* blk = blob + ((int64_t)seg_start[s] << 7);
       if (HOMO) {
-        reinterpret_cast<uint16_t*>(blk)[rank] = (uint16_t)(c & mask);
+        reinterpret_cast<uint16_t*>(blk)[rank] = (uint16_t)loc;
       } else {
         const float w = (float)WTraits<W>::load(weights, j);
         reinterpret_cast<float*>(blk)[rank] = w;
-        reinterpret_cast<uint16_t*>(blk + (size_t)seg_n4[s] * 16)[rank] = (uint16_t)(c & mask);
+        reinterpret_cast<uint16_t*>(blk + (size_t)seg_n4[s] * 16)[rank] = (uint16_t)loc;
         const uint32_t ab = __float_as_uint(w) & 0x7fffffffu;
         my_max = ab > my_max ? ab : my_max;
         if (ab != 0u) my_min = ab < my_min ? ab : my_min;
@@ -874,9 +875,9 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
 // out[j] = sum over the parts of slice(j); partial is [batch][part][slice][S]
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO>::type* __restrict__ partial, int parts,
-                                                     int n_slices, int slice_shift, int64_t k, double inv_scale,
-                                                     const W* __restrict__ weights, W* __restrict__ out, int64_t partial_stride,
-                                                     uint32_t* __restrict__ count) {
+                                                     int n_slices, int slice_shift, uint32_t slice_width, int64_t k,
+                                                     double inv_scale, const W* __restrict__ weights, W* __restrict__ out,
+                                                     int64_t partial_stride, uint32_t* __restrict__ count) {
   if (blockIdx.x == 0 && threadIdx.x == 0) count[blockIdx.y] = 0u;   // re-arm the spike counter for the next call
   partial += (int64_t)blockIdx.y * partial_stride;
   out += (int64_t)blockIdx.y * k;
@@ -886,8 +887,8 @@ __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO
   if (HOMO) w0 = WTraits<W>::load(weights, 0);
   const int64_t pstep = (int64_t)n_slices * S;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < k; j += stride) {
-    const int64_t slice = j >> slice_shift;
-    const int loc = (int)(j & (S - 1));
+    const int64_t slice = (int64_t)((uint32_t)j / slice_width);       // k <= 2^32 (column ids are int32)
+    const int loc = (int)((uint32_t)j - (uint32_t)slice * slice_width);
     const typename PlanAcc<HOMO>::type* p = partial + slice * S + loc;
     if (HOMO) {
       uint32_t c = 0;
@@ -1485,30 +1486,41 @@ int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t*
 }
 
 // ---------------------------------------------------------------- scatter plan
-static inline int n_slices_of(int64_t k, int slice_shift) { return (int)((k + (1ll << slice_shift) - 1) >> slice_shift); }
+// slices are `slice_width` output neurons wide (0 = the LDS capacity 2^slice_shift); a width below the capacity lets
+// the caller balance the slices (k = 1M: 64 slices of 15625 instead of 61 full ones and a sliver)
+static inline int64_t width_of(int slice_shift, int slice_width) { return slice_width > 0 ? slice_width : (1ll << slice_shift); }
+static inline int n_slices_of(int64_t k, int slice_shift, int slice_width = 0) {
+  const int64_t w = width_of(slice_shift, slice_width);
+  return (int)((k + w - 1) / w);
+}
+static inline bool width_ok(int slice_shift, int slice_width) {
+  return slice_width >= 0 && slice_width <= (1 << slice_shift);
+}
 
-int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift) {
-  const int64_t n = (int64_t)n_slices_of(k, slice_shift) * m;
+int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width) {
+  const int64_t n = (int64_t)n_slices_of(k, slice_shift, slice_width) * m;
   const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
   return be_align_up((n_blocks + 2) * 8, 256);
 }
 
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
-                          int64_t k, int slice_shift, int homo, void* seg, void* scratch, int64_t scratch_bytes,
-                          int64_t* blob_bytes_host, be_stream_t stream) {
+                          int64_t k, int slice_shift, int slice_width, int homo, void* seg, void* scratch,
+                          int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
-  const int n_slices = n_slices_of(k, slice_shift);
+  const int n_slices = n_slices_of(k, slice_shift, slice_width);
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
   BE_REQUIRE(seg && scratch && blob_bytes_host, BE_ERR_INVALID, "null pointer");
-  BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift), BE_ERR_WORKSPACE, "scratch too small");
+  BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift, slice_width), BE_ERR_WORKSPACE,
+             "scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
   const int64_t n = (int64_t)n_slices * m;
   uint2* sg = static_cast<uint2*>(seg);
-  hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m, slice_shift, n_slices,
-                     homo, sg);
+  hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m,
+                     (uint32_t)width_of(slice_shift, slice_width), n_slices, homo, sg);
   BE_LAUNCH_CHECK();
   uint64_t* sums = static_cast<uint64_t*>(scratch);
   const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
@@ -1528,14 +1540,15 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
 }
 
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
-                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, const void* seg,
-                         void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
+                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
+                         const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(seg && maxabs_bits && blob, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(homo || weights, BE_ERR_INVALID, "hetero plan needs weights");
-  const int n_slices = n_slices_of(k, slice_shift);
+  const int n_slices = n_slices_of(k, slice_shift, slice_width);
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
@@ -1544,29 +1557,31 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   const int grid = grid_for(m, 1, 256 * 16);
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_fill<W, HOMO>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),
-                                   indices, rp, m, slice_shift, n_slices, static_cast<const uint2*>(seg),
-                                   static_cast<unsigned char*>(blob), maxabs_bits));
+                                   indices, rp, m, slice_shift, (uint32_t)width_of(slice_shift, slice_width), n_slices,
+                                   static_cast<const uint2*>(seg), static_cast<unsigned char*>(blob), maxabs_bits));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
-int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int parts, int homo) {
-  const int64_t n_slices = n_slices_of(k, slice_shift);
+int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
+                                               int parts, int homo) {
+  const int64_t n_slices = n_slices_of(k, slice_shift, slice_width);
   const int64_t acc_bytes = homo ? 4 : 8;
   return counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
          be_align_up(n_batch * n_slices * parts * (1ll << slice_shift) * acc_bytes, 256);
 }
-int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo) {
-  return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, parts, homo);
+int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo) {
+  return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, slice_width, parts, homo);
 }
 
 int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int64_t n_batch,
-                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
-                           be_stream_t stream) {
-  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+                           int slice_shift, int slice_width, int parts, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll && k <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
   BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
   BE_REQUIRE(parts >= 1 && parts <= 64, BE_ERR_INVALID, "parts must be in [1, 64]");
   BE_REQUIRE(seg && spikes && out && blob, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(!homo || weights != nullptr, BE_ERR_INVALID, "missing weights");
@@ -1575,7 +1590,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const size_t lds = ((size_t)(S + 1) * (homo ? 4 : 8) + 15) & ~(size_t)15;
   BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
   BE_REQUIRE(workspace != nullptr &&
-                 workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, parts, homo),
+                 workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo),
              BE_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
@@ -1583,7 +1598,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + counts_bytes(n_batch));
   const int64_t astride = active_stride_of(m);
   void* partial = wsb + counts_bytes(n_batch) + n_batch * astride * 4;
-  const int n_slices = n_slices_of(k, slice_shift);
+  const int n_slices = n_slices_of(k, slice_shift, slice_width);
   // the per-batch counters at the head of the workspace are zero on entry (caller contract) and are zeroed
   // again by k_plan_reduce once the accumulate kernel has consumed them: saves a 5 us memset node per step
   ActiveList al;
@@ -1613,16 +1628,17 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid, (unsigned)n_batch), dim3(256), 0, st,
                                    static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, n_slices, slice_shift,
-                                   k, inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride, count));
+                                   (uint32_t)width_of(slice_shift, slice_width), k, inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride, count));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
 
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
-                           const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift, int parts,
-                           int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
-  return be_binary_csrmm_t_plan(weights, homo, wdtype, blob, seg, spikes, spike_dtype, out, m, k, 1, slice_shift, parts,
-                                scale_exp, workspace, workspace_bytes, stream);
+                           const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
+                           int slice_width, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           be_stream_t stream) {
+  return be_binary_csrmm_t_plan(weights, homo, wdtype, blob, seg, spikes, spike_dtype, out, m, k, 1, slice_shift, slice_width,
+                                parts, scale_exp, workspace, workspace_bytes, stream);
 }
 
 

@@ -127,7 +127,11 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  * (brainevent/_csr/main.py:58-88, brainevent/_csr/hybrid_config.py:298-324): built once per matrix,
  * cached by the CSR object, passed to every call.
  *
- * Layout: output neurons are cut into slices of 2^slice_shift.  For row r and slice s the entries of row r
+ * Layout: output neurons are cut into slices of `slice_width` columns (slice = column / slice_width, local column =
+ * column % slice_width); 2^slice_shift is the accumulator capacity of a workgroup (LDS) and the stride of its
+ * partial sums, slice_width <= 2^slice_shift, and slice_width = 0 means 2^slice_shift.  A width below the capacity
+ * balances the slices (k = 1M, shift 14: 64 slices of 15625 instead of 61 full ones and a sliver of 576).
+ * For row r and slice s the entries of row r
  * whose column falls in slice s form one 128-byte-aligned block inside `blob`:
  *     hetero: [ f32 weight x 4*ng ][ uint16 local column x 4*ng ]   with ng = ceil(count / 4) lane groups
  *     homo  : [ uint16 local column x 8*ng ]                          with ng = ceil(count / 8)
@@ -141,12 +145,12 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *           to maxabs_bits[0] and maxabs_bits[1] (device uint32[2]) so that the caller can pick the fixed-point exponent
  *           and refuse matrices whose dynamic range the 64-bit fixed-point sums cannot resolve.
  * ---------------------------------------------------------------------------------------------- */
-int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift);
+int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width);
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len,
-                          int64_t m, int64_t k, int slice_shift, int homo, void* seg, void* scratch,
+                          int64_t m, int64_t k, int slice_shift, int slice_width, int homo, void* seg, void* scratch,
                           int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream);
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
-                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
+                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
                          const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream);
 
 /* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
@@ -155,20 +159,21 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
  *               weight is accumulated as round(w * 2^scale_exp) in a 64-bit integer (order independent,
  *               bitwise reproducible); |w|max * 2^scale_exp * m must stay below 2^62.
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
- *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, parts, homo) bytes.
+ *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) bytes.
  *               Its first 4 * n_batch bytes (the spike counters) must be ZERO on entry; they are zero again when the
  *               call has completed, so a workspace zero-filled once can be reused for every step.
  */
-int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int parts, int homo);
-int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int parts,
-                                               int homo);
+int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo);
+int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
+                                               int parts, int homo);
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
-                           int parts, int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+                           int slice_width, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           be_stream_t stream);
 int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m, int64_t k, int64_t n_batch,
-                           int slice_shift, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
-                           be_stream_t stream);
+                           int slice_shift, int slice_width, int parts, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * binned scatter: the event-driven transpose=True product for a matrix WITHOUT a plan (raw CSR / fixed-length rows),

@@ -384,8 +384,9 @@ def test_plan_refuses_weights_it_cannot_resolve_and_class_falls_back(be, oracle,
     assert csr.buffers['scatter_plan'] is None and np.isinf(got[idx[7]])
 
 
+@pytest.mark.parametrize('width', [None, 300, 511])
 @pytest.mark.parametrize('homo', [True, False])
-def test_scatter_plan_preserves_structure_bit_exactly(be, homo):
+def test_scatter_plan_preserves_structure_bit_exactly(be, homo, width):
     """Decode the planned layout (seg table + 128-byte aligned blocks) back to (row, column, weight) triples on the
     host: it must be exactly the CSR's multiset — integer structure and weight bit patterns."""
     from brainevent_amd._csr import ScatterPlan
@@ -393,10 +394,12 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo):
     m, k, shift = 300, 5000, 9
     lens = rng.integers(0, 120, m); lens[::11] = 0
     w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
     seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
     blob = plan.blob.cpu().numpy()
-    S = 1 << shift
+    S = 1 << shift                       # pad marker / accumulator capacity
+    Wd = plan.slice_width                # columns per slice
+    assert Wd == (width or S) and plan.n_slices == -(-k // Wd)
     got = []
     for r in range(m):
         for s in range(plan.n_slices):
@@ -415,12 +418,28 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo):
                 if c == S:                       # pad entry
                     assert wb == 0
                     continue
-                assert c < S
-                got.append((r, s * S + int(c), int(wb)))
+                assert c < Wd
+                got.append((r, s * Wd + int(c), int(wb)))
     wbits = np.zeros(idx.size, np.uint32) if homo else w.view(np.uint32)
     rows = np.repeat(np.arange(m), np.diff(ptr))
     ref = sorted(zip(rows.tolist(), idx.tolist(), wbits.tolist()))
     assert sorted(got) == ref
+    # and the product through this layout matches the oracle
+    from oracle import oracle_np as O
+    v = np.random.default_rng(5).random(m) < 0.3
+    got_y = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+    np.testing.assert_allclose(got_y, O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
+
+
+def test_balanced_slice_width():
+    from brainevent_amd._csr import ScatterPlan
+    assert ScatterPlan.balanced_width(1_000_000, 14) == 15625          # 64 slices x 4 parts = 256 workgroups
+    assert ScatterPlan.balanced_width(1_000_000, 15) == 31250          # 32 slices x 8 parts
+    for k, shift in ((5, 4), (16, 4), (17, 4), (4000, 12), (125_000, 14), (10_000_000, 14), (70001, 9), (1 << 24, 14)):
+        wd = ScatterPlan.balanced_width(k, shift)
+        n = -(-k // wd)
+        assert 1 <= wd <= (1 << shift) and n * wd >= k
+        assert n <= max(256, (-(-k // (1 << shift)) + 7) // 8 * 8)
 
 
 def test_fixed_point_gate_accepts_wide_uniform_weights(be, oracle):
