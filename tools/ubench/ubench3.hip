@@ -23,7 +23,14 @@ __global__ void __launch_bounds__(1024) k_rand_blocks(const uint4* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       uint64_t b;
-      if (group > 1) {   // waves of one group share a random base region, each takes its own block in it
+      if (group == -1 || group == -2) {
+        // the planned kernel's pattern: workgroup = (slice, part) with 64 slices x 4 parts; wave w of a workgroup walks
+        // its own rows.  -1: row-major layout (the 64 slices' blocks of one row are adjacent: 64 workgroups read one
+        // 64 KB window at about the same time); -2: slice-major layout (every slice has its own contiguous region)
+        const uint32_t slice = blockIdx.x & 63, part = blockIdx.x >> 6, wv = threadIdx.x >> 6;
+        const uint64_t row = ((uint64_t)mix32((part * 16u + wv) * 7919u + (uint32_t)(s + u) * 104729u + 1u) * 2654435761ull) % (n_blocks / 64);
+        b = (group == -1) ? row * 64 + slice : (uint64_t)slice * (n_blocks / 64) + row;
+      } else if (group > 1) {   // waves of one group share a random base region, each takes its own block in it
         const uint64_t region = ((uint64_t)mix32((wave / group) * 7919u + (uint32_t)(s + u) * 104729u + 1u) * 2654435761ull) % (n_blocks / group);
         b = region * group + (wave % group);
       } else {
@@ -69,5 +76,10 @@ int main() {
     run<4>(buf, g, 1, sink);
     run<1>(buf, g, 64, sink);
   }
+  printf("planned-kernel pattern (64 slices x 4 parts), group -1 = row-major blocks, -2 = slice-major blocks\n");
+  run<1>(buf, big, -1, sink);
+  run<1>(buf, big, -2, sink);
+  run<1>(buf, big, -1, sink);
+  run<1>(buf, big, -2, sink);
   return 0;
 }
