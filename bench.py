@@ -328,13 +328,17 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    key = f"{'homo' if args.homo else 'hetero'}_n{args.n}"
-                    traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
+                    # PMC figures exist for the default workload only (density 1 %, firing 1 %), per block layout
+                    lay = 'd8' if (args.route == 'plan' and getattr(plan, 'layout', 0) == 1) else 'u16'
+                    key = f"{'homo' if args.homo else 'hetero'}_{lay}_n{args.n}"
+                    if args.conn == 0.01 and args.fire == 0.01 and args.route == 'plan' and world == 1:
+                        traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'kernel': 'k_plan_accumulate' if args.route == 'plan' else 'k_csrmv_t_direct',
+                    'kernel': (('k_plan_accumulate_d8' if getattr(plan, 'layout', 0) == 1 else 'k_plan_accumulate')
+                               if args.route == 'plan' else 'k_csrmv_t_direct'),
                     'kernel_ms': round(kern_ms, 5), 'algorithmic_bytes_per_launch': int(alg_bytes)}
         line = {
             'metric': 'synaptic updates/sec (Geff/s), BinaryArray @ CSR scatter',
@@ -347,7 +351,8 @@ def main():
                        'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
                        'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange})' if use_dist else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
-                       'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts' if args.route == 'plan' else None),
+                       'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '
+                                       f"layout {'d8 (5 B/entry)' if plan.layout == 1 else 'u16'}" if args.route == 'plan' else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},
             'roofline': roof,
         }

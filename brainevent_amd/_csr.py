@@ -54,8 +54,13 @@ class ScatterPlan:
     #: a plan is refused when its smallest non-zero weight would be represented with fewer bits than this
     MIN_WEIGHT_BITS = 16
 
-    def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype, slice_width=0):
+    #: block layouts (C ABI codes BE_PLAN_U16 / BE_PLAN_D8)
+    LAYOUT_U16, LAYOUT_D8 = 0, 1
+    D8_MAX_ROW, D8_MAX_SLICES = 16384, 1024
+
+    def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype, slice_width=0, layout=0):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
+        self.layout = int(layout)
         self.slice_shift = int(slice_shift)
         self.slice_width = int(slice_width) if slice_width else (1 << self.slice_shift)   # columns per slice
         self.n_slices = (self.k + self.slice_width - 1) // self.slice_width
@@ -105,10 +110,13 @@ class ScatterPlan:
     # -- construction ---------------------------------------------------------------------------
     @classmethod
     def build(cls, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], *, shape,
-              row_len: int = -1, slice_shift: Optional[int] = None, slice_width: Optional[int] = None) -> 'ScatterPlan':
+              row_len: int = -1, slice_shift: Optional[int] = None, slice_width: Optional[int] = None,
+              layout: Optional[str] = None) -> 'ScatterPlan':
         """Build the plan on the device.  ``indptr=None`` + ``row_len`` describes fixed-length rows.  ``slice_shift``
         (accumulator capacity) and ``slice_width`` (columns per slice) default to the LDS-filling capacity and the
-        balanced width; an explicit ``slice_shift`` alone means full-capacity slices."""
+        balanced width; an explicit ``slice_shift`` alone means full-capacity slices.  ``layout``: ``'u16'`` (uint16
+        local columns, 6 B per weighted entry), ``'d8'`` (sorted columns as uint8 deltas, 5 B per entry: heterogeneous
+        weights, rows of at most 16384 entries, at most 1024 slices) or ``None`` = ``'d8'`` whenever it applies."""
         m, k = int(shape[0]), int(shape[1])
         weights = A.to_device(weights).reshape(-1)
         indices = A.to_device(indices).reshape(-1)
@@ -127,20 +135,31 @@ class ScatterPlan:
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         if indptr is not None:
             indptr = A.to_device(indptr)
+        if layout not in (None, 'u16', 'd8'):
+            raise ValueError(f"layout must be 'u16', 'd8' or None, got {layout!r}.")
+        d8_ok = (not homo) and n_slices <= cls.D8_MAX_SLICES and weights.dtype != torch.float64
+        if d8_ok and layout != 'u16':
+            max_row = int(row_len) if indptr is None else (int((indptr[1:] - indptr[:-1]).max().item()) if m > 0 else 0)
+            d8_ok = max_row <= cls.D8_MAX_ROW
+        if layout == 'd8' and not d8_ok:
+            raise ValueError("the d8 layout needs heterogeneous f32/f16/bf16 weights, rows of at most 16384 entries and "
+                             "at most 1024 slices.")
+        lay = cls.LAYOUT_D8 if (d8_ok and layout != 'u16') else cls.LAYOUT_U16
         seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
         f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
         scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
         blob_bytes = c_i64(0)
         f_cnt = fn('be_scatter_plan_count', c_int,
-                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
-        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, slice_width, int(homo), A.ptr(seg),
+                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64),
+                    c_vp])
+        check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, slice_width, int(homo), lay, A.ptr(seg),
                     A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
         blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
         maxabs = torch.zeros(2, dtype=torch.int32, device=dev)      # f32 bits of max |w| and of the smallest non-zero |w|
         f_fill = fn('be_scatter_plan_fill', c_int,
-                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp])
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp])
         check(f_fill(A.ptr(weights), int(homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, m, k,
-                     slice_shift, slice_width, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
+                     slice_shift, slice_width, lay, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
         scale_exp = 0
         if not homo:
             mm = maxabs.cpu().numpy().view(np.uint32)
@@ -154,7 +173,7 @@ class ScatterPlan:
             if int(mm[1]) != 0xFFFFFFFF and not _fixed_point_resolves(weights, indices, k, scale_exp, wmin):
                 raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
                                 f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
-        return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width)
+        return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width, lay)
 
 
 def _abs_range(weights: torch.Tensor, chunk: int = 1 << 27):
@@ -250,9 +269,11 @@ def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor
         parts = max(1, min(parts, 512 // (plan.n_slices * nb)))
     ws = plan.workspace(parts, nb)
     f = fn('be_binary_csrmm_t_plan', c_int,
-           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp])
+           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp, c_i64,
+            c_vp])
     check(f(A.ptr(weights), int(plan.homo), A.wcode(out_bm), A.ptr(plan.blob), A.ptr(plan.seg), A.ptr(spikes_bm), sd,
-            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, plan.slice_width, parts, plan.scale_exp, A.ptr(ws), ws.numel(),
+            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, plan.slice_width, plan.layout, parts, plan.scale_exp, A.ptr(ws),
+            ws.numel(),
             A.stream_ptr()), 'be_binary_csrmm_t_plan')
 
 

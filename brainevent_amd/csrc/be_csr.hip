@@ -1376,6 +1376,314 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restr
 }
 
 
+// =================================================================================================
+// "d8" layout of the scatter plan (heterogeneous weights): 5 bytes per entry instead of 6.
+//   block(r, s) = [ f32 weight x 4*ng ][ uint8 delta x 4*ng ]   (20 * ng bytes, padded to 128)
+//   seg[r][s]   = { block start / 128 B,  ng | (local column of the first entry << 16) }
+// The entries of a block are sorted by column; an entry's column is the previous one's plus its delta (the first delta
+// is 0).  A gap above 255 is bridged by escape entries (weight 0, delta 255): they add zero to some accumulator of the
+// slice, so the step kernel has no special case at all — column = base + inclusive prefix sum of the deltas, add
+// weight.  Tail pads are (weight 0, delta 0).  A 1-KB block of the u16 layout becomes ~0.9 KB: one 128-B line less.
+// Build: one workgroup sorts a row in LDS (bitonic, 64-bit keys column << 16 | position), rows of at most kD8MaxRow
+// entries and at most kD8MaxSlices slices (the caller falls back to the u16 layout otherwise).
+// =================================================================================================
+constexpr int kD8MaxRow = 16384;
+constexpr int kD8MaxSlices = 1024;
+
+__host__ __device__ __forceinline__ uint32_t d8_block_units(uint32_t ng) { return (ng * 20u + 127u) >> 7; }
+
+// loads the row's (column, position) keys into LDS and sorts them; returns the row length
+__device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32_t* __restrict__ indices, int64_t b, int64_t e) {
+  const int len = (int)(e - b);
+  int n2 = 2;
+  while (n2 < len) n2 <<= 1;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x)
+    keys[i] = i < len ? (((unsigned long long)(uint32_t)indices[b + i] << 16) | (unsigned long long)i) : ~0ull;
+  __syncthreads();
+  for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const unsigned long long a = keys[lo], c = keys[hi];
+        if ((a > c) == ((lo & k2) == 0)) {
+          keys[lo] = c;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  return len;
+}
+
+// (slice, local column, first-of-block, escapes before it, delta byte) of sorted position i
+struct D8Item { uint32_t s, loc, esc, rem; bool first; };
+__device__ __forceinline__ D8Item d8_item(const unsigned long long* keys, int i, uint32_t W) {
+  D8Item it;
+  const uint32_t col = (uint32_t)(keys[i] >> 16);
+  it.s = col / W;
+  it.loc = col - it.s * W;
+  uint32_t gap = 0;
+  it.first = true;
+  if (i > 0) {
+    const uint32_t prev = (uint32_t)(keys[i - 1] >> 16);
+    if (prev / W == it.s) {
+      it.first = false;
+      gap = col - prev;
+    }
+  }
+  it.esc = gap ? (gap - 1u) / 255u : 0u;
+  it.rem = gap - 255u * it.esc;
+  return it;
+}
+
+__global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
+                                                        uint32_t slice_width, int n_slices, uint2* __restrict__ seg) {
+  extern __shared__ unsigned long long d8_keys[];
+  __shared__ uint32_t tot[kD8MaxSlices], base_s[kD8MaxSlices];
+  for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) { tot[s] = 0; base_s[s] = 0; }
+    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1));   // ends with a barrier
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      const D8Item it = d8_item(d8_keys, i, slice_width);
+      atomicAdd(&tot[it.s], 1u + it.esc);
+      if (it.first) base_s[it.s] = it.loc;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
+      const uint32_t ng = (tot[s] + 3u) >> 2;          // < 2^16: a row has at most kD8MaxRow entries + W/255 escapes
+      seg[r * n_slices + s] = make_uint2(d8_block_units(ng), ng | (base_s[s] << 16));
+    }
+    __syncthreads();
+  }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                       RowPtr rp, int64_t m, uint32_t slice_width, int n_slices,
+                                                       const uint2* __restrict__ seg, unsigned char* __restrict__ blob,
+                                                       uint32_t* __restrict__ maxabs_bits) {
+  extern __shared__ unsigned long long d8_keys[];
+  __shared__ uint32_t first_idx[kD8MaxSlices], e_first[kD8MaxSlices], seg_start[kD8MaxSlices], seg_ng[kD8MaxSlices],
+      tot[kD8MaxSlices];
+  __shared__ uint32_t wtot[16];
+  uint32_t my_max = 0, my_min = 0xffffffffu;
+  for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
+      const uint2 sg = seg[r * n_slices + s];
+      seg_start[s] = sg.x;
+      seg_ng[s] = sg.y & 0xffffu;
+      tot[s] = 0;
+    }
+    const int64_t rb = rp.at(r);
+    const int len = d8_sort_row(d8_keys, indices, rb, rp.at(r + 1));
+    // inclusive prefix sums of the escape counts over the sorted row: a thread owns `per` consecutive positions
+    const int per = (len + 1023) >> 10;
+    const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
+    uint32_t mine = 0;
+    for (int i = i0; i < i1; ++i) mine += d8_item(d8_keys, i, slice_width).esc;
+    const uint32_t excl = block_scan_1024(mine, wtot) - mine;
+    uint32_t run = excl;
+    for (int i = i0; i < i1; ++i) {
+      const D8Item it = d8_item(d8_keys, i, slice_width);
+      run += it.esc;
+      if (it.first) { first_idx[it.s] = (uint32_t)i; e_first[it.s] = run; }
+    }
+    __syncthreads();
+    run = excl;
+    for (int i = i0; i < i1; ++i) {
+      const D8Item it = d8_item(d8_keys, i, slice_width);
+      run += it.esc;
+      const uint32_t pos = ((uint32_t)i - first_idx[it.s]) + (run - e_first[it.s]);
+      unsigned char* blk = blob + ((int64_t)seg_start[it.s] << 7);
+      float* wp = reinterpret_cast<float*>(blk);
+      unsigned char* dp = blk + (size_t)seg_ng[it.s] * 16;
+      for (uint32_t q = pos - it.esc; q < pos; ++q) { wp[q] = 0.f; dp[q] = 255; }
+      const float w = (float)WTraits<W>::load(weights, rb + (int64_t)(d8_keys[i] & 0xffffull));
+      wp[pos] = w;
+      dp[pos] = (unsigned char)it.rem;
+      atomicMax(&tot[it.s], pos + 1u);
+      const uint32_t ab = __float_as_uint(w) & 0x7fffffffu;
+      my_max = ab > my_max ? ab : my_max;
+      if (ab != 0u) my_min = ab < my_min ? ab : my_min;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {   // tail pads
+      unsigned char* blk = blob + ((int64_t)seg_start[s] << 7);
+      for (uint32_t q = tot[s]; q < seg_ng[s] * 4u; ++q) {
+        reinterpret_cast<float*>(blk)[q] = 0.f;
+        (blk + (size_t)seg_ng[s] * 16)[q] = 0;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = __shfl_down(my_max, off, 64);
+    my_max = o > my_max ? o : my_max;
+  }
+  if (lane_id() == 0 && my_max != 0) atomicMax(maxabs_bits, my_max);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = __shfl_down(my_min, off, 64);
+    my_min = o < my_min ? o : my_min;
+  }
+  if (lane_id() == 0) atomicMin(maxabs_bits + 1, my_min);
+}
+
+// ---- step kernel for the d8 layout: k_plan_accumulate<false> with the column decode in front of the adds
+// wave-wide inclusive prefix sum (DPP row shifts + row broadcasts: 6 VALU adds, no LDS traffic); all 64 lanes active
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// one lane-group: 4 deltas (one dword) + 4 weights; `before` = column of the entry preceding this lane-group
+__device__ __forceinline__ void d8_add4(unsigned long long* acc, uint32_t before, uint32_t d, const be_v4u& wv, float scale) {
+  const uint32_t c0 = before + (d & 0xffu), c1 = c0 + ((d >> 8) & 0xffu), c2 = c1 + ((d >> 16) & 0xffu), c3 = c2 + (d >> 24);
+  atomicAdd(&acc[c0], fixed_from_f32(__uint_as_float(wv.x), scale));
+  atomicAdd(&acc[c1], fixed_from_f32(__uint_as_float(wv.y), scale));
+  atomicAdd(&acc[c2], fixed_from_f32(__uint_as_float(wv.z), scale));
+  atomicAdd(&acc[c3], fixed_from_f32(__uint_as_float(wv.w), scale));
+}
+__device__ __forceinline__ uint32_t d8_sum4(uint32_t d) { return (d & 0xffu) + ((d >> 8) & 0xffu) + ((d >> 16) & 0xffu) + (d >> 24); }
+
+struct SegGroupD8 {
+  uint32_t start[4], ng[4], base[4];
+  uint32_t dv[4];
+  be_v4u wv[4];
+};
+
+__device__ __forceinline__ void d8_issue(SegGroupD8& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
+                                         const unsigned char* __restrict__ blob) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int src = (i + q) & 63;
+    g.start[q] = __builtin_amdgcn_readlane(st_v, src);
+    const uint32_t y = (i + q < nvalid) ? __builtin_amdgcn_readlane(n4_v, src) : 0u;
+    g.ng[q] = y & 0xffffu;
+    g.base[q] = y >> 16;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned char* blk = const_cast<unsigned char*>(blob) + ((uint64_t)g.start[q] << 7);
+    auto rw = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(g.ng[q] * 16u), kBufFlags);
+    g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, 0);
+    auto rd = __builtin_amdgcn_make_buffer_rsrc(blk + (uint64_t)g.ng[q] * 16u, 0, (int)(g.ng[q] * 4u), kBufFlags);
+    g.dv[q] = __builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 0, 0);     // lanes past the block read 0
+  }
+}
+
+__device__ __forceinline__ void d8_consume(const SegGroupD8& g, unsigned long long* acc, int lane, float scale,
+                                           const unsigned char* __restrict__ blob) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // the prefix sum runs on all 64 lanes (out-of-range lanes hold delta 0: range-checked loads); only the adds are masked
+    const uint32_t t = d8_sum4(g.dv[q]);
+    const uint32_t before = g.base[q] + wave_incl_scan_u32(t) - t;
+    if ((uint32_t)lane < g.ng[q]) d8_add4(acc, before, g.dv[q], g.wv[q], scale);
+  }
+  if ((g.ng[0] | g.ng[1] | g.ng[2] | g.ng[3]) > 64u) {      // long blocks: remaining chunks of 64 lane-groups
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (g.ng[q] <= 64u) continue;
+      const unsigned char* blk = blob + ((uint64_t)g.start[q] << 7);
+      const uint32_t t0 = d8_sum4(g.dv[q]);
+      uint32_t carry = g.base[q] + __builtin_amdgcn_readlane(wave_incl_scan_u32(t0), 63);
+      for (uint32_t o0 = 64; o0 < g.ng[q]; o0 += 64) {
+        const uint32_t o = o0 + lane;
+        const bool in = o < g.ng[q];
+        const uint32_t d = in ? reinterpret_cast<const uint32_t*>(blk + (uint64_t)g.ng[q] * 16u)[o] : 0u;
+        be_v4u wv = {0u, 0u, 0u, 0u};
+        if (in) {
+          const uint4 x = reinterpret_cast<const uint4*>(blk)[o];
+          wv = be_v4u{x.x, x.y, x.z, x.w};
+        }
+        const uint32_t t = d8_sum4(d);
+        const uint32_t incl = wave_incl_scan_u32(t);
+        if (in) d8_add4(acc, carry + incl - t, d, wv, scale);
+        carry += __builtin_amdgcn_readlane(incl, 63);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
+                                                             const uint32_t* __restrict__ active,
+                                                             const uint32_t* __restrict__ n_active_p, int n_slices,
+                                                             int slice_shift, int parts, float scale,
+                                                             unsigned long long* __restrict__ partial, int64_t active_stride) {
+  using acc_t = unsigned long long;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
+  const int S = 1 << slice_shift;
+  const int per_xcd = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int n_tasks = n_slices * parts;
+  if (L >= n_tasks) return;
+  const int part = L / n_slices;
+  const int slice = L - part * n_slices;
+  active += (int64_t)blockIdx.y * active_stride;
+  partial += ((int64_t)blockIdx.y * n_tasks + L) * S;
+  {
+    uint4* z = reinterpret_cast<uint4*>(smem_raw);
+    const int n16 = (int)(((size_t)(S + 1) * sizeof(acc_t) + 15) / 16);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  const uint32_t n_active = n_active_p[blockIdx.y];
+  const uint2* sp = seg + slice;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint64_t a0 = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a_step = (uint64_t)parts * nw * 64;
+  if (n_active > 0) {
+    const uint64_t last = n_active - 1;
+    uint64_t a = a0;
+    bool v_n = a < n_active;
+    uint32_t r_n = active[a < last ? a : last];
+    a += a_step;
+    uint2 sg = sp[(uint64_t)r_n * n_slices];
+    uint32_t st_v = sg.x, n4_v = v_n ? sg.y : 0u;
+    bool v_c = v_n;
+    v_n = a < n_active;
+    r_n = active[a < last ? a : last];
+    a += a_step;
+    while (__ballot(v_c) != 0ull) {
+      const int nvalid = __popcll(__ballot(v_c));
+      const uint2 sgn = sp[(uint64_t)r_n * n_slices];
+      const bool v_nn = a < n_active;
+      const uint32_t r_nn = active[a < last ? a : last];
+      a += a_step;
+      SegGroupD8 gA, gB;
+      d8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
+      for (int i = 0; i < nvalid; i += 8) {
+        d8_issue(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
+        d8_consume(gA, acc, lane, scale, blob);
+        d8_issue(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
+        d8_consume(gB, acc, lane, scale, blob);
+      }
+      st_v = sgn.x;
+      n4_v = v_n ? sgn.y : 0u;
+      v_c = v_n;
+      v_n = v_nn;
+      r_n = r_nn;
+    }
+  }
+  __syncthreads();
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
+    uint4* dst = reinterpret_cast<uint4*>(partial);
+    const int n16 = (int)((size_t)S * sizeof(acc_t) / 16);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1504,7 +1812,7 @@ int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int
 }
 
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
-                          int64_t k, int slice_shift, int slice_width, int homo, void* seg, void* scratch,
+                          int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg, void* scratch,
                           int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
@@ -1519,8 +1827,18 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
   RowPtr rp{indptr, indptr_is_i64, row_len};
   const int64_t n = (int64_t)n_slices * m;
   uint2* sg = static_cast<uint2*>(seg);
-  hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m,
-                     (uint32_t)width_of(slice_shift, slice_width), n_slices, homo, sg);
+  if (layout == BE_PLAN_D8) {
+    BE_REQUIRE(!homo, BE_ERR_INVALID, "the d8 layout is for heterogeneous weights");
+    BE_REQUIRE(n_slices <= kD8MaxSlices, BE_ERR_RANGE, "too many slices for the d8 layout");
+    auto kern = k_plan_d8_count;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kD8MaxRow * 8));
+    hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
+                       (uint32_t)width_of(slice_shift, slice_width), n_slices, sg);
+  } else {
+    BE_REQUIRE(layout == BE_PLAN_U16, BE_ERR_INVALID, "unknown plan layout");
+    hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m,
+                       (uint32_t)width_of(slice_shift, slice_width), n_slices, homo, sg);
+  }
   BE_LAUNCH_CHECK();
   uint64_t* sums = static_cast<uint64_t*>(scratch);
   const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
@@ -1541,7 +1859,7 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
 
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                          int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
-                         const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
+                         int layout, const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
@@ -1554,6 +1872,29 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   RowPtr rp{indptr, indptr_is_i64, row_len};
   BE_HIP(hipMemsetAsync(maxabs_bits, 0, 4, st));
   BE_HIP(hipMemsetAsync(maxabs_bits + 1, 0xff, 4, st));
+  if (layout == BE_PLAN_D8) {
+    BE_REQUIRE(!homo && n_slices <= kD8MaxSlices, BE_ERR_INVALID, "d8 layout: heterogeneous weights, <= 1024 slices");
+    const int g8 = grid_for(m, 1, 256 * 8);
+    const uint32_t wdt = (uint32_t)width_of(slice_shift, slice_width);
+#define BE_D8_FILL(WT)                                                                                                   \
+    {                                                                                                                    \
+      auto kern = k_plan_d8_fill<WT>;                                                                                    \
+      BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                 kD8MaxRow * 8));                                                                        \
+      hipLaunchKernelGGL(kern, dim3(g8), dim3(1024), kD8MaxRow * 8, st, static_cast<const WT*>(weights), indices, rp, m, \
+                         wdt, n_slices, static_cast<const uint2*>(seg), static_cast<unsigned char*>(blob), maxabs_bits); \
+    }
+    switch (wdtype) {
+      case BE_F32: BE_D8_FILL(float) break;
+      case BE_F16: BE_D8_FILL(__half) break;
+      case BE_BF16: BE_D8_FILL(__hip_bfloat16) break;
+      default: be_set_error("d8 layout: f32 / f16 / bf16 weights"); return BE_ERR_UNSUPPORTED;
+    }
+#undef BE_D8_FILL
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
+  BE_REQUIRE(layout == BE_PLAN_U16, BE_ERR_INVALID, "unknown plan layout");
   const int grid = grid_for(m, 1, 256 * 16);
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_fill<W, HOMO>), dim3(grid), dim3(256), 0, st, static_cast<const W*>(weights),
@@ -1576,9 +1917,10 @@ int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_s
 
 int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int64_t n_batch,
-                           int slice_shift, int slice_width, int parts, int scale_exp, void* workspace,
+                           int slice_shift, int slice_width, int layout, int parts, int scale_exp, void* workspace,
                            int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll && k <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(layout == BE_PLAN_U16 || (layout == BE_PLAN_D8 && !homo), BE_ERR_INVALID, "bad plan layout");
   BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
@@ -1614,6 +1956,12 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride);
+  } else if (layout == BE_PLAN_D8) {
+    auto kern = k_plan_accumulate_d8;
+    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
+                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
+                       astride);
   } else {
     auto kern = k_plan_accumulate<false>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1635,10 +1983,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
 
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
-                           int slice_width, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
+                           int slice_width, int layout, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
                            be_stream_t stream) {
   return be_binary_csrmm_t_plan(weights, homo, wdtype, blob, seg, spikes, spike_dtype, out, m, k, 1, slice_shift, slice_width,
-                                parts, scale_exp, workspace, workspace_bytes, stream);
+                                layout, parts, scale_exp, workspace, workspace_bytes, stream);
 }
 
 

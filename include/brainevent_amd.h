@@ -137,6 +137,10 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *     homo  : [ uint16 local column x 8*ng ]                          with ng = ceil(count / 8)
  * pads carry local column 2^slice_shift (a dummy accumulator) and weight 0.
  *     seg[(r * n_slices + s)] = { uint32 block start in 128-B units, uint32 ng }     (8 bytes per entry)
+ * layout BE_PLAN_D8 (heterogeneous weights, rows of at most 16384 entries, at most 1024 slices): 5 bytes per entry —
+ *     block: [ f32 weight x 4*ng ][ uint8 delta x 4*ng ], entries sorted by column, column = previous column + delta
+ *     (first delta 0), gaps above 255 bridged by escape entries (weight 0, delta 255), tail pads (weight 0, delta 0);
+ *     seg = { block start in 128-B units, ng | (local column of the first entry << 16) }.
  *
  *   step 1  be_scatter_plan_count : fills seg (m * n_slices entries of 8 B) and returns the size of `blob`
  *           in *blob_bytes_host.  SYNCHRONOUS (it reads the total back).
@@ -145,13 +149,15 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *           to maxabs_bits[0] and maxabs_bits[1] (device uint32[2]) so that the caller can pick the fixed-point exponent
  *           and refuse matrices whose dynamic range the 64-bit fixed-point sums cannot resolve.
  * ---------------------------------------------------------------------------------------------- */
+#define BE_PLAN_U16 0 /* uint16 local columns (both weight kinds) */
+#define BE_PLAN_D8 1  /* sorted columns as uint8 deltas (heterogeneous weights) */
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width);
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len,
-                          int64_t m, int64_t k, int slice_shift, int slice_width, int homo, void* seg, void* scratch,
-                          int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream);
+                          int64_t m, int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg,
+                          void* scratch, int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream);
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                          int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
-                         const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream);
+                         int layout, const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream);
 
 /* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
  *   weights : device pointer to weights[0] (homo only; may be NULL for hetero)
@@ -168,11 +174,11 @@ int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_b
                                                int parts, int homo);
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
-                           int slice_width, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
-                           be_stream_t stream);
+                           int slice_width, int layout, int parts, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream);
 int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m, int64_t k, int64_t n_batch,
-                           int slice_shift, int slice_width, int parts, int scale_exp, void* workspace,
+                           int slice_shift, int slice_width, int layout, int parts, int scale_exp, void* workspace,
                            int64_t workspace_bytes, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

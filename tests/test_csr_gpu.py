@@ -394,7 +394,8 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo, width):
     m, k, shift = 300, 5000, 9
     lens = rng.integers(0, 120, m); lens[::11] = 0
     w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='u16')
+    assert plan.layout == ScatterPlan.LAYOUT_U16
     seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
     blob = plan.blob.cpu().numpy()
     S = 1 << shift                       # pad marker / accumulator capacity
@@ -429,6 +430,74 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo, width):
     v = np.random.default_rng(5).random(m) < 0.3
     got_y = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
     np.testing.assert_allclose(got_y, O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('width,k', [(None, 5000), (300, 5000), (511, 5000), (16384, 70000)])
+def test_scatter_plan_d8_layout_decodes_bit_exactly(be, width, k):
+    """The sorted uint8-delta layout: prefix sums of the deltas from the block's base column give back exactly the CSR's
+    (row, column, weight bits) multiset; escapes / pads carry weight 0; gaps above 255 are bridged."""
+    from brainevent_amd._csr import ScatterPlan
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(123)
+    m = 200
+    shift = 9 if k == 5000 else 14
+    lens = rng.integers(0, 150, m); lens[::13] = 0; lens[5] = 3000
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=False)
+    idx[ptr[7]:ptr[8]] = idx[ptr[7]]                       # a row that hits one column many times (delta 0)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    assert plan.layout == ScatterPlan.LAYOUT_D8
+    seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
+    blob = plan.blob.cpu().numpy()
+    Wd = plan.slice_width
+    got, n_escape = [], 0
+    for r in range(m):
+        for s in range(plan.n_slices):
+            start, y = int(seg[r, s, 0]), int(seg[r, s, 1])
+            ng, base = y & 0xffff, y >> 16
+            if ng == 0:
+                continue
+            b0 = start * 128
+            ws = blob[b0:b0 + ng * 16].view(np.uint32)
+            ds = blob[b0 + ng * 16:b0 + ng * 20]
+            cols = base + np.cumsum(ds.astype(np.int64))
+            assert cols.max() < Wd
+            for c, wb, d in zip(cols, ws, ds):
+                if wb == 0 and (w.view(np.uint32) != 0).all():      # escape or pad
+                    n_escape += int(d == 255)
+                    continue
+                got.append((r, s * Wd + int(c), int(wb)))
+    rows = np.repeat(np.arange(m), np.diff(ptr))
+    ref = sorted(zip(rows.tolist(), idx.tolist(), w.view(np.uint32).tolist()))
+    assert sorted(got) == ref
+    if k == 70000:
+        assert n_escape > 0                                     # sparse rows over wide slices need escapes
+    for fire in (0.3, 1.0):
+        v = rng.random(m) < fire
+        got_y = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+        np.testing.assert_allclose(got_y, O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
+    # same numbers, bit for bit, as the uint16 layout (integer sums do not depend on the entry order)
+    plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='u16')
+    v = rng.random(m) < 0.5
+    np.testing.assert_array_equal(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan),
+                                  be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
+
+
+def test_d8_layout_falls_back_when_it_does_not_apply(be):
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(4)
+    m, k = 3, 40000
+    lens = [20000, 10, 0]                                    # a row longer than the LDS sort
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=False)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k))
+    assert plan.layout == ScatterPlan.LAYOUT_U16
+    with pytest.raises(ValueError):
+        ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='d8')
+    wh, idxh, ptrh = rand_csr(rng, 50, 3000, [40] * 50, homo=True)
+    assert ScatterPlan.build(wh, idxh, torch.tensor(ptrh), shape=(50, 3000)).layout == ScatterPlan.LAYOUT_U16
+    v = rng.random(m) < 0.7
+    from oracle import oracle_np as O
+    np.testing.assert_allclose(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan),
+                               O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
 
 
 def test_balanced_slice_width():
