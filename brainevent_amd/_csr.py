@@ -56,7 +56,7 @@ class ScatterPlan:
 
     #: block layouts (C ABI codes BE_PLAN_U16 / BE_PLAN_D8)
     LAYOUT_U16, LAYOUT_D8 = 0, 1
-    D8_MAX_ROW, D8_MAX_SLICES = 16384, 1024
+    D8_MAX_ROW, D8_MAX_SLICES, D8_CAP = 16384, 1024, 20000
 
     def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype, slice_width=0, layout=0):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
@@ -81,7 +81,12 @@ class ScatterPlan:
         """Slice width that fills the chip evenly: as many slices as the capacity ``2^slice_shift`` needs, rounded up
         so that ``n_slices * parts`` lands on a multiple of the 256 CUs (k = 1M, shift 14: 62 -> 64 slices of 15625,
         4 workgroups each = 256 equal workgroups instead of 244 full ones and 4 nearly empty)."""
-        cap = 1 << slice_shift
+        return ScatterPlan.balanced_width_cap(k, 1 << slice_shift)
+
+    @staticmethod
+    def balanced_width_cap(k: int, cap: int) -> int:
+        """:meth:`balanced_width` for an accumulator capacity of ``cap`` columns (the d8 layout is not tied to powers of
+        two: 20000 eight-byte accumulators fill the LDS, k = 1M -> 51 slices of 19608 x 5 parts)."""
         n_min = (int(k) + cap - 1) // cap
         if n_min >= 256:
             n = (n_min + 7) // 8 * 8
@@ -122,29 +127,36 @@ class ScatterPlan:
         indices = A.to_device(indices).reshape(-1)
         assert indices.dtype == torch.int32
         homo = weights.numel() == 1
+        if layout not in (None, 'u16', 'd8'):
+            raise ValueError(f"layout must be 'u16', 'd8' or None, got {layout!r}.")
         if slice_shift is None:
             slice_shift = cls.default_shift(k, homo)
-            if slice_width is None:
-                slice_width = cls.balanced_width(k, slice_shift)
-        if slice_width is None:
-            slice_width = 1 << slice_shift
-        assert 0 < slice_width <= (1 << slice_shift)
-        n_slices = (k + slice_width - 1) // slice_width
         dev = A.device()
         st = A.stream_ptr()
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         if indptr is not None:
             indptr = A.to_device(indptr)
-        if layout not in (None, 'u16', 'd8'):
-            raise ValueError(f"layout must be 'u16', 'd8' or None, got {layout!r}.")
-        d8_ok = (not homo) and n_slices <= cls.D8_MAX_SLICES and weights.dtype != torch.float64
-        if d8_ok and layout != 'u16':
+        # block layout: d8 whenever it applies (heterogeneous non-f64 weights, rows the LDS sort holds, <= 1024 slices)
+        d8_ok = (not homo) and weights.dtype != torch.float64 and layout != 'u16'
+        if d8_ok:
             max_row = int(row_len) if indptr is None else (int((indptr[1:] - indptr[:-1]).max().item()) if m > 0 else 0)
             d8_ok = max_row <= cls.D8_MAX_ROW
+        auto_width = slice_width is None
+        if auto_width:   # balanced slices; the d8 layout may use the whole LDS (no power-of-two capacity) at the default shift
+            cap = cls.D8_CAP if (d8_ok and slice_shift >= cls.HETERO_SHIFT) else (1 << slice_shift)
+            slice_width = cls.balanced_width_cap(k, cap)
+        n_slices = (k + slice_width - 1) // slice_width
+        if d8_ok and n_slices > cls.D8_MAX_SLICES:
+            d8_ok = False
+            if auto_width:
+                slice_width = cls.balanced_width_cap(k, 1 << slice_shift)
+                n_slices = (k + slice_width - 1) // slice_width
         if layout == 'd8' and not d8_ok:
             raise ValueError("the d8 layout needs heterogeneous f32/f16/bf16 weights, rows of at most 16384 entries and "
                              "at most 1024 slices.")
-        lay = cls.LAYOUT_D8 if (d8_ok and layout != 'u16') else cls.LAYOUT_U16
+        lay = cls.LAYOUT_D8 if d8_ok else cls.LAYOUT_U16
+        if not (0 < slice_width <= (1 << slice_shift) or (lay == cls.LAYOUT_D8 and 0 < slice_width <= cls.D8_CAP)):
+            raise ValueError(f"slice_width {slice_width} exceeds the accumulator capacity of this layout.")
         seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
         f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
         scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
@@ -552,8 +564,7 @@ class CompressedSparseData:
             if self.nse / (m * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096 and \
                     self.data.dtype != torch.float64:
                 try:
-                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift,
-                                             slice_width=ScatterPlan.balanced_width(k, shift))
+                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
                 except MathError:
                     plan = None       # inf / nan / extreme dynamic range: float atomics (direct route) handle those
             elif BinnedScatter.applicable(self.data, k):
@@ -601,8 +612,7 @@ class CompressedSparseData:
             n_slices = (m + (1 << shift) - 1) >> shift
             try:
                 if nse / (k * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096:
-                    mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift,
-                                                       slice_width=ScatterPlan.balanced_width(m, shift))
+                    mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift)
                 elif BinnedScatter.applicable(t_data, m):
                     mirror['plan'] = BinnedScatter(t_data, k, m, nse, indices=t_indices)
             except MathError:        # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel

@@ -217,8 +217,7 @@ class FixedNumConn:
             if self.num_conn / n_slices >= PLAN_MIN_SEGMENT and n_slices <= 4096:
                 try:
                     plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols),
-                                             row_len=self.num_conn, slice_shift=shift,
-                                             slice_width=ScatterPlan.balanced_width(n_cols, shift))
+                                             row_len=self.num_conn, slice_shift=shift)
                 except _csr_mod.MathError:
                     plan = None
             elif BinnedScatter.applicable(self.data, n_cols):

@@ -875,14 +875,14 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
 // out[j] = sum over the parts of slice(j); partial is [batch][part][slice][S]
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO>::type* __restrict__ partial, int parts,
-                                                     int n_slices, int slice_shift, uint32_t slice_width, int64_t k,
+                                                     int n_slices, int cap, uint32_t slice_width, int64_t k,
                                                      double inv_scale, const W* __restrict__ weights, W* __restrict__ out,
                                                      int64_t partial_stride, uint32_t* __restrict__ count) {
   if (blockIdx.x == 0 && threadIdx.x == 0) count[blockIdx.y] = 0u;   // re-arm the spike counter for the next call
   partial += (int64_t)blockIdx.y * partial_stride;
   out += (int64_t)blockIdx.y * k;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int S = 1 << slice_shift;
+  const int S = cap;                     // accumulators per (slice, part) task = stride of its partial sums
   typename WTraits<W>::acc w0 = 0;
   if (HOMO) w0 = WTraits<W>::load(weights, 0);
   const int64_t pstep = (int64_t)n_slices * S;
@@ -1617,12 +1617,12 @@ __device__ __forceinline__ void d8_consume(const SegGroupD8& g, unsigned long lo
 __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                              const uint32_t* __restrict__ active,
                                                              const uint32_t* __restrict__ n_active_p, int n_slices,
-                                                             int slice_shift, int parts, float scale,
+                                                             int cap, int parts, float scale,
                                                              unsigned long long* __restrict__ partial, int64_t active_stride) {
   using acc_t = unsigned long long;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
-  const int S = 1 << slice_shift;
+  const int S = cap;                     // even; >= slice width (the d8 layout needs no pad slot)
   const int per_xcd = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int n_tasks = n_slices * parts;
@@ -1801,8 +1801,13 @@ static inline int n_slices_of(int64_t k, int slice_shift, int slice_width = 0) {
   const int64_t w = width_of(slice_shift, slice_width);
   return (int)((k + w - 1) / w);
 }
-static inline bool width_ok(int slice_shift, int slice_width) {
-  return slice_width >= 0 && slice_width <= (1 << slice_shift);
+constexpr int kD8MaxWidth = 20000;     // d8 blocks need no pad slot and no power-of-two capacity: 20000 x 8 B = 156 KiB of LDS
+static inline bool width_ok(int slice_shift, int slice_width, int layout = BE_PLAN_U16) {
+  return slice_width >= 0 && (slice_width <= (1 << slice_shift) || (layout == BE_PLAN_D8 && slice_width <= kD8MaxWidth));
+}
+// accumulators per task (= stride of a task's partial sums)
+static inline int64_t cap_of(int slice_shift, int slice_width, int layout) {
+  return layout == BE_PLAN_D8 ? ((width_of(slice_shift, slice_width) + 1) & ~1ll) : (1ll << slice_shift);
 }
 
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width) {
@@ -1816,7 +1821,7 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
                           int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
-  BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
+  BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   const int n_slices = n_slices_of(k, slice_shift, slice_width);
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
@@ -1862,7 +1867,7 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
                          int layout, const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
-  BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
+  BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(seg && maxabs_bits && blob, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(homo || weights, BE_ERR_INVALID, "hetero plan needs weights");
@@ -1909,7 +1914,7 @@ int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_b
   const int64_t n_slices = n_slices_of(k, slice_shift, slice_width);
   const int64_t acc_bytes = homo ? 4 : 8;
   return counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
-         be_align_up(n_batch * n_slices * parts * (1ll << slice_shift) * acc_bytes, 256);
+         be_align_up(n_batch * n_slices * parts * std::max<int64_t>(1ll << slice_shift, slice_width + 1) * acc_bytes, 256);
 }
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo) {
   return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, slice_width, parts, homo);
@@ -1923,12 +1928,12 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   BE_REQUIRE(layout == BE_PLAN_U16 || (layout == BE_PLAN_D8 && !homo), BE_ERR_INVALID, "bad plan layout");
   BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
-  BE_REQUIRE(width_ok(slice_shift, slice_width), BE_ERR_INVALID, "slice_width must be in [0, 2^slice_shift]");
+  BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
   BE_REQUIRE(parts >= 1 && parts <= 64, BE_ERR_INVALID, "parts must be in [1, 64]");
   BE_REQUIRE(seg && spikes && out && blob, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(!homo || weights != nullptr, BE_ERR_INVALID, "missing weights");
   BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
-  const int64_t S = 1ll << slice_shift;
+  const int64_t S = cap_of(slice_shift, slice_width, layout);
   const size_t lds = ((size_t)(S + 1) * (homo ? 4 : 8) + 15) & ~(size_t)15;
   BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
   BE_REQUIRE(workspace != nullptr &&
@@ -1960,8 +1965,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     auto kern = k_plan_accumulate_d8;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
-                       astride);
+                       al.ids, al.count, n_slices, (int)S, parts, scale, static_cast<unsigned long long*>(partial), astride);
   } else {
     auto kern = k_plan_accumulate<false>;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1975,7 +1979,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const int64_t pstride = (int64_t)n_tasks * S;
   BE_DISPATCH_W(wdtype, homo,
                 hipLaunchKernelGGL((k_plan_reduce<W, HOMO>), dim3(rgrid, (unsigned)n_batch), dim3(256), 0, st,
-                                   static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, n_slices, slice_shift,
+                                   static_cast<const typename PlanAcc<HOMO>::type*>(partial), parts, n_slices, (int)S,
                                    (uint32_t)width_of(slice_shift, slice_width), k, inv_scale, static_cast<const W*>(weights), static_cast<W*>(out), pstride, count));
   BE_LAUNCH_CHECK();
   return BE_OK;

@@ -394,7 +394,8 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo, width):
     m, k, shift = 300, 5000, 9
     lens = rng.integers(0, 120, m); lens[::11] = 0
     w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='u16')
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width or (1 << shift),
+                             layout='u16')
     assert plan.layout == ScatterPlan.LAYOUT_U16
     seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
     blob = plan.blob.cpu().numpy()
@@ -432,7 +433,7 @@ def test_scatter_plan_preserves_structure_bit_exactly(be, homo, width):
     np.testing.assert_allclose(got_y, O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('width,k', [(None, 5000), (300, 5000), (511, 5000), (16384, 70000)])
+@pytest.mark.parametrize('width,k', [(None, 5000), (300, 5000), (511, 5000), (16384, 70000), (None, 70000), (20000, 70000)])
 def test_scatter_plan_d8_layout_decodes_bit_exactly(be, width, k):
     """The sorted uint8-delta layout: prefix sums of the deltas from the block's base column give back exactly the CSR's
     (row, column, weight bits) multiset; escapes / pads carry weight 0; gaps above 255 are bridged."""
@@ -476,7 +477,8 @@ def test_scatter_plan_d8_layout_decodes_bit_exactly(be, width, k):
         got_y = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
         np.testing.assert_allclose(got_y, O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
     # same numbers, bit for bit, as the uint16 layout (integer sums do not depend on the entry order)
-    plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='u16')
+    plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift,
+                               slice_width=None if width is None else min(width, 1 << shift), layout='u16')
     v = rng.random(m) < 0.5
     np.testing.assert_array_equal(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan),
                                   be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
@@ -503,6 +505,7 @@ def test_d8_layout_falls_back_when_it_does_not_apply(be):
 def test_balanced_slice_width():
     from brainevent_amd._csr import ScatterPlan
     assert ScatterPlan.balanced_width(1_000_000, 14) == 15625          # 64 slices x 4 parts = 256 workgroups
+    assert ScatterPlan.balanced_width_cap(1_000_000, 20000) == 19608   # d8: 51 slices x 5 parts = 255 workgroups
     assert ScatterPlan.balanced_width(1_000_000, 15) == 31250          # 32 slices x 8 parts
     for k, shift in ((5, 4), (16, 4), (17, 4), (4000, 12), (125_000, 14), (10_000_000, 14), (70001, 9), (1 << 24, 14)):
         wd = ScatterPlan.balanced_width(k, shift)
