@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
     ap.add_argument('--parts', type=int, default=0)
     ap.add_argument('--shift', type=int, default=0)
+    ap.add_argument('--width', type=int, default=0, help='columns per slice of the scatter plan (0 = balanced automatically)')
     ap.add_argument('--workload', choices=['csr', 'jitc', 'fcn', 'dense'], default='csr',
                     help='csr = the headline C2 config; the others are the secondary BASELINE.json configs (single GPU)')
     ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
@@ -248,7 +249,7 @@ def main():
     if args.route == 'plan':
         # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
         csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post),
-                                                          slice_shift=args.shift or None)
+                                                          slice_shift=args.shift or None, slice_width=args.width or None)
         plan = csr.buffers['scatter_plan']
         plan_bytes = plan.nbytes()
         if args.parts:
