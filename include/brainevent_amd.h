@@ -161,9 +161,10 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
 
 /* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
  *   weights : device pointer to weights[0] (homo only; may be NULL for hetero)
- *   scale_exp : fixed-point exponent chosen by the caller from max|w| and m (hetero only): every stored
- *               weight is accumulated as round(w * 2^scale_exp) in a 64-bit integer (order independent,
- *               bitwise reproducible); |w|max * 2^scale_exp * m must stay below 2^62.
+ *   scale_exp : fixed-point exponent chosen by the caller (hetero only): every stored weight is accumulated as
+ *               round(w * 2^scale_exp) in a 64-bit integer (order independent, bitwise reproducible).  The largest
+ *               column sum of |w| times 2^scale_exp must stay below 2^62 (a row may list a column several times, so
+ *               "rows x max|w|" is NOT a bound); sums that exceed it wrap silently.
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
  *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) bytes.
  *               Its first 4 * n_batch bytes (the spike counters) must be ZERO on entry; they are zero again when the

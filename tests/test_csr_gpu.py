@@ -538,3 +538,68 @@ def test_fixed_point_gate_accepts_wide_uniform_weights(be, oracle):
     w2 = w.copy(); col = idx[0]; w2[idx == col] = np.float32(2.0 ** -45)
     with pytest.raises(be.MathError):
         ScatterPlan.build(w2, idx, torch.tensor(ptr), shape=(m, k))
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_d8_layout_randomized_against_oracle_and_u16(be, oracle, seed):
+    """Random shapes through the d8 layout: long blocks (> 256 entries: the carried prefix of the tail chunks), gaps far
+    above 255 (chains of escapes), duplicates, empty rows, odd slice widths, batches, f16 weights.  Checked against the
+    oracle and, bit for bit, against the u16 layout."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(1, 400))
+    k = int(rng.choice([7, 300, 5000, 40000, 250000]))
+    shift = int(rng.integers(4, 15))
+    cap = 1 << shift
+    if -(-k // cap) > 1024:
+        shift = max(shift, int(np.ceil(np.log2(k / 1024))) + 1)
+        cap = 1 << shift
+    width = int(rng.integers(max(1, -(-k // 1024)), cap + 1)) if rng.random() < 0.7 else None
+    style = seed % 4
+    if style == 0:
+        lens = rng.integers(0, 60, m)
+    elif style == 1:
+        lens = rng.integers(0, 3000, m)                       # long blocks when there are few slices
+    elif style == 2:
+        lens = np.where(rng.random(m) < 0.2, rng.integers(1000, 16384, m), rng.integers(0, 5, m))
+    else:
+        lens = rng.integers(0, 400, m)
+    dtype = np.float16 if seed % 5 == 4 else np.float32
+    w, idx, ptr = rand_csr(rng, m, k, lens, dtype=dtype)
+    if style == 3 and idx.size:                               # clustered columns: many zero / tiny deltas and huge gaps
+        idx[:] = (idx // 1000 * 1000 + idx % 3).clip(0, k - 1)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    assert plan.layout == ScatterPlan.LAYOUT_D8
+    w16 = None if width is None else min(width, cap)
+    plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=w16, layout='u16')
+    tol = 1e-5 if dtype == np.float32 else 2e-2
+    for fire in (0.05, 0.5, 1.0):
+        v = rng.random(m) < fire
+        got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+        ref = oracle.binary_csrmv(w.astype(np.float32), idx, ptr, v, (m, k), True)
+        np.testing.assert_allclose(np.asarray(got, np.float32), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+        np.testing.assert_array_equal(got, be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
+    B = rng.random((m, 5)) < 0.3
+    got = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)
+    np.testing.assert_array_equal(got, be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan16))
+
+
+def test_fixed_point_exponent_bounds_columns_not_rows(be, oracle):
+    """Rows that list the same column many times: a column receives far more addends than there are rows, so the
+    exponent has to come from the largest column sum (rows x max|w| would let the 64-bit sums wrap)."""
+    from brainevent_amd._csr import ScatterPlan, BinnedScatter
+    rng = np.random.default_rng(3)
+    m, k = 20, 4
+    w, idx, ptr = rand_csr(rng, m, k, [4000] * m)
+    v = np.ones(m, bool)
+    ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), True)            # ~ 11000 per output, 20000 addends each
+    for layout in ('d8', 'u16'):
+        plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout=layout)
+        np.testing.assert_allclose(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan), ref,
+                                   rtol=1e-5)
+    wd, idd = torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda()
+    for ind in (idd, None):
+        ws = BinnedScatter(wd, m, k, idx.size, indices=ind, max_active_fraction=1.0)
+        got = be.binary_csrmv(wd, idd, torch.from_numpy(ptr).cuda(), torch.from_numpy(v).cuda(), shape=(m, k), transpose=True,
+                              workspace=ws)
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5)
