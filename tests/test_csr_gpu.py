@@ -603,3 +603,38 @@ def test_fixed_point_exponent_bounds_columns_not_rows(be, oracle):
         got = be.binary_csrmv(wd, idd, torch.from_numpy(ptr).cuda(), torch.from_numpy(v).cuda(), shape=(m, k), transpose=True,
                               workspace=ws)
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_binned_and_gather_routes_randomized(be, oracle, seed):
+    """Random shapes through the binned scatter route (with and without room in the bins) and the gather kernels
+    (sub-wave, wave-per-row, fused-over-batch), duplicates and empty rows included."""
+    from brainevent_amd._csr import BinnedScatter
+    rng = np.random.default_rng(2000 + seed)
+    m = int(rng.integers(1, 600))
+    k = int(rng.choice([9, 700, 33000, 200000]))
+    lens = [rng.integers(0, 8, m), rng.integers(0, 300, m), rng.integers(200, 3000, m),
+            np.where(rng.random(m) < 0.1, rng.integers(2000, 9000, m), rng.integers(0, 3, m))][seed % 4]
+    homo = bool(seed & 1)
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+    wd, idd, ptd = torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(ptr).cuda()
+    if idx.size:
+        shift = int(rng.integers(6, 15)) if k > 64 else 4
+        while -(-k // (1 << shift)) > 2048:
+            shift += 1
+        for frac in (1.0, 0.002):
+            ws = BinnedScatter(wd, m, k, idx.size, indices=idd, max_active_fraction=frac, slice_shift=shift)
+            for fire in (0.1, 1.0):
+                v = rng.random(m) < fire
+                got = be.binary_csrmv(wd, idd, ptd, torch.from_numpy(v).cuda(), shape=(m, k), transpose=True, workspace=ws)
+                ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), True)
+                np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    for fire in (0.05, 0.6):
+        s = rng.random(k) < fire
+        ref = oracle.binary_csrmv(w, idx, ptr, s, (m, k), False)
+        got = be.binary_csrmv(w, idx, ptr, s, shape=(m, k), transpose=False)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    B = rng.random((k, int(rng.integers(2, 40)))) < 0.1
+    ref = oracle.binary_csrmm(w, idx, ptr, B, (m, k), False)
+    got = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=False)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))

@@ -103,3 +103,34 @@ def test_densemm_mfma_both_directions(be, oracle, dtype, shape, nb):
     ref = oracle.binary_densemm(Wd, S_t.cpu().numpy(), True)
     assert tuple(got.shape) == (shape[1], nb)
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_dense_randomized_shapes(be, oracle, seed):
+    """Random weight shapes (odd sizes, vector-unfriendly strides), batch sizes on both sides of the MFMA threshold,
+    very sparse and very dense spikes, all weight dtypes, both directions, mv and mm."""
+    rng = np.random.default_rng(3000 + seed)
+    rows = int(rng.choice([1, 7, 64, 1000, 4096, 5003]))
+    cols = int(rng.choice([1, 8, 24, 100, 1024, 2056]))
+    dtype = [torch.float32, torch.float16, torch.bfloat16, torch.float64][seed % 4]
+    W = torch.tensor(rng.normal(0, 1, (rows, cols)), dtype=dtype, device='cuda')
+    Wd = W.double().cpu().numpy()
+    tol = {torch.float32: 1e-5, torch.float64: 1e-10, torch.float16: 2e-3, torch.bfloat16: 2e-2}[dtype]
+    for fire in (0.01, 0.9):
+        for nb in (1, 3, 8, 40):
+            S = rng.random((cols, nb)) < fire
+            got = be.binary_densemm(W, torch.tensor(S, device='cuda'), transpose=False)
+            ref = oracle.binary_densemm(Wd, S, False)
+            np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+            S = rng.random((rows, nb)) < fire
+            got = be.binary_densemm(W, torch.tensor(S, device='cuda'), transpose=True)
+            ref = oracle.binary_densemm(Wd, S, True)
+            np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+        s = rng.random(cols) < fire
+        got = be.binary_densemv(W, torch.tensor(s, device='cuda'), transpose=False)
+        ref = oracle.binary_densemv(Wd, s, False)
+        np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+        s = rng.random(rows) < fire
+        got = be.binary_densemv(W, torch.tensor(s, device='cuda'), transpose=True)
+        ref = oracle.binary_densemv(Wd, s, True)
+        np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
