@@ -84,9 +84,16 @@ def wants_numpy(*xs) -> bool:
     return not any(isinstance(x, torch.Tensor) or (isinstance(x, (PackedSpikes, ActiveIds)) and not x.numpy_result) for x in xs)
 
 
+_DEVICES = {}
+
+
 def device() -> torch.device:
     require_device()
-    return torch.device('cuda', torch.cuda.current_device())
+    i = torch.cuda.current_device()
+    d = _DEVICES.get(i)
+    if d is None:
+        d = _DEVICES[i] = torch.device('cuda', i)
+    return d
 
 
 def to_device(x, dtype=None) -> torch.Tensor:
@@ -152,7 +159,13 @@ def ptr(t) -> ctypes.c_void_p:
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)     # the raw hipStream_t without a Stream object
+
+
 def stream_ptr() -> ctypes.c_void_p:
+    """``hipStream_t`` the calls are issued on: torch's current stream (honours stream contexts and graph capture)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
