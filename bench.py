@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--jit-shard', type=int, default=1, help='jitc workload: run rank 0 of an N-way walk-class partition')
     ap.add_argument('--exchange', choices=['bits', 'bytes'], default='bits', help='payload of the per-step spike all-gather (N > 1)')
+    ap.add_argument('--exchange-ahead', type=int, default=0, help='N > 1: 1 = post the all-gather of step t+1 before scattering '
+                    'step t (synaptic delay >= 2 steps); default 0 = exchange and scatter strictly in sequence (on one rank the '
+                    'pipelined schedule measured 16 us/step slower: the cross-stream waits cost more than the local copy hides)')
     ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
     ap.add_argument('--parts', type=int, default=0)
     ap.add_argument('--shift', type=int, default=0)
@@ -278,8 +281,18 @@ def main():
     else:
         active_per_vec = local_spikes.sum(dim=1).cpu().numpy()
 
+    ahead = use_dist and args.exchange == 'bits' and args.exchange_ahead
+    ticket = [exchange.post(local_spikes[0])] if ahead else None
+
     def step(i):
         s = local_spikes[i % n_batch]
+        if ahead:
+            # step i's spikes were posted during step i - 1: post step i + 1's now (the collective overlaps with the
+            # scatter below), then consume step i's.  Every timed step still issues one exchange and one scatter.
+            nxt = exchange.post(local_spikes[(i + 1) % n_batch])
+            ev = exchange.wait_events(ticket[0])
+            ticket[0] = nxt
+            return ev @ csr
         if use_dist:
             return exchange.gather_events(s) @ csr
         return be.BinaryArray(s) @ csr
@@ -301,6 +314,8 @@ def main():
         out = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    if ahead:
+        ticket[0][1].wait()      # the exchange posted by the last step (never consumed)
     ms = (ctypes.c_float * args.steps)()
     n_rec = prof_read(ctypes.cast(ms, ctypes.c_void_p), args.steps)
     prof_enable(0)
@@ -350,7 +365,7 @@ def main():
                                    f"{n_pre} pre x {n_post_total} post, {args.conn:g} density "
                                    f"({n_conn} synapses/row/shard), route={args.route}",
                        'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
-                       'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange})' if use_dist else ''),
+                       'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange}' + (', posted one step ahead' if ahead else '') + ')' if use_dist else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
                        'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '
                                        f"layout {'d8 (5 B/entry)' if plan.layout == 1 else 'u16'}" if args.route == 'plan' else None),

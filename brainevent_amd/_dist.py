@@ -154,7 +154,7 @@ class SpikeExchange:
                 self._chunks = [torch.empty(self._pad, dtype=torch.uint8, device=device) for _ in sizes]
 
     # -- packed path ------------------------------------------------------------------------------------
-    def _gather_words(self, local_spikes: torch.Tensor) -> torch.Tensor:
+    def _pack_into(self, local_spikes: torch.Tensor, local_words: torch.Tensor) -> None:
         n_local = self.hi - self.lo
         if local_spikes.is_cuda:
             import ctypes
@@ -164,14 +164,49 @@ class SpikeExchange:
             if n_local:
                 f = fn('be_pack_spikes', ctypes.c_int,
                        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p])
-                check(f(A.ptr(sp), sd, n_local, A.ptr(self._local_words), A.stream_ptr()), 'be_pack_spikes')
+                check(f(A.ptr(sp), sd, n_local, A.ptr(local_words), A.stream_ptr()), 'be_pack_spikes')
         else:           # CPU tensors (gloo tests): same words through tensor arithmetic
             by = _pack_bits(local_spikes != 0)
-            buf = self._local_words.view(torch.uint8)
+            buf = local_words.view(torch.uint8)
             buf.zero_()
             buf[:by.numel()] = by
+
+    def _gather_words(self, local_spikes: torch.Tensor) -> torch.Tensor:
+        self._pack_into(local_spikes, self._local_words)
         self.dist.all_gather_into_tensor(self._full_words, self._local_words, group=self.group)
         return self._full_words
+
+    # -- pipelined exchange (packed mode): post step t+1's spikes, then work on step t ---------------------------
+    def post(self, local_spikes: torch.Tensor):
+        """Start the exchange of this rank's spikes and return a ticket for :meth:`wait_events`.
+
+        The collective is issued with ``async_op=True``: it runs on the backend's own stream behind whatever is already
+        queued on the current stream, so it overlaps with the work queued *after* this call — post the spikes of step
+        ``t + 1``, then scatter step ``t``.  That is the schedule of a network whose synaptic delays are at least two
+        steps (the spikes a step delivers were emitted before the previous step started).  Two buffers alternate: at most
+        one ticket may be in flight while another is being consumed."""
+        assert self.packed, "post()/wait_events() use the bit-packed exchange"
+        assert local_spikes.numel() == self.hi - self.lo
+        if not hasattr(self, '_slots'):
+            self._slots = [(self._local_words, self._full_words),
+                           (torch.zeros_like(self._local_words), torch.zeros_like(self._full_words))]
+            self._next = 0
+        slot = self._next
+        self._next ^= 1
+        local_words, full_words = self._slots[slot]
+        self._pack_into(local_spikes, local_words)
+        work = self.dist.all_gather_into_tensor(full_words, local_words, group=self.group, async_op=True)
+        return slot, work
+
+    def wait_events(self, ticket):
+        """The full spike vector of a posted exchange as an event container (the current stream waits for it)."""
+        from ._event import BinaryArray, BitPackedBinary
+        slot, work = ticket
+        work.wait()
+        words = self._slots[slot][1]
+        if words.is_cuda:
+            return BitPackedBinary.from_packed(words, self.n_pre)
+        return BinaryArray(_unpack_bits(words.view(torch.uint8), self.n_pre))
 
     def gather_events(self, local_spikes: torch.Tensor):
         """This rank's spikes ``[hi - lo]`` -> the full spike vector as an event container usable as ``ev @ shard``."""

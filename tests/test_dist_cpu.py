@@ -50,6 +50,15 @@ def _worker(rank, world, port, packed, n_pre, n_post, q):
             got_full = ds.exchange.gather(local)
             assert np.array_equal(got_full.numpy(), full_ref)
             outs.append(ds.step(local))
+        if packed:      # pipelined schedule: post step t+1, then consume step t
+            refs = [np.random.default_rng(500 + t).random(n_pre) < 0.3 for t in range(5)]
+            plo, phi = ds.exchange.lo, ds.exchange.hi
+            ticket = ds.exchange.post(torch.from_numpy(refs[0][plo:phi].copy()))
+            for t in range(5):
+                nxt = ds.exchange.post(torch.from_numpy(refs[t + 1][plo:phi].copy())) if t + 1 < 5 else None
+                got = ds.exchange.wait_events(ticket).value
+                assert np.array_equal(got.numpy(), refs[t]), f"pipelined exchange, step {t}"
+                ticket = nxt
         q.put((rank, lo, hi, np.stack(outs)))
     finally:
         dist.destroy_process_group()
