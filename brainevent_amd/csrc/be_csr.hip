@@ -29,16 +29,17 @@ namespace {
 // 256 * kCompactPerThread elements: per-thread activity bits stay in registers, one LDS scan gives the
 // offsets and ONE global atomic per workgroup reserves the output range (a returning atomic per wave
 // serialises at ~11 ns each on one address: 85 us for 1M spikes at 1 % firing, measured).
-template <typename SP, int kCompactPerThread>
-__global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
+template <typename SP, int kCompactPerThread, int kThreads>
+__global__ void __launch_bounds__(kThreads) k_compact_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
                                                         uint32_t* __restrict__ active, uint32_t* __restrict__ count,
                                                         int64_t active_stride) {
   spikes += (int64_t)blockIdx.y * n;          // batch-major spike matrix [n_batch, n]
   active += (int64_t)blockIdx.y * active_stride;
   count += blockIdx.y;
-  __shared__ uint32_t wave_tot[4];
+  constexpr int kWaves = kThreads / 64;
+  __shared__ uint32_t wave_tot[kWaves];
   __shared__ uint32_t block_base;
-  const int64_t tile = (int64_t)blockIdx.x * (256 * kCompactPerThread);
+  const int64_t tile = (int64_t)blockIdx.x * (kThreads * kCompactPerThread);
   const int64_t first = tile + (int64_t)threadIdx.x * kCompactPerThread;
   // activity bits of this thread's kCompactPerThread consecutive elements (16 per word)
   constexpr int NW = kCompactPerThread / 16;
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(256) k_compact_spikes(const typename SP::type*
   __syncthreads();
   uint32_t wave_off = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < kWaves; ++w) {
     if (w < wave) wave_off += wave_tot[w];
     total += wave_tot[w];
   }
@@ -935,13 +936,17 @@ int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, 
   if (n == 0 || nb == 0) return BE_OK;
   // one returning atomic per workgroup serialises at ~11 ns each on one address: keep the number of workgroups
   // per spike vector in the hundreds (4096 elements per workgroup up to 2M spikes, 16384 beyond)
-  if (n <= (2ll << 20)) {
+  if (n <= (64ll << 10)) {          // small vectors: more, smaller workgroups
     const int64_t tiles = (n + 256 * 16 - 1) / (256 * 16);
-    hipLaunchKernelGGL((k_compact_spikes<SP, 16>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_compact_spikes<SP, 16, 256>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
+                       static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
+  } else if (n <= (2ll << 20)) {    // 16384 elements per workgroup: 61 reservations for 1M spikes instead of 244
+    const int64_t tiles = (n + 1024 * 16 - 1) / (1024 * 16);
+    hipLaunchKernelGGL((k_compact_spikes<SP, 16, 1024>), dim3((unsigned)tiles, (unsigned)nb), dim3(1024), 0, st,
                        static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
   } else {
-    const int64_t tiles = (n + 256 * 64 - 1) / (256 * 64);
-    hipLaunchKernelGGL((k_compact_spikes<SP, 64>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st,
+    const int64_t tiles = (n + 1024 * 64 - 1) / (1024 * 64);
+    hipLaunchKernelGGL((k_compact_spikes<SP, 64, 1024>), dim3((unsigned)tiles, (unsigned)nb), dim3(1024), 0, st,
                        static_cast<const typename SP::type*>(spikes), n, active, count, active_stride);
   }
   BE_LAUNCH_CHECK();
