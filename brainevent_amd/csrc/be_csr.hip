@@ -1399,7 +1399,9 @@ __host__ __device__ __forceinline__ uint32_t d8_block_units(uint32_t ng) { retur
 
 // loads the row's (column, position) keys into LDS and sorts them; returns the row length
 __device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32_t* __restrict__ indices, int64_t b, int64_t e) {
-  const int len = (int)(e - b);
+  // caller contract: rows have at most kD8MaxRow entries (the Python side checks it and falls back to the u16 layout);
+  // a longer row is cut here rather than written past the LDS array
+  const int len = (e - b) > (int64_t)kD8MaxRow ? kD8MaxRow : (int)(e - b);
   int n2 = 2;
   while (n2 < len) n2 <<= 1;
   for (int i = threadIdx.x; i < n2; i += blockDim.x)
@@ -1839,6 +1841,7 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
   uint2* sg = static_cast<uint2*>(seg);
   if (layout == BE_PLAN_D8) {
     BE_REQUIRE(!homo, BE_ERR_INVALID, "the d8 layout is for heterogeneous weights");
+    BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 layout: rows of at most 16384 entries");
     BE_REQUIRE(n_slices <= kD8MaxSlices, BE_ERR_RANGE, "too many slices for the d8 layout");
     auto kern = k_plan_d8_count;
     BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kD8MaxRow * 8));
@@ -1884,6 +1887,7 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   BE_HIP(hipMemsetAsync(maxabs_bits + 1, 0xff, 4, st));
   if (layout == BE_PLAN_D8) {
     BE_REQUIRE(!homo && n_slices <= kD8MaxSlices, BE_ERR_INVALID, "d8 layout: heterogeneous weights, <= 1024 slices");
+    BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 layout: rows of at most 16384 entries");
     const int g8 = grid_for(m, 1, 256 * 8);
     const uint32_t wdt = (uint32_t)width_of(slice_shift, slice_width);
 #define BE_D8_FILL(WT)                                                                                                   \

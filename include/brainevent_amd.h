@@ -137,7 +137,8 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *     homo  : [ uint16 local column x 8*ng ]                          with ng = ceil(count / 8)
  * pads carry local column 2^slice_shift (a dummy accumulator) and weight 0.
  *     seg[(r * n_slices + s)] = { uint32 block start in 128-B units, uint32 ng }     (8 bytes per entry)
- * layout BE_PLAN_D8 (heterogeneous weights, rows of at most 16384 entries, at most 1024 slices): 5 bytes per entry —
+ * layout BE_PLAN_D8 (heterogeneous weights, at most 1024 slices, rows of at most 16384 entries — a caller contract for
+ * CSR rows: longer rows are truncated, never written out of bounds): 5 bytes per entry —
  *     block: [ f32 weight x 4*ng ][ uint8 delta x 4*ng ], entries sorted by column, column = previous column + delta
  *     (first delta 0), gaps above 255 bridged by escape entries (weight 0, delta 255), tail pads (weight 0, delta 0);
  *     seg = { block start in 128-B units, ng | (local column of the first entry << 16) }.
