@@ -29,6 +29,8 @@ class EventRepresentation:
     __slots__ = ('_value',)
 
     def __init__(self, value):
+        if type(self) is EventRepresentation:      # abstract in the reference too (``_event/base_test.py:26-28``)
+            raise TypeError("EventRepresentation is abstract; use BinaryArray (or another concrete event type).")
         if isinstance(value, EventRepresentation):
             value = value.value
         if isinstance(value, (list, tuple)):

@@ -176,3 +176,21 @@ def test_jit_host_helpers():
         J._validate_prob(float('nan'))
     with pytest.raises(ValueError):
         J._validate_prob(np.array([0.1, 0.2]))
+
+
+def test_event_representation_minimal_api():
+    """The container contract of the reference's ``brainevent/_event/base_test.py:25-66`` (pytree round trip excepted)."""
+    import brainevent_amd as be
+    with pytest.raises(TypeError):
+        be.EventRepresentation(np.array([1, 2, 3]))                 # abstract
+    arr = be.BinaryArray(np.array([1, 2, 3]))
+    assert arr.shape == (3,) and arr.ndim == 1 and arr.size == 3 and arr.dtype == arr.value.dtype
+    assert arr[0] == 1 and list(arr) == [1, 2, 3]
+    arr2 = arr.with_value(np.array([4, 5, 6]))
+    assert isinstance(arr2, be.BinaryArray) and arr2 is not arr
+    assert np.array_equal(arr.value, [1, 2, 3]) and np.array_equal(arr2.value, [4, 5, 6])
+    assert np.array_equal(np.asarray(arr), [1, 2, 3])
+    with pytest.raises(TypeError):
+        arr[0] = 5                                                   # item assignment is not supported
+    # encodings exist on the CPU as types (their constructors need the device)
+    assert issubclass(be.BitPackedBinary, be.EventRepresentation) and hasattr(be.CompactBinary, 'from_array')
