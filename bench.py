@@ -215,9 +215,11 @@ def secondary(args):
 
 def main():
     args = parse()
-    if args.workload != 'csr':
-        return secondary(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    multi = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'
+    is_fcn = args.workload == 'fcn'
+    if args.workload != 'csr' and not (is_fcn and multi):
+        return secondary(args)       # jitc / dense, and fcn on one GPU without the exchange
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world and world > 1:
@@ -241,15 +243,39 @@ def main():
     import brainevent_amd as be
     from brainevent_amd import _csr as C, _lib
 
-    n_pre = args.n
-    n_post_total = args.n * world if args.scaling == 'weak' else args.n
-    n_post = n_post_total // world                     # this rank's post slice
-    n_conn = max(1, int(n_post * args.conn))           # stored synapses per (row, shard)
+    plan, plan_bytes = None, 0
     t_setup = time.perf_counter()
-    weights, indices, indptr = gen_csr_on_device(n_pre, n_post, n_conn, args.homo, 1234 + rank, dev)
-    csr = be.CSR((weights, indices, indptr), shape=(n_pre, n_post), check_structure=False)
-    plan_bytes = 0
-    if args.route == 'plan':
+    if is_fcn:
+        # C4: FixedNumPerPre K = 1000, N = 10M, post-sliced (strong scaling: the problem is fixed, a rank holds the K / world
+        # synapses per row that land in its N / world outputs).  The shard of a uniform random matrix is generated directly:
+        # K / world targets per row, uniform over the rank's slice (the exact shard is ragged around that, §4 of DESIGN.md).
+        n_pre = args.n if args.n != 1_000_000 else 10_000_000
+        n_post_total = args.n_post or n_pre
+        n_post = n_post_total // world
+        n_conn = max(1, args.k // world)
+        args.scaling = 'strong'
+        g0 = torch.Generator(device=dev)
+        g0.manual_seed(4321 + rank)
+        idx = torch.empty((n_pre, n_conn), dtype=torch.int32, device=dev)
+        for lo in range(0, n_pre, 200_000):
+            hi = min(n_pre, lo + 200_000)
+            idx[lo:hi] = torch.randint(0, n_post, (hi - lo, n_conn), dtype=torch.int32, device=dev, generator=g0)
+        wts = torch.ones(1, device=dev) if args.homo else torch.empty((n_pre, n_conn), device=dev).uniform_(0, 1, generator=g0)
+        csr = be.FixedNumPerPre((wts, idx), shape=(n_pre, n_post), check_indices=False).prepare()
+        ws_obj = csr.buffers.get('scatter_plan')
+        args.route = type(ws_obj).__name__ if ws_obj is not None else 'direct'
+        if isinstance(ws_obj, C.ScatterPlan):
+            plan, plan_bytes = ws_obj, ws_obj.nbytes()
+    else:
+        n_pre = args.n
+        n_post_total = args.n * world if args.scaling == 'weak' else args.n
+        n_post = n_post_total // world                     # this rank's post slice
+        n_conn = max(1, int(n_post * args.conn))           # stored synapses per (row, shard)
+        weights, indices, indptr = gen_csr_on_device(n_pre, n_post, n_conn, args.homo, 1234 + rank, dev)
+        csr = be.CSR((weights, indices, indptr), shape=(n_pre, n_post), check_structure=False)
+    if is_fcn:
+        pass
+    elif args.route == 'plan':
         # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
         csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post),
                                                           slice_shift=args.shift or None, slice_width=args.width or None)
@@ -257,7 +283,7 @@ def main():
         plan_bytes = plan.nbytes()
         if args.parts:
             plan.default_parts = lambda: args.parts
-    else:
+    elif not is_fcn:
         csr.buffers['scatter_plan'] = None
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
@@ -351,24 +377,29 @@ def main():
                         traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
+            kernel_name = {'plan': 'k_plan_accumulate_d8' if getattr(plan, 'layout', 0) == 1 else 'k_plan_accumulate',
+                           'ScatterPlan': 'k_plan_accumulate_d8' if getattr(plan, 'layout', 0) == 1 else 'k_plan_accumulate',
+                           'BinnedScatter': 'k_bin_rows'}.get(args.route, 'k_csrmv_t_direct')
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'kernel': (('k_plan_accumulate_d8' if getattr(plan, 'layout', 0) == 1 else 'k_plan_accumulate')
-                               if args.route == 'plan' else 'k_csrmv_t_direct'),
+                    'kernel': kernel_name,
                     'kernel_ms': round(kern_ms, 5), 'algorithmic_bytes_per_launch': int(alg_bytes)}
         line = {
-            'metric': 'synaptic updates/sec (Geff/s), BinaryArray @ CSR scatter',
+            'metric': 'synaptic updates/sec (Geff/s), BinaryArray @ ' + ('FixedNumPerPre scatter' if is_fcn else 'CSR scatter'),
             'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f"BinaryArray({args.fire:g} fire) @ CSR f32 {'homo' if args.homo else 'hetero'}, "
-                                   f"{n_pre} pre x {n_post_total} post, {args.conn:g} density "
-                                   f"({n_conn} synapses/row/shard), route={args.route}",
+            'config': {'workload': (f"BinaryArray({args.fire:g} fire) @ FixedNumPerPre K={args.k} f32 "
+                                    f"{'homo' if args.homo else 'hetero'}, {n_pre} pre x {n_post_total} post "
+                                    f"({n_conn} synapses/row/shard), route={args.route}" if is_fcn else
+                                    f"BinaryArray({args.fire:g} fire) @ CSR f32 {'homo' if args.homo else 'hetero'}, "
+                                    f"{n_pre} pre x {n_post_total} post, {args.conn:g} density "
+                                    f"({n_conn} synapses/row/shard), route={args.route}"),
                        'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
                        'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange}' + (', posted one step ahead' if ahead else '') + ')' if use_dist else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
                        'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '
-                                       f"layout {'d8 (5 B/entry)' if plan.layout == 1 else 'u16'}" if args.route == 'plan' else None),
+                                       f"layout {'d8 (5 B/entry)' if plan.layout == 1 else 'u16'}" if plan is not None else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},
             'roofline': roof,
         }
