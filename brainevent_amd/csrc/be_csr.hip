@@ -156,6 +156,29 @@ __global__ void __launch_bounds__(256) k_unpack_spikes(const uint32_t* __restric
     out[i] = (uint8_t)((words[i >> 5] >> (i & 31)) & 1u);
 }
 
+// 1-byte spikes, 16-byte aligned rows: a thread turns 32 bytes (two 16-B loads) into one word
+__global__ void __launch_bounds__(256) k_pack_spikes_vec(const uint8_t* __restrict__ spikes, int64_t n, uint32_t* __restrict__ bits,
+                                                         int64_t words_stride) {
+  spikes += (int64_t)blockIdx.y * n;
+  bits += (int64_t)blockIdx.y * words_stride;
+  const int64_t n_words = (n + 31) >> 5;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+    uint32_t word = 0;
+    if (w * 32 + 32 <= n) {
+      const uint4 a = reinterpret_cast<const uint4*>(spikes)[2 * w], b = reinterpret_cast<const uint4*>(spikes)[2 * w + 1];
+      const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) word |= (((v[q] >> (8 * e)) & 0xffu) != 0u ? 1u : 0u) << (4 * q + e);
+    } else {
+      for (int e = 0; e < 32 && w * 32 + e < n; ++e) word |= (spikes[w * 32 + e] != 0 ? 1u : 0u) << e;
+    }
+    bits[w] = word;
+  }
+}
+
 template <typename SP>
 __global__ void __launch_bounds__(256) k_pack_spikes(const typename SP::type* __restrict__ spikes, int64_t n,
                                                      uint32_t* __restrict__ bits, int64_t words_stride) {
@@ -1000,6 +1023,12 @@ int resolve_active(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* 
 template <typename SP>
 int launch_pack(const void* spikes, int64_t n, int64_t nb, uint32_t* bits, int64_t words_stride, hipStream_t st) {
   if (n == 0 || nb == 0) return BE_OK;
+  if (sizeof(typename SP::type) == 1 && (reinterpret_cast<uintptr_t>(spikes) & 15) == 0 && (nb == 1 || (n & 15) == 0)) {
+    hipLaunchKernelGGL(k_pack_spikes_vec, dim3(grid_for((n + 31) / 32, 256, 4096), (unsigned)nb), dim3(256), 0, st,
+                       static_cast<const uint8_t*>(spikes), n, bits, words_stride);
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
   hipLaunchKernelGGL(k_pack_spikes<SP>, dim3(grid_for(n, 256, 2048), (unsigned)nb), dim3(256), 0, st,
                      static_cast<const typename SP::type*>(spikes), n, bits, words_stride);
   BE_LAUNCH_CHECK();
@@ -1170,6 +1199,66 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wave_t
   return base + incl;
 }
 
+// Streams the entries of a batch's row pieces through `consume(column, weight)`: wave w takes pieces w, w + nw, ...; a
+// piece is cut into chunks of 256 entries (4 per lane) and kBinDepth chunks are kept in flight across piece boundaries —
+// a piece is a random 0.5 .. 4 KB read, and one chunk at a time left the wave idle for a full HBM round trip per chunk
+// (K = 1000 rows: 4 round trips per row; K = 125 shard rows: one per row).  Loads are unconditional (clamped index).
+constexpr int kBinDepth = 4;
+template <bool WITH_W, typename W, typename F>
+__device__ __forceinline__ void bin_stream_pieces(const int32_t* __restrict__ indices, const W* __restrict__ weights,
+                                                  const int64_t* s_begin, const uint32_t* s_lens, uint32_t nrows, int wave,
+                                                  int nw, int lane, F&& consume) {
+  uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(wave), j0 = 0;
+  while (i < nrows && s_lens[i] == 0) i += nw;
+  int64_t cb[kBinDepth];
+  uint32_t cl[kBinDepth], cj[kBinDepth];
+  uint32_t c[kBinDepth][4];
+  float wv[kBinDepth][4];
+  auto issue = [&](int d) {
+    const bool valid = i < nrows;
+    cb[d] = valid ? s_begin[i] : 0;
+    cl[d] = valid ? s_lens[i] : 0u;
+    cj[d] = j0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + 64 * u + lane;
+      const int64_t e = cb[d] + (cl[d] ? (j < cl[d] ? j : cl[d] - 1) : 0u);
+      c[d][u] = (uint32_t)indices[e];
+      wv[d][u] = WITH_W ? (float)WTraits<W>::load(weights, e) : 0.f;
+    }
+    if (valid) {           // wave-uniform: next chunk of this piece, or the wave's next non-empty piece
+      j0 += 256;
+      if (j0 >= cl[d]) {
+        j0 = 0;
+        do { i += nw; } while (i < nrows && s_lens[i] == 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < kBinDepth; ++d) issue(d);
+  while (cl[0] != 0u) {      // chunks are issued in order: an exhausted oldest slot means all are
+#pragma unroll
+    for (int d = 0; d < kBinDepth; ++d) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (cj[d] + 64 * u + lane < cl[d]) consume(c[d][u], wv[d][u]);
+      issue(d);
+    }
+  }
+}
+
+// one launch instead of three memset nodes: output <- 0, bin cursors <- 0, bin valid extents <- "all of it"
+__global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int64_t k, uint32_t* __restrict__ cursor,
+                                                   uint32_t* __restrict__ valid, int n_bins) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const int64_t k4 = k >> 2;                       // out comes from the caller's allocator: 16-byte aligned
+  for (int64_t i = t; i < k4; i += stride) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (k4 << 2) + t; i < k; i += stride) out[i] = 0.f;
+  for (int64_t i = t; i < n_bins; i += stride) { cursor[i] = 0u; valid[i] = 0xffffffffu; }
+}
+
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
                                                    const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
@@ -1247,21 +1336,8 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
 
     // ---- phase 1: histogram of the batch over the bins (wave per row piece, 4 independent loads in flight:
     //      clamped index + predicate instead of a conditional load)
-    for (uint32_t i = wave; i < nrows; i += nw) {
-      const int64_t b = s_begin[i];
-      const uint32_t len = s_lens[i];
-      for (uint32_t j0 = 0; j0 < len; j0 += 256) {
-        uint32_t c[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t j = j0 + 64 * u + lane;
-          c[u] = (uint32_t)indices[b + (j < len ? j : len - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j0 + 64 * u + lane < len) atomicAdd(&hist[c[u] >> slice_shift], 1u);
-      }
-    }
+    bin_stream_pieces<false, W>(indices, weights, s_begin, s_lens, nrows, wave, nw, lane,
+                                [&](uint32_t col, float) { atomicAdd(&hist[col >> slice_shift], 1u); });
     __syncthreads();
     // ---- phase 2: exclusive scan of hist (n_bins <= 2048: two per thread) + one range reservation per bin
     {
@@ -1278,30 +1354,12 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
     }
     __syncthreads();
     // ---- phase 3: place the entries into the LDS batch sorted by bin (second read of the rows comes from L2)
-    for (uint32_t i = wave; i < nrows; i += nw) {
-      const int64_t b = s_begin[i];
-      const uint32_t len = s_lens[i];
-      for (uint32_t j0 = 0; j0 < len; j0 += 256) {
-        uint32_t c[4];
-        float wv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t j = j0 + 64 * u + lane;
-          const int64_t e = b + (j < len ? j : len - 1);
-          c[u] = (uint32_t)indices[e];
-          wv[u] = HOMO ? 0.f : (float)WTraits<W>::load(weights, e);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (j0 + 64 * u + lane < len) {
-            const uint32_t bin = c[u] >> slice_shift;
-            const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
-            s_idx[pos] = (uint16_t)(c[u] & mask);
-            if (!HOMO) s_w[pos] = wv[u];
-          }
-        }
-      }
-    }
+    bin_stream_pieces<!HOMO, W>(indices, weights, s_begin, s_lens, nrows, wave, nw, lane, [&](uint32_t col, float w) {
+      const uint32_t bin = col >> slice_shift;
+      const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
+      s_idx[pos] = (uint16_t)(col & mask);
+      if (!HOMO) s_w[pos] = w;
+    });
     __syncthreads();
     // ---- phase 4: copy the runs out, one wave per bin; runs that do not fit go through global atomics
     for (int bin = wave; bin < n_bins; bin += nw) {
@@ -2042,9 +2100,15 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   uint16_t* bin_idx = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(valid) + be_align_up((int64_t)n_bins * 4, 256));
   float* bin_w = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_idx) + be_align_up((int64_t)n_bins * cap * 2, 256));
   RowPtr rp{indptr, indptr_is_i64, row_len};
-  BE_HIP(hipMemsetAsync(out, 0, (size_t)k * 4, st));
-  BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_bins * 4, st));
-  BE_HIP(hipMemsetAsync(valid, 0xff, (size_t)n_bins * 4, st));
+  if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, cursor,
+                       valid, n_bins);
+    BE_LAUNCH_CHECK();
+  } else {
+    BE_HIP(hipMemsetAsync(out, 0, (size_t)k * 4, st));
+    BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_bins * 4, st));
+    BE_HIP(hipMemsetAsync(valid, 0xff, (size_t)n_bins * 4, st));
+  }
   ActiveList al;
   int rc = resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, true, &al);
   if (rc != BE_OK) return rc;
@@ -2056,7 +2120,9 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
     hipLaunchKernelGGL((k_bin_rows<float, false>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
                        al.ids, al.count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
   BE_LAUNCH_CHECK();
-  int parts = 512 / (n_bins > 0 ? n_bins : 1);
+  // n_bins * parts ~ 256: every workgroup fills a CU (128 KB of LDS) and its slice is merged into the output with float
+  // atomics, one per non-zero accumulator, so more parts than CUs only add merge traffic (39 bins: 13 parts took 55 us, 6 take 30)
+  int parts = 256 / (n_bins > 0 ? n_bins : 1);
   parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
   const float scale = ldexpf(1.0f, scale_exp - 32);
   const double inv_scale = ldexp(1.0, -scale_exp);
