@@ -273,9 +273,7 @@ def main():
         n_conn = max(1, int(n_post * args.conn))           # stored synapses per (row, shard)
         weights, indices, indptr = gen_csr_on_device(n_pre, n_post, n_conn, args.homo, 1234 + rank, dev)
         csr = be.CSR((weights, indices, indptr), shape=(n_pre, n_post), check_structure=False)
-    if is_fcn:
-        pass
-    elif args.route == 'plan':
+    if not is_fcn and args.route == 'plan':
         # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
         csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post),
                                                           slice_shift=args.shift or None, slice_width=args.width or None)
@@ -283,7 +281,7 @@ def main():
         plan_bytes = plan.nbytes()
         if args.parts:
             plan.default_parts = lambda: args.parts
-    elif not is_fcn:
+    elif not is_fcn:                      # --route direct: global atomics
         csr.buffers['scatter_plan'] = None
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
