@@ -253,17 +253,17 @@ class FixedNumConn:
         if value.ndim == 1:
             r = self._binary_matvec(value, transpose_W)
         elif value.ndim == 2:
+            # binary_fcnmm returns (out_len, n) for an operand (in_len, n): ``events @ M`` hands it the transposed events and
+            # transposes the result back.  (The orientation is fixed here, not guessed from the shapes: a square result —
+            # batch size equal to the output length — would make such a guess ambiguous.)
             if transpose_W:
                 expected = (value.shape[0], self.shape[1])
-                r = self._binary_matmat(value.T, transpose_W)
+                r = self._binary_matmat(value.T, transpose_W).T
             else:
                 expected = (self.shape[0], value.shape[1])
                 r = self._binary_matmat(value, transpose_W)
             if tuple(r.shape) != tuple(expected):
-                if r.ndim == 2 and tuple(r.T.shape) == tuple(expected):
-                    r = r.T
-                else:
-                    raise ValueError(f'binary matmat output shape mismatch: got {tuple(r.shape)}, expected {expected}.')
+                raise ValueError(f'binary matmat output shape mismatch: got {tuple(r.shape)}, expected {expected}.')
         else:
             raise NotImplementedError(f"matmul with object of shape {value.shape}")
         return A.to_result(r, self._numpy_result) if A.wants_numpy(value) else r

@@ -540,7 +540,7 @@ def test_fixed_point_gate_accepts_wide_uniform_weights(be, oracle):
         ScatterPlan.build(w2, idx, torch.tensor(ptr), shape=(m, k))
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 12))))
 def test_d8_layout_randomized_against_oracle_and_u16(be, oracle, seed):
     """Random shapes through the d8 layout: long blocks (> 256 entries: the carried prefix of the tail chunks), gaps far
     above 255 (chains of escapes), duplicates, empty rows, odd slice widths, batches, f16 weights.  Checked against the
@@ -605,7 +605,7 @@ def test_fixed_point_exponent_bounds_columns_not_rows(be, oracle):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5)
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 8))))
 def test_binned_and_gather_routes_randomized(be, oracle, seed):
     """Random shapes through the binned scatter route (with and without room in the bins) and the gather kernels
     (sub-wave, wave-per-row, fused-over-batch), duplicates and empty rows included."""

@@ -105,7 +105,7 @@ def test_densemm_mfma_both_directions(be, oracle, dtype, shape, nb):
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
 
 
-@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 10))))
 def test_dense_randomized_shapes(be, oracle, seed):
     """Random weight shapes (odd sizes, vector-unfriendly strides), batch sizes on both sides of the MFMA threshold,
     very sparse and very dense spikes, all weight dtypes, both directions, mv and mm."""

@@ -129,3 +129,34 @@ def test_csrmm_gather_fused_over_batch_long_rows(homo, wdtype, nb, spike_kind):
     # the class route (CSR @ B) gives the same numbers
     got2 = be.CSR((w, idx, ptr), shape=(m, k)) @ be.BinaryArray(Bv)
     np.testing.assert_allclose(np.asarray(got2, np.float32), np.asarray(got, np.float32), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 8))))
+def test_fixed_num_randomized(be, oracle, monkeypatch, seed):
+    """Random FixedNumPerPre / PerPost matrices through the class surface: all routes (direct, planned d8 / u16, binned),
+    both operand orders, vectors and batches, plain / bit-packed / compacted events, against the oracle's dense view."""
+    import brainevent_amd._csr as C
+    rng = np.random.default_rng(5000 + seed)
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', int(rng.choice([1, 10 ** 9])))       # plan / binned when they apply, or direct
+    n_pre, n_post = int(rng.integers(1, 500)), int(rng.choice([5, 300, 20000, 90000]))
+    n_conn = int(rng.choice([1, 7, 64, 300]))
+    homo = bool(seed & 1)
+    idx = rng.integers(0, n_post, (n_pre, n_conn)).astype(np.int32)
+    w = np.array([0.25], np.float32) if homo else rng.uniform(-1, 1, (n_pre, n_conn)).astype(np.float32)
+    conn = be.FixedNumPerPre((w, idx), shape=(n_pre, n_post))
+    dense = conn.todense().astype(np.float64)
+    tol = dict(rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(dense).sum(axis=0).max())))
+    for fire in (0.1, 0.9):
+        s = spikes_of(rng, n_pre, fire, 'bool')
+        ref = s.astype(np.float64) @ dense
+        np.testing.assert_allclose(be.BinaryArray(s) @ conn, ref, **tol)
+        np.testing.assert_allclose(be.BinaryArray(s).bitpack() @ conn, ref, **tol)
+        np.testing.assert_allclose(be.CompactBinary.from_array(s) @ conn, ref, **tol)
+        np.testing.assert_allclose(conn.T @ be.BinaryArray(s), ref, **tol)
+        s2 = spikes_of(rng, n_post, fire, 'float')
+        ref2 = dense @ (s2 > 0).astype(np.float64)
+        tol2 = dict(rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(dense).sum(axis=1).max())))
+        np.testing.assert_allclose(conn @ be.BinaryArray(s2), ref2, **tol2)
+        np.testing.assert_allclose(be.BinaryArray(s2) @ conn.T, ref2, **tol2)
+    S = np.stack([spikes_of(rng, n_pre, 0.3, 'bool') for _ in range(int(rng.integers(1, 6)))], axis=0)
+    np.testing.assert_allclose(be.BinaryArray(S) @ conn, S.astype(np.float64) @ dense, **tol)

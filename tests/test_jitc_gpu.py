@@ -264,3 +264,30 @@ def test_scatter_shards_tile_the_output(cls_name, params, world):
         total += out
     assert (seen == 1).all()
     np.testing.assert_array_equal(total, full)
+
+
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 10))))
+def test_jit_randomized_against_oracle(be, oracle, seed):
+    """Random shapes / probabilities / seeds / families / orientations, vector and batched, against the numpy oracle."""
+    rng = np.random.default_rng(4000 + seed)
+    shape = (int(rng.integers(1, 90)), int(rng.integers(1, 400)))
+    prob = float(rng.choice([0.01, 0.05, 0.2, 0.5, 1.0]))
+    rseed = int(rng.integers(0, 2 ** 31 - 1))
+    family = 'sun'[seed % 3]
+    transpose, corder = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    in_len = shape[0] if transpose else shape[1]
+    args = {'s': (np.float32(0.75),), 'u': (np.float32(-0.3), np.float32(1.1)), 'n': (np.float32(0.1), np.float32(0.7))}[family]
+    w0, w1 = (args + (0.0,))[:2]
+    tol = 1e-4 if family == 'n' else 1e-5
+    fmv = {'s': be.binary_jitsmv, 'u': be.binary_jitumv, 'n': be.binary_jitnmv}[family]
+    fmm = {'s': be.binary_jitsmm, 'u': be.binary_jitumm, 'n': be.binary_jitnmm}[family]
+    for fire in (0.05, 0.7):
+        v = spikes_of(rng, in_len, fire, 'bool')
+        got = fmv(*args, prob, v, rseed, shape=shape, transpose=transpose, corder=corder)
+        ref = oracle.binary_jitmv(family, w0, w1, prob, v, rseed, shape=shape, transpose=transpose, corder=corder)
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+    nb = int(rng.integers(1, 40))
+    B = np.stack([spikes_of(rng, in_len, 0.3, 'bool') for _ in range(nb)], axis=1)
+    got = fmm(*args, prob, B, rseed, shape=shape, transpose=transpose, corder=corder)
+    ref = oracle.binary_jitmm(family, w0, w1, prob, B, rseed, shape=shape, transpose=transpose, corder=corder)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
