@@ -638,3 +638,58 @@ def test_binned_and_gather_routes_randomized(be, oracle, seed):
     ref = oracle.binary_csrmm(w, idx, ptr, B, (m, k), False)
     got = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=False)
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 10))))
+def test_class_surface_randomized_including_square_shapes(be, monkeypatch, seed):
+    """CSR / CSC / JITC / dense through the ``@`` operator, all four operand orders, vectors and batches — with batch
+    sizes deliberately equal to the matrix dimensions now and then (orientation must not be guessed from shapes).
+    The checker is the dense view of the same matrix."""
+    import brainevent_amd._csr as C
+    rng = np.random.default_rng(6000 + seed)
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', int(rng.choice([1, 10 ** 9])))
+    m, k = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+    if seed % 3 == 0:
+        k = m                                                  # square matrix
+    nb = int(rng.choice([m, k, 1, 7]))                         # batch size colliding with a dimension
+    lens = rng.integers(0, 30, m)
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=bool(seed & 1))
+    csr = be.CSR((w, idx, ptr), shape=(m, k))
+    if seed % 4 == 0:
+        csr.prepare(mirror=True)
+    dense = csr.todense().astype(np.float64)
+    assert dense.shape == (m, k)
+    tol = dict(rtol=1e-5, atol=1e-4)
+    sm, sk = rng.random(m) < 0.4, rng.random(k) < 0.4
+    Sm_b, Sk_b = rng.random((nb, m)) < 0.4, rng.random((nb, k)) < 0.4          # batch-major events for ``S @ M``
+    Sm_c, Sk_c = rng.random((m, nb)) < 0.4, rng.random((k, nb)) < 0.4          # column-major events for ``M @ S``
+    for M, D in ((csr, dense), (csr.T, dense.T)):
+        rows, cols = D.shape
+        v_r, v_c = (sm, sk) if M is csr else (sk, sm)          # events matching M's rows / columns
+        np.testing.assert_allclose(be.BinaryArray(v_r) @ M, v_r.astype(np.float64) @ D, **tol)
+        np.testing.assert_allclose(M @ be.BinaryArray(v_c), D @ v_c.astype(np.float64), **tol)
+        B_r = (Sm_b if M is csr else Sk_b)
+        B_c = (Sk_c if M is csr else Sm_c)
+        got = be.BinaryArray(B_r) @ M
+        assert got.shape == (nb, cols)
+        np.testing.assert_allclose(got, B_r.astype(np.float64) @ D, **tol)
+        got = M @ be.BinaryArray(B_c)
+        assert got.shape == (rows, nb)
+        np.testing.assert_allclose(got, D @ B_c.astype(np.float64), **tol)
+    # dense right / left operands
+    W = rng.standard_normal((m, k)).astype(np.float32)
+    np.testing.assert_allclose(be.BinaryArray(Sm_b) @ W, Sm_b.astype(np.float64) @ W, **tol)
+    np.testing.assert_allclose(W @ be.BinaryArray(Sk_c), W.astype(np.float64) @ Sk_c, **tol)
+    # JIT connectivity, both class kinds: compare with the materialised matrix
+    for cls in (be.JITCUniformR, be.JITCUniformC):
+        J = cls((np.float32(-0.5), np.float32(1.0), 0.2, 100 + seed), shape=(m, k), corder=bool(seed & 2))
+        Jd = J.tocsr('mv').todense().astype(np.float64)
+        np.testing.assert_allclose(be.BinaryArray(sm) @ J, sm.astype(np.float64) @ Jd, **tol)
+        np.testing.assert_allclose(J @ be.BinaryArray(sk), Jd @ sk.astype(np.float64), **tol)
+        Jm = J.tocsr('mm').todense().astype(np.float64)
+        got = be.BinaryArray(Sm_b) @ J
+        assert got.shape == (nb, k)
+        np.testing.assert_allclose(got, Sm_b.astype(np.float64) @ Jm, **tol)
+        got = J @ be.BinaryArray(Sk_c)
+        assert got.shape == (m, nb)
+        np.testing.assert_allclose(got, Jm @ Sk_c.astype(np.float64), **tol)
