@@ -41,6 +41,29 @@ int g_prof_n = 0;
 }  // namespace
 
 // called by the launch helpers; returns the slot or -1
+namespace {
+__global__ void __launch_bounds__(256) k_fill_bytes(unsigned char* __restrict__ p, size_t n, unsigned char v) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;       // bytes before the first 16-B boundary
+  const size_t h = head < n ? head : n;
+  const size_t n16 = (n - h) >> 4;
+  const unsigned w = 0x01010101u * v;
+  uint4* q = reinterpret_cast<uint4*>(p + h);
+  for (size_t i = t; i < n16; i += stride) q[i] = make_uint4(w, w, w, w);
+  for (size_t i = t; i < h; i += stride) p[i] = v;
+  for (size_t i = h + (n16 << 4) + t; i < n; i += stride) p[i] = v;
+}
+}  // namespace
+
+hipError_t be_fill_async(void* p, int byte_value, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  size_t blocks = (bytes / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(k_fill_bytes, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<unsigned char*>(p), bytes,
+                     (unsigned char)byte_value);
+  return hipGetLastError();
+}
+
 int be_prof_begin(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_n >= g_prof_cap) return -1;

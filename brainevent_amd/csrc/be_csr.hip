@@ -955,7 +955,7 @@ inline int64_t direct_ws_bytes(int64_t m, int64_t k, int wdtype, int64_t nb) {
 template <typename SP>
 int launch_compact(const void* spikes, int64_t n, int64_t nb, uint32_t* active, int64_t active_stride, uint32_t* count,
                    hipStream_t st, bool zero_first) {
-  if (zero_first) BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
+  if (zero_first) BE_HIP(be_fill_async(count, 0, (size_t)nb * 4, st));
   if (n == 0 || nb == 0) return BE_OK;
   // one returning atomic per workgroup serialises at ~11 ns each on one address: keep the number of workgroups
   // per spike vector in the hundreds (4096 elements per workgroup up to 2M spikes, 16384 beyond)
@@ -981,7 +981,7 @@ int compact_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* act
   if (sd == BE_SPIKE_BOOL) return launch_compact<SpikeBool>(spikes, n, nb, active, active_stride, count, st, zero_first);
   if (sd == BE_SPIKE_FLOAT) return launch_compact<SpikeFloat>(spikes, n, nb, active, active_stride, count, st, zero_first);
   if (sd == BE_SPIKE_BITS) {
-    if (zero_first) BE_HIP(hipMemsetAsync(count, 0, (size_t)nb * 4, st));
+    if (zero_first) BE_HIP(be_fill_async(count, 0, (size_t)nb * 4, st));
     if (n == 0 || nb == 0) return BE_OK;
     const int64_t n_words = (n + 31) / 32;
     if (n <= (2ll << 20)) {
@@ -1012,7 +1012,7 @@ int resolve_active(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* 
     BE_REQUIRE(s->active_ids != nullptr && s->n_active != nullptr, BE_ERR_INVALID, "null id list");
     al->ids = s->active_ids;
     al->count = s->n_active;
-    if (zero_first) BE_HIP(hipMemsetAsync(ws_count, 0, 4, st));
+    if (zero_first) BE_HIP(be_fill_async(ws_count, 0, 4, st));
     return BE_OK;
   }
   al->ids = ws_active;
@@ -1052,7 +1052,7 @@ int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const
   constexpr bool via_f32 = std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value;
   using ACC = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
   ACC* acc = via_f32 ? reinterpret_cast<ACC*>(wsb + counts_bytes(nb) + nb * astride * 4) : static_cast<ACC*>(out);
-  if (k > 0 && nb > 0) BE_HIP(hipMemsetAsync(acc, 0, (size_t)k * nb * sizeof(ACC), st));
+  if (k > 0 && nb > 0) BE_HIP(be_fill_async(acc, 0, (size_t)k * nb * sizeof(ACC), st));
   ActiveList al;
   int rc = resolve_active(spikes, sd, m, nb, active, astride, count, st, true, &al);
   if (rc != BE_OK) return rc;
@@ -1941,8 +1941,8 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
-  BE_HIP(hipMemsetAsync(maxabs_bits, 0, 4, st));
-  BE_HIP(hipMemsetAsync(maxabs_bits + 1, 0xff, 4, st));
+  BE_HIP(be_fill_async(maxabs_bits, 0, 4, st));
+  BE_HIP(be_fill_async(maxabs_bits + 1, 0xff, 4, st));
   if (layout == BE_PLAN_D8) {
     BE_REQUIRE(!homo && n_slices <= kD8MaxSlices, BE_ERR_INVALID, "d8 layout: heterogeneous weights, <= 1024 slices");
     BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 layout: rows of at most 16384 entries");
@@ -2105,9 +2105,9 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
                        valid, n_bins);
     BE_LAUNCH_CHECK();
   } else {
-    BE_HIP(hipMemsetAsync(out, 0, (size_t)k * 4, st));
-    BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_bins * 4, st));
-    BE_HIP(hipMemsetAsync(valid, 0xff, (size_t)n_bins * 4, st));
+    BE_HIP(be_fill_async(out, 0, (size_t)k * 4, st));
+    BE_HIP(be_fill_async(cursor, 0, (size_t)n_bins * 4, st));
+    BE_HIP(be_fill_async(valid, 0xff, (size_t)n_bins * 4, st));
   }
   ActiveList al;
   int rc = resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, true, &al);

@@ -785,7 +785,7 @@ int be_binary_densemm(const void* weights, int wdtype, const void* spikes_bm, in
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t esz = (wdtype == BE_F64) ? 8 : (wdtype == BE_F32 ? 4 : 2);
   if (k == 0) {
-    BE_HIP(hipMemsetAsync(out_bm, 0, (size_t)out_len * n_batch * esz, st));
+    BE_HIP(be_fill_async(out_bm, 0, (size_t)out_len * n_batch * esz, st));
     return BE_OK;
   }
   BE_REQUIRE(weights && spikes_bm, BE_ERR_INVALID, "null pointer");

@@ -661,7 +661,7 @@ static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t esz = (wdtype == BE_F64) ? 8 : (wdtype == BE_F32 ? 4 : 2);
   if (in_len == 0 || clen <= 0) {   // empty walk or prob == 0: all zeros (documented choice)
-    BE_HIP(hipMemsetAsync(out, 0, (size_t)out_len * esz, st));
+    BE_HIP(be_fill_async(out, 0, (size_t)out_len * esz, st));
     return BE_OK;
   }
   BE_REQUIRE(spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
@@ -675,7 +675,7 @@ static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, 
     p.cls_begin = class_begin;
     p.cls_count = class_count;
     if (class_count == 0) {
-      BE_HIP(hipMemsetAsync(out, 0, (size_t)out_len * esz, st));
+      BE_HIP(be_fill_async(out, 0, (size_t)out_len * esz, st));
       return BE_OK;
     }
   }
@@ -706,7 +706,7 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t esz = (wdtype == BE_F64) ? 8 : (wdtype == BE_F32 ? 4 : 2);
   if (in_len == 0 || clen <= 0) {
-    BE_HIP(hipMemsetAsync(out_bm, 0, (size_t)out_len * n_batch * esz, st));
+    BE_HIP(be_fill_async(out_bm, 0, (size_t)out_len * n_batch * esz, st));
     return BE_OK;
   }
   BE_REQUIRE(spikes_bm != nullptr, BE_ERR_INVALID, "spikes is NULL");
@@ -739,7 +739,7 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
   const bool direct = (wdtype == BE_F32 || wdtype == BE_F64);   // kernels write f32 / f64; f16 / bf16 via f32 scratch
   void* dst = direct ? out_bm : scratch;
   const size_t asz = f64 ? 8 : 4;
-  if (!gather) BE_HIP(hipMemsetAsync(dst, 0, (size_t)out_len * n_batch * asz, st));
+  if (!gather) BE_HIP(be_fill_async(dst, 0, (size_t)out_len * n_batch * asz, st));
   const size_t spk_sz = (spike_dtype == BE_SPIKE_FLOAT) ? 4 : 1;
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < n_batch; b0 += 32) {
@@ -789,7 +789,7 @@ int be_jitc_csr_count(int64_t clen, uint32_t seed, int64_t shape1, int64_t n_row
   if (n_rows == 0) return BE_OK;
   BE_REQUIRE(row_counts != nullptr, BE_ERR_INVALID, "null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  BE_HIP(hipMemsetAsync(row_counts, 0, (size_t)n_rows * 4, st));
+  BE_HIP(be_fill_async(row_counts, 0, (size_t)n_rows * 4, st));
   if (walk_len == 0 || clen <= 0) return BE_OK;
   const JitP p = make_params(shape1, walk_len, seed, clen, stride, 0, 0);
   hipLaunchKernelGGL(k_jit_csr_count, dim3(gcap(n_rows * p.n_chunks * stride, 256, 8192)), dim3(256), 0, st, p, n_rows,
@@ -808,7 +808,7 @@ int be_jitc_csr_fill(int mode, double w0, double w1, int64_t clen, uint32_t seed
   if (n_rows == 0 || walk_len == 0 || clen <= 0) return BE_OK;
   BE_REQUIRE(indptr && cursor && indices && (mode == MODE_SCALAR || weights), BE_ERR_INVALID, "null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  BE_HIP(hipMemsetAsync(cursor, 0, (size_t)n_rows * 4, st));
+  BE_HIP(be_fill_async(cursor, 0, (size_t)n_rows * 4, st));
   const JitP p = make_params(shape1, walk_len, seed, clen, stride, w0, w1);
   const dim3 grid(gcap(n_rows * p.n_chunks * stride, 256, 8192));
   if (mode == MODE_SCALAR) hipLaunchKernelGGL(k_jit_csr_fill<MODE_SCALAR>, grid, dim3(256), 0, st, p, n_rows, indptr, cursor, indices, weights);
