@@ -1,0 +1,72 @@
+"""The multi-GPU step on the device with a one-rank RCCL process group (the only multi-rank configuration a one-GPU box
+can run): bit-packed exchange -> packed events -> planned scatter, sequential and pipelined schedules, JITC walk-class
+shard.  The partition logic itself is covered under gloo with two ranks in test_dist_cpu.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def one_rank_group():
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_exchange_and_scatter_on_device(one_rank_group):
+    import brainevent_amd as be
+    from brainevent_amd import _dist as D
+    from brainevent_amd._csr import ScatterPlan
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(0)
+    dev = torch.device('cuda', 0)
+    n_pre, n_post = 5003, 30011
+    lens = rng.integers(0, 60, n_pre)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, n_post, ptr[-1]).astype(np.int32)
+    w = rng.random(ptr[-1]).astype(np.float32)
+    sw, si, sp, sshape = D.shard_csr_by_post(torch.from_numpy(w).to(dev), torch.from_numpy(idx).to(dev),
+                                             torch.from_numpy(ptr).to(dev), (n_pre, n_post), 1, 0)
+    shard = be.CSR((sw, si, sp), shape=sshape, check_structure=False)
+    shard.buffers['scatter_plan'] = ScatterPlan.build(sw, si, sp, shape=sshape)
+    for packed in (True, False):
+        ds = D.DistributedScatter(shard, n_pre, packed=packed, device=dev)
+        assert (ds.exchange.lo, ds.exchange.hi) == (0, n_pre)
+        for step in range(3):
+            s = rng.random(n_pre) < 0.1
+            out = ds.step(torch.from_numpy(s).to(dev))
+            ref = O.binary_csrmv(w, idx, ptr, s, (n_pre, n_post), True)
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+            np.testing.assert_array_equal(ds.exchange.gather(torch.from_numpy(s).to(dev)).cpu().numpy(), s)
+    # pipelined schedule: post step t + 1, consume step t
+    ex = D.SpikeExchange(n_pre, packed=True, device=dev)
+    spikes = [rng.random(n_pre) < 0.2 for _ in range(5)]
+    ticket = ex.post(torch.from_numpy(spikes[0]).to(dev))
+    for t in range(5):
+        nxt = ex.post(torch.from_numpy(spikes[t + 1]).to(dev)) if t + 1 < 5 else None
+        out = ex.wait_events(ticket) @ shard
+        np.testing.assert_allclose(out.cpu().numpy(), O.binary_csrmv(w, idx, ptr, spikes[t], (n_pre, n_post), True),
+                                   rtol=1e-5, atol=1e-5)
+        ticket = nxt
+
+
+def test_jitc_shard_behind_the_exchange(one_rank_group):
+    import brainevent_amd as be
+    from brainevent_amd import _dist as D
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(1)
+    n = 4000
+    M = be.JITCScalarR((np.float32(1.0), 0.02, 9), shape=(n, n), corder=True)
+    ds = D.DistributedScatter(M.scatter_shard(1, 0), n, packed=True, device=dev)
+    s = rng.random(n) < 0.1
+    got = ds.step(torch.from_numpy(s).to(dev))
+    np.testing.assert_array_equal(got.cpu().numpy(), be.BinaryArray(s) @ M)
