@@ -67,8 +67,16 @@ def _worker(rank, world, port, packed, n_pre, n_post, q):
 @pytest.mark.parametrize('packed,n_pre,n_post', [(False, 64, 50), (False, 67, 53), (True, 64, 53), (True, 67, 50), (True, 20, 9),
                                                  (True, 200, 31)])
 def test_post_sliced_scatter_world2(packed, n_pre, n_post):
+    _run_world(2, packed, n_pre, n_post)
+
+
+def test_post_sliced_scatter_world8():
+    """Eight ranks (the driver's node size) under gloo: word-aligned pre slices with uneven and empty owners."""
+    _run_world(8, True, 1000, 203)
+
+
+def _run_world(world, packed, n_pre, n_post):
     from oracle import oracle_np as O
-    world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -80,7 +88,7 @@ def test_post_sliced_scatter_world2(packed, n_pre, n_post):
         p.join(timeout=60)
         assert p.exitcode == 0
     res.sort()
-    assert res[0][1] == 0 and res[-1][2] == n_post and res[0][2] == res[1][1]       # slices tile the post population
+    assert res[0][1] == 0 and res[-1][2] == n_post and all(res[i][2] == res[i + 1][1] for i in range(world - 1))   # slices tile
     rng = np.random.default_rng(0)
     lens = rng.integers(0, 40, n_pre)
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
