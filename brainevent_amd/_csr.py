@@ -396,6 +396,34 @@ def binary_csrmv_p_call(weights, indices, indptr, vector, workspace=None, *, sha
                            backend=backend),)
 
 
+binary_csrmv_p.def_call(binary_csrmv_p_call)
+
+
+def _binary_csrmv_benchmark_data(*, platform):
+    """A small slice of the reference's sweep (``brainevent/_csr/binary.py:760-800``: square matrices, size x density x
+    direction x weight kind x event type), generated on the device."""
+    dev = A.device()
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    for n in (1000, 10000):
+        for conn_prob in (0.01, 0.1):
+            n_conn = max(1, int(n * conn_prob))
+            indptr = torch.arange(n + 1, dtype=torch.int32, device=dev) * n_conn
+            indices = torch.randint(0, n, (n * n_conn,), dtype=torch.int32, device=dev, generator=g)
+            for transpose in (False, True):
+                for homo in (True, False):
+                    weights = torch.ones(1 if homo else n * n_conn, device=dev)
+                    for event_type in ('float', 'bool'):
+                        data = torch.rand(n, device=dev, generator=g) < 0.01
+                        vector = data.float() if event_type == 'float' else data
+                        name = (f"{n}x{n},p={int(round(conn_prob * 100))}%,{'T' if transpose else 'NT'},"
+                                f"{'homo' if homo else 'hetero'},{event_type}")
+                        yield name, (weights, indices, indptr, vector, None), {'shape': (n, n), 'transpose': transpose}
+
+
+binary_csrmv_p.def_benchmark_data(_binary_csrmv_benchmark_data)
+
+
 def binary_csrmv(data, indices, indptr, v, *, shape, workspace=None, transpose: bool = False,
                  backend: Optional[str] = None):
     """Event-driven ``A @ v`` (``transpose=False``) or ``A.T @ v`` (``transpose=True``) for CSR ``A``.
@@ -447,6 +475,9 @@ def binary_csrmm_p_call(weights, indices, indptr, B, workspace=None, *, shape, t
         weights = weights.reshape(1)
     return (binary_csrmm_p(weights, indices, indptr, B, shape=shape, transpose=transpose, workspace=workspace,
                            backend=backend),)
+
+
+binary_csrmm_p.def_call(binary_csrmm_p_call)
 
 
 def binary_csrmm(data, indices, indptr, B, *, shape, workspace=None, transpose: bool = False,

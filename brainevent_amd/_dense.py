@@ -76,6 +76,9 @@ def binary_densemv_p_call(weights, spikes, *, transpose, backend=None):
     return [binary_densemv_p(weights, spikes, transpose=transpose, backend=backend)]
 
 
+binary_densemv_p.def_call(binary_densemv_p_call)
+
+
 def binary_densemm_p_call(weights, spikes, *, transpose, backend=None):
     assert weights.ndim == 2 and spikes.ndim == 2, "weights and spikes must be 2D."
     if transpose:
@@ -87,6 +90,9 @@ def binary_densemm_p_call(weights, spikes, *, transpose, backend=None):
             f"weights.shape[1] ({weights.shape[1]}) != spikes.shape[0] ({spikes.shape[0]}), "
             f"weights: {tuple(weights.shape)}, spikes: {tuple(spikes.shape)}")
     return [binary_densemm_p(weights, spikes, transpose=transpose, backend=backend)]
+
+
+binary_densemm_p.def_call(binary_densemm_p_call)
 
 
 def _as_arr(x):

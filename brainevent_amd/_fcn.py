@@ -100,6 +100,9 @@ def binary_fcnmv_p_call(weights, indices, spikes, *, shape, transpose, backend=N
                            backend=backend),)
 
 
+binary_fcnmv_p.def_call(binary_fcnmv_p_call)
+
+
 def binary_fcnmm_p_call(weights, indices, matrix, *, shape, transpose, backend=None, workspace=None):
     """Validation + dispatch of the matrix op (reference ``brainevent/_fcn/binary.py:1077-1137``)."""
     assert matrix.ndim == 2, "matrix must be 2D."
@@ -108,6 +111,9 @@ def binary_fcnmm_p_call(weights, indices, matrix, *, shape, transpose, backend=N
     weights = weights.reshape(1) if weights.numel() == 1 else weights
     return (binary_fcnmm_p(weights, indices, matrix, shape=shape, transpose=transpose, workspace=workspace,
                            backend=backend),)
+
+
+binary_fcnmm_p.def_call(binary_fcnmm_p_call)
 
 
 def _prep(weights, indices):

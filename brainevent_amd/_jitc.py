@@ -187,10 +187,16 @@ def binary_jitsmv_p_call(weight, clen, vector, seed, *, shape, transpose, corder
                             out_dtype=_weight_dtype(weight), backend=backend)]
 
 
+binary_jitsmv_p.def_call(binary_jitsmv_p_call)
+
+
 def binary_jitsmm_p_call(weight, clen, B, seed, *, shape, transpose, corder, backend=None):
     _check_mm(B, shape, transpose)
     return [binary_jitsmm_p(weight, None, clen, B, seed, shape=tuple(shape), transpose=transpose, corder=corder,
                             out_dtype=_weight_dtype(weight), backend=backend)]
+
+
+binary_jitsmm_p.def_call(binary_jitsmm_p_call)
 
 
 def binary_jitsmv(weight, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False,
@@ -219,10 +225,16 @@ def binary_jitumv_p_call(w_low, w_high, clen, vector, seed, *, shape, transpose,
                             out_dtype=_weight_dtype(w_low, w_high), backend=backend)]
 
 
+binary_jitumv_p.def_call(binary_jitumv_p_call)
+
+
 def binary_jitumm_p_call(w_low, w_high, clen, B, seed, *, shape, transpose, corder, backend=None):
     _check_mm(B, shape, transpose)
     return [binary_jitumm_p(w_low, w_high, clen, B, seed, shape=tuple(shape), transpose=transpose, corder=corder,
                             out_dtype=_weight_dtype(w_low, w_high), backend=backend)]
+
+
+binary_jitumm_p.def_call(binary_jitumm_p_call)
 
 
 def binary_jitumv(w_low, w_high, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False,
@@ -249,10 +261,16 @@ def binary_jitnmv_p_call(w_loc, w_scale, clen, vector, seed, *, shape, transpose
                             out_dtype=_weight_dtype(w_loc, w_scale), backend=backend)]
 
 
+binary_jitnmv_p.def_call(binary_jitnmv_p_call)
+
+
 def binary_jitnmm_p_call(w_loc, w_scale, clen, B, seed, *, shape, transpose, corder, backend=None):
     _check_mm(B, shape, transpose)
     return [binary_jitnmm_p(w_loc, w_scale, clen, B, seed, shape=tuple(shape), transpose=transpose, corder=corder,
                             out_dtype=_weight_dtype(w_loc, w_scale), backend=backend)]
+
+
+binary_jitnmm_p.def_call(binary_jitnmm_p_call)
 
 
 def binary_jitnmv(w_loc, w_scale, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False,

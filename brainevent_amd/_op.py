@@ -25,6 +25,8 @@ class OpKernel:
         self._kernels: Dict[str, Dict[str, Callable]] = {}
         self._defaults: Dict[str, str] = {}
         self.tags: Set[str] = set()
+        self._call_fn: Optional[Callable] = None
+        self._benchmark_data_fn: Optional[Callable] = None
         register_primitive(name, self)
 
     # -- registration -------------------------------------------------------------------------
@@ -69,3 +71,62 @@ class OpKernel:
 
     def __call__(self, *args, backend: Optional[str] = None, **kwargs):
         return self.resolve(backend)(*args, **kwargs)
+
+    # -- call function and benchmark harness (reference ``_op/main.py:1084-1150`` def_call / call,
+    #    ``:1237-1439`` benchmark: warm-up, then timed runs around a device synchronisation) --------------
+    def def_call(self, fn: Callable):
+        """Associate the user-facing call function (e.g. ``binary_csrmv_p_call``) with this operator."""
+        self._call_fn = fn
+
+    def call(self, *args, **kwargs):
+        if self._call_fn is None:
+            raise ValueError(f"No call function registered for '{self.name}'. "
+                             "Use def_call() to register one before calling.")
+        return self._call_fn(*args, **kwargs)
+
+    def def_benchmark_data(self, fn: Callable):
+        """``fn(platform=...)`` -> iterable of ``(config_name, args, kwargs)`` for :meth:`benchmark`."""
+        self._benchmark_data_fn = fn
+
+    def benchmark(self, *, platform: str = PLATFORM, n_warmup: int = 5, n_runs: int = 20, n_batch_per_run: int = 1,
+                  compare_results: bool = True, rtol: float = 1e-3, atol: float = 1e-3, verbose: bool = False,
+                  catch_errors: bool = True, backends: Optional[list] = None):
+        """Time the call function on every registered backend over the configured data; returns a list of records
+        ``{name, backend, mean_ms, std_ms, min_ms, success, error}`` (per-call times)."""
+        import time
+        import numpy as np
+        import torch
+        if self._call_fn is None or self._benchmark_data_fn is None:
+            raise ValueError(f"benchmark() of '{self.name}' needs def_call() and def_benchmark_data().")
+        records = []
+        for cfg_name, args, kwargs in self._benchmark_data_fn(platform=platform):
+            ref_out = None
+            for backend in (backends or self.available_backends(platform)):
+                rec = {'name': cfg_name, 'backend': backend, 'mean_ms': None, 'std_ms': None, 'min_ms': None,
+                       'success': True, 'error': None}
+                try:
+                    for _ in range(n_warmup):
+                        out = self._call_fn(*args, backend=backend, **kwargs)
+                    torch.cuda.synchronize()
+                    times = []
+                    for _ in range(n_runs):
+                        t0 = time.perf_counter()
+                        for _ in range(n_batch_per_run):
+                            out = self._call_fn(*args, backend=backend, **kwargs)
+                        torch.cuda.synchronize()
+                        times.append((time.perf_counter() - t0) / n_batch_per_run * 1e3)
+                    rec.update(mean_ms=float(np.mean(times)), std_ms=float(np.std(times)), min_ms=float(np.min(times)))
+                    first = out[0] if isinstance(out, (tuple, list)) else out
+                    if compare_results and ref_out is not None and not torch.allclose(first.float(), ref_out.float(),
+                                                                                      rtol=rtol, atol=atol):
+                        warnings.warn(f"{self.name}[{cfg_name}]: backend {backend!r} disagrees with the first backend.")
+                    if ref_out is None:
+                        ref_out = first
+                except Exception as e:      # noqa: BLE001 - mirrored from the reference's catch_errors switch
+                    if not catch_errors:
+                        raise
+                    rec.update(success=False, error=repr(e))
+                if verbose:
+                    print(rec)
+                records.append(rec)
+        return records

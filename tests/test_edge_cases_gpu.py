@@ -101,3 +101,15 @@ def test_backend_keyword_contract(be):
         be.CSR((w, np.array([0, 5], np.int32), ptr), shape=(1, 2))                                 # column out of range
     with pytest.raises(ValueError):
         be.CSR((w, idx, np.array([0, 3], np.int32)), shape=(1, 2))                                 # indptr[-1] != nse
+
+
+def test_operator_benchmark_harness():
+    """``OpKernel.benchmark`` (reference ``XLACustomKernel.benchmark``, ``_op/main.py:1237``): per-call timing records for
+    every registered backend over the operator's own data generator."""
+    import brainevent_amd as be
+    recs = be.binary_csrmv_p.benchmark(platform='gpu', n_warmup=1, n_runs=2, n_batch_per_run=2)
+    assert len(recs) == 2 * 2 * 2 * 2 * 2
+    assert all(r['success'] and r['backend'] == 'hip' and r['mean_ms'] > 0 and r['min_ms'] <= r['mean_ms'] for r in recs)
+    assert recs[0]['name'].startswith('1000x1000,p=1%,NT,homo')
+    bad = be.binary_csrmv_p.benchmark(platform='gpu', n_warmup=0, n_runs=1, backends=['nope'])
+    assert all((not r['success']) and 'nope' in r['error'] for r in bad)

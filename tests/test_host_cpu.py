@@ -194,3 +194,20 @@ def test_event_representation_minimal_api():
         arr[0] = 5                                                   # item assignment is not supported
     # encodings exist on the CPU as types (their constructors need the device)
     assert issubclass(be.BitPackedBinary, be.EventRepresentation) and hasattr(be.CompactBinary, 'from_array')
+
+
+def test_operator_call_function_contract():
+    """``def_call`` / ``call`` of the operator object (reference ``brainevent/_op/main.py:1084-1150``)."""
+    import brainevent_amd as be
+    from brainevent_amd._op import OpKernel
+    op = OpKernel('test_call_contract_op')
+    with pytest.raises(ValueError, match="No call function registered"):
+        op.call(1, 2)
+    op.def_call(lambda a, b, backend=None: a + b)
+    assert op.call(1, 2) == 3
+    with pytest.raises(ValueError):
+        op.benchmark(platform='gpu')                       # no benchmark data registered
+    for name in ('binary_csrmv', 'binary_csrmm', 'binary_fcnmv', 'binary_fcnmm', 'binary_densemv', 'binary_densemm',
+                 'binary_jitsmv', 'binary_jitsmm', 'binary_jitumv', 'binary_jitumm', 'binary_jitnmv', 'binary_jitnmm'):
+        prim = getattr(be, name + '_p')
+        assert prim._call_fn is getattr(be, name + '_p_call')
