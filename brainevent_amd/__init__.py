@@ -5,6 +5,7 @@ Only the spike-triggered SpMV/SpMM hot path of chaobrain/brainevent is provided:
 functional ``binary_*`` operators, running hand-written HIP kernels (gfx950) through a C ABI.
 """
 from ._version import __version__
+__version_info__ = tuple(int(p) for p in __version__.split('.')[:3] if p.isdigit())
 from ._error import (BrainEventError, MathError, KernelError, KernelNotAvailableError, KernelCompilationError,
                      KernelFallbackExhaustedError, KernelExecutionError, KernelLoadError, UnsupportedOperationError)
 from . import config
@@ -14,9 +15,11 @@ from ._csr import (CSR, CSC, ScatterPlan, BinnedScatter, binary_csrmv, binary_cs
                    binary_csrmv_p_call, binary_csrmm_p_call)
 from ._fcn import (FixedNumConn, FixedNumPerPre, FixedNumPerPost, binary_fcnmv, binary_fcnmm, binary_fcnmv_p,
                    binary_fcnmm_p, binary_fcnmv_p_call, binary_fcnmm_p_call)
-from ._dense import (binary_densemv, binary_densemm, binary_densemv_p, binary_densemm_p, binary_densemv_p_call,
+from ._dense import (Dense, binary_densemv, binary_densemm, binary_densemv_p, binary_densemm_p, binary_densemv_p_call,
                      binary_densemm_p_call)
-from ._jitc import (JITCScalarR, JITCScalarC, JITCUniformR, JITCUniformC, JITCNormalR, JITCNormalC,
+from ._op import OpKernel
+XLACustomKernel = OpKernel      # the operator object under the reference's name (no XLA underneath)
+from ._jitc import (JITCMatrix, JITCScalarR, JITCScalarC, JITCUniformR, JITCUniformC, JITCNormalR, JITCNormalC,
                     binary_jitsmv, binary_jitsmm, binary_jitumv, binary_jitumm, binary_jitnmv, binary_jitnmm,
                     binary_jitsmv_p, binary_jitsmm_p, binary_jitumv_p, binary_jitumm_p, binary_jitnmv_p, binary_jitnmm_p,
                     binary_jitsmv_p_call, binary_jitsmm_p_call, binary_jitumv_p_call, binary_jitumm_p_call,

@@ -20,7 +20,7 @@ from . import _array as A
 from ._lib import check, fn
 from ._op import OpKernel
 
-__all__ = ['binary_densemv', 'binary_densemm', 'binary_densemv_p', 'binary_densemm_p', 'binary_densemv_p_call',
+__all__ = ['Dense', 'binary_densemv', 'binary_densemm', 'binary_densemv_p', 'binary_densemm_p', 'binary_densemv_p_call',
            'binary_densemm_p_call']
 
 c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
@@ -119,3 +119,76 @@ def binary_densemm(weights, spikes, *, transpose, backend: Optional[str] = None)
     w, s = _as_arr(weights), _as_arr(spikes)
     _float_weights(w)
     return A.to_result(binary_densemm_p_call(w, s, transpose=transpose, backend=backend)[0], as_np)
+
+
+class Dense:
+    """Explicit dense matrix with the representation contract of the sparse families (reference
+    ``brainevent/_dense/main.py:60-490``, minus units, pytree plumbing and plasticity): ``data``, ``shape``,
+    ``backend``, ``buffers``, ``with_data``, ``todense``, ``T`` / ``transpose`` and event-driven ``@``.
+
+    ``Dense @ events`` -> ``binary_densemv/mm(transpose=False)``; ``events @ Dense`` -> ``transpose=True``
+    (``_dense/main.py:426-476``).  Non-event operands are outside the accelerated path."""
+
+    def __init__(self, data, shape=None, backend: Optional[str] = None, buffers: Optional[dict] = None):
+        self._numpy_result = not isinstance(data, torch.Tensor)
+        self.data = A.to_device(data)
+        if self.data.ndim != 2:
+            raise ValueError(f"Dense data must be two-dimensional, got {self.data.ndim}D.")
+        if shape is not None and tuple(shape) != tuple(self.data.shape):
+            raise ValueError(f"shape {tuple(shape)} does not match the data shape {tuple(self.data.shape)}.")
+        self.shape = (int(self.data.shape[0]), int(self.data.shape[1]))
+        self.backend = backend
+        self.buffers = dict(buffers) if buffers else {}
+
+    dtype = property(lambda self: self.data.dtype)
+    ndim = property(lambda self: 2)
+
+    def with_data(self, data) -> 'Dense':
+        d = A.to_device(data)
+        assert tuple(d.shape) == tuple(self.data.shape) and d.dtype == self.data.dtype
+        out = Dense(d, shape=self.shape, backend=self.backend, buffers=self.buffers)
+        out._numpy_result = self._numpy_result
+        return out
+
+    def todense(self):
+        return A.to_result(self.data, self._numpy_result)
+
+    def transpose(self, axes=None) -> 'Dense':
+        assert axes is None, f"axes must be None, got {axes}."
+        out = Dense(self.data.T.contiguous(), shape=self.shape[::-1], backend=self.backend, buffers=self.buffers)
+        out._numpy_result = self._numpy_result
+        return out
+
+    T = property(lambda self: self.transpose())
+
+    def __getitem__(self, index):
+        return self.todense()[index]
+
+    def _event(self, other):
+        from ._event import is_event, event_operand
+        if not is_event(other):
+            raise NotImplementedError("only event operands are on the accelerated path (plain dense matmul is out of scope).")
+        return event_operand(other, allow_packed=False)
+
+    def __matmul__(self, other):          # dense @ events
+        ev = self._event(other)
+        if ev.ndim == 1:
+            r = binary_densemv_p_call(self.data, ev, transpose=False, backend=self.backend)[0]
+        elif ev.ndim == 2:
+            r = binary_densemm_p_call(self.data, ev, transpose=False, backend=self.backend)[0]
+        else:
+            raise NotImplementedError(f"matmul with object of shape {ev.shape}")
+        return A.to_result(r, self._numpy_result and A.wants_numpy(ev))
+
+    def __rmatmul__(self, other):         # events @ dense
+        ev = self._event(other)
+        if ev.ndim == 1:
+            r = binary_densemv_p_call(self.data, ev, transpose=True, backend=self.backend)[0]
+        elif ev.ndim == 2:
+            r = binary_densemm_p_call(self.data, ev.T, transpose=True, backend=self.backend)[0].T
+        else:
+            raise NotImplementedError(f"matmul with object of shape {ev.shape}")
+        return A.to_result(r, self._numpy_result and A.wants_numpy(ev))
+
+    def __repr__(self):
+        return f"Dense(shape={self.shape}, dtype={self.dtype}, backend={self.backend})"

@@ -134,3 +134,32 @@ def test_dense_randomized_shapes(be, oracle, seed):
         got = be.binary_densemv(W, torch.tensor(s, device='cuda'), transpose=True)
         ref = oracle.binary_densemv(Wd, s, True)
         np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+
+
+def test_dense_container(be, oracle):
+    """``Dense`` (reference ``brainevent/_dense/main.py:60-490``): the representation contract + event-driven ``@``."""
+    rng = np.random.default_rng(12)
+    W = rng.standard_normal((37, 21)).astype(np.float32)
+    D = be.Dense(W)
+    assert D.shape == (37, 21) and D.ndim == 2 and D.T.shape == (21, 37)
+    np.testing.assert_array_equal(D.todense(), W)
+    np.testing.assert_array_equal(D.T.todense(), W.T)
+    np.testing.assert_array_equal(D[3], W[3])
+    with pytest.raises(ValueError):
+        be.Dense(W, shape=(21, 37))
+    with pytest.raises(ValueError):
+        be.Dense(W[0])
+    s_rows, s_cols = rng.random(37) < 0.4, rng.random(21) < 0.4
+    np.testing.assert_allclose(be.BinaryArray(s_rows) @ D, oracle.binary_densemv(W, s_rows, True), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(D @ be.BinaryArray(s_cols), oracle.binary_densemv(W, s_cols, False), rtol=1e-5, atol=1e-5)
+    S_b = rng.random((5, 37)) < 0.4                                   # batch-major events @ D
+    np.testing.assert_allclose(be.BinaryArray(S_b) @ D, S_b.astype(np.float32) @ W, rtol=1e-5, atol=1e-5)
+    S_c = rng.random((21, 21)) < 0.4                                  # square: orientation must not be guessed
+    np.testing.assert_allclose(D @ be.BinaryArray(S_c), W @ S_c.astype(np.float32), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(be.BinaryArray(s_rows).bitpack() @ D, oracle.binary_densemv(W, s_rows, True), rtol=1e-5, atol=1e-5)
+    D2 = D.with_data(W * 2)
+    np.testing.assert_allclose(be.BinaryArray(s_rows) @ D2, 2 * oracle.binary_densemv(W, s_rows, True), rtol=1e-5, atol=1e-5)
+    out = be.BinaryArray(torch.tensor(s_rows, device='cuda')) @ be.Dense(torch.tensor(W, device='cuda'))
+    assert isinstance(out, torch.Tensor)
+    with pytest.raises(NotImplementedError):
+        D @ np.ones(21, np.float32)
