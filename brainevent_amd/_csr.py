@@ -643,15 +643,10 @@ class CompressedSparseData:
         if nse > (1 << 31):
             raise MemoryError("build_mirror: the device sort of > 2^31 entries is not supported; "
                               "the gather kernel is used instead")
-        rows = torch.repeat_interleave(torch.arange(m, dtype=torch.int32, device=self.indices.device),
-                                       (self.indptr[1:] - self.indptr[:-1]).to(torch.int64))
-        order = torch.argsort(self.indices, stable=True)
-        t_indices = rows[order].contiguous()           # secondary ids of the mirror = primary ids here
-        counts = torch.bincount(self.indices.to(torch.int64), minlength=k)
-        t_indptr = torch.zeros(k + 1, dtype=torch.int64, device=self.indices.device)
-        torch.cumsum(counts, 0, out=t_indptr[1:])
+        from ._convert import csr_to_csc_index
+        t_indptr, t_indices, order = csr_to_csc_index(self.indptr, self.indices, shape=(m, k))   # secondary ids = rows here
         t_indptr = t_indptr.to(self.indptr.dtype)
-        t_data = self.data if self.data.numel() == 1 else self.data[order].contiguous()
+        t_data = self.data if self.data.numel() == 1 else self.data[order.long()].contiguous()
         mirror = {'data': t_data, 'indices': t_indices, 'indptr': t_indptr, 'shape': (k, m), 'plan': None}
         homo = t_data.numel() == 1
         if nse >= PLAN_MIN_NNZ and t_data.dtype != torch.float64:

@@ -113,3 +113,44 @@ def test_operator_benchmark_harness():
     assert recs[0]['name'].startswith('1000x1000,p=1%,NT,homo')
     bad = be.binary_csrmv_p.benchmark(platform='gpu', n_warmup=0, n_runs=1, backends=['nope'])
     assert all((not r['success']) and 'nope' in r['error'] for r in bad)
+
+
+def test_index_structure_conversions_match_scipy():
+    """csr_to_coo / coo_to_csc / coo2csr / csr_to_csc / csc_to_csr (reference ``brainevent/_misc.py:871-1085``, ``:1516-1700``)
+    against scipy, including the reference's docstring example; the permutation reorders CSR data into CSC order."""
+    import scipy.sparse as sp
+    import brainevent_amd as be
+    ptr, idx, perm = be.csr_to_csc_index(np.array([0, 2, 3, 5]), np.array([0, 2, 1, 0, 3]), shape=(3, 4))
+    np.testing.assert_array_equal(ptr, [0, 2, 3, 4, 5])
+    np.testing.assert_array_equal(idx, [0, 2, 1, 0, 2])
+    np.testing.assert_array_equal(perm, [0, 3, 2, 1, 4])
+    rng = np.random.default_rng(0)
+    for m, k in ((1, 1), (17, 5), (40, 300), (300, 40)):
+        lens = rng.integers(0, 12, m)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        indices = np.concatenate([np.sort(rng.choice(k, min(l, k), replace=False)) for l in lens] + [np.zeros(0, int)]).astype(np.int32)
+        indptr = np.concatenate([[0], np.cumsum([min(l, k) for l in lens])]).astype(np.int32)
+        data = rng.random(indices.size).astype(np.float32)
+        ref = sp.csr_matrix((data, indices, indptr), shape=(m, k)).tocsc()
+        cptr, cidx, perm = be.csr_to_csc_index(indptr, indices, shape=(m, k))
+        assert cidx.dtype == np.int32
+        np.testing.assert_array_equal(cptr, ref.indptr)
+        np.testing.assert_array_equal(cidx, ref.indices)
+        np.testing.assert_array_equal(data[perm], ref.data)
+        assert be.csr_to_csc_index(indptr, indices, shape=(m, k), include_perm=False)[2] is None
+        rows, cols = be.csr_to_coo_index(indptr, indices)
+        np.testing.assert_array_equal(rows, np.repeat(np.arange(m), np.diff(indptr)))
+        p2, i2, _ = be.coo_to_csc_index(rows, cols, shape=(m, k))
+        np.testing.assert_array_equal(p2, ref.indptr); np.testing.assert_array_equal(i2, ref.indices)
+        shuffle = rng.permutation(indices.size)
+        p3, i3, pos = be.coo2csr(rows[shuffle], cols[shuffle], shape=(m, k))
+        np.testing.assert_array_equal(p3, indptr)
+        np.testing.assert_array_equal(np.sort(i3), np.sort(indices))
+        np.testing.assert_array_equal(cols[shuffle][pos], i3)
+        rptr, ridx, rperm = be.csc_to_csr_index(cptr, cidx, shape=(m, k))          # round trip
+        np.testing.assert_array_equal(rptr, indptr); np.testing.assert_array_equal(ridx, indices)
+        np.testing.assert_array_equal(ref.data[rperm], data)
+    t = be.csr_to_csc_index(torch.tensor([0, 1, 2], device='cuda'), torch.tensor([1, 0], dtype=torch.int32, device='cuda'), shape=(2, 2))
+    assert all(isinstance(x, torch.Tensor) and x.is_cuda for x in t)
+    with pytest.raises(ValueError):
+        be.csr_to_csc_index(np.array([0, 1]), np.array([0]), shape=(1, 1), method='bogus')
