@@ -31,7 +31,7 @@ from ._misc import _as_indptr, _as_int32_indices, _check_compressed_structure
 from ._op import OpKernel
 
 __all__ = ['CSR', 'CSC', 'ScatterPlan', 'BinnedScatter', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p', 'binary_csrmm_p',
-           'binary_csrmv_p_call', 'binary_csrmm_p_call']
+           'binary_csrmv_p_call', 'binary_csrmm_p_call', 'binary_csrmv_indexed', 'binary_csrmm_indexed']
 
 c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 
@@ -494,6 +494,38 @@ def binary_csrmm(data, indices, indptr, B, *, shape, workspace=None, transpose: 
         ptr_ = _as_indptr(ptr_, idx.shape[0], 'auto', 'binary_csrmm')
     Bm = B if isinstance(B, torch.Tensor) else np.asarray(B)
     res = binary_csrmm_p_call(w, idx, ptr_, Bm, workspace, shape=tuple(shape), transpose=transpose, backend=backend)[0]
+    return A.to_result(res, as_np)
+
+
+def _indexed_weights(data, perm):
+    w = A.to_device(data)
+    if w.numel() == 1:
+        return w                      # homogeneous weight: perm is ignored, as in the reference
+    p = A.to_device(perm)
+    return w.reshape(-1)[p.long()]
+
+
+def binary_csrmv_indexed(data, indices, indptr, perm, v, *, shape, workspace=None, transpose: bool = False,
+                         backend: Optional[str] = None):
+    """``binary_csrmv(data[perm], indices, indptr, v, ...)``: the product over a *re-indexed* structure (typically the CSC
+    view of a CSR matrix, ``perm`` from :func:`csr_to_csc_index`) with the weights left in their canonical order
+    (reference ``brainevent/_csr/binary_indexed.py:70-140``).  Here the gather ``data[perm]`` is one device pass per call
+    and the product runs the ordinary kernels; when the same structure is used every step, ``CSR.prepare(mirror=True)``
+    keeps a planned copy instead (event-driven, no per-call gather)."""
+    as_np = A.wants_numpy(data, indices, indptr, perm, v)
+    res = binary_csrmv(_indexed_weights(data, perm), A.to_device(indices), A.to_device(indptr),
+                       v if isinstance(v, torch.Tensor) else A.to_device(np.asarray(v)), shape=shape, workspace=workspace,
+                       transpose=transpose, backend=backend)
+    return A.to_result(res, as_np)
+
+
+def binary_csrmm_indexed(data, indices, indptr, perm, B, *, shape, workspace=None, transpose: bool = False,
+                         backend: Optional[str] = None):
+    """Matrix-operand twin of :func:`binary_csrmv_indexed` (reference ``_csr/binary_indexed.py:615``)."""
+    as_np = A.wants_numpy(data, indices, indptr, perm, B)
+    res = binary_csrmm(_indexed_weights(data, perm), A.to_device(indices), A.to_device(indptr),
+                       B if isinstance(B, torch.Tensor) else A.to_device(np.asarray(B)), shape=shape, workspace=workspace,
+                       transpose=transpose, backend=backend)
     return A.to_result(res, as_np)
 
 

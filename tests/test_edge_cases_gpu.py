@@ -154,3 +154,26 @@ def test_index_structure_conversions_match_scipy():
     assert all(isinstance(x, torch.Tensor) and x.is_cuda for x in t)
     with pytest.raises(ValueError):
         be.csr_to_csc_index(np.array([0, 1]), np.array([0]), shape=(1, 1), method='bogus')
+
+
+def test_indexed_products_equal_the_reindexed_matrix():
+    """binary_csrmv/mm_indexed (reference ``_csr/binary_indexed.py``): the CSC view of a CSR matrix with the weights left
+    in CSR order and reached through the permutation — same numbers as the products on the CSR matrix itself."""
+    import brainevent_amd as be
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(5)
+    m, k = 60, 45
+    lens = rng.integers(0, 9, m)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    for w in (rng.random(ptr[-1]).astype(np.float32), np.array([0.5], np.float32)):
+        cptr, cidx, perm = be.csr_to_csc_index(ptr, idx, shape=(m, k))
+        sm, sk = rng.random(m) < 0.4, rng.random(k) < 0.4
+        # the CSC arrays are the CSR arrays of the transpose (k x m): scatter over it = gather over the original, and back
+        np.testing.assert_allclose(be.binary_csrmv_indexed(w, cidx, cptr, perm, sk, shape=(k, m), transpose=True),
+                                   O.binary_csrmv(w, idx, ptr, sk, (m, k), False), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(be.binary_csrmv_indexed(w, cidx, cptr, perm, sm, shape=(k, m), transpose=False),
+                                   O.binary_csrmv(w, idx, ptr, sm, (m, k), True), rtol=1e-5, atol=1e-5)
+        B = rng.random((k, 4)) < 0.4
+        np.testing.assert_allclose(be.binary_csrmm_indexed(w, cidx, cptr, perm, B, shape=(k, m), transpose=True),
+                                   O.binary_csrmm(w, idx, ptr, B, (m, k), False), rtol=1e-5, atol=1e-5)
