@@ -7,7 +7,8 @@ functional ``binary_*`` operators, running hand-written HIP kernels (gfx950) thr
 from ._version import __version__
 __version_info__ = tuple(int(p) for p in __version__.split('.')[:3] if p.isdigit())
 from ._error import (BrainEventError, MathError, KernelError, KernelNotAvailableError, KernelCompilationError,
-                     KernelFallbackExhaustedError, KernelExecutionError, KernelLoadError, UnsupportedOperationError)
+                     KernelFallbackExhaustedError, KernelExecutionError, KernelLoadError, UnsupportedOperationError,
+                     BenchmarkDataFnNotProvidedError, KernelToolchainError, CompilationError, KernelRegistrationError)
 from . import config
 from ._registry import get_registry, get_primitives_by_tags, get_all_primitive_names
 from ._event import EventRepresentation, BinaryArray, BitPackedBinary, CompactBinary, bitpack

@@ -42,3 +42,23 @@ class KernelExecutionError(KernelError):
 
 class KernelLoadError(KernelError):
     """``libbrainevent_amd.so`` is missing or cannot be loaded."""
+
+
+class BenchmarkDataFnNotProvidedError(BrainEventError, ValueError):
+    """``benchmark()`` was called on an operator without a registered data generator (``def_benchmark_data``)."""
+
+
+class KernelToolchainError(KernelError):
+    """The compilation toolchain (hipcc) is missing or incompatible."""
+
+
+class CompilationError(KernelCompilationError):
+    """Compilation failed; carries the compiler output like the reference's class of the same name."""
+
+    def __init__(self, message: str, compiler_output: str = "", command: str = "", stage: str = "compile"):
+        super().__init__(message)
+        self.compiler_output, self.command, self.stage = compiler_output, command, stage
+
+
+class KernelRegistrationError(KernelError):
+    """Registering a kernel with the operator table failed."""

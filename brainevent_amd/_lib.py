@@ -15,7 +15,8 @@ import threading
 from pathlib import Path
 from typing import List, Optional
 
-from ._error import KernelCompilationError, KernelExecutionError, KernelLoadError, KernelNotAvailableError
+from ._error import (KernelCompilationError, KernelExecutionError, KernelLoadError, KernelNotAvailableError,
+                     KernelToolchainError)
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC_DIR = PKG_DIR / 'csrc'
@@ -41,7 +42,7 @@ def hipcc_path() -> str:
     for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and Path(cand).exists():
             return cand
-    raise KernelCompilationError("hipcc not found (set HIPCC or put /opt/rocm/bin on PATH).")
+    raise KernelToolchainError("hipcc not found (set HIPCC or put /opt/rocm/bin on PATH).")
 
 
 def needs_build() -> bool:

@@ -13,7 +13,7 @@ import warnings
 from typing import Callable, Dict, Optional, Set
 
 from . import config
-from ._error import KernelFallbackExhaustedError, KernelNotAvailableError
+from ._error import BenchmarkDataFnNotProvidedError, KernelFallbackExhaustedError, KernelNotAvailableError
 from ._registry import register_primitive
 
 PLATFORM = 'gpu'
@@ -96,8 +96,10 @@ class OpKernel:
         import time
         import numpy as np
         import torch
-        if self._call_fn is None or self._benchmark_data_fn is None:
-            raise ValueError(f"benchmark() of '{self.name}' needs def_call() and def_benchmark_data().")
+        if self._benchmark_data_fn is None:
+            raise BenchmarkDataFnNotProvidedError(f"benchmark() of '{self.name}' needs def_benchmark_data().")
+        if self._call_fn is None:
+            raise ValueError(f"benchmark() of '{self.name}' needs def_call().")
         records = []
         for cfg_name, args, kwargs in self._benchmark_data_fn(platform=platform):
             ref_out = None
