@@ -756,6 +756,18 @@ class CSR(CompressedSparseData):
         return CSC._from_parts(self.data, self.indices, self.indptr, shape=self.shape[::-1], backend=self.backend,
                                numpy_result=self._numpy_result)
 
+    def tocsr(self):
+        return self
+
+    def tocsc(self):
+        """The *same* matrix (same ``shape``) re-encoded column-major (reference ``_csr/main.py:1198-1218``); unlike
+        :meth:`transpose`, which reinterprets the arrays as ``W.T``."""
+        from ._convert import csr_to_csc_index
+        cptr, cidx, perm = csr_to_csc_index(self.indptr, self.indices, shape=self.shape)
+        cdata = self.data if self.data.numel() == 1 else self.data[perm.long()]
+        return CSC._from_parts(cdata, cidx, cptr.to(self.indptr.dtype), shape=self.shape, backend=self.backend,
+                               numpy_result=self._numpy_result)
+
     @property
     def T(self):
         return self.transpose()
@@ -805,6 +817,17 @@ class CSC(CompressedSparseData):
     def transpose(self, axes=None):
         assert axes is None, "transpose does not support axes argument."
         return CSR._from_parts(self.data, self.indices, self.indptr, shape=self.shape[::-1], backend=self.backend,
+                               numpy_result=self._numpy_result)
+
+    def tocsc(self):
+        return self
+
+    def tocsr(self):
+        """The *same* matrix (same ``shape``) re-encoded row-major (reference ``_csr/main.py:2107-2135``)."""
+        from ._convert import csc_to_csr_index
+        rptr, ridx, perm = csc_to_csr_index(self.indptr, self.indices, shape=self.shape)
+        rdata = self.data if self.data.numel() == 1 else self.data[perm.long()]
+        return CSR._from_parts(rdata, ridx, rptr.to(self.indptr.dtype), shape=self.shape, backend=self.backend,
                                numpy_result=self._numpy_result)
 
     @property

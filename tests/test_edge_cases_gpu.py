@@ -177,3 +177,19 @@ def test_indexed_products_equal_the_reindexed_matrix():
         B = rng.random((k, 4)) < 0.4
         np.testing.assert_allclose(be.binary_csrmm_indexed(w, cidx, cptr, perm, B, shape=(k, m), transpose=True),
                                    O.binary_csrmm(w, idx, ptr, B, (m, k), False), rtol=1e-5, atol=1e-5)
+
+
+def test_tocsc_tocsr_keep_the_matrix():
+    import brainevent_amd as be
+    rng = np.random.default_rng(6)
+    dense = (rng.random((23, 31)) < 0.2) * rng.standard_normal((23, 31)).astype(np.float32)
+    csr = be.CSR.fromdense(dense)
+    csc = csr.tocsc()
+    assert isinstance(csc, be.CSC) and csc.shape == csr.shape and csr.tocsr() is csr and csc.tocsc() is csc
+    np.testing.assert_array_equal(csc.todense(), dense)
+    back = csc.tocsr()
+    assert isinstance(back, be.CSR)
+    np.testing.assert_array_equal(back.todense(), dense)
+    np.testing.assert_array_equal(back.indices.cpu().numpy(), csr.indices.cpu().numpy())
+    s = rng.random(23) < 0.5
+    np.testing.assert_allclose(be.BinaryArray(s) @ csc, s.astype(np.float32) @ dense, rtol=1e-5, atol=1e-5)
