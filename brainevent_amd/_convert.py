@@ -36,6 +36,8 @@ def csr_to_coo_index(indptr, indices):
 def _group(keys: torch.Tensor, values: torch.Tensor, n_groups: int):
     """Stable grouping of ``values`` by ``keys`` in ``[0, n_groups)``: (offsets, grouped values, permutation)."""
     nnz = int(keys.numel())
+    if nnz > (1 << 31):
+        raise MemoryError("index conversion: the device sort of more than 2^31 entries is not supported.")
     od = _offset_dtype(nnz)
     order = torch.argsort(keys, stable=True)
     counts = torch.bincount(keys.to(torch.int64), minlength=n_groups)

@@ -280,6 +280,65 @@ class FixedNumConn:
     def __rmatmul__(self, other):
         return self._dispatch(other, transpose_W=True)
 
+    # -- conversions (reference ``_fcn/main.py:857-897`` / ``:1118-1160`` fromdense, ``tocsr`` / ``tocsc``) ---------------
+    @classmethod
+    def fromdense(cls, mat, *, num_conn=None, backend=None):
+        """Encode a dense ``(num_pre, num_post)`` matrix: ``num_conn`` connections per pre row (``FixedNumPerPre``) or per
+        post column (``FixedNumPerPost``); explicit zeros are absent; short rows are padded with a zero-weight entry at
+        index 0; ``num_conn=None`` requires a uniform count.  Host-side helper."""
+        dense = mat.cpu().numpy() if isinstance(mat, torch.Tensor) else np.asarray(mat)
+        if dense.ndim != 2:
+            raise ValueError(f"{cls.__name__}.fromdense expects a 2-D matrix; got {dense.ndim}-D.")
+        view = dense if cls is FixedNumPerPre or issubclass(cls, FixedNumPerPre) else dense.T
+        mask = view != 0
+        nnz = mask.sum(axis=1)
+        if num_conn is None:
+            if view.shape[0] == 0:
+                num_conn = 0
+            elif not bool((nnz == nnz[0]).all()):
+                raise ValueError(f"{cls.__name__}.fromdense: rows have a non-uniform number of connections (min {int(nnz.min())}, "
+                                 f"max {int(nnz.max())}). Pass num_conn= to pad to a fixed count, or use CSR.fromdense / "
+                                 f"CSC.fromdense for an irregular matrix.")
+            else:
+                num_conn = int(nnz[0])
+        num_conn = int(num_conn)
+        if view.shape[0] and bool((nnz > num_conn).any()):
+            raise ValueError(f"{cls.__name__}.fromdense: num_conn={num_conn} is too small; a row has {int(nnz.max())} connections.")
+        data = np.zeros((view.shape[0], num_conn), dtype=dense.dtype)
+        indices = np.zeros((view.shape[0], num_conn), dtype=np.int32)
+        for r in range(view.shape[0]):
+            cols = np.flatnonzero(mask[r])
+            data[r, :cols.size] = view[r, cols]
+            indices[r, :cols.size] = cols
+        obj = cls((data, indices), shape=dense.shape, backend=backend)
+        obj._numpy_result = not isinstance(mat, torch.Tensor)
+        return obj
+
+    def _as_compressed(self):
+        """(data, indices, indptr) of the stored rows: row ``r`` holds ``num_conn`` entries."""
+        n_rows, n_conn = int(self.indices.shape[0]), int(self.indices.shape[1])
+        indptr = torch.arange(n_rows + 1, dtype=torch.int64, device=self.indices.device) * n_conn
+        if indptr[-1].item() <= np.iinfo(np.int32).max:
+            indptr = indptr.to(torch.int32)
+        data = self.data if self.data.numel() == 1 else self.data.reshape(-1)
+        return data, self.indices.reshape(-1), indptr
+
+    def tocsr(self):
+        """The same matrix as a :class:`CSR` (``FixedNumPerPre`` rows are CSR rows; ``FixedNumPerPost`` is re-encoded)."""
+        from ._csr import CSR, CSC
+        data, idx, ptr = self._as_compressed()
+        native = (CSR if isinstance(self, FixedNumPerPre) else CSC)._from_parts(data, idx, ptr, shape=self.shape, backend=self.backend,
+                                                                             numpy_result=self._numpy_result)
+        return native.tocsr()
+
+    def tocsc(self):
+        """The same matrix as a :class:`CSC`."""
+        from ._csr import CSR, CSC
+        data, idx, ptr = self._as_compressed()
+        native = (CSR if isinstance(self, FixedNumPerPre) else CSC)._from_parts(data, idx, ptr, shape=self.shape, backend=self.backend,
+                                                                             numpy_result=self._numpy_result)
+        return native.tocsc()
+
     def todense(self):
         idx = self.indices.cpu().numpy()
         w = (self.data.float() if self.data.dtype == torch.bfloat16 else self.data).cpu().numpy()

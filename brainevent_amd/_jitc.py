@@ -387,6 +387,16 @@ class JITCMatrix:
 
     # -- materialisation (reference: ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``, ``_jit_scalar/main.py`` mode views) ----
     def tocsr(self, matrix_mode: str = 'mv'):
+        """The drawn connectivity as a :class:`CSR` of ``self.shape`` (reference ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``).
+        When the walk owners are the logical columns the native form is column-major and this re-encodes it (a device
+        sort: sizes up to 2^31 entries); :meth:`materialize` returns the native form without that step."""
+        return self.materialize(matrix_mode).tocsr()
+
+    def tocsc(self, matrix_mode: str = 'mv'):
+        """The drawn connectivity as a :class:`CSC` of ``self.shape``."""
+        return self.materialize(matrix_mode).tocsc()
+
+    def materialize(self, matrix_mode: str = 'mv'):
         """Materialise the drawn connectivity on the device.  ``matrix_mode`` picks the matrix of the ``mv`` ops
         (lane stride 32) or of the ``mm`` ops (stride 4) — they differ, as in the reference.
 

@@ -160,3 +160,33 @@ def test_fixed_num_randomized(be, oracle, monkeypatch, seed):
         np.testing.assert_allclose(be.BinaryArray(s2) @ conn.T, ref2, **tol2)
     S = np.stack([spikes_of(rng, n_pre, 0.3, 'bool') for _ in range(int(rng.integers(1, 6)))], axis=0)
     np.testing.assert_allclose(be.BinaryArray(S) @ conn, S.astype(np.float64) @ dense, **tol)
+
+
+def test_fixed_num_conversions(be):
+    """fromdense (uniform, padded, error cases) and tocsr / tocsc (reference ``_fcn/main.py:857-897``, ``:1118-1160``)."""
+    rng = np.random.default_rng(3)
+    dense = np.zeros((6, 9), np.float32)
+    for r in range(6):
+        dense[r, rng.choice(9, 3, replace=False)] = rng.uniform(0.5, 1.5, 3)
+    pre = be.FixedNumPerPre.fromdense(dense)
+    assert pre.shape == (6, 9) and tuple(pre.indices.shape) == (6, 3)
+    np.testing.assert_array_equal(pre.todense(), dense)
+    np.testing.assert_array_equal(pre.tocsr().todense(), dense)
+    np.testing.assert_array_equal(pre.tocsc().todense(), dense)
+    assert isinstance(pre.tocsr(), be.CSR) and isinstance(pre.tocsc(), be.CSC)
+    dense[0, :] = 0; dense[0, 4] = 2.0                                  # now ragged
+    with pytest.raises(ValueError, match='non-uniform'):
+        be.FixedNumPerPre.fromdense(dense)
+    with pytest.raises(ValueError, match='too small'):
+        be.FixedNumPerPre.fromdense(dense, num_conn=2)
+    padded = be.FixedNumPerPre.fromdense(dense, num_conn=4)             # zero-weight sentinel at index 0
+    np.testing.assert_array_equal(padded.todense(), dense)
+    s = rng.random(6) < 0.6
+    np.testing.assert_allclose(be.BinaryArray(s) @ padded, s.astype(np.float32) @ dense, rtol=1e-6, atol=1e-6)
+    post = be.FixedNumPerPost.fromdense(dense, num_conn=5)
+    assert post.shape == (6, 9) and tuple(post.indices.shape) == (9, 5)
+    np.testing.assert_array_equal(post.todense(), dense)
+    np.testing.assert_array_equal(post.tocsr().todense(), dense)
+    np.testing.assert_array_equal(post.tocsc().todense(), dense)
+    with pytest.raises(ValueError):
+        be.FixedNumPerPre.fromdense(dense[0])

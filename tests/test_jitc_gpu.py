@@ -199,8 +199,12 @@ def test_jitc_materialisation_matches_ops_and_oracle(be, oracle, family, cls_kin
     rng = np.random.default_rng(0)
     for mode in ('mv', 'mm'):
         S = M.tocsr(mode)
-        assert S.shape == shape
+        assert S.shape == shape and isinstance(S, be.CSR)
+        C2 = M.tocsc(mode)
+        assert isinstance(C2, be.CSC) and C2.shape == shape
         D = S.todense()
+        np.testing.assert_array_equal(C2.todense(), D)
+        np.testing.assert_array_equal(M.materialize(mode).todense(), D)
         # oracle: D[out, in] of `M @ v`
         if cls_kind == 'R':
             gshape, transpose = shape, False
