@@ -386,6 +386,24 @@ class JITCMatrix:
         return JITCScatterShard(self, world, rank)
 
     # -- materialisation (reference: ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``, ``_jit_scalar/main.py`` mode views) ----
+    # -- materialisation views: ``mat.mv`` / ``mat.mm`` (reference ``_jit_scalar/main.py:40-110``, ``:404-413``) ----------
+    @property
+    def mv(self) -> '_JITCModeView':
+        """Materialisation view of the matrix ``mat @ vector`` uses (lane stride 32)."""
+        return _JITCModeView(self, 'mv')
+
+    @property
+    def mm(self) -> '_JITCModeView':
+        """Materialisation view of the matrix ``mat @ matrix`` uses (lane stride 4) — a different draw, as in the reference."""
+        return _JITCModeView(self, 'mm')
+
+    def todense(self, matrix_mode: Optional[str] = None):
+        """Ambiguous without a mode (the mv and mm kernels draw different matrices): use ``mat.mv.todense()`` or
+        ``mat.mm.todense()`` — or pass ``matrix_mode``."""
+        if matrix_mode is None:
+            raise ValueError("todense() is ambiguous for a JIT-connectivity matrix: use mat.mv.todense() or mat.mm.todense().")
+        return self.materialize(matrix_mode).todense()
+
     def tocsr(self, matrix_mode: str = 'mv'):
         """The drawn connectivity as a :class:`CSR` of ``self.shape`` (reference ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``).
         When the walk owners are the logical columns the native form is column-major and this re-encodes it (a device
@@ -526,6 +544,23 @@ class JITCNormalC(_NormalInit):
 JITCScalarR._transposed_cls, JITCScalarC._transposed_cls = JITCScalarC, JITCScalarR
 JITCUniformR._transposed_cls, JITCUniformC._transposed_cls = JITCUniformC, JITCUniformR
 JITCNormalR._transposed_cls, JITCNormalC._transposed_cls = JITCNormalC, JITCNormalR
+
+
+class _JITCModeView:
+    """``todense`` / ``tocsr`` / ``tocsc`` of a JIT-connectivity matrix for a fixed ``matrix_mode``."""
+    __slots__ = ('_mat', '_mode')
+
+    def __init__(self, mat, mode):
+        self._mat, self._mode = mat, mode
+
+    def todense(self):
+        return self._mat.materialize(self._mode).todense()
+
+    def tocsr(self):
+        return self._mat.tocsr(self._mode)
+
+    def tocsc(self):
+        return self._mat.tocsc(self._mode)
 
 
 # =====================================================================================================

@@ -205,6 +205,11 @@ def test_jitc_materialisation_matches_ops_and_oracle(be, oracle, family, cls_kin
         D = S.todense()
         np.testing.assert_array_equal(C2.todense(), D)
         np.testing.assert_array_equal(M.materialize(mode).todense(), D)
+        view = M.mv if mode == 'mv' else M.mm
+        np.testing.assert_array_equal(view.todense(), D)
+        assert isinstance(view.tocsr(), be.CSR) and isinstance(view.tocsc(), be.CSC)
+    with pytest.raises(ValueError, match='ambiguous'):
+        M.todense()
         # oracle: D[out, in] of `M @ v`
         if cls_kind == 'R':
             gshape, transpose = shape, False
