@@ -693,3 +693,50 @@ def test_class_surface_randomized_including_square_shapes(be, monkeypatch, seed)
         got = J @ be.BinaryArray(Sk_c)
         assert got.shape == (m, nb)
         np.testing.assert_allclose(got, Jm @ Sk_c.astype(np.float64), **tol)
+
+
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 10))))
+def test_csr_type_zoo_randomized(be, oracle, monkeypatch, seed):
+    """Random combinations of structure dtypes (int32 / int64 indptr, int64 indices that are cast), weight dtypes, spike
+    dtypes and containers (numpy / device tensors), routes (plan / direct), both directions, vector and batch."""
+    import brainevent_amd._csr as C
+    rng = np.random.default_rng(7000 + seed)
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', int(rng.choice([1, 10 ** 9])))
+    m, k = int(rng.integers(1, 200)), int(rng.integers(1, 3000))
+    lens = rng.integers(0, 50, m)
+    homo = bool(rng.integers(0, 2))
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+    wdt = [np.float32, np.float64, np.float16][int(rng.integers(0, 3))]
+    w = w.astype(wdt)
+    ptr = ptr.astype([np.int32, np.int64][int(rng.integers(0, 2))])
+    idx_in = idx.astype([np.int32, np.int64][int(rng.integers(0, 2))])
+    on_device = bool(rng.integers(0, 2))
+    conv = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if on_device else (lambda a: a)
+    csr = be.CSR((conv(w), conv(idx_in), conv(ptr)), shape=(m, k))
+    assert csr.indices.dtype == torch.int32
+    tol = {np.float32: 1e-5, np.float64: 1e-10, np.float16: 2e-2}[wdt]
+    sdt = [np.bool_, np.uint8, np.int8, np.int32, np.float32, np.float64, np.float16][int(rng.integers(0, 7))]
+
+    def spikes(n, fire, shape_tail=()):
+        a = rng.random((n,) + shape_tail) < fire
+        if np.issubdtype(sdt, np.floating):
+            return np.where(a, rng.uniform(0.5, 2.0, a.shape), rng.uniform(-1.0, 0.0, a.shape)).astype(sdt), a
+        return a.astype(sdt), a
+
+    def out_np(x):
+        return x.double().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, np.float64)
+
+    w64 = w.astype(np.float64)
+    for fire in (0.1, 0.8):
+        sv, sa = spikes(m, fire)
+        ref = oracle.binary_csrmv(w64, idx, ptr, sa, (m, k), True)
+        got = be.BinaryArray(conv(sv)) @ csr
+        assert isinstance(got, torch.Tensor) == on_device
+        np.testing.assert_allclose(out_np(got), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+        sv, sa = spikes(k, fire)
+        ref = oracle.binary_csrmv(w64, idx, ptr, sa, (m, k), False)
+        np.testing.assert_allclose(out_np(csr @ be.BinaryArray(conv(sv))), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+    nb = int(rng.integers(1, 6))
+    Sv, Sa = spikes(nb, 0.3, (m,))
+    ref = np.stack([oracle.binary_csrmv(w64, idx, ptr, Sa[b], (m, k), True) for b in range(nb)])
+    np.testing.assert_allclose(out_np(be.BinaryArray(conv(Sv)) @ csr), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
