@@ -356,6 +356,22 @@ def main():
     value = total_upd / elapsed / 1e9
     checksum = float(out.double().sum().item())
 
+    copy_gbps = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 29, dtype=torch.float32, device=dev)       # 2 GiB
+            dst = torch.empty_like(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dst.copy_(src)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception:
+            copy_gbps = None
     if rank == 0:
         bytes_per_upd = 4 if args.homo else 8           # int32 index (+ f32 weight)
         mean_active = float(np.mean([active_per_vec[(args.warmup + i) % n_batch] for i in range(args.steps)]))
@@ -380,6 +396,10 @@ def main():
                            'BinnedScatter': 'k_bin_rows'}.get(args.route, 'k_csrmv_t_direct')
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    # the same run's device-copy ceiling (bytes read + written per second of a 2 GiB
+                    # device-to-device copy) next to the nominal peak, and the kernel's real traffic rate against it
+                    'device_copy_GBps': copy_gbps,
+                    'traffic_GBps': (round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None),
                     'kernel': kernel_name,
                     'kernel_ms': round(kern_ms, 5), 'algorithmic_bytes_per_launch': int(alg_bytes)}
         line = {
