@@ -344,6 +344,7 @@ def main():
     n_rec = prof_read(ctypes.cast(ms, ctypes.c_void_p), args.steps)
     prof_enable(0)
     kern_ms = float(np.mean(ms[:n_rec])) if n_rec > 0 else None
+    kern_ms_median = float(np.median(ms[:n_rec])) if n_rec > 0 else None
 
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -401,7 +402,8 @@ def main():
                     'device_copy_GBps': copy_gbps,
                     'traffic_GBps': (round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None),
                     'kernel': kernel_name,
-                    'kernel_ms': round(kern_ms, 5), 'algorithmic_bytes_per_launch': int(alg_bytes)}
+                    'kernel_ms': round(kern_ms, 5), 'kernel_ms_median': round(kern_ms_median, 5),
+                    'algorithmic_bytes_per_launch': int(alg_bytes)}
         line = {
             'metric': 'synaptic updates/sec (Geff/s), BinaryArray @ ' + ('FixedNumPerPre scatter' if is_fcn else 'CSR scatter'),
             'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
