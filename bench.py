@@ -106,12 +106,36 @@ def cpu_baseline(args, n_post, n_conn):
         t_used += time.perf_counter() - t0
         upd += int(s.sum()) * n_conn
         steps += 1
-    return {
+    res = {
         'value': upd / t_used / 1e9, 'unit': 'Geff/s', 'cores': 1, 'kind': 'port',
         'sample': f'{rows} of {args.n} pre rows (n_post={n_post}, {n_conn} synapses/row, fire={args.fire}), '
                   f'{steps} steps, C port of the reference numba loop _csr/binary.py:446-451, gcc -O3 -march=native',
         'host_cpus': os.cpu_count(),
     }
+    # the all-cores variant next to it (OpenMP over the active rows + atomic adds).  NOT the reference's
+    # algorithm (its scatter is serial by construction) — and on this host slower than the serial loop: float atomics on a
+    # shared 4 MB vector bounce cache lines between cores.  A few seconds only.
+    try:
+        avail = len(os.sched_getaffinity(0))
+        best = None
+        for n_thr in sorted({min(avail, t) for t in (4, 16, 64, avail)}):     # the best thread count is the bound
+            oracle_c.csrmv_t_f32_parallel(w, indices, indptr, spikes[0], (rows, n_post), n_thr)
+            upd_p, t_p, steps_p = 0, 0.0, 0
+            while t_p < 1.0 and steps_p < 10000:
+                s = spikes[steps_p % len(spikes)]
+                t0 = time.perf_counter()
+                oracle_c.csrmv_t_f32_parallel(w, indices, indptr, s, (rows, n_post), n_thr)
+                t_p += time.perf_counter() - t0
+                upd_p += int(s.sum()) * n_conn
+                steps_p += 1
+            if best is None or upd_p / t_p > best[0]:
+                best = (upd_p / t_p, n_thr)
+        res['parallel_atomics_variant'] = {'value': best[0] / 1e9, 'unit': 'Geff/s', 'cores': best[1], 'cores_available': avail,
+                                        'what': 'same loop, OpenMP over active rows + atomic adds, best of 4 / 16 / 64 / all '
+                                                'threads (not the reference algorithm)'}
+    except Exception as e:
+        res['parallel_atomics_variant'] = {'error': repr(e)}
+    return res
 
 
 def time_steps(step, steps, warmup):

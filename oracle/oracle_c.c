@@ -34,6 +34,28 @@ void oracle_csrmv_t_f32(const float* w, int homo, const int32_t* indices, const 
   }
 }
 
+/* ---- CSR, transpose=True, f32, all host cores (NOT what the reference does) ----------------------------------
+ * An upper bound for the CPU side: the same loop with the active rows spread over OpenMP threads and
+ * the scatter made safe with atomic adds.  The reference's kernel is serial ("Cannot parallelize due to race
+ * condition", brainevent/_csr/binary.py:397/:444); this variant only answers "what if it were not". */
+void oracle_csrmv_t_f32_parallel(const float* w, int homo, const int32_t* indices, const int64_t* indptr, const void* v,
+                                 int v_is_float, int64_t m, int64_t k, float* posts, int n_threads) {
+  memset(posts, 0, (size_t)k * sizeof(float));
+  const uint8_t* vb = (const uint8_t*)v;
+  const float* vf = (const float*)v;
+  const float w0 = w[0];
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+  for (int64_t i = 0; i < m; ++i) {
+    const int on = v_is_float ? (vf[i] > 0.f) : (vb[i] != 0);
+    if (!on) continue;
+    for (int64_t j = indptr[i]; j < indptr[i + 1]; ++j) {
+      const float x = homo ? w0 : w[j];
+#pragma omp atomic
+      posts[indices[j]] += x;
+    }
+  }
+}
+
 /* ---- CSR, transpose=False, f32 ------------------------------------------------------------------
  * brainevent/_csr/binary.py:421-428, :432-439 (homo), :466-472, :476-482 (hetero): prange over rows. */
 void oracle_csrmv_nt_f32(const float* w, int homo, const int32_t* indices, const int64_t* indptr,

@@ -47,6 +47,24 @@ def csrmv_f32(w, indices, indptr, v, shape, transpose):
     return out
 
 
+def csrmv_t_f32_parallel(w, indices, indptr, v, shape, n_threads=8):
+    """All-cores upper bound of the scatter (OpenMP + atomic adds); NOT the reference's algorithm, see oracle_c.c."""
+    w = np.ascontiguousarray(w, dtype=np.float32).reshape(-1)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    v = np.ascontiguousarray(v)
+    is_float = int(v.dtype == np.float32)
+    if not is_float:
+        v = v.astype(np.uint8)
+    m, k = shape
+    out = np.empty(k, dtype=np.float32)
+    f = lib().oracle_csrmv_t_f32_parallel
+    f.argtypes = [_vp, _int, _vp, _vp, _vp, _int, _i64, _i64, _vp, _int]
+    f.restype = None
+    f(_p(w), int(w.size == 1), _p(indices), _p(indptr), _p(v), is_float, m, k, _p(out), int(n_threads))
+    return out
+
+
 def densemv_f32(w, s, transpose):
     w = np.ascontiguousarray(w, dtype=np.float32)
     s = np.ascontiguousarray(s)

@@ -135,3 +135,18 @@ def test_c_oracle_jit_and_dense_match_numpy_oracle():
     for transpose in (True, False):
         s = rng.random(11 if transpose else 13) < 0.5
         np.testing.assert_allclose(oracle_c.densemv_f32(W, s, transpose), O.binary_densemv(W, s, transpose), rtol=1e-6, atol=1e-6)
+
+
+def test_c_oracle_parallel_variant_equals_serial():
+    """The OpenMP + atomics variant timed by bench.py's cpu_baseline (not the reference's algorithm) adds the same numbers."""
+    from oracle import oracle_c
+    rng = np.random.default_rng(0)
+    m, k = 300, 2000
+    lens = rng.integers(0, 40, m)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    v = rng.random(m) < 0.4
+    for w in (np.ones(1, np.float32), rng.integers(1, 8, ptr[-1]).astype(np.float32)):     # integers: order independent
+        a = oracle_c.csrmv_t_f32_parallel(w, idx, ptr, v, (m, k), 4)
+        b = oracle_c.csrmv_f32(w, idx, ptr, v, (m, k), True)
+        np.testing.assert_array_equal(a, b)
