@@ -39,7 +39,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--n', type=int, default=1_000_000, help='pre = post population per GPU shard')
+    ap.add_argument('--n', '--neurons', dest='n', type=int, default=1_000_000, help='pre = post population per GPU shard '
+                    '(--neurons: the spelling to use under torch.distributed.run, whose own parser trips over --n)')
     ap.add_argument('--conn', type=float, default=0.01)
     ap.add_argument('--fire', type=float, default=0.01)
     ap.add_argument('--homo', action='store_true', help='homogeneous weight (4 B/update) instead of hetero f32')
@@ -250,8 +251,9 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % n_dev)          # (rehearsals put several ranks on one card; the driver has one GPU per rank)
+    dev = torch.device('cuda', local_rank % n_dev)
     dist = None
     # BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, all-gather, max-reduce) with a single rank:
     # the only way to exercise it on a one-GPU box
@@ -262,7 +264,11 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('BENCH_BACKEND', 'nccl')      # nccl = RCCL; 'gloo' only to rehearse several ranks on one card
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import brainevent_amd as be
     from brainevent_amd import _csr as C, _lib
