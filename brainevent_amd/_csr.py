@@ -201,6 +201,29 @@ def _fixed_point_exponent(weights: torch.Tensor, indices: torch.Tensor, k: int) 
     return max(-90, min(150, 62 - eb))                                         # 2^(e-32) must be a normal f32
 
 
+def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str:
+    """``'plan'``, ``'binned'`` or ``'direct'`` for a matrix of ``nse`` entries, ``m`` stored rows and ``k`` outputs.
+
+    Measured on FixedNumPerPre K = 1000, 1 % firing (``tools/exp_plan_vs_binned.py``; entries per (row, slice) -> planned vs
+    binned, us/step): homo 62: 33 / 66, 31: 48 / 74, 20: 81 / 93, 16: 122 / 109, 8: 310 / 137; hetero 40: 40 / 69,
+    20: 82 / 99, 12: 165 / 123, 8: 295 / 153.  The planned layout pays per block, the binned route per entry: they cross
+    at about 18 entries per block."""
+    if nse < PLAN_MIN_NNZ or m <= 0 or k <= 0 or weights.dtype == torch.float64:
+        return 'direct'
+    homo = weights.numel() == 1
+    shift = ScatterPlan.default_shift(k, homo)
+    cap = (1 << shift) if homo or shift < ScatterPlan.HETERO_SHIFT else ScatterPlan.D8_CAP
+    n_slices = -(-k // ScatterPlan.balanced_width_cap(k, cap))
+    per_block = nse / (m * n_slices)
+    if n_slices <= 4096 and per_block >= PLAN_MIN_SEGMENT:
+        return 'plan'
+    if BinnedScatter.applicable(weights, k):
+        return 'binned'
+    if n_slices <= 4096 and per_block >= PLAN_MIN_SEGMENT_NO_BINNED:
+        return 'plan'
+    return 'direct'
+
+
 def _abs_range(weights: torch.Tensor, chunk: int = 1 << 27):
     """``(max |w|, smallest non-zero |w| or inf)`` in chunks (1e10 weights: no 40 GB temporaries; nan -> max is nan)."""
     flat = weights.reshape(-1)
@@ -535,7 +558,8 @@ def binary_csrmm_indexed(data, indices, indptr, perm, B, *, shape, workspace=Non
 #: matrices with fewer stored elements than this use the direct kernel (plan build is not worth it)
 PLAN_MIN_NNZ = 1 << 22
 #: below this average number of entries per (row, slice) segment the plan degenerates into pointer chasing
-PLAN_MIN_SEGMENT = 8
+PLAN_MIN_SEGMENT = 18       # entries per (row, slice) from which the planned layout beats the binned route (measured: choose_scatter_route)
+PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply
 
 
 class CompressedSparseData:
@@ -637,20 +661,14 @@ class CompressedSparseData:
         m, k = self._plan_shape()
         plan = None
         if self.nse >= PLAN_MIN_NNZ and m > 0 and k > 0:
-            homo = self.data.numel() == 1
-            shift = ScatterPlan.default_shift(k, homo)
-            n_slices = (k + (1 << shift) - 1) >> shift
-            if self.nse / (m * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096 and \
-                    self.data.dtype != torch.float64:
-                try:
-                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k), slice_shift=shift)
-                except MathError:
-                    plan = None       # inf / nan / extreme dynamic range: float atomics (direct route) handle those
-            elif BinnedScatter.applicable(self.data, k):
-                try:
+            route = choose_scatter_route(self.nse, m, k, self.data)
+            try:
+                if route == 'plan':
+                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k))
+                elif route == 'binned':
                     plan = BinnedScatter(self.data, m, k, self.nse, indices=self.indices)
-                except MathError:
-                    plan = None
+            except MathError:
+                plan = None           # inf / nan / extreme dynamic range: float atomics (direct route) handle those
         self.buffers['scatter_plan'] = plan
         return plan
 
@@ -680,17 +698,14 @@ class CompressedSparseData:
         t_indptr = t_indptr.to(self.indptr.dtype)
         t_data = self.data if self.data.numel() == 1 else self.data[order.long()].contiguous()
         mirror = {'data': t_data, 'indices': t_indices, 'indptr': t_indptr, 'shape': (k, m), 'plan': None}
-        homo = t_data.numel() == 1
-        if nse >= PLAN_MIN_NNZ and t_data.dtype != torch.float64:
-            shift = ScatterPlan.default_shift(m, homo)
-            n_slices = (m + (1 << shift) - 1) >> shift
-            try:
-                if nse / (k * n_slices) >= PLAN_MIN_SEGMENT and n_slices <= 4096:
-                    mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m), slice_shift=shift)
-                elif BinnedScatter.applicable(t_data, m):
-                    mirror['plan'] = BinnedScatter(t_data, k, m, nse, indices=t_indices)
-            except MathError:        # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel
-                mirror['plan'] = None
+        route = choose_scatter_route(nse, k, m, t_data)
+        try:
+            if route == 'plan':
+                mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m))
+            elif route == 'binned':
+                mirror['plan'] = BinnedScatter(t_data, k, m, nse, indices=t_indices)
+        except MathError:            # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel
+            mirror['plan'] = None
         self.buffers['mirror'] = mirror
         return mirror
 

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _array as A
-from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, _csrmm_generic, PLAN_MIN_SEGMENT
+from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, _csrmm_generic
 from . import _csr as _csr_mod
 from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
@@ -216,21 +216,14 @@ class FixedNumConn:
             return self.buffers['scatter_plan']
         n_rows, n_cols = self._a_shape
         plan = None
-        if self.nse >= _csr_mod.PLAN_MIN_NNZ and n_rows > 0 and n_cols > 0 and self.data.dtype != torch.float64:
-            homo = self.data.numel() == 1
-            shift = ScatterPlan.default_shift(n_cols, homo)
-            n_slices = (n_cols + (1 << shift) - 1) >> shift
-            if self.num_conn / n_slices >= PLAN_MIN_SEGMENT and n_slices <= 4096:
-                try:
-                    plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols),
-                                             row_len=self.num_conn, slice_shift=shift)
-                except _csr_mod.MathError:
-                    plan = None
-            elif BinnedScatter.applicable(self.data, n_cols):
-                try:
-                    plan = BinnedScatter(self.data, n_rows, n_cols, self.nse, indices=self.indices)
-                except _csr_mod.MathError:
-                    plan = None
+        route = _csr_mod.choose_scatter_route(self.nse, n_rows, n_cols, self.data)
+        try:
+            if route == 'plan':
+                plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols), row_len=self.num_conn)
+            elif route == 'binned':
+                plan = BinnedScatter(self.data, n_rows, n_cols, self.nse, indices=self.indices)
+        except _csr_mod.MathError:
+            plan = None
         self.buffers['scatter_plan'] = plan
         return plan
 
