@@ -67,6 +67,7 @@ class ScatterPlan:
         self.seg, self.blob = seg, blob
         self.scale_exp = int(scale_exp)
         self.weight_dtype = weight_dtype
+        self.nnz = 0                      # stored entries (set by build): sizes the number of parts
         self._ws: Dict = {}
 
     # -- sizing ---------------------------------------------------------------------------------
@@ -96,8 +97,13 @@ class ScatterPlan:
         return max(1, min(cap, (int(k) + n - 1) // n))
 
     def default_parts(self) -> int:
-        # one 1024-thread workgroup per CU: aim for ~256 workgroups in total
-        return int(max(1, min(64, 256 // max(self.n_slices, 1))))
+        """Workgroups per slice.  One 1024-thread workgroup per CU at most (~256 in total), but not more than the matrix can
+        feed: every part writes the slice's accumulators once and the reduce reads them back, so a 100k-column matrix cut
+        into 51 parts moved 80 MB of partial sums per step for 1e5 updates (33-40 us per step; 24 us, the host's issue
+        rate, with parts sized by the entries per slice; ``tools/exp_plan_vs_direct.py``)."""
+        by_chip = 256 // max(self.n_slices, 1)
+        by_work = -(-self.nnz // (max(self.n_slices, 1) << 17)) if self.nnz else by_chip
+        return int(max(1, min(64, by_chip, max(1, by_work))))
 
     def nbytes(self) -> int:
         return self.seg.numel() * 4 + self.blob.numel()
@@ -182,7 +188,9 @@ class ScatterPlan:
             if int(mm[1]) != 0xFFFFFFFF and not _fixed_point_resolves(weights, indices, k, scale_exp, wmin):
                 raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
                                 f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
-        return cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width, lay)
+        plan = cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width, lay)
+        plan.nnz = int(indices.numel())
+        return plan
 
 
 def _fixed_point_exponent(weights: torch.Tensor, indices: torch.Tensor, k: int) -> int:
@@ -556,7 +564,7 @@ def binary_csrmm_indexed(data, indices, indptr, perm, B, *, shape, workspace=Non
 # containers
 # =====================================================================================================
 #: matrices with fewer stored elements than this use the direct kernel (plan build is not worth it)
-PLAN_MIN_NNZ = 1 << 22
+PLAN_MIN_NNZ = 1 << 18          # below this the direct kernel is as fast (both are at the host issue floor) and needs no build
 #: below this average number of entries per (row, slice) segment the plan degenerates into pointer chasing
 PLAN_MIN_SEGMENT = 18       # entries per (row, slice) from which the planned layout beats the binned route (measured: choose_scatter_route)
 PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply
