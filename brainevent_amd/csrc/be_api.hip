@@ -31,6 +31,7 @@ int be_device_count(void) {
 // stream that kernel is launched on (bench.py reads them back for the roofline figure).
 // ------------------------------------------------------------------------------------------------
 #include <vector>
+#include <tuple>
 #include <mutex>
 
 namespace {
@@ -54,6 +55,26 @@ __global__ void __launch_bounds__(256) k_fill_bytes(unsigned char* __restrict__ 
   for (size_t i = h + (n16 << 4) + t; i < n; i += stride) p[i] = v;
 }
 }  // namespace
+
+hipError_t be_allow_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::tuple<const void*, int, int>> granted;      // (kernel, device, largest size granted)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& g : granted) {
+    if (std::get<0>(g) == kernel && std::get<1>(g) == dev) {
+      if (std::get<2>(g) >= bytes) return hipSuccess;
+      e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) std::get<2>(g) = bytes;
+      return e;
+    }
+  }
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) granted.emplace_back(kernel, dev, bytes);
+  return e;
+}
 
 hipError_t be_fill_async(void* p, int byte_value, size_t bytes, hipStream_t st) {
   if (bytes == 0) return hipSuccess;

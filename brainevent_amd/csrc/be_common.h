@@ -21,6 +21,8 @@ void be_set_error(const std::string& msg);
 // Byte fill by a kernel.  Used instead of hipMemsetAsync everywhere on the step paths: a captured memset node of a few
 // hundred KB replayed wrongly on this ROCm (half of a 160 KB buffer kept its old contents), kernels capture reliably.
 hipError_t be_fill_async(void* p, int byte_value, size_t bytes, hipStream_t st);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): the call costs host time on every launch
+hipError_t be_allow_lds(const void* kernel, int bytes);
 // optional HIP-event timing of an op's dominant kernel (be_api.hip); slot -1 = profiling off
 int be_prof_begin(hipStream_t st);
 void be_prof_end(int slot, hipStream_t st);

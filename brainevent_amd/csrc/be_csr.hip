@@ -1081,7 +1081,7 @@ int csrmv_nt_launch(const void* weights, const int32_t* indices, RowPtr rp, cons
   const int prof = be_prof_begin(st);
   if (lds <= 150 * 1024) {
     auto kern = k_csrmv_nt<W, HOMO, LPR, true>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(256), lds, st, static_cast<const W*>(weights), indices, rp,
                        bits, n_words, static_cast<W*>(out), m);
   } else {
@@ -1103,7 +1103,7 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     uint32_t* mask = static_cast<uint32_t*>(ws);
     const size_t lds = (size_t)1024 * kFusedSlots * 4;
     auto kern = k_csrmm_nt_fused<W, HOMO>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     const size_t ssz = sd == BE_SPIKE_FLOAT ? 4 : 1;
     for (int64_t c0 = 0; c0 < nb; c0 += 32) {
       const int nc = (int)std::min<int64_t>(32, nb - c0);
@@ -1138,7 +1138,7 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     const int prof = be_prof_begin(st);
     if (lds <= 150 * 1024) {
       auto kern = k_csrmv_nt_wave<W, HOMO, true>;
-      BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
       hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
                          bits, n_words, static_cast<W*>(out), m);
     } else {
@@ -1902,7 +1902,7 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
     BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 layout: rows of at most 16384 entries");
     BE_REQUIRE(n_slices <= kD8MaxSlices, BE_ERR_RANGE, "too many slices for the d8 layout");
     auto kern = k_plan_d8_count;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kD8MaxRow * 8));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
     hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
                        (uint32_t)width_of(slice_shift, slice_width), n_slices, sg);
   } else {
@@ -1951,7 +1951,7 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
 #define BE_D8_FILL(WT)                                                                                                   \
     {                                                                                                                    \
       auto kern = k_plan_d8_fill<WT>;                                                                                    \
-      BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,        \
+      BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern),        \
                                  kD8MaxRow * 8));                                                                        \
       hipLaunchKernelGGL(kern, dim3(g8), dim3(1024), kD8MaxRow * 8, st, static_cast<const WT*>(weights), indices, rp, m, \
                          wdt, n_slices, static_cast<const uint2*>(seg), static_cast<unsigned char*>(blob), maxabs_bits); \
@@ -2025,17 +2025,17 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const int prof = be_prof_begin(st);
   if (homo) {
     auto kern = k_plan_accumulate<true>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride);
   } else if (layout == BE_PLAN_D8) {
     auto kern = k_plan_accumulate_d8;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, (int)S, parts, scale, static_cast<unsigned long long*>(partial), astride);
   } else {
     auto kern = k_plan_accumulate<false>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
                        astride);
@@ -2128,12 +2128,12 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   const double inv_scale = ldexp(1.0, -scale_exp);
   if (homo) {
     auto kern = k_bin_accumulate<true>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap,
                        slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(weights), static_cast<float*>(out));
   } else {
     auto kern = k_bin_accumulate<false>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap,
                        slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(nullptr), static_cast<float*>(out));
   }

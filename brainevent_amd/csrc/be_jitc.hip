@@ -500,7 +500,7 @@ int jit_mv_gather(const JitP& p, const void* spikes, int sd, void* out, int64_t 
   const int prof = be_prof_begin(st);
   if (lds <= 150 * 1024) {
     auto kern = k_jit_mv_gather<MODE, true>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, p, bits, m, partial);
   } else {
     hipLaunchKernelGGL((k_jit_mv_gather<MODE, false>), grid, dim3(1024), 0, st, p, bits, m, partial);
@@ -542,12 +542,12 @@ int jit_scatter_batched(const JitP& p, const void* spikes_bm, int sd, void* out_
   const int prof = be_prof_begin(st);
   if (g.pieces == 1) {
     auto kern = k_jit_mv_scatter<MODE, true>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial,
                        astride);
   } else {
     auto kern = k_jit_mv_scatter<MODE, false>;
-    BE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, active, count, g.pieces, g.parts, g.piece_len, fx_scale, partial,
                        astride);
   }
