@@ -101,6 +101,8 @@ class ScatterPlan:
         feed: every part writes the slice's accumulators once and the reduce reads them back, so a 100k-column matrix cut
         into 51 parts moved 80 MB of partial sums per step for 1e5 updates (33-40 us per step; 24 us, the host's issue
         rate, with parts sized by the entries per slice; ``tools/exp_plan_vs_direct.py``)."""
+        if self.n_slices == 1 and 0 < self.nnz <= (1 << 20):
+            return 1          # small matrix: the single-launch kernel (k_plan_single) takes the whole step
         by_chip = 256 // max(self.n_slices, 1)
         by_work = -(-self.nnz // (max(self.n_slices, 1) << 17)) if self.nnz else by_chip
         return int(max(1, min(64, by_chip, max(1, by_work))))
@@ -564,7 +566,7 @@ def binary_csrmm_indexed(data, indices, indptr, perm, B, *, shape, workspace=Non
 # containers
 # =====================================================================================================
 #: matrices with fewer stored elements than this use the direct kernel (plan build is not worth it)
-PLAN_MIN_NNZ = 1 << 18          # below this the direct kernel is as fast (both are at the host issue floor) and needs no build
+PLAN_MIN_NNZ = 1 << 15          # below this the direct kernel is used (nothing to gain from a layout)
 #: below this average number of entries per (row, slice) segment the plan degenerates into pointer chasing
 PLAN_MIN_SEGMENT = 18       # entries per (row, slice) from which the planned layout beats the binned route (measured: choose_scatter_route)
 PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply

@@ -740,3 +740,34 @@ def test_csr_type_zoo_randomized(be, oracle, monkeypatch, seed):
     Sv, Sa = spikes(nb, 0.3, (m,))
     ref = np.stack([oracle.binary_csrmv(w64, idx, ptr, Sa[b], (m, k), True) for b in range(nb)])
     np.testing.assert_allclose(out_np(be.BinaryArray(conv(Sv)) @ csr), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize('layout', ['d8', 'u16', 'homo'])
+@pytest.mark.parametrize('m', [1, 700, 4096, 4097, 20000])
+def test_single_launch_planned_step(be, oracle, layout, m):
+    """Small matrices (one output slice, one part) run compaction + accumulate + output conversion in one single-workgroup
+    launch (k_plan_single): spike vectors shorter, equal and longer than the 4096-spike compaction pass, all layouts, bool
+    and float spikes, f32 and f16 weights, no / all / some rows active."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(m)
+    k = 3000
+    lens = rng.integers(0, 12, m)
+    if m >= 700:
+        lens[5] = 900                                     # one long row (several 64-lane chunks of a block)
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=(layout == 'homo'))
+    for wdt in (np.float32, np.float16):
+        ww = w.astype(wdt)
+        plan = ScatterPlan.build(ww, idx, torch.tensor(ptr), shape=(m, k), layout=None if layout == 'homo' else layout)
+        assert plan.n_slices == 1 and plan.default_parts() == 1
+        tol = 1e-5 if wdt == np.float32 else 2e-2
+        for v in (np.zeros(m, bool), np.ones(m, bool), rng.random(m) < 0.1, np.where(rng.random(m) < 0.5, 1.5, -2.0).astype(np.float32)):
+            ref = oracle.binary_csrmv(ww.astype(np.float32), idx, ptr, v, (m, k), True)
+            got = be.binary_csrmv(ww, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+            np.testing.assert_allclose(np.asarray(got, np.float32), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+            # same numbers as the three-kernel path (two parts force it): integer sums do not depend on the split
+            got3 = torch.empty(k, dtype=torch.float32 if wdt == np.float32 else torch.float16, device='cuda')
+            from brainevent_amd._csr import _plan_call
+            from brainevent_amd import _array as A
+            sp, sd = A.spikes_to_device(v)
+            _plan_call(plan, A.to_device(ww), sp, sd, got3.reshape(1, -1), parts=2)
+            np.testing.assert_array_equal(got3.float().cpu().numpy(), np.asarray(got, np.float32))
