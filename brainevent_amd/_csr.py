@@ -42,7 +42,10 @@ c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 class ScatterPlan:
     """Post-sliced row segments of a CSR / fixed-number-connectivity matrix (device resident).
 
-    Built once per matrix (structure + weights), reused by every ``spk @ matrix`` call.  Fields:
+    Built once per matrix (structure + weights), reused by every ``spk @ matrix`` call.  The plan owns one workspace
+    (active list, partial sums, a counter that every call leaves zeroed for the next): calls on one plan must be ordered
+    on a stream (any single stream, or streams that wait on each other) — two streams running the same plan concurrently
+    would share that workspace.  Fields:
     ``seg`` int32 view of ``{uint32 block start / 128 B, uint32 n4}`` per (row, slice), ``blob`` uint8 (the
     128-byte aligned blocks ``[f32 weights][uint16 local columns]``), ``slice_shift``, ``scale_exp``
     (fixed-point exponent).  See ``include/brainevent_amd.h`` for the exact layout.
