@@ -19,6 +19,7 @@ from ._fcn import (FixedNumConn, FixedNumPerPre, FixedNumPerPost, binary_fcnmv, 
 from ._dense import (Dense, binary_densemv, binary_densemm, binary_densemv_p, binary_densemm_p, binary_densemv_p_call,
                      binary_densemm_p_call)
 from ._convert import csr_to_coo_index, coo_to_csc_index, coo2csr, csr_to_csc_index, csc_to_csr_index
+from ._graph import GraphedStep, capture_step
 from ._hybrid import HybridConfig, get_hybrid_config, hybrid_task_capacity
 from ._op import OpKernel
 XLACustomKernel = OpKernel      # the operator object under the reference's name (no XLA underneath)

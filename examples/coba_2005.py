@@ -56,19 +56,12 @@ def run_graph(scale=1.0, steps=10000, dt=0.1):
         st['ge'].copy_(ge); st['gi'].copy_(gi); st['spk'].copy_(s)
         st['count'] += s
 
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            step()                       # warm up outside capture (workspaces, caches)
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
+    graphed = be.capture_step(step)      # warm-up on a side stream (plans, workspaces), then one capture
     st['count'].zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        graph.replay()
+        graphed()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return n, el, float(st['count'].sum().item()) / n / (steps * dt * 1e-3)
