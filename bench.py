@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--parts', type=int, default=0)
     ap.add_argument('--shift', type=int, default=0)
     ap.add_argument('--width', type=int, default=0, help='columns per slice of the scatter plan (0 = balanced automatically)')
+    ap.add_argument('--layout', choices=['u16', 'd8', 'h8'], default=None, help='block layout of the scatter plan (default: '
+                    'the delta layout that applies)')
     ap.add_argument('--workload', choices=['csr', 'jitc', 'fcn', 'dense'], default='csr',
                     help='csr = the headline C2 config; the others are the secondary BASELINE.json configs (single GPU)')
     ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
@@ -306,7 +308,8 @@ def main():
     if not is_fcn and args.route == 'plan':
         # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
         csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post),
-                                                          slice_shift=args.shift or None, slice_width=args.width or None)
+                                                          slice_shift=args.shift or None, slice_width=args.width or None,
+                                                          layout=args.layout or None)
         plan = csr.buffers['scatter_plan']
         plan_bytes = plan.nbytes()
         if args.parts:
@@ -416,14 +419,14 @@ def main():
                 try:
                     tj = json.load(open(tpath))
                     # PMC figures exist for the default workload only (density 1 %, firing 1 %), per block layout
-                    lay = 'd8' if (args.route == 'plan' and getattr(plan, 'layout', 0) == 1) else 'u16'
+                    lay = {1: 'd8', 2: 'h8'}.get(getattr(plan, 'layout', 0) if args.route == 'plan' else 0, 'u16')
                     key = f"{'homo' if args.homo else 'hetero'}_{lay}_n{args.n}"
                     if args.conn == 0.01 and args.fire == 0.01 and args.route == 'plan' and world == 1:
                         traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
-            kernel_name = {'plan': 'k_plan_accumulate_d8' if getattr(plan, 'layout', 0) == 1 else 'k_plan_accumulate',
-                           'ScatterPlan': 'k_plan_accumulate_d8' if getattr(plan, 'layout', 0) == 1 else 'k_plan_accumulate',
+            plan_kernel = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate')
+            kernel_name = {'plan': plan_kernel, 'ScatterPlan': plan_kernel,
                            'BinnedScatter': 'k_bin_rows'}.get(args.route, 'k_csrmv_t_direct')
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
@@ -449,7 +452,7 @@ def main():
                        'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange}' + (', posted one step ahead' if ahead else '') + ')' if use_dist else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
                        'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '
-                                       f"layout {'d8 (5 B/entry)' if plan.layout == 1 else 'u16'}" if plan is not None else None),
+                                       f"layout {({1: 'd8 (5 B/entry)', 2: 'h8 (1 B/entry)'}.get(plan.layout, 'u16'))}" if plan is not None else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},
             'roofline': roof,
         }

@@ -57,9 +57,9 @@ class ScatterPlan:
     #: a plan is refused when its smallest non-zero weight would be represented with fewer bits than this
     MIN_WEIGHT_BITS = 16
 
-    #: block layouts (C ABI codes BE_PLAN_U16 / BE_PLAN_D8)
-    LAYOUT_U16, LAYOUT_D8 = 0, 1
-    D8_MAX_ROW, D8_MAX_SLICES, D8_CAP = 16384, 1024, 20000
+    #: block layouts (C ABI codes BE_PLAN_U16 / BE_PLAN_D8 / BE_PLAN_H8)
+    LAYOUT_U16, LAYOUT_D8, LAYOUT_H8 = 0, 1, 2
+    D8_MAX_ROW, D8_MAX_SLICES, D8_CAP, H8_CAP = 16384, 1024, 20000, 40000
 
     def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype, slice_width=0, layout=0):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
@@ -131,15 +131,18 @@ class ScatterPlan:
         """Build the plan on the device.  ``indptr=None`` + ``row_len`` describes fixed-length rows.  ``slice_shift``
         (accumulator capacity) and ``slice_width`` (columns per slice) default to the LDS-filling capacity and the
         balanced width; an explicit ``slice_shift`` alone means full-capacity slices.  ``layout``: ``'u16'`` (uint16
-        local columns, 6 B per weighted entry), ``'d8'`` (sorted columns as uint8 deltas, 5 B per entry: heterogeneous
-        weights, rows of at most 16384 entries, at most 1024 slices) or ``None`` = ``'d8'`` whenever it applies."""
+        local columns, 6 B per weighted entry / 2 B per counted one), ``'d8'`` (sorted columns as uint8 deltas, 5 B per
+        entry: heterogeneous weights), ``'h8'`` (uint8 advance codes, 1 B per entry: one homogeneous weight) — both for
+        rows of at most 16384 entries and at most 1024 slices — or ``None`` = the delta layout whenever it applies."""
         m, k = int(shape[0]), int(shape[1])
         weights = A.to_device(weights).reshape(-1)
         indices = A.to_device(indices).reshape(-1)
         assert indices.dtype == torch.int32
         homo = weights.numel() == 1
-        if layout not in (None, 'u16', 'd8'):
-            raise ValueError(f"layout must be 'u16', 'd8' or None, got {layout!r}.")
+        if layout not in (None, 'u16', 'd8', 'h8'):
+            raise ValueError(f"layout must be 'u16', 'd8', 'h8' or None, got {layout!r}.")
+        if layout == ('h8', 'd8')[homo]:
+            raise ValueError("d8 is the layout of heterogeneous weights, h8 the one of a homogeneous weight.")
         if slice_shift is None:
             slice_shift = cls.default_shift(k, homo)
         dev = A.device()
@@ -147,26 +150,27 @@ class ScatterPlan:
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         if indptr is not None:
             indptr = A.to_device(indptr)
-        # block layout: d8 whenever it applies (heterogeneous non-f64 weights, rows the LDS sort holds, <= 1024 slices)
-        d8_ok = (not homo) and weights.dtype != torch.float64 and layout != 'u16'
+        # block layout: sorted deltas (d8 / h8) whenever they apply (non-f64 weights, rows the LDS sort holds, <= 1024 slices)
+        d8_ok = weights.dtype != torch.float64 and layout != 'u16'
         if d8_ok:
             max_row = int(row_len) if indptr is None else (int((indptr[1:] - indptr[:-1]).max().item()) if m > 0 else 0)
             d8_ok = max_row <= cls.D8_MAX_ROW
+        delta_cap = cls.H8_CAP if homo else cls.D8_CAP
         auto_width = slice_width is None
-        if auto_width:   # balanced slices; the d8 layout may use the whole LDS (no power-of-two capacity) at the default shift
-            cap = cls.D8_CAP if (d8_ok and slice_shift >= cls.HETERO_SHIFT) else (1 << slice_shift)
-            slice_width = cls.balanced_width_cap(k, cap)
+        if auto_width:   # balanced slices; the delta layouts may use the whole LDS (no power-of-two capacity) at the default shift
+            full = slice_shift >= (cls.HOMO_SHIFT if homo else cls.HETERO_SHIFT)
+            slice_width = cls.balanced_width_cap(k, delta_cap if (d8_ok and full) else (1 << slice_shift))
         n_slices = (k + slice_width - 1) // slice_width
         if d8_ok and n_slices > cls.D8_MAX_SLICES:
             d8_ok = False
             if auto_width:
                 slice_width = cls.balanced_width_cap(k, 1 << slice_shift)
                 n_slices = (k + slice_width - 1) // slice_width
-        if layout == 'd8' and not d8_ok:
-            raise ValueError("the d8 layout needs heterogeneous f32/f16/bf16 weights, rows of at most 16384 entries and "
-                             "at most 1024 slices.")
-        lay = cls.LAYOUT_D8 if d8_ok else cls.LAYOUT_U16
-        if not (0 < slice_width <= (1 << slice_shift) or (lay == cls.LAYOUT_D8 and 0 < slice_width <= cls.D8_CAP)):
+        if layout in ('d8', 'h8') and not d8_ok:
+            raise ValueError("the d8 / h8 layouts need f32/f16/bf16 weights, rows of at most 16384 entries and at most 1024 "
+                             "slices.")
+        lay = (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8) if d8_ok else cls.LAYOUT_U16
+        if not (0 < slice_width <= (1 << slice_shift) or (lay != cls.LAYOUT_U16 and 0 < slice_width <= delta_cap)):
             raise ValueError(f"slice_width {slice_width} exceeds the accumulator capacity of this layout.")
         seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
         f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
@@ -225,7 +229,10 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
         return 'direct'
     homo = weights.numel() == 1
     shift = ScatterPlan.default_shift(k, homo)
-    cap = (1 << shift) if homo or shift < ScatterPlan.HETERO_SHIFT else ScatterPlan.D8_CAP
+    if homo:
+        cap = ScatterPlan.H8_CAP if shift >= ScatterPlan.HOMO_SHIFT else (1 << shift)
+    else:
+        cap = ScatterPlan.D8_CAP if shift >= ScatterPlan.HETERO_SHIFT else (1 << shift)
     n_slices = -(-k // ScatterPlan.balanced_width_cap(k, cap))
     per_block = nse / (m * n_slices)
     if n_slices <= 4096 and per_block >= PLAN_MIN_SEGMENT:

@@ -1484,6 +1484,9 @@ __device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32
 
 // (slice, local column, first-of-block, escapes before it, delta byte) of sorted position i
 struct D8Item { uint32_t s, loc, esc, rem; bool first; };
+// H8 = the homogeneous-weight variant of the encoding (see "h8" below): code 255 is reserved for the escape itself,
+// so a gap is esc x 255 + rem with rem in [0, 254]; d8 keeps rem in [1, 255] for a non-zero gap.
+template <bool H8 = false>
 __device__ __forceinline__ D8Item d8_item(const unsigned long long* keys, int i, uint32_t W) {
   D8Item it;
   const uint32_t col = (uint32_t)(keys[i] >> 16);
@@ -1498,11 +1501,13 @@ __device__ __forceinline__ D8Item d8_item(const unsigned long long* keys, int i,
       gap = col - prev;
     }
   }
-  it.esc = gap ? (gap - 1u) / 255u : 0u;
+  it.esc = H8 ? gap / 255u : (gap ? (gap - 1u) / 255u : 0u);
   it.rem = gap - 255u * it.esc;
   return it;
 }
+__host__ __device__ __forceinline__ uint32_t h8_block_units(uint32_t ng) { return (ng * 8u + 127u) >> 7; }
 
+template <bool H8>
 __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
                                                         uint32_t slice_width, int n_slices, uint2* __restrict__ seg) {
   extern __shared__ unsigned long long d8_keys[];
@@ -1511,14 +1516,15 @@ __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restric
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) { tot[s] = 0; base_s[s] = 0; }
     const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1));   // ends with a barrier
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
-      const D8Item it = d8_item(d8_keys, i, slice_width);
+      const D8Item it = d8_item<H8>(d8_keys, i, slice_width);
       atomicAdd(&tot[it.s], 1u + it.esc);
       if (it.first) base_s[it.s] = it.loc;
     }
     __syncthreads();
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
-      const uint32_t ng = (tot[s] + 3u) >> 2;          // < 2^16: a row has at most kD8MaxRow entries + W/255 escapes
-      seg[r * n_slices + s] = make_uint2(d8_block_units(ng), ng | (base_s[s] << 16));
+      // ng < 2^16: a row has at most kD8MaxRow entries + W/255 escapes
+      const uint32_t ng = H8 ? (tot[s] + 7u) >> 3 : (tot[s] + 3u) >> 2;
+      seg[r * n_slices + s] = make_uint2(H8 ? h8_block_units(ng) : d8_block_units(ng), ng | (base_s[s] << 16));
     }
     __syncthreads();
   }
@@ -1750,6 +1756,193 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
 }
 
 // =================================================================================================
+// "h8" layout of the scatter plan (homogeneous weight): 1 byte per entry instead of 2.
+//   block(r, s) = [ uint8 code x 8*ng ]   (padded to 128 B);   seg[r][s] = { start / 128 B, ng | first local column << 16 }
+// Same sorted-column delta idea as d8, but a counted entry has no weight to zero out, so the escape is its own code:
+//   code c < 255: advance c columns and count one entry;   c = 255: advance 255 columns, count nothing (also the tail pad).
+// A gap g is g / 255 escapes followed by the code g % 255.  One lane decodes 8 codes (one 8-byte load): a C2 block
+// (312 entries + ~25 escapes) is three 128-B lines instead of five.
+// =================================================================================================
+__global__ void __launch_bounds__(1024) k_plan_h8_fill(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
+                                                       uint32_t slice_width, int n_slices, const uint2* __restrict__ seg,
+                                                       unsigned char* __restrict__ blob) {
+  extern __shared__ unsigned long long d8_keys[];
+  __shared__ uint32_t first_idx[kD8MaxSlices], e_first[kD8MaxSlices], seg_start[kD8MaxSlices], seg_ng[kD8MaxSlices],
+      tot[kD8MaxSlices];
+  __shared__ uint32_t wtot[16];
+  for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {
+      const uint2 sg = seg[r * n_slices + s];
+      seg_start[s] = sg.x;
+      seg_ng[s] = sg.y & 0xffffu;
+      tot[s] = 0;
+    }
+    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1));
+    const int per = (len + 1023) >> 10;
+    const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
+    uint32_t mine = 0;
+    for (int i = i0; i < i1; ++i) mine += d8_item<true>(d8_keys, i, slice_width).esc;
+    const uint32_t excl = block_scan_1024(mine, wtot) - mine;
+    uint32_t run = excl;
+    for (int i = i0; i < i1; ++i) {
+      const D8Item it = d8_item<true>(d8_keys, i, slice_width);
+      run += it.esc;
+      if (it.first) { first_idx[it.s] = (uint32_t)i; e_first[it.s] = run; }
+    }
+    __syncthreads();
+    run = excl;
+    for (int i = i0; i < i1; ++i) {
+      const D8Item it = d8_item<true>(d8_keys, i, slice_width);
+      run += it.esc;
+      const uint32_t pos = ((uint32_t)i - first_idx[it.s]) + (run - e_first[it.s]);
+      unsigned char* blk = blob + ((int64_t)seg_start[it.s] << 7);
+      for (uint32_t q = pos - it.esc; q < pos; ++q) blk[q] = 255;
+      blk[pos] = (unsigned char)it.rem;
+      atomicMax(&tot[it.s], pos + 1u);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slices; s += blockDim.x) {   // tail pads
+      unsigned char* blk = blob + ((int64_t)seg_start[s] << 7);
+      for (uint32_t q = tot[s]; q < seg_ng[s] * 8u; ++q) blk[q] = 255;
+    }
+    __syncthreads();
+  }
+}
+
+// one lane-group: 8 codes (two dwords); `before` = column reached before this lane-group
+__device__ __forceinline__ void h8_add8(uint32_t* acc, uint32_t before, uint32_t d0, uint32_t d1) {
+  uint32_t pos = before;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const uint32_t c = ((b < 4 ? d0 : d1) >> (8 * (b & 3))) & 0xffu;
+    pos += c;
+    if (c != 255u) atomicAdd(&acc[pos], 1u);
+  }
+}
+__device__ __forceinline__ uint32_t h8_sum8(uint32_t d0, uint32_t d1) {
+  return __builtin_amdgcn_sad_u8(d1, 0u, __builtin_amdgcn_sad_u8(d0, 0u, 0u));
+}
+
+struct SegGroupH8 {
+  uint32_t start[4], ng[4], base[4];
+  be_v2u dv[4];
+};
+
+__device__ __forceinline__ void h8_issue(SegGroupH8& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
+                                         const unsigned char* __restrict__ blob) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int src = (i + q) & 63;
+    g.start[q] = __builtin_amdgcn_readlane(st_v, src);
+    const uint32_t y = (i + q < nvalid) ? __builtin_amdgcn_readlane(n4_v, src) : 0u;
+    g.ng[q] = y & 0xffffu;
+    g.base[q] = y >> 16;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned char* blk = const_cast<unsigned char*>(blob) + ((uint64_t)g.start[q] << 7);
+    auto rd = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(g.ng[q] * 8u), kBufFlags);
+    g.dv[q] = __builtin_amdgcn_raw_buffer_load_b64(rd, lane * 8, 0, 0);     // lanes past the block read 0
+  }
+}
+
+__device__ __forceinline__ void h8_consume(const SegGroupH8& g, uint32_t* acc, int lane, const unsigned char* __restrict__ blob) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t t = h8_sum8(g.dv[q].x, g.dv[q].y);
+    const uint32_t before = g.base[q] + wave_incl_scan_u32(t) - t;
+    if ((uint32_t)lane < g.ng[q]) h8_add8(acc, before, g.dv[q].x, g.dv[q].y);
+  }
+  if ((g.ng[0] | g.ng[1] | g.ng[2] | g.ng[3]) > 64u) {      // long blocks: remaining chunks of 64 lane-groups
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (g.ng[q] <= 64u) continue;
+      const uint2* blk = reinterpret_cast<const uint2*>(blob + ((uint64_t)g.start[q] << 7));
+      uint32_t carry = g.base[q] + __builtin_amdgcn_readlane(wave_incl_scan_u32(h8_sum8(g.dv[q].x, g.dv[q].y)), 63);
+      for (uint32_t o0 = 64; o0 < g.ng[q]; o0 += 64) {
+        const uint32_t o = o0 + lane;
+        const bool in = o < g.ng[q];
+        uint2 d = make_uint2(0u, 0u);
+        if (in) d = blk[o];
+        const uint32_t t = h8_sum8(d.x, d.y);
+        const uint32_t incl = wave_incl_scan_u32(t);
+        if (in) h8_add8(acc, carry + incl - t, d.x, d.y);
+        carry += __builtin_amdgcn_readlane(incl, 63);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_plan_accumulate_h8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
+                                                             const uint32_t* __restrict__ active,
+                                                             const uint32_t* __restrict__ n_active_p, int n_slices,
+                                                             int cap, int parts, uint32_t* __restrict__ partial,
+                                                             int64_t active_stride) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  uint32_t* acc = reinterpret_cast<uint32_t*>(smem_raw);
+  const int S = cap;                     // multiple of 4; >= slice width
+  const int per_xcd = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int n_tasks = n_slices * parts;
+  if (L >= n_tasks) return;
+  const int part = L / n_slices;
+  const int slice = L - part * n_slices;
+  active += (int64_t)blockIdx.y * active_stride;
+  partial += ((int64_t)blockIdx.y * n_tasks + L) * S;
+  {
+    uint4* z = reinterpret_cast<uint4*>(smem_raw);
+    const int n16 = (int)((size_t)S * 4 / 16);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  const uint32_t n_active = n_active_p[blockIdx.y];
+  const uint2* sp = seg + slice;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint64_t a0 = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a_step = (uint64_t)parts * nw * 64;
+  if (n_active > 0) {
+    const uint64_t last = n_active - 1;
+    uint64_t a = a0;
+    bool v_n = a < n_active;
+    uint32_t r_n = active[a < last ? a : last];
+    a += a_step;
+    uint2 sg = sp[(uint64_t)r_n * n_slices];
+    uint32_t st_v = sg.x, n4_v = v_n ? sg.y : 0u;
+    bool v_c = v_n;
+    v_n = a < n_active;
+    r_n = active[a < last ? a : last];
+    a += a_step;
+    while (__ballot(v_c) != 0ull) {
+      const int nvalid = __popcll(__ballot(v_c));
+      const uint2 sgn = sp[(uint64_t)r_n * n_slices];
+      const bool v_nn = a < n_active;
+      const uint32_t r_nn = active[a < last ? a : last];
+      a += a_step;
+      SegGroupH8 gA, gB;
+      h8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
+      for (int i = 0; i < nvalid; i += 8) {
+        h8_issue(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
+        h8_consume(gA, acc, lane, blob);
+        h8_issue(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
+        h8_consume(gB, acc, lane, blob);
+      }
+      st_v = sgn.x;
+      n4_v = v_n ? sgn.y : 0u;
+      v_c = v_n;
+      v_n = v_nn;
+      r_n = r_nn;
+    }
+  }
+  __syncthreads();
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
+    uint4* dst = reinterpret_cast<uint4*>(partial);
+    const int n16 = (int)((size_t)S * 4 / 16);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
+// =================================================================================================
 // Small matrices: the whole planned step in ONE launch.  When the output is a single slice and one part is enough
 // (k <= 16384 weighted / 32768 counted accumulators, up to ~1M entries), one workgroup compacts the spikes itself (4096
 // at a time, into LDS), walks the active rows' blocks, and converts its accumulators straight into the output: no
@@ -1758,12 +1951,12 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
 // =================================================================================================
 constexpr int kSingleChunk = 4096;       // spikes compacted per pass (4 per thread)
 
-template <int LAYOUT /* 0: u16 weighted, 1: u16 counted, 2: d8 */, typename SP, typename W>
+template <int LAYOUT /* 0: u16 weighted, 1: u16 counted, 2: d8, 3: h8 */, typename SP, typename W>
 __global__ void __launch_bounds__(1024) k_plan_single(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                       const typename SP::type* __restrict__ spikes, int64_t m, int64_t k,
                                                       int cap, float scale, double inv_scale, const W* __restrict__ weights,
                                                       W* __restrict__ out) {
-  constexpr bool HOMO = LAYOUT == 1;
+  constexpr bool HOMO = LAYOUT == 1 || LAYOUT == 3;
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
@@ -1799,6 +1992,19 @@ __global__ void __launch_bounds__(1024) k_plan_single(const unsigned char* __res
           const uint32_t t = d8_sum4(d);
           const uint32_t incl = wave_incl_scan_u32(t);
           if (in) d8_add4(reinterpret_cast<unsigned long long*>(acc), carry + incl - t, d, wv, scale);
+          carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+      } else if (LAYOUT == 3) {
+        const uint32_t ng = sg.y & 0xffffu;
+        uint32_t carry = sg.y >> 16;
+        for (uint32_t o0 = 0; o0 < ng; o0 += 64) {
+          const uint32_t o = o0 + lane;
+          const bool in = o < ng;
+          uint2 d = make_uint2(0u, 0u);
+          if (in) d = reinterpret_cast<const uint2*>(blk)[o];
+          const uint32_t t = h8_sum8(d.x, d.y);
+          const uint32_t incl = wave_incl_scan_u32(t);
+          if (in) h8_add8(reinterpret_cast<uint32_t*>(acc), carry + incl - t, d.x, d.y);
           carry += __builtin_amdgcn_readlane(incl, 63);
         }
       } else {
@@ -1963,12 +2169,16 @@ static inline int n_slices_of(int64_t k, int slice_shift, int slice_width = 0) {
   return (int)((k + w - 1) / w);
 }
 constexpr int kD8MaxWidth = 20000;     // d8 blocks need no pad slot and no power-of-two capacity: 20000 x 8 B = 156 KiB of LDS
+constexpr int kH8MaxWidth = 40000;     // h8: the same LDS in 4-byte counters
 static inline bool width_ok(int slice_shift, int slice_width, int layout = BE_PLAN_U16) {
-  return slice_width >= 0 && (slice_width <= (1 << slice_shift) || (layout == BE_PLAN_D8 && slice_width <= kD8MaxWidth));
+  return slice_width >= 0 && (slice_width <= (1 << slice_shift) || (layout == BE_PLAN_D8 && slice_width <= kD8MaxWidth) ||
+                              (layout == BE_PLAN_H8 && slice_width <= kH8MaxWidth));
 }
-// accumulators per task (= stride of a task's partial sums)
+// accumulators per task (= stride of a task's partial sums; a multiple of 16 bytes)
 static inline int64_t cap_of(int slice_shift, int slice_width, int layout) {
-  return layout == BE_PLAN_D8 ? ((width_of(slice_shift, slice_width) + 1) & ~1ll) : (1ll << slice_shift);
+  if (layout == BE_PLAN_D8) return (width_of(slice_shift, slice_width) + 1) & ~1ll;
+  if (layout == BE_PLAN_H8) return (width_of(slice_shift, slice_width) + 3) & ~3ll;
+  return 1ll << slice_shift;
 }
 
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width) {
@@ -1993,11 +2203,11 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
   RowPtr rp{indptr, indptr_is_i64, row_len};
   const int64_t n = (int64_t)n_slices * m;
   uint2* sg = static_cast<uint2*>(seg);
-  if (layout == BE_PLAN_D8) {
-    BE_REQUIRE(!homo, BE_ERR_INVALID, "the d8 layout is for heterogeneous weights");
-    BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 layout: rows of at most 16384 entries");
-    BE_REQUIRE(n_slices <= kD8MaxSlices, BE_ERR_RANGE, "too many slices for the d8 layout");
-    auto kern = k_plan_d8_count;
+  if (layout == BE_PLAN_D8 || layout == BE_PLAN_H8) {
+    BE_REQUIRE((layout == BE_PLAN_H8) == (homo != 0), BE_ERR_INVALID, "d8 is the heterogeneous layout, h8 the homogeneous one");
+    BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 / h8 layout: rows of at most 16384 entries");
+    BE_REQUIRE(n_slices <= kD8MaxSlices, BE_ERR_RANGE, "too many slices for the d8 / h8 layout");
+    auto kern = layout == BE_PLAN_H8 ? k_plan_d8_count<true> : k_plan_d8_count<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
     hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
                        (uint32_t)width_of(slice_shift, slice_width), n_slices, sg);
@@ -2039,6 +2249,17 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   RowPtr rp{indptr, indptr_is_i64, row_len};
   BE_HIP(be_fill_async(maxabs_bits, 0, 4, st));
   BE_HIP(be_fill_async(maxabs_bits + 1, 0xff, 4, st));
+  if (layout == BE_PLAN_H8) {
+    BE_REQUIRE(homo && n_slices <= kD8MaxSlices, BE_ERR_INVALID, "h8 layout: homogeneous weight, <= 1024 slices");
+    BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "h8 layout: rows of at most 16384 entries");
+    auto kern = k_plan_h8_fill;
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
+    hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
+                       (uint32_t)width_of(slice_shift, slice_width), n_slices, static_cast<const uint2*>(seg),
+                       static_cast<unsigned char*>(blob));
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
   if (layout == BE_PLAN_D8) {
     BE_REQUIRE(!homo && n_slices <= kD8MaxSlices, BE_ERR_INVALID, "d8 layout: heterogeneous weights, <= 1024 slices");
     BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 layout: rows of at most 16384 entries");
@@ -2088,7 +2309,8 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
                            int slice_shift, int slice_width, int layout, int parts, int scale_exp, void* workspace,
                            int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll && k <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
-  BE_REQUIRE(layout == BE_PLAN_U16 || (layout == BE_PLAN_D8 && !homo), BE_ERR_INVALID, "bad plan layout");
+  BE_REQUIRE(layout == BE_PLAN_U16 || (layout == BE_PLAN_D8 && !homo) || (layout == BE_PLAN_H8 && homo), BE_ERR_INVALID,
+             "bad plan layout");
   BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
@@ -2115,7 +2337,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     // small matrix: compaction + accumulate + output conversion in one single-workgroup launch (k_plan_single)
     const float sc1 = ldexpf(1.0f, scale_exp - 32);
     const double isc1 = ldexp(1.0, -scale_exp);
-    const int lay = homo ? 1 : (layout == BE_PLAN_D8 ? 2 : 0);
+    const int lay = homo ? (layout == BE_PLAN_H8 ? 3 : 1) : (layout == BE_PLAN_D8 ? 2 : 0);
     const int prof1 = be_prof_begin(st);
     int rc1 = BE_ERR_INVALID;
 #define BE_SINGLE(LAY, WT) rc1 = launch_plan_single<LAY, WT>(blob, seg, spikes, spike_dtype, m, k, (int)S, sc1, isc1, weights, out, lds, st)
@@ -2126,7 +2348,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
       case BE_BF16: BE_SINGLE(LAY, __hip_bfloat16); break;                   \
       default: be_set_error("planned scatter: f32 / f16 / bf16 outputs"); rc1 = BE_ERR_UNSUPPORTED; \
     }
-    if (lay == 0) { BE_SINGLE_W(0) } else if (lay == 1) { BE_SINGLE_W(1) } else { BE_SINGLE_W(2) }
+    if (lay == 0) { BE_SINGLE_W(0) } else if (lay == 1) { BE_SINGLE_W(1) } else if (lay == 2) { BE_SINGLE_W(2) } else { BE_SINGLE_W(3) }
 #undef BE_SINGLE_W
 #undef BE_SINGLE
     be_prof_end(prof1, st);
@@ -2142,7 +2364,12 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const int n_tasks = n_slices * parts;
   const dim3 grid((unsigned)((n_tasks + 7) / 8 * 8), (unsigned)n_batch), block(1024);
   const int prof = be_prof_begin(st);
-  if (homo) {
+  if (layout == BE_PLAN_H8) {
+    auto kern = k_plan_accumulate_h8;
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
+                       al.ids, al.count, n_slices, (int)S, parts, static_cast<uint32_t*>(partial), astride);
+  } else if (homo) {
     auto kern = k_plan_accumulate<true>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),

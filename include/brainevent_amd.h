@@ -142,6 +142,10 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *     block: [ f32 weight x 4*ng ][ uint8 delta x 4*ng ], entries sorted by column, column = previous column + delta
  *     (first delta 0), gaps above 255 bridged by escape entries (weight 0, delta 255), tail pads (weight 0, delta 0);
  *     seg = { block start in 128-B units, ng | (local column of the first entry << 16) }.
+ * layout BE_PLAN_H8 (one homogeneous weight; same limits as d8; slice_width up to 40000): 1 byte per entry —
+ *     block: [ uint8 code x 8*ng ], entries sorted by column; code c < 255: advance c columns and count one entry,
+ *     c = 255: advance 255 columns and count nothing (a gap g is g / 255 escapes followed by the code g % 255; tail pads
+ *     are 255); the first code is 0 and seg is as for d8.
  *
  *   step 1  be_scatter_plan_count : fills seg (m * n_slices entries of 8 B) and returns the size of `blob`
  *           in *blob_bytes_host.  SYNCHRONOUS (it reads the total back).
@@ -152,6 +156,7 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  * ---------------------------------------------------------------------------------------------- */
 #define BE_PLAN_U16 0 /* uint16 local columns (both weight kinds) */
 #define BE_PLAN_D8 1  /* sorted columns as uint8 deltas (heterogeneous weights) */
+#define BE_PLAN_H8 2  /* sorted columns as uint8 advance codes (one homogeneous weight) */
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width);
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len,
                           int64_t m, int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg,

@@ -147,7 +147,7 @@ def test_csrmv_plan_homo_counts_exact(be, oracle):
     w, idx, ptr = rand_csr(rng, m, k, [400] * m, homo=True)
     w[:] = 1.0
     plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k))
-    assert plan.slice_shift == 15 and plan.n_slices == 3
+    assert plan.slice_shift == 15 and plan.layout == ScatterPlan.LAYOUT_H8 and plan.n_slices == 2    # 2 x 35000 columns
     v = spikes_of(rng, m, 0.1, 'bool')
     spikes, sd = A.spikes_to_device(v)
     out = torch.empty(k, dtype=torch.float32, device='cuda')
@@ -484,6 +484,96 @@ def test_scatter_plan_d8_layout_decodes_bit_exactly(be, width, k):
                                   be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
 
 
+@pytest.mark.parametrize('width,k', [(None, 5000), (300, 5000), (511, 5000), (32768, 150000), (None, 150000), (40000, 150000)])
+def test_scatter_plan_h8_layout_decodes_bit_exactly(be, width, k):
+    """The homogeneous-weight delta layout: one byte per entry, code c < 255 = advance c columns and count, 255 = advance
+    255 columns without counting (escape / tail pad).  Decoding gives back exactly the CSR's (row, column) multiset."""
+    from brainevent_amd._csr import ScatterPlan
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(321)
+    m = 200
+    shift = 9 if k == 5000 else 15
+    lens = rng.integers(0, 150, m); lens[::13] = 0; lens[5] = 3000
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=True)
+    idx[ptr[7]:ptr[8]] = idx[ptr[7]]                       # one column many times (code 0)
+    idx[ptr[9]:ptr[9] + 2] = [0, 255]                      # a gap of exactly 255: escape + code 0
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    assert plan.layout == ScatterPlan.LAYOUT_H8
+    seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
+    blob = plan.blob.cpu().numpy()
+    Wd = plan.slice_width
+    got, n_escape = [], 0
+    for r in range(m):
+        for s in range(plan.n_slices):
+            start, y = int(seg[r, s, 0]), int(seg[r, s, 1])
+            ng, base = y & 0xffff, y >> 16
+            if ng == 0:
+                continue
+            codes = blob[start * 128:start * 128 + ng * 8]
+            cols = base + np.cumsum(codes.astype(np.int64))
+            real = codes != 255
+            assert cols[real].max() < Wd and codes[0] == 0
+            n_escape += int((~real).sum())
+            got += [(r, s * Wd + int(c)) for c in cols[real]]
+    rows = np.repeat(np.arange(m), np.diff(ptr))
+    assert sorted(got) == sorted(zip(rows.tolist(), idx.tolist()))
+    assert n_escape > 0
+    plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift,
+                               slice_width=None if width is None else min(width, 1 << shift), layout='u16')
+    assert plan16.layout == ScatterPlan.LAYOUT_U16
+    for fire in (0.3, 1.0):
+        v = rng.random(m) < fire
+        got_y = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+        np.testing.assert_allclose(got_y, O.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(got_y, be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
+
+
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('BE_STRESS_SEEDS', 8))))
+def test_h8_layout_randomized(be, oracle, seed):
+    """Random shapes / row-length styles / widths through the h8 layout: counts are integers, so every result equals the
+    uint16 layout's bit for bit and the oracle's to float rounding; vectors, batches and the part split included."""
+    from brainevent_amd._csr import ScatterPlan, _plan_call
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(7000 + seed)
+    m = int(rng.integers(1, 900))
+    k = int(rng.choice([37, 4000, 41000, 300000]))
+    shift = int(rng.choice([6, 11, 15]))
+    width = None if rng.random() < 0.5 else int(rng.integers(16, min(k, 40000 if shift == 15 else 1 << shift) + 1))
+    style = seed % 4
+    if style == 0:
+        lens = rng.integers(0, 60, m)
+    elif style == 1:
+        lens = rng.integers(0, 3000, m)
+    elif style == 2:
+        lens = np.where(rng.random(m) < 0.2, rng.integers(1000, 16384, m), rng.integers(0, 5, m))
+    else:
+        lens = rng.integers(0, 400, m)
+    if k // max(width or (1 << shift), 1) > 1000:
+        shift, width = 15, None
+    dtype = np.float16 if seed % 5 == 4 else np.float32
+    w, idx, ptr = rand_csr(rng, m, k, lens, dtype=dtype, homo=True)
+    if style == 3 and idx.size:
+        idx[:] = (idx // 1000 * 1000 + idx % 3).clip(0, k - 1)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    assert plan.layout == ScatterPlan.LAYOUT_H8
+    w16 = None if width is None else min(width, 1 << shift)
+    plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=w16, layout='u16')
+    tol = 1e-6 if dtype == np.float32 else 2e-3
+    for fire in (0.05, 0.5, 1.0):
+        v = rng.random(m) < fire
+        got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
+        ref = oracle.binary_csrmv(w.astype(np.float32), idx, ptr, v, (m, k), True)
+        np.testing.assert_allclose(np.asarray(got, np.float32), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+        np.testing.assert_array_equal(got, be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
+        sp, sd = A.spikes_to_device(v)
+        out_p = torch.empty(k, dtype=A.to_device(w).dtype, device='cuda')
+        _plan_call(plan, A.to_device(w), sp, sd, out_p, parts=3)          # the multi-launch path, three parts
+        np.testing.assert_array_equal(out_p.cpu().numpy(), np.asarray(got))
+    B = rng.random((m, 5)) < 0.3
+    got = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)
+    np.testing.assert_array_equal(got, be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan16))
+
+
 def test_d8_layout_falls_back_when_it_does_not_apply(be):
     from brainevent_amd._csr import ScatterPlan
     rng = np.random.default_rng(4)
@@ -495,7 +585,12 @@ def test_d8_layout_falls_back_when_it_does_not_apply(be):
     with pytest.raises(ValueError):
         ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='d8')
     wh, idxh, ptrh = rand_csr(rng, 50, 3000, [40] * 50, homo=True)
-    assert ScatterPlan.build(wh, idxh, torch.tensor(ptrh), shape=(50, 3000)).layout == ScatterPlan.LAYOUT_U16
+    assert ScatterPlan.build(wh, idxh, torch.tensor(ptrh), shape=(50, 3000)).layout == ScatterPlan.LAYOUT_H8
+    for wrong, args in (('d8', (wh, idxh, ptrh, (50, 3000))), ('h8', (w, idx, ptr, (m, k)))):
+        with pytest.raises(ValueError):
+            ScatterPlan.build(args[0], args[1], torch.tensor(args[2]), shape=args[3], layout=wrong)
+    wl, idxl, ptrl = rand_csr(rng, m, k, lens, homo=True)           # the long row again, one weight
+    assert ScatterPlan.build(wl, idxl, torch.tensor(ptrl), shape=(m, k)).layout == ScatterPlan.LAYOUT_U16
     v = rng.random(m) < 0.7
     from oracle import oracle_np as O
     np.testing.assert_allclose(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan),
@@ -742,7 +837,7 @@ def test_csr_type_zoo_randomized(be, oracle, monkeypatch, seed):
     np.testing.assert_allclose(out_np(be.BinaryArray(conv(Sv)) @ csr), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
 
 
-@pytest.mark.parametrize('layout', ['d8', 'u16', 'homo'])
+@pytest.mark.parametrize('layout', ['d8', 'u16', 'homo', 'homo_u16'])
 @pytest.mark.parametrize('m', [1, 700, 4096, 4097, 20000])
 def test_single_launch_planned_step(be, oracle, layout, m):
     """Small matrices (one output slice, one part) run compaction + accumulate + output conversion in one single-workgroup
@@ -754,11 +849,12 @@ def test_single_launch_planned_step(be, oracle, layout, m):
     lens = rng.integers(0, 12, m)
     if m >= 700:
         lens[5] = 900                                     # one long row (several 64-lane chunks of a block)
-    w, idx, ptr = rand_csr(rng, m, k, lens, homo=(layout == 'homo'))
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=layout.startswith('homo'))
     for wdt in (np.float32, np.float16):
         ww = w.astype(wdt)
-        plan = ScatterPlan.build(ww, idx, torch.tensor(ptr), shape=(m, k), layout=None if layout == 'homo' else layout)
+        plan = ScatterPlan.build(ww, idx, torch.tensor(ptr), shape=(m, k), layout={'homo': None, 'homo_u16': 'u16'}.get(layout, layout))
         assert plan.n_slices == 1 and plan.default_parts() == 1
+        assert plan.layout == {'d8': 1, 'u16': 0, 'homo': 2, 'homo_u16': 0}[layout]
         tol = 1e-5 if wdt == np.float32 else 2e-2
         for v in (np.zeros(m, bool), np.ones(m, bool), rng.random(m) < 0.1, np.where(rng.random(m) < 0.5, 1.5, -2.0).astype(np.float32)):
             ref = oracle.binary_csrmv(ww.astype(np.float32), idx, ptr, v, (m, k), True)
