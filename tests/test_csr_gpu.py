@@ -563,7 +563,10 @@ def test_h8_layout_randomized(be, oracle, seed):
         v = rng.random(m) < fire
         got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)
         ref = oracle.binary_csrmv(w.astype(np.float32), idx, ptr, v, (m, k), True)
-        np.testing.assert_allclose(np.asarray(got, np.float32), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+        with np.errstate(over='ignore'):
+            ref = ref.astype(dtype).astype(np.float32)       # f16 outputs overflow to inf above 65504, as the product's do
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(np.asarray(got, np.float32), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref[fin]).max()) if fin.any() else 1.0))
         np.testing.assert_array_equal(got, be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan16))
         sp, sd = A.spikes_to_device(v)
         out_p = torch.empty(k, dtype=A.to_device(w).dtype, device='cuda')
