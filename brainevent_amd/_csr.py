@@ -104,11 +104,68 @@ class ScatterPlan:
         feed: every part writes the slice's accumulators once and the reduce reads them back, so a 100k-column matrix cut
         into 51 parts moved 80 MB of partial sums per step for 1e5 updates (33-40 us per step; 24 us, the host's issue
         rate, with parts sized by the entries per slice; ``tools/exp_plan_vs_direct.py``)."""
-        if self.n_slices == 1 and 0 < self.nnz <= (1 << 20):
+        return self.parts_for(self.n_slices, self.nnz)
+
+    @staticmethod
+    def parts_for(n_slices: int, nnz: int) -> int:
+        if n_slices == 1 and 0 < nnz <= (1 << 20):
             return 1          # small matrix: the single-launch kernel (k_plan_single) takes the whole step
-        by_chip = 256 // max(self.n_slices, 1)
-        by_work = -(-self.nnz // (max(self.n_slices, 1) << 17)) if self.nnz else by_chip
+        by_chip = 256 // max(n_slices, 1)
+        by_work = -(-nnz // (max(n_slices, 1) << 17)) if nnz else by_chip
         return int(max(1, min(64, by_chip, max(1, by_work))))
+
+    #: entries of one block that a wave handles in a single 64-lane pass (4 per lane with weights, 8 without); longer
+    #: blocks go through a tail loop whose loads are not prefetched
+    HETERO_PASS, HOMO_PASS = 256, 512
+    #: auto_geometry thresholds (stored rows per workgroup-part; entries per block; slice width with small partial sums)
+    D8_MIN_ROWS_PER_PART, H8_MIN_ROWS_PER_PART, H8_MIN_BLOCK = 20000, 32768, 192
+    D8_SMALL_WIDTH, H8_SMALL_WIDTH = 8192, 16384
+
+    @classmethod
+    def pass_sized_width(cls, k: int, cap: int, row: float, homo: bool) -> int:
+        """Balanced slice width for an accumulator capacity of ``cap`` columns, narrowed until an average (row, slice) block
+        fits one 64-lane pass.  Narrow slices also mean small partial sums: K = 10000 over 100k columns ran 39 us as 7
+        slices x 36 parts (32 MB of partial sums per step) and 24-28 us as 51 slices x 5 parts (4 MB)."""
+        n_need = max(1, int(math.ceil(row / (0.82 * (cls.HOMO_PASS if homo else cls.HETERO_PASS)))))
+        return cls.balanced_width_cap(k, max(16, min(cap, -(-int(k) // n_need))))
+
+    @classmethod
+    def auto_geometry(cls, m: int, k: int, nnz: int, homo: bool, slice_shift: int, delta_ok: bool = True,
+                      force: Optional[str] = None):
+        """``(layout, slice_width)`` of a plan built without explicit choices (``force``: ``'u16'`` or ``'delta'``).
+
+        Measured (``tools/exp_layouts.py``, FixedNumPerPre K = 1000 ... 16000, 1 % firing).  Geometry: blocks longer than
+        one decode pass are slow in the sorted layouts (K = 16000 homo: 640 entries per block 108 us, 400 per block 71 us;
+        hetero 444 -> 141 us, 200 -> 129 us) and wide slices mean large partial sums, so every layout gets pass-sized
+        slices (:meth:`pass_sized_width`).  Layout, at equal geometry: ``d8`` beats ``u16`` by 10-14 % and ``h8`` by
+        10-15 % when blocks are pass-sized (K = 10000, N = 100k ... 1M); with short rows the sorted layouts' serial decode
+        (wave prefix sum + dependent adds) costs 2-5 us whenever a wave meets only a handful of blocks per step, and
+        ``h8`` needs blocks long enough for the bytes to matter (N = 1M, K = 3000: 48 us u16, 54 h8).  Hence: ``d8`` when a
+        workgroup-part holds >= 20000 stored rows or the slices are narrow (small partial sums) or there is one slice
+        (the single-launch kernel; d8 reaches 20000 columns where u16 stops at 16384); ``h8`` when additionally an average
+        block has >= 192 entries."""
+        U16, delta = cls.LAYOUT_U16, (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8)
+        cap16 = 1 << slice_shift
+        row = nnz / max(m, 1)
+        w16 = cls.pass_sized_width(k, cap16, row, homo)
+        if not delta_ok or force == 'u16':
+            return U16, w16
+        full = slice_shift >= (cls.HOMO_SHIFT if homo else cls.HETERO_SHIFT)
+        cap = (cls.H8_CAP if homo else cls.D8_CAP) if full else cap16
+        wd = cls.pass_sized_width(k, cap, row, homo)
+        n_d = -(-int(k) // wd)
+        if n_d > cls.D8_MAX_SLICES:
+            return U16, w16
+        if force == 'delta':
+            return delta, wd
+        if n_d == 1:
+            return (delta, wd) if (not homo or k > cap16) else (U16, w16)
+        busy = m / cls.parts_for(n_d, nnz)
+        if homo:
+            ok = row / n_d >= cls.H8_MIN_BLOCK and (busy >= cls.H8_MIN_ROWS_PER_PART or wd <= cls.H8_SMALL_WIDTH)
+        else:
+            ok = busy >= cls.D8_MIN_ROWS_PER_PART or wd <= cls.D8_SMALL_WIDTH
+        return (delta, wd) if ok else (U16, w16)
 
     def nbytes(self) -> int:
         return self.seg.numel() * 4 + self.blob.numel()
@@ -150,26 +207,27 @@ class ScatterPlan:
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         if indptr is not None:
             indptr = A.to_device(indptr)
-        # block layout: sorted deltas (d8 / h8) whenever they apply (non-f64 weights, rows the LDS sort holds, <= 1024 slices)
+        # block layout: the sorted-delta layouts (d8 / h8) apply to non-f64 weights, rows the LDS sort holds and <= 1024
+        # slices; without explicit choices auto_geometry picks by the measured regime
+        nnz = int(indices.numel())
         d8_ok = weights.dtype != torch.float64 and layout != 'u16'
         if d8_ok:
             max_row = int(row_len) if indptr is None else (int((indptr[1:] - indptr[:-1]).max().item()) if m > 0 else 0)
             d8_ok = max_row <= cls.D8_MAX_ROW
         delta_cap = cls.H8_CAP if homo else cls.D8_CAP
-        auto_width = slice_width is None
-        if auto_width:   # balanced slices; the delta layouts may use the whole LDS (no power-of-two capacity) at the default shift
-            full = slice_shift >= (cls.HOMO_SHIFT if homo else cls.HETERO_SHIFT)
-            slice_width = cls.balanced_width_cap(k, delta_cap if (d8_ok and full) else (1 << slice_shift))
+        if slice_width is None:
+            lay, slice_width = cls.auto_geometry(m, k, nnz, homo, slice_shift, delta_ok=d8_ok,
+                                                 force={'d8': 'delta', 'h8': 'delta', 'u16': 'u16'}.get(layout))
+        else:
+            lay = (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8) if d8_ok else cls.LAYOUT_U16
+            if lay != cls.LAYOUT_U16 and layout is None and slice_width <= (1 << slice_shift):
+                lay = cls.auto_geometry(m, k, nnz, homo, slice_shift)[0]     # the width is given, the layout is not
         n_slices = (k + slice_width - 1) // slice_width
-        if d8_ok and n_slices > cls.D8_MAX_SLICES:
-            d8_ok = False
-            if auto_width:
-                slice_width = cls.balanced_width_cap(k, 1 << slice_shift)
-                n_slices = (k + slice_width - 1) // slice_width
-        if layout in ('d8', 'h8') and not d8_ok:
+        if lay != cls.LAYOUT_U16 and n_slices > cls.D8_MAX_SLICES:
+            lay = cls.LAYOUT_U16
+        if layout in ('d8', 'h8') and lay == cls.LAYOUT_U16:
             raise ValueError("the d8 / h8 layouts need f32/f16/bf16 weights, rows of at most 16384 entries and at most 1024 "
                              "slices.")
-        lay = (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8) if d8_ok else cls.LAYOUT_U16
         if not (0 < slice_width <= (1 << slice_shift) or (lay != cls.LAYOUT_U16 and 0 < slice_width <= delta_cap)):
             raise ValueError(f"slice_width {slice_width} exceeds the accumulator capacity of this layout.")
         seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
@@ -198,7 +256,7 @@ class ScatterPlan:
                 raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
                                 f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
         plan = cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width, lay)
-        plan.nnz = int(indices.numel())
+        plan.nnz = nnz
         return plan
 
 
@@ -229,11 +287,7 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
         return 'direct'
     homo = weights.numel() == 1
     shift = ScatterPlan.default_shift(k, homo)
-    if homo:
-        cap = ScatterPlan.H8_CAP if shift >= ScatterPlan.HOMO_SHIFT else (1 << shift)
-    else:
-        cap = ScatterPlan.D8_CAP if shift >= ScatterPlan.HETERO_SHIFT else (1 << shift)
-    n_slices = -(-k // ScatterPlan.balanced_width_cap(k, cap))
+    n_slices = -(-k // ScatterPlan.auto_geometry(m, k, nse, homo, shift)[1])
     per_block = nse / (m * n_slices)
     if n_slices <= 4096 and per_block >= PLAN_MIN_SEGMENT:
         return 'plan'

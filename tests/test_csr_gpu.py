@@ -147,7 +147,7 @@ def test_csrmv_plan_homo_counts_exact(be, oracle):
     w, idx, ptr = rand_csr(rng, m, k, [400] * m, homo=True)
     w[:] = 1.0
     plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k))
-    assert plan.slice_shift == 15 and plan.layout == ScatterPlan.LAYOUT_H8 and plan.n_slices == 2    # 2 x 35000 columns
+    assert plan.slice_shift == 15 and plan.layout == ScatterPlan.LAYOUT_U16 and plan.n_slices == 3
     v = spikes_of(rng, m, 0.1, 'bool')
     spikes, sd = A.spikes_to_device(v)
     out = torch.empty(k, dtype=torch.float32, device='cuda')
@@ -445,7 +445,7 @@ def test_scatter_plan_d8_layout_decodes_bit_exactly(be, width, k):
     lens = rng.integers(0, 150, m); lens[::13] = 0; lens[5] = 3000
     w, idx, ptr = rand_csr(rng, m, k, lens, homo=False)
     idx[ptr[7]:ptr[8]] = idx[ptr[7]]                       # a row that hits one column many times (delta 0)
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='d8')
     assert plan.layout == ScatterPlan.LAYOUT_D8
     seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
     blob = plan.blob.cpu().numpy()
@@ -497,7 +497,7 @@ def test_scatter_plan_h8_layout_decodes_bit_exactly(be, width, k):
     w, idx, ptr = rand_csr(rng, m, k, lens, homo=True)
     idx[ptr[7]:ptr[8]] = idx[ptr[7]]                       # one column many times (code 0)
     idx[ptr[9]:ptr[9] + 2] = [0, 255]                      # a gap of exactly 255: escape + code 0
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='h8')
     assert plan.layout == ScatterPlan.LAYOUT_H8
     seg = plan.seg.cpu().numpy().view(np.uint32).reshape(m, plan.n_slices, 2)
     blob = plan.blob.cpu().numpy()
@@ -554,7 +554,7 @@ def test_h8_layout_randomized(be, oracle, seed):
     w, idx, ptr = rand_csr(rng, m, k, lens, dtype=dtype, homo=True)
     if style == 3 and idx.size:
         idx[:] = (idx // 1000 * 1000 + idx % 3).clip(0, k - 1)
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='h8')
     assert plan.layout == ScatterPlan.LAYOUT_H8
     w16 = None if width is None else min(width, 1 << shift)
     plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=w16, layout='u16')
@@ -588,7 +588,8 @@ def test_d8_layout_falls_back_when_it_does_not_apply(be):
     with pytest.raises(ValueError):
         ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='d8')
     wh, idxh, ptrh = rand_csr(rng, 50, 3000, [40] * 50, homo=True)
-    assert ScatterPlan.build(wh, idxh, torch.tensor(ptrh), shape=(50, 3000)).layout == ScatterPlan.LAYOUT_H8
+    assert ScatterPlan.build(wh, idxh, torch.tensor(ptrh), shape=(50, 3000)).layout == ScatterPlan.LAYOUT_U16    # auto: too small for h8
+    assert ScatterPlan.build(wh, idxh, torch.tensor(ptrh), shape=(50, 3000), layout='h8').layout == ScatterPlan.LAYOUT_H8
     for wrong, args in (('d8', (wh, idxh, ptrh, (50, 3000))), ('h8', (w, idx, ptr, (m, k)))):
         with pytest.raises(ValueError):
             ScatterPlan.build(args[0], args[1], torch.tensor(args[2]), shape=args[3], layout=wrong)
@@ -666,7 +667,7 @@ def test_d8_layout_randomized_against_oracle_and_u16(be, oracle, seed):
     w, idx, ptr = rand_csr(rng, m, k, lens, dtype=dtype)
     if style == 3 and idx.size:                               # clustered columns: many zero / tiny deltas and huge gaps
         idx[:] = (idx // 1000 * 1000 + idx % 3).clip(0, k - 1)
-    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=width, layout='d8')
     assert plan.layout == ScatterPlan.LAYOUT_D8
     w16 = None if width is None else min(width, cap)
     plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=w16, layout='u16')
@@ -855,7 +856,7 @@ def test_single_launch_planned_step(be, oracle, layout, m):
     w, idx, ptr = rand_csr(rng, m, k, lens, homo=layout.startswith('homo'))
     for wdt in (np.float32, np.float16):
         ww = w.astype(wdt)
-        plan = ScatterPlan.build(ww, idx, torch.tensor(ptr), shape=(m, k), layout={'homo': None, 'homo_u16': 'u16'}.get(layout, layout))
+        plan = ScatterPlan.build(ww, idx, torch.tensor(ptr), shape=(m, k), layout={'homo': 'h8', 'homo_u16': 'u16'}.get(layout, layout))
         assert plan.n_slices == 1 and plan.default_parts() == 1
         assert plan.layout == {'d8': 1, 'u16': 0, 'homo': 2, 'homo_u16': 0}[layout]
         tol = 1e-5 if wdt == np.float32 else 2e-2

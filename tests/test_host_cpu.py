@@ -231,3 +231,34 @@ def test_hybrid_workspace_sizing_contract(monkeypatch):
     assert be.hybrid_task_capacity(np.array([0, 11, 250])) == 1 + 3
     monkeypatch.delenv('BRAINEVENT_CSR_HYBRID_CONFIG')
     be.get_hybrid_config.cache_clear()
+
+
+def test_scatter_plan_auto_geometry():
+    """Layout / slice-width rules of a plan built without explicit choices (measured: tools/exp_layouts.py)."""
+    from brainevent_amd._csr import ScatterPlan as P
+    U16, D8, H8 = P.LAYOUT_U16, P.LAYOUT_D8, P.LAYOUT_H8
+
+    def geo(m, k, row, homo, **kw):
+        lay, w = P.auto_geometry(m, k, m * row, homo, P.default_shift(k, homo), **kw)
+        return lay, -(-k // w)
+
+    # the headline configs: whole-LDS slices, 5 / 10 parts
+    assert geo(1_000_000, 1_000_000, 10000, False) == (D8, 51)
+    assert geo(1_000_000, 1_000_000, 10000, True) == (H8, 25)
+    # long rows over few columns: slices narrowed until a block fits one decode pass (and the partial sums shrink with them)
+    assert geo(100_000, 100_000, 10000, False) == (D8, 51)
+    assert geo(100_000, 100_000, 10000, True) == (H8, 25)
+    assert geo(700_000, 700_000, 16000, True) == (H8, 42)
+    assert geo(100_000, 100_000, 10000, True, force='u16') == (U16, 25)
+    # short rows: h8 has nothing to gain (blocks of a line or two), d8 only when the step is throughput-bound
+    assert geo(1_000_000, 1_000_000, 1000, True) == (U16, 32)
+    assert geo(1_000_000, 1_000_000, 1000, False) == (D8, 51)
+    assert geo(100_000, 100_000, 1000, False) == (U16, 7)
+    assert geo(300_000, 300_000, 3000, True)[0] == U16
+    # one slice: d8 (reaches 20000 columns in a single launch), counted entries stay u16
+    assert geo(4000, 4000, 80, False) == (D8, 1) and geo(4000, 18000, 80, False) == (D8, 1)
+    assert geo(4000, 4000, 80, True) == (U16, 1)
+    # sorted layouts not applicable (f64 weights, rows beyond the LDS sort): u16 with the same pass-sized slices
+    assert geo(100_000, 100_000, 10000, False, delta_ok=False) == (U16, 51)
+    # more than 1024 slices: u16
+    assert geo(10_000_000, 30_000_000, 1000, False)[0] == U16

@@ -8,13 +8,13 @@ import brainevent_amd._csr as C
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev); g.manual_seed(0)
 K = 1000
-for n in (500_000, 1_000_000, 1_500_000):
+for n in [int(x) for x in os.environ.get('BE_EXP_NS', '500000,1000000,1500000').split(',')]:
     idx = torch.empty((n, K), dtype=torch.int32, device=dev)
     for lo in range(0, n, 200_000):
         hi = min(n, lo + 200_000)
         idx[lo:hi] = torch.randint(0, n, (hi - lo, K), dtype=torch.int32, device=dev, generator=g)
     spikes = [torch.rand(n, device=dev, generator=g) < 0.01 for _ in range(10)]
-    for homo in (True, False):
+    for homo in ((True,) if os.environ.get('BE_EXP_HOMO_ONLY') else (True, False)):
         w = torch.ones(1, device=dev) if homo else torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
         for seg_min in (1, 1000):
             C.PLAN_MIN_SEGMENT = seg_min
