@@ -121,12 +121,25 @@ class ScatterPlan:
     D8_MIN_ROWS_PER_PART, H8_MIN_ROWS_PER_PART, H8_MIN_BLOCK = 20000, 32768, 192
     D8_SMALL_WIDTH, H8_SMALL_WIDTH = 8192, 16384
 
+    #: slices a matrix is cut into when neither the LDS capacity nor the pass size asks for more, and the shortest
+    #: average block that is worth it
+    TARGET_SLICES, TARGET_MIN_BLOCK = 24, 32
+
     @classmethod
-    def pass_sized_width(cls, k: int, cap: int, row: float, homo: bool) -> int:
-        """Balanced slice width for an accumulator capacity of ``cap`` columns, narrowed until an average (row, slice) block
-        fits one 64-lane pass.  Narrow slices also mean small partial sums: K = 10000 over 100k columns ran 39 us as 7
-        slices x 36 parts (32 MB of partial sums per step) and 24-28 us as 51 slices x 5 parts (4 MB)."""
-        n_need = max(1, int(math.ceil(row / (0.82 * (cls.HOMO_PASS if homo else cls.HETERO_PASS)))))
+    def pass_sized_width(cls, k: int, cap: int, row: float, homo: bool, nnz: int = 0) -> int:
+        """Balanced slice width for an accumulator capacity of ``cap`` columns.  More slices than the capacity needs when
+
+        * an average (row, slice) block would not fit one 64-lane pass (``HETERO_PASS`` / ``HOMO_PASS`` entries), or
+        * the output is small: every workgroup writes its slice of partial sums and the reduce reads them back, so few
+          wide slices x many parts move ~32 MB per step whatever the work (N = 100k, K = 1000: 4 slices x 64 parts 33 us,
+          32 x 8 19 us; K = 10000: 7 x 36 39 us, 51 x 5 24 us; the cost model in DESIGN.md puts the optimum at 22-31).  Up to ``TARGET_SLICES`` slices as long as an average
+          block keeps ``TARGET_MIN_BLOCK`` entries (N = 350k, K = 1000: 11 slices 31 us, 20: 27, 40: 29, 80: 41).
+
+        A matrix that the single-launch kernel takes whole (one slice, <= 1M entries) stays one slice."""
+        if int(k) <= cap and 0 < nnz <= (1 << 20):
+            return max(1, int(k))
+        n_need = max(1, int(math.ceil(row / (0.82 * (cls.HOMO_PASS if homo else cls.HETERO_PASS)))),
+                     min(cls.TARGET_SLICES, int(row // cls.TARGET_MIN_BLOCK)))
         return cls.balanced_width_cap(k, max(16, min(cap, -(-int(k) // n_need))))
 
     @classmethod
@@ -147,12 +160,12 @@ class ScatterPlan:
         U16, delta = cls.LAYOUT_U16, (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8)
         cap16 = 1 << slice_shift
         row = nnz / max(m, 1)
-        w16 = cls.pass_sized_width(k, cap16, row, homo)
+        w16 = cls.pass_sized_width(k, cap16, row, homo, nnz)
         if not delta_ok or force == 'u16':
             return U16, w16
         full = slice_shift >= (cls.HOMO_SHIFT if homo else cls.HETERO_SHIFT)
         cap = (cls.H8_CAP if homo else cls.D8_CAP) if full else cap16
-        wd = cls.pass_sized_width(k, cap, row, homo)
+        wd = cls.pass_sized_width(k, cap, row, homo, nnz)
         n_d = -(-int(k) // wd)
         if n_d > cls.D8_MAX_SLICES:
             return U16, w16

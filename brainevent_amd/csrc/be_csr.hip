@@ -821,7 +821,9 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
                                                           const uint32_t* __restrict__ n_active_p, int n_slices,
                                                           int slice_shift, int parts, float scale,
                                                           typename PlanAcc<HOMO>::type* __restrict__ partial,
-                                                          int64_t active_stride) {
+                                                          int64_t active_stride, int stride) {
+  // `stride` = accumulators a task hands to the reduce (slice width rounded up to 16 bytes): the LDS holds 2^slice_shift
+  // slots + the pad slot whatever the width, but only the slice's own columns travel through memory
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
@@ -833,7 +835,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
   const int part = L / n_slices;
   const int slice = L - part * n_slices;
   active += (int64_t)blockIdx.y * active_stride;
-  partial += ((int64_t)blockIdx.y * n_tasks + L) * S;
+  partial += ((int64_t)blockIdx.y * n_tasks + L) * stride;
   {
     uint4* z = reinterpret_cast<uint4*>(smem_raw);
     const int n16 = (int)(((size_t)(S + 1) * sizeof(acc_t) + 15) / 16);
@@ -888,12 +890,27 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
   }
   __syncthreads();
   {
-    // S * sizeof(acc_t) is a multiple of 16 (slice_shift >= 4)
+    // stride * sizeof(acc_t) is a multiple of 16
     const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
     uint4* dst = reinterpret_cast<uint4*>(partial);
-    const int n16 = (int)((size_t)S * sizeof(acc_t) / 16);
+    const int n16 = (int)((size_t)stride * sizeof(acc_t) / 16);
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
   }
+}
+
+// sum of p[q * pstep], q < parts, with eight loads in flight (two per iteration left a 64-part reduce latency-bound)
+template <typename A>
+__device__ __forceinline__ A sum_parts(const A* __restrict__ p, int parts, int64_t pstep) {
+  A s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int q = 0;
+  for (; q + 8 <= parts; q += 8) {
+    const A* b = p + (int64_t)q * pstep;
+    const A v0 = b[0], v1 = b[pstep], v2 = b[2 * pstep], v3 = b[3 * pstep], v4 = b[4 * pstep], v5 = b[5 * pstep],
+            v6 = b[6 * pstep], v7 = b[7 * pstep];
+    s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+  }
+  for (; q < parts; ++q) s0 += p[(int64_t)q * pstep];
+  return (s0 + s1) + (s2 + s3);
 }
 
 // out[j] = sum over the parts of slice(j); partial is [batch][part][slice][S]
@@ -915,13 +932,9 @@ __global__ void __launch_bounds__(256) k_plan_reduce(const typename PlanAcc<HOMO
     const int loc = (int)((uint32_t)j - (uint32_t)slice * slice_width);
     const typename PlanAcc<HOMO>::type* p = partial + slice * S + loc;
     if (HOMO) {
-      uint32_t c = 0;
-      for (int q = 0; q < parts; ++q) c += p[(int64_t)q * pstep];
-      WTraits<W>::store(out, j, (typename WTraits<W>::acc)c * w0);
+      WTraits<W>::store(out, j, (typename WTraits<W>::acc)sum_parts(p, parts, pstep) * w0);
     } else {
-      unsigned long long s = 0;
-      for (int q = 0; q < parts; ++q) s += p[(int64_t)q * pstep];
-      WTraits<W>::store_d(out, j, (double)(long long)s * inv_scale);
+      WTraits<W>::store_d(out, j, (double)(long long)sum_parts(p, parts, pstep) * inv_scale);
     }
   }
 }
@@ -2175,10 +2188,15 @@ static inline bool width_ok(int slice_shift, int slice_width, int layout = BE_PL
                               (layout == BE_PLAN_H8 && slice_width <= kH8MaxWidth));
 }
 // accumulators per task (= stride of a task's partial sums; a multiple of 16 bytes)
-static inline int64_t cap_of(int slice_shift, int slice_width, int layout) {
+static inline int64_t cap_of(int slice_shift, int slice_width, int layout, int homo) {
   if (layout == BE_PLAN_D8) return (width_of(slice_shift, slice_width) + 1) & ~1ll;
   if (layout == BE_PLAN_H8) return (width_of(slice_shift, slice_width) + 3) & ~3ll;
-  return 1ll << slice_shift;
+  const int64_t w = width_of(slice_shift, slice_width);      // u16: the slice's own columns (the LDS holds 2^shift + pad)
+  return homo ? (w + 3) & ~3ll : (w + 1) & ~1ll;
+}
+// accumulator slots a workgroup keeps in LDS (the u16 layouts address a pad slot at 2^slice_shift)
+static inline int64_t lds_slots_of(int slice_shift, int slice_width, int layout, int homo) {
+  return layout == BE_PLAN_U16 ? (1ll << slice_shift) : cap_of(slice_shift, slice_width, layout, homo);
 }
 
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width) {
@@ -2318,8 +2336,9 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   BE_REQUIRE(seg && spikes && out && blob, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(!homo || weights != nullptr, BE_ERR_INVALID, "missing weights");
   BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
-  const int64_t S = cap_of(slice_shift, slice_width, layout);
-  const size_t lds = ((size_t)(S + 1) * (homo ? 4 : 8) + 15) & ~(size_t)15;
+  const int64_t S = cap_of(slice_shift, slice_width, layout, homo);                 // stride of a task's partial sums
+  const int64_t slots = lds_slots_of(slice_shift, slice_width, layout, homo);
+  const size_t lds = ((size_t)(slots + 1) * (homo ? 4 : 8) + 15) & ~(size_t)15;
   BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
   BE_REQUIRE(workspace != nullptr &&
                  workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo),
@@ -2340,7 +2359,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     const int lay = homo ? (layout == BE_PLAN_H8 ? 3 : 1) : (layout == BE_PLAN_D8 ? 2 : 0);
     const int prof1 = be_prof_begin(st);
     int rc1 = BE_ERR_INVALID;
-#define BE_SINGLE(LAY, WT) rc1 = launch_plan_single<LAY, WT>(blob, seg, spikes, spike_dtype, m, k, (int)S, sc1, isc1, weights, out, lds, st)
+#define BE_SINGLE(LAY, WT) rc1 = launch_plan_single<LAY, WT>(blob, seg, spikes, spike_dtype, m, k, (int)slots, sc1, isc1, weights, out, lds, st)
 #define BE_SINGLE_W(LAY)                                                    \
     switch (wdtype) {                                                        \
       case BE_F32: BE_SINGLE(LAY, float); break;                             \
@@ -2373,7 +2392,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     auto kern = k_plan_accumulate<true>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride);
+                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride, (int)S);
   } else if (layout == BE_PLAN_D8) {
     auto kern = k_plan_accumulate_d8;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
@@ -2384,7 +2403,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
-                       astride);
+                       astride, (int)S);
   }
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();

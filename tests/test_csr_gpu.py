@@ -147,7 +147,7 @@ def test_csrmv_plan_homo_counts_exact(be, oracle):
     w, idx, ptr = rand_csr(rng, m, k, [400] * m, homo=True)
     w[:] = 1.0
     plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k))
-    assert plan.slice_shift == 15 and plan.layout == ScatterPlan.LAYOUT_U16 and plan.n_slices == 3
+    assert plan.slice_shift == 15 and plan.layout == ScatterPlan.LAYOUT_U16 and plan.n_slices == 12   # 400 per row / 32 per block
     v = spikes_of(rng, m, 0.1, 'bool')
     spikes, sd = A.spikes_to_device(v)
     out = torch.empty(k, dtype=torch.float32, device='cuda')

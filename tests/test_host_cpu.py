@@ -250,12 +250,14 @@ def test_scatter_plan_auto_geometry():
     assert geo(100_000, 100_000, 10000, True) == (H8, 25)
     assert geo(700_000, 700_000, 16000, True) == (H8, 42)
     assert geo(100_000, 100_000, 10000, True, force='u16') == (U16, 25)
-    # short rows: h8 has nothing to gain (blocks of a line or two), d8 only when the step is throughput-bound
+    # mid-size outputs: ~24 slices (25 x 10 parts) instead of the few the LDS capacity would allow, blocks of >= 32 entries
+    assert geo(100_000, 100_000, 1000, True) == (U16, 25) and geo(100_000, 100_000, 1000, False) == (D8, 25)
+    assert geo(100_000, 100_000, 300, True) == (U16, 9)
+    # short rows: h8 has nothing to gain (blocks of a line or two)
     assert geo(1_000_000, 1_000_000, 1000, True) == (U16, 32)
     assert geo(1_000_000, 1_000_000, 1000, False) == (D8, 51)
-    assert geo(100_000, 100_000, 1000, False) == (U16, 7)
     assert geo(300_000, 300_000, 3000, True)[0] == U16
-    # one slice: d8 (reaches 20000 columns in a single launch), counted entries stay u16
+    # one slice, <= 1M entries: the single-launch kernel (d8 reaches 20000 columns), counted entries stay u16
     assert geo(4000, 4000, 80, False) == (D8, 1) and geo(4000, 18000, 80, False) == (D8, 1)
     assert geo(4000, 4000, 80, True) == (U16, 1)
     # sorted layouts not applicable (f64 weights, rows beyond the LDS sort): u16 with the same pass-sized slices
