@@ -1191,7 +1191,7 @@ inline bool check_rows(const void* indptr, int64_t row_len) { return indptr != n
 // =================================================================================================
 constexpr int kMaxBins = 2048;       // 4 x 4 B x 2048 = 32 KiB of LDS bookkeeping
 // entries per LDS batch of (uint16 column [, f32 weight]) payload
-template <bool HOMO> struct BinBatch { static constexpr int n = HOMO ? 49152 : 16384; };   // 96 KiB of payload
+template <bool HOMO> struct BinBatch { static constexpr int n = HOMO ? 32768 : 16384; };   // 64 / 96 KiB of payload
 
 // block-wide inclusive scan over 1024 threads (wave shuffles + one LDS hop): 2 barriers instead of 20
 __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wave_tot /* [16] in LDS */) {
@@ -1212,54 +1212,6 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wave_t
   return base + incl;
 }
 
-// Streams the entries of a batch's row pieces through `consume(column, weight)`: wave w takes pieces w, w + nw, ...; a
-// piece is cut into chunks of 256 entries (4 per lane) and kBinDepth chunks are kept in flight across piece boundaries —
-// a piece is a random 0.5 .. 4 KB read, and one chunk at a time left the wave idle for a full HBM round trip per chunk
-// (K = 1000 rows: 4 round trips per row; K = 125 shard rows: one per row).  Loads are unconditional (clamped index).
-constexpr int kBinDepth = 4;
-template <bool WITH_W, typename W, typename F>
-__device__ __forceinline__ void bin_stream_pieces(const int32_t* __restrict__ indices, const W* __restrict__ weights,
-                                                  const int64_t* s_begin, const uint32_t* s_lens, uint32_t nrows, int wave,
-                                                  int nw, int lane, F&& consume) {
-  uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(wave), j0 = 0;
-  while (i < nrows && s_lens[i] == 0) i += nw;
-  int64_t cb[kBinDepth];
-  uint32_t cl[kBinDepth], cj[kBinDepth];
-  uint32_t c[kBinDepth][4];
-  float wv[kBinDepth][4];
-  auto issue = [&](int d) {
-    const bool valid = i < nrows;
-    cb[d] = valid ? s_begin[i] : 0;
-    cl[d] = valid ? s_lens[i] : 0u;
-    cj[d] = j0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t j = j0 + 64 * u + lane;
-      const int64_t e = cb[d] + (cl[d] ? (j < cl[d] ? j : cl[d] - 1) : 0u);
-      c[d][u] = (uint32_t)indices[e];
-      wv[d][u] = WITH_W ? (float)WTraits<W>::load(weights, e) : 0.f;
-    }
-    if (valid) {           // wave-uniform: next chunk of this piece, or the wave's next non-empty piece
-      j0 += 256;
-      if (j0 >= cl[d]) {
-        j0 = 0;
-        do { i += nw; } while (i < nrows && s_lens[i] == 0);
-      }
-    }
-  };
-#pragma unroll
-  for (int d = 0; d < kBinDepth; ++d) issue(d);
-  while (cl[0] != 0u) {      // chunks are issued in order: an exhausted oldest slot means all are
-#pragma unroll
-    for (int d = 0; d < kBinDepth; ++d) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (cj[d] + 64 * u + lane < cl[d]) consume(c[d][u], wv[d][u]);
-      issue(d);
-    }
-  }
-}
-
 // one launch instead of three memset nodes: output <- 0, bin cursors <- 0, bin valid extents <- "all of it"
 __global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int64_t k, uint32_t* __restrict__ cursor,
                                                    uint32_t* __restrict__ valid, int n_bins) {
@@ -1272,24 +1224,34 @@ __global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int6
   for (int64_t i = t; i < n_bins; i += stride) { cursor[i] = 0u; valid[i] = 0xffffffffu; }
 }
 
+// A batch is cut into chunks of 64 consecutive entries of one row piece (one per lane); wave w owns chunks
+// w * SLOTS .. w * SLOTS + SLOTS - 1 of the batch and keeps them in REGISTERS from the first read to the placement:
+// every load of the batch is in flight at once (16 / 48 independent 256-byte reads per wave — a row is a random
+// 0.5 .. 4 KB read, and the first version, four chunks in flight and a second pass over the rows for the placement,
+// spent most of a batch waiting for HBM round trips: 28 us per 16384 entries, 2.5 TB/s), and the rows are read once.
+template <bool HOMO> struct BinSlots { static constexpr int n = HOMO ? 32 : 16; };     // registers per lane: 32 / 16 + 16
+
 template <typename W, bool HOMO>
 __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
                                                    const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
                                                    int slice_shift, int n_bins, uint32_t cap, uint32_t* __restrict__ bin_cursor,
                                                    uint32_t* __restrict__ bin_valid, uint16_t* __restrict__ bin_idx,
                                                    float* __restrict__ bin_w, float* __restrict__ out) {
-  constexpr uint32_t kBatch = BinBatch<HOMO>::n;
+  constexpr int SLOTS = BinSlots<HOMO>::n;
+  constexpr uint32_t kChunks = 16u * SLOTS;            // chunks per batch (16 waves)
+  constexpr uint32_t kBatch = kChunks * 64u;           // entries per batch
+  static_assert(kBatch == (uint32_t)BinBatch<HOMO>::n, "LDS batch size");
   __shared__ uint32_t hist[kMaxBins], offs[kMaxBins], fill[kMaxBins], gpos[kMaxBins];
   __shared__ uint16_t s_idx[kBatch];
   __shared__ float s_w[HOMO ? 1 : kBatch];
-  __shared__ uint32_t s_rows[1024];       // batch: row id
-  __shared__ uint32_t s_lens[1024];       //        piece length
+  __shared__ uint32_t s_lens[1024];       // batch: piece length
+  __shared__ uint32_t s_cstart[1024];     //        first chunk of the piece
   __shared__ int64_t s_begin[1024];       //        first entry of the piece
   __shared__ uint32_t s_wtot[16];
-  __shared__ uint32_t s_nrows;
+  __shared__ uint32_t s_nrows, s_nchunks;
   __shared__ uint64_t s_next;             // next list position of this workgroup
   __shared__ int64_t s_carry_begin;       // unfinished tail of a long row
-  __shared__ uint32_t s_carry_row, s_carry_len;
+  __shared__ uint32_t s_carry_len;
 
   const uint32_t n_active = *n_active_p;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -1301,45 +1263,46 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
 
   for (;;) {
     // ---- form a batch: thread t looks at this workgroup's t-th next row (loads in parallel), a block scan of
-    //      the row lengths picks the longest prefix that fits one batch; a row longer than a batch is processed
-    //      alone, one batch-sized piece at a time (carry)
+    //      the rows' chunk counts picks the longest prefix that fits one batch; a row longer than a batch is
+    //      processed alone, one batch-sized piece at a time (carry)
     for (int b = tid; b < n_bins; b += blockDim.x) { hist[b] = 0; fill[b] = 0; }
     if (s_carry_len) {               // uniform: shared state
       __syncthreads();
       if (tid == 0) {
         const uint32_t take = s_carry_len < kBatch ? s_carry_len : kBatch;
-        s_rows[0] = s_carry_row; s_begin[0] = s_carry_begin; s_lens[0] = take;
+        s_begin[0] = s_carry_begin; s_lens[0] = take; s_cstart[0] = 0;
         s_carry_begin += take; s_carry_len -= take;
-        s_nrows = 1;
+        s_nrows = 1; s_nchunks = (take + 63u) >> 6;
       }
       __syncthreads();
     } else {
       const uint64_t a = s_next + (uint64_t)tid * gridDim.x;
-      uint32_t r = 0; int64_t rb = 0; uint64_t len = 0;
+      int64_t rb = 0; uint64_t len = 0;
       if (a < n_active) {
-        r = active[a];
+        const uint32_t r = active[a];
         rb = rp.at(r);
         len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
       }
-      const uint32_t len32 = len > 0xfffffffeull ? 0xfffffffeu : (uint32_t)len;
-      // lengths saturate at kBatch + 1 per row; 1024 of them cannot overflow 32 bits
-      const uint32_t incl = block_scan_1024(len32 > kBatch ? kBatch + 1u : len32, s_wtot);
+      // chunk counts saturate at kChunks + 1 per row; 1024 of them cannot overflow 32 bits
+      const uint32_t nch = len > (uint64_t)kBatch ? kChunks + 1u : (uint32_t)((len + 63u) >> 6);
+      const uint32_t incl = block_scan_1024(nch, s_wtot);
       const bool in_list = a < n_active;
-      const bool fits = in_list && incl <= kBatch;
+      const bool fits = in_list && incl <= kChunks;
       const int nfit = __syncthreads_count(fits);          // rows 0 .. nfit-1 (a prefix: the scan is monotone)
-      if (fits) { s_rows[tid] = r; s_begin[tid] = rb; s_lens[tid] = len32; }
+      if (fits) { s_begin[tid] = rb; s_lens[tid] = (uint32_t)len; s_cstart[tid] = incl - nch; }
+      if (fits && tid == nfit - 1) s_nchunks = incl;
       if (tid == 0) {
         if (nfit > 0) {
           s_nrows = nfit;
           s_next += (uint64_t)nfit * gridDim.x;
         } else if (in_list) {                               // the first row alone exceeds a batch: start carrying it
-          s_rows[0] = r; s_begin[0] = rb; s_lens[0] = kBatch;
-          s_carry_row = r; s_carry_begin = rb + kBatch;
+          s_begin[0] = rb; s_lens[0] = kBatch; s_cstart[0] = 0;
+          s_carry_begin = rb + kBatch;
           s_carry_len = (len - kBatch) > 0xffffffffull ? 0xffffffffu : (uint32_t)(len - kBatch);
-          s_nrows = 1;
+          s_nrows = 1; s_nchunks = kChunks;
           s_next += gridDim.x;
         } else {
-          s_nrows = 0;
+          s_nrows = 0; s_nchunks = 0;
         }
       }
       __syncthreads();
@@ -1347,10 +1310,45 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
     const uint32_t nrows = s_nrows;
     if (nrows == 0) break;
 
-    // ---- phase 1: histogram of the batch over the bins (wave per row piece, 4 independent loads in flight:
-    //      clamped index + predicate instead of a conditional load)
-    bin_stream_pieces<false, W>(indices, weights, s_begin, s_lens, nrows, wave, nw, lane,
-                                [&](uint32_t col, float) { atomicAdd(&hist[col >> slice_shift], 1u); });
+    // ---- this wave's chunks: lane s < SLOTS finds the piece of chunk wave * SLOTS + s (last piece whose first chunk
+    //      is <= the chunk id: empty pieces share their start with the piece that follows them)
+    int64_t my_e0 = 0;
+    uint32_t my_n = 0;
+    {
+      const uint32_t cid = (uint32_t)wave * SLOTS + (uint32_t)lane;
+      if (lane < SLOTS && cid < s_nchunks) {
+        uint32_t lo = 0, hi = nrows;                        // first piece with cstart > cid
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_cstart[mid] > cid) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t pc = lo - 1u;
+        const uint32_t j0 = (cid - s_cstart[pc]) << 6;
+        my_e0 = s_begin[pc] + j0;
+        const uint32_t left = s_lens[pc] - j0;
+        my_n = left < 64u ? left : 64u;
+      }
+    }
+    // ---- every load of the batch at once (clamped index + predicate instead of conditional loads)
+    uint32_t col[SLOTS];
+    float wv[HOMO ? 1 : SLOTS];
+    uint32_t cnt_mask_lo = 0, cnt_mask_hi = 0;              // bit s: this lane holds an entry in slot s
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)my_n, sl);
+      const uint32_t e_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_e0 & 0xffffffffll), sl);
+      const uint32_t e_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_e0 >> 32), sl);
+      const int64_t e0 = (int64_t)(((uint64_t)e_hi << 32) | e_lo);
+      const uint32_t l = n_s ? ((uint32_t)lane < n_s ? (uint32_t)lane : n_s - 1u) : 0u;
+      const int64_t e = n_s ? e0 + l : 0;
+      col[sl] = (uint32_t)indices[e];
+      if (!HOMO) wv[sl] = (float)WTraits<W>::load(weights, e);
+      if ((uint32_t)lane < n_s) { if (sl < 32) cnt_mask_lo |= 1u << (sl & 31); else cnt_mask_hi |= 1u << (sl & 31); }
+    }
+    // ---- phase 1: histogram of the batch over the bins
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl)
+      if ((sl < 32 ? cnt_mask_lo : cnt_mask_hi) >> (sl & 31) & 1u) atomicAdd(&hist[col[sl] >> slice_shift], 1u);
     __syncthreads();
     // ---- phase 2: exclusive scan of hist (n_bins <= 2048: two per thread) + one range reservation per bin
     {
@@ -1366,31 +1364,46 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
       }
     }
     __syncthreads();
-    // ---- phase 3: place the entries into the LDS batch sorted by bin (second read of the rows comes from L2)
-    bin_stream_pieces<!HOMO, W>(indices, weights, s_begin, s_lens, nrows, wave, nw, lane, [&](uint32_t col, float w) {
-      const uint32_t bin = col >> slice_shift;
-      const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
-      s_idx[pos] = (uint16_t)(col & mask);
-      if (!HOMO) s_w[pos] = w;
-    });
+    // ---- phase 3: place the entries into the LDS batch sorted by bin, straight from the registers
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if ((sl < 32 ? cnt_mask_lo : cnt_mask_hi) >> (sl & 31) & 1u) {
+        const uint32_t bin = col[sl] >> slice_shift;
+        const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
+        s_idx[pos] = (uint16_t)(col[sl] & mask);
+        if (!HOMO) s_w[pos] = wv[sl];
+      }
+    }
     __syncthreads();
-    // ---- phase 4: copy the runs out, one wave per bin; runs that do not fit go through global atomics
-    for (int bin = wave; bin < n_bins; bin += nw) {
-      const uint32_t cnt = hist[bin];
-      if (cnt == 0) continue;
-      const uint32_t o = offs[bin], g = gpos[bin];
-      if ((uint64_t)g + cnt <= cap) {
+    // ---- phase 4: copy the runs out, 16 lanes per bin (a run has ~27 entries at C4: one wave per bin spent its time in
+    //      the chain of dependent LDS reads per bin, 38 bins per wave: 16 us of a 28 us batch); runs that do not fit
+    //      go through global atomics
+    {
+      // lanes per bin from the expected run length (batch entries / bins): 16 ... 64
+      const uint32_t run = kBatch / (uint32_t)n_bins;
+      const int lpb_shift = run >= 192u ? 6 : (run >= 64u ? 5 : 4);
+      const int LPB = 1 << lpb_shift, BPW = 64 >> lpb_shift;      // lanes per bin, bins per wave and iteration
+      const int grp = lane >> lpb_shift, gl = lane & (LPB - 1);
+      for (int bin0 = wave * BPW; bin0 < n_bins; bin0 += nw * BPW) {
+        const int bin = bin0 + grp;
+        uint32_t cnt = 0, o = 0, g = 0;
+        if (bin < n_bins) { cnt = hist[bin]; o = offs[bin]; g = gpos[bin]; }
+        const bool fits = (uint64_t)g + cnt <= cap;
+        // a full bin: everything from position g on is NOT in the bin (later reservations start even higher)
+        if (cnt && !fits && gl == 0) atomicMin(&bin_valid[bin], g);
         uint16_t* di = bin_idx + (int64_t)bin * cap + g;
         float* dw = bin_w + (int64_t)bin * cap + g;
-        for (uint32_t j = lane; j < cnt; j += 64) {
-          di[j] = s_idx[o + j];
-          if (!HOMO) dw[j] = s_w[o + j];
-        }
-      } else {
-        // the bin is full: everything from position g on is NOT in the bin (later reservations start even higher)
-        if (lane == 0) atomicMin(&bin_valid[bin], g);
         float* dst = out + ((int64_t)bin << slice_shift);
-        for (uint32_t j = lane; j < cnt; j += 64) atomicAdd(dst + s_idx[o + j], HOMO ? w0 : s_w[o + j]);
+        for (uint32_t j = gl; j < cnt; j += LPB) {
+          const uint16_t c = s_idx[o + j];
+          const float w = HOMO ? w0 : s_w[o + j];
+          if (fits) {
+            di[j] = c;
+            if (!HOMO) dw[j] = w;
+          } else {
+            atomicAdd(dst + c, w);
+          }
+        }
       }
     }
     __syncthreads();
