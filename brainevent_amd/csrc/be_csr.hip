@@ -1214,9 +1214,10 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wave_t
 
 // one launch instead of three memset nodes: output <- 0, bin cursors <- 0, bin valid extents <- "all of it"
 __global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int64_t k, uint32_t* __restrict__ cursor,
-                                                   uint32_t* __restrict__ valid, int n_bins) {
+                                                   uint32_t* __restrict__ valid, int n_bins, uint32_t* __restrict__ count) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) count[0] = 0u;                       // the spike counter of the compaction that follows
   float4* o4 = reinterpret_cast<float4*>(out);
   const int64_t k4 = k >> 2;                       // out comes from the caller's allocator: 16-byte aligned
   for (int64_t i = t; i < k4; i += stride) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2480,15 +2481,16 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   RowPtr rp{indptr, indptr_is_i64, row_len};
   if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, cursor,
-                       valid, n_bins);
+                       valid, n_bins, count);
     BE_LAUNCH_CHECK();
   } else {
     BE_HIP(be_fill_async(out, 0, (size_t)k * 4, st));
     BE_HIP(be_fill_async(cursor, 0, (size_t)n_bins * 4, st));
     BE_HIP(be_fill_async(valid, 0xff, (size_t)n_bins * 4, st));
+    BE_HIP(be_fill_async(count, 0, 4, st));
   }
   ActiveList al;
-  int rc = resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, true, &al);
+  int rc = resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, /*zero_first=*/false, &al);
   if (rc != BE_OK) return rc;
   const int prof = be_prof_begin(st);
   if (homo)
