@@ -898,19 +898,35 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
   }
 }
 
-// sum of p[q * pstep], q < parts, with eight loads in flight (two per iteration left a 64-part reduce latency-bound)
+// sum of p[q * pstep], q < parts, with up to eight loads in flight (two per iteration left a 64-part reduce latency-bound;
+// a switch on the remainder keeps a 5-part reduce at one round trip too)
+template <typename A, int N>
+__device__ __forceinline__ A sum_n(const A* __restrict__ b, int64_t pstep) {
+  A v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = b[(int64_t)i * pstep];
+  A s = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) s += v[i];
+  return s;
+}
 template <typename A>
 __device__ __forceinline__ A sum_parts(const A* __restrict__ p, int parts, int64_t pstep) {
-  A s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  A s = 0;
   int q = 0;
-  for (; q + 8 <= parts; q += 8) {
-    const A* b = p + (int64_t)q * pstep;
-    const A v0 = b[0], v1 = b[pstep], v2 = b[2 * pstep], v3 = b[3 * pstep], v4 = b[4 * pstep], v5 = b[5 * pstep],
-            v6 = b[6 * pstep], v7 = b[7 * pstep];
-    s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+  for (; q + 8 <= parts; q += 8) s += sum_n<A, 8>(p + (int64_t)q * pstep, pstep);
+  const A* b = p + (int64_t)q * pstep;
+  switch (parts - q) {      // wave-uniform
+    case 1: s += sum_n<A, 1>(b, pstep); break;
+    case 2: s += sum_n<A, 2>(b, pstep); break;
+    case 3: s += sum_n<A, 3>(b, pstep); break;
+    case 4: s += sum_n<A, 4>(b, pstep); break;
+    case 5: s += sum_n<A, 5>(b, pstep); break;
+    case 6: s += sum_n<A, 6>(b, pstep); break;
+    case 7: s += sum_n<A, 7>(b, pstep); break;
+    default: break;
   }
-  for (; q < parts; ++q) s0 += p[(int64_t)q * pstep];
-  return (s0 + s1) + (s2 + s3);
+  return s;
 }
 
 // out[j] = sum over the parts of slice(j); partial is [batch][part][slice][S]
