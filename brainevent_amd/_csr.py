@@ -13,7 +13,7 @@ Semantics (``e(x)`` = ``x`` for bool, ``x > 0`` for float):
 
 The per-matrix workspace of the reference (a task queue sized by ``hybrid_task_capacity``) becomes
 here a :class:`ScatterPlan` — the post-sliced row-segment layout consumed by the LDS-accumulating
-scatter kernel (see ``csrc/be_csr.hip``).  ``workspace=None`` selects the preprocessing-free
+scatter kernel (see ``csrc/be_csr_plan.hip``; the binned route is ``csrc/be_csr_binned.hip``).  ``workspace=None`` selects the preprocessing-free
 "direct" kernel (global atomics).
 """
 import ctypes

@@ -1,0 +1,367 @@
+// be_csr_binned.hip — the binned scatter route (no per-matrix layout) for gfx950; see the section comment below.
+#include "be_csr_shared.h"
+
+namespace {
+
+// =================================================================================================
+// binned route: event-driven scatter for matrices WITHOUT a plan (or whose rows put too few entries into
+// one output slice for the plan to pay: FixedNumPerPre K=1000 over 10M outputs has 1.6 entries per (row, slice)).
+//
+//   pass B (k_bin_rows)   : persistent workgroups take active rows round-robin, fill an LDS batch of <= kBinBatch
+//                           entries, counting-sort it by output slice ("bin") in LDS, reserve one range per
+//                           (workgroup, bin) in that bin's global region (one returning atomic each) and copy the
+//                           runs out coalesced as (uint16 local column, f32 weight).
+//   pass C (k_bin_accumulate): one workgroup per (bin, part) streams the bin and accumulates in LDS with integer
+//                           atomics exactly like the planned route, then adds its slice to the output.
+//   A bin region that overflows its capacity never corrupts anything: that run is delivered with global float
+//   atomics instead (slow path, still correct).
+// HBM traffic per update (hetero): 8 B read (pass B) + 6 B write + 6 B read = 20 B  vs  8 B algorithmic.
+// =================================================================================================
+constexpr int kMaxBins = 2048;       // 4 x 4 B x 2048 = 32 KiB of LDS bookkeeping
+// entries per LDS batch of (uint16 column [, f32 weight]) payload
+template <bool HOMO> struct BinBatch { static constexpr int n = HOMO ? 32768 : 16384; };   // 64 / 96 KiB of payload
+
+// one launch instead of three memset nodes: output <- 0, bin cursors <- 0, bin valid extents <- "all of it"
+__global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int64_t k, uint32_t* __restrict__ cursor,
+                                                   uint32_t* __restrict__ valid, int n_bins, uint32_t* __restrict__ count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) count[0] = 0u;                       // the spike counter of the compaction that follows
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const int64_t k4 = k >> 2;                       // out comes from the caller's allocator: 16-byte aligned
+  for (int64_t i = t; i < k4; i += stride) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (k4 << 2) + t; i < k; i += stride) out[i] = 0.f;
+  for (int64_t i = t; i < n_bins; i += stride) { cursor[i] = 0u; valid[i] = 0xffffffffu; }
+}
+
+// A batch is cut into chunks of 64 consecutive entries of one row piece (one per lane); wave w owns chunks
+// w * SLOTS .. w * SLOTS + SLOTS - 1 of the batch and keeps them in REGISTERS from the first read to the placement:
+// every load of the batch is in flight at once (16 / 48 independent 256-byte reads per wave — a row is a random
+// 0.5 .. 4 KB read, and the first version, four chunks in flight and a second pass over the rows for the placement,
+// spent most of a batch waiting for HBM round trips: 28 us per 16384 entries, 2.5 TB/s), and the rows are read once.
+template <bool HOMO> struct BinSlots { static constexpr int n = HOMO ? 32 : 16; };     // registers per lane: 32 / 16 + 16
+
+template <typename W, bool HOMO>
+__global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
+                                                   const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
+                                                   int slice_shift, int n_bins, uint32_t cap, uint32_t* __restrict__ bin_cursor,
+                                                   uint32_t* __restrict__ bin_valid, uint16_t* __restrict__ bin_idx,
+                                                   float* __restrict__ bin_w, float* __restrict__ out) {
+  constexpr int SLOTS = BinSlots<HOMO>::n;
+  constexpr uint32_t kChunks = 16u * SLOTS;            // chunks per batch (16 waves)
+  constexpr uint32_t kBatch = kChunks * 64u;           // entries per batch
+  static_assert(kBatch == (uint32_t)BinBatch<HOMO>::n, "LDS batch size");
+  __shared__ uint32_t hist[kMaxBins], offs[kMaxBins], fill[kMaxBins], gpos[kMaxBins];
+  __shared__ uint16_t s_idx[kBatch];
+  __shared__ float s_w[HOMO ? 1 : kBatch];
+  __shared__ uint32_t s_lens[1024];       // batch: piece length
+  __shared__ uint32_t s_cstart[1024];     //        first chunk of the piece
+  __shared__ int64_t s_begin[1024];       //        first entry of the piece
+  __shared__ uint32_t s_wtot[16];
+  __shared__ uint32_t s_nrows, s_nchunks;
+  __shared__ uint64_t s_next;             // next list position of this workgroup
+  __shared__ int64_t s_carry_begin;       // unfinished tail of a long row
+  __shared__ uint32_t s_carry_len;
+
+  const uint32_t n_active = *n_active_p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const uint32_t mask = (1u << slice_shift) - 1u;
+  float w0 = 0.f;
+  if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
+  if (tid == 0) { s_next = blockIdx.x; s_carry_len = 0; }
+  __syncthreads();
+
+  for (;;) {
+    // ---- form a batch: thread t looks at this workgroup's t-th next row (loads in parallel), a block scan of
+    //      the rows' chunk counts picks the longest prefix that fits one batch; a row longer than a batch is
+    //      processed alone, one batch-sized piece at a time (carry)
+    for (int b = tid; b < n_bins; b += blockDim.x) { hist[b] = 0; fill[b] = 0; }
+    if (s_carry_len) {               // uniform: shared state
+      __syncthreads();
+      if (tid == 0) {
+        const uint32_t take = s_carry_len < kBatch ? s_carry_len : kBatch;
+        s_begin[0] = s_carry_begin; s_lens[0] = take; s_cstart[0] = 0;
+        s_carry_begin += take; s_carry_len -= take;
+        s_nrows = 1; s_nchunks = (take + 63u) >> 6;
+      }
+      __syncthreads();
+    } else {
+      const uint64_t a = s_next + (uint64_t)tid * gridDim.x;
+      int64_t rb = 0; uint64_t len = 0;
+      if (a < n_active) {
+        const uint32_t r = active[a];
+        rb = rp.at(r);
+        len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
+      }
+      // chunk counts saturate at kChunks + 1 per row; 1024 of them cannot overflow 32 bits
+      const uint32_t nch = len > (uint64_t)kBatch ? kChunks + 1u : (uint32_t)((len + 63u) >> 6);
+      const uint32_t incl = block_scan_1024(nch, s_wtot);
+      const bool in_list = a < n_active;
+      const bool fits = in_list && incl <= kChunks;
+      const int nfit = __syncthreads_count(fits);          // rows 0 .. nfit-1 (a prefix: the scan is monotone)
+      if (fits) { s_begin[tid] = rb; s_lens[tid] = (uint32_t)len; s_cstart[tid] = incl - nch; }
+      if (fits && tid == nfit - 1) s_nchunks = incl;
+      if (tid == 0) {
+        if (nfit > 0) {
+          s_nrows = nfit;
+          s_next += (uint64_t)nfit * gridDim.x;
+        } else if (in_list) {                               // the first row alone exceeds a batch: start carrying it
+          s_begin[0] = rb; s_lens[0] = kBatch; s_cstart[0] = 0;
+          s_carry_begin = rb + kBatch;
+          s_carry_len = (len - kBatch) > 0xffffffffull ? 0xffffffffu : (uint32_t)(len - kBatch);
+          s_nrows = 1; s_nchunks = kChunks;
+          s_next += gridDim.x;
+        } else {
+          s_nrows = 0; s_nchunks = 0;
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t nrows = s_nrows;
+    if (nrows == 0) break;
+
+    // ---- this wave's chunks: lane s < SLOTS finds the piece of chunk wave * SLOTS + s (last piece whose first chunk
+    //      is <= the chunk id: empty pieces share their start with the piece that follows them)
+    int64_t my_e0 = 0;
+    uint32_t my_n = 0;
+    {
+      const uint32_t cid = (uint32_t)wave * SLOTS + (uint32_t)lane;
+      if (lane < SLOTS && cid < s_nchunks) {
+        uint32_t lo = 0, hi = nrows;                        // first piece with cstart > cid
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_cstart[mid] > cid) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t pc = lo - 1u;
+        const uint32_t j0 = (cid - s_cstart[pc]) << 6;
+        my_e0 = s_begin[pc] + j0;
+        const uint32_t left = s_lens[pc] - j0;
+        my_n = left < 64u ? left : 64u;
+      }
+    }
+    // ---- every load of the batch at once (clamped index + predicate instead of conditional loads)
+    uint32_t col[SLOTS];
+    float wv[HOMO ? 1 : SLOTS];
+    uint32_t cnt_mask_lo = 0, cnt_mask_hi = 0;              // bit s: this lane holds an entry in slot s
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)my_n, sl);
+      const uint32_t e_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_e0 & 0xffffffffll), sl);
+      const uint32_t e_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_e0 >> 32), sl);
+      const int64_t e0 = (int64_t)(((uint64_t)e_hi << 32) | e_lo);
+      const uint32_t l = n_s ? ((uint32_t)lane < n_s ? (uint32_t)lane : n_s - 1u) : 0u;
+      const int64_t e = n_s ? e0 + l : 0;
+      col[sl] = (uint32_t)indices[e];
+      if (!HOMO) wv[sl] = (float)WTraits<W>::load(weights, e);
+      if ((uint32_t)lane < n_s) { if (sl < 32) cnt_mask_lo |= 1u << (sl & 31); else cnt_mask_hi |= 1u << (sl & 31); }
+    }
+    // ---- phase 1: histogram of the batch over the bins
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl)
+      if ((sl < 32 ? cnt_mask_lo : cnt_mask_hi) >> (sl & 31) & 1u) atomicAdd(&hist[col[sl] >> slice_shift], 1u);
+    __syncthreads();
+    // ---- phase 2: exclusive scan of hist (n_bins <= 2048: two per thread) + one range reservation per bin
+    {
+      const uint32_t v0 = (2 * tid < n_bins) ? hist[2 * tid] : 0u, v1 = (2 * tid + 1 < n_bins) ? hist[2 * tid + 1] : 0u;
+      const uint32_t excl = block_scan_1024(v0 + v1, s_wtot) - (v0 + v1);
+      if (2 * tid < n_bins) {
+        offs[2 * tid] = excl;
+        gpos[2 * tid] = v0 ? atomicAdd(&bin_cursor[2 * tid], v0) : 0u;
+      }
+      if (2 * tid + 1 < n_bins) {
+        offs[2 * tid + 1] = excl + v0;
+        gpos[2 * tid + 1] = v1 ? atomicAdd(&bin_cursor[2 * tid + 1], v1) : 0u;
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: place the entries into the LDS batch sorted by bin, straight from the registers
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if ((sl < 32 ? cnt_mask_lo : cnt_mask_hi) >> (sl & 31) & 1u) {
+        const uint32_t bin = col[sl] >> slice_shift;
+        const uint32_t pos = offs[bin] + atomicAdd(&fill[bin], 1u);
+        s_idx[pos] = (uint16_t)(col[sl] & mask);
+        if (!HOMO) s_w[pos] = wv[sl];
+      }
+    }
+    __syncthreads();
+    // ---- phase 4: copy the runs out, 16 lanes per bin (a run has ~27 entries at C4: one wave per bin spent its time in
+    //      the chain of dependent LDS reads per bin, 38 bins per wave: 16 us of a 28 us batch); runs that do not fit
+    //      go through global atomics
+    {
+      // lanes per bin from the expected run length (batch entries / bins): 16 ... 64
+      const uint32_t run = kBatch / (uint32_t)n_bins;
+      const int lpb_shift = run >= 192u ? 6 : (run >= 64u ? 5 : 4);
+      const int LPB = 1 << lpb_shift, BPW = 64 >> lpb_shift;      // lanes per bin, bins per wave and iteration
+      const int grp = lane >> lpb_shift, gl = lane & (LPB - 1);
+      for (int bin0 = wave * BPW; bin0 < n_bins; bin0 += nw * BPW) {
+        const int bin = bin0 + grp;
+        uint32_t cnt = 0, o = 0, g = 0;
+        if (bin < n_bins) { cnt = hist[bin]; o = offs[bin]; g = gpos[bin]; }
+        const bool fits = (uint64_t)g + cnt <= cap;
+        // a full bin: everything from position g on is NOT in the bin (later reservations start even higher)
+        if (cnt && !fits && gl == 0) atomicMin(&bin_valid[bin], g);
+        uint16_t* di = bin_idx + (int64_t)bin * cap + g;
+        float* dw = bin_w + (int64_t)bin * cap + g;
+        float* dst = out + ((int64_t)bin << slice_shift);
+        for (uint32_t j = gl; j < cnt; j += LPB) {
+          const uint16_t c = s_idx[o + j];
+          const float w = HOMO ? w0 : s_w[o + j];
+          if (fits) {
+            di[j] = c;
+            if (!HOMO) dw[j] = w;
+          } else {
+            atomicAdd(dst + c, w);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <bool HOMO>
+__global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restrict__ bin_idx, const float* __restrict__ bin_w,
+                                                         const uint32_t* __restrict__ bin_cursor,
+                                                         const uint32_t* __restrict__ bin_valid, uint32_t cap, int slice_shift,
+                                                         int parts, int64_t k, float scale, double inv_scale,
+                                                         const float* __restrict__ w0p, float* __restrict__ out) {
+  using acc_t = typename PlanAcc<HOMO>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
+  const int S = 1 << slice_shift;
+  const int bin = blockIdx.x / parts, part = blockIdx.x - bin * parts;
+  uint32_t cnt = bin_cursor[bin];
+  const uint32_t valid = bin_valid[bin];         // first position that was NOT written (cap if the bin never overflowed)
+  cnt = cnt < valid ? cnt : valid;
+  cnt = cnt < cap ? cnt : cap;
+  const float w0 = HOMO ? w0p[0] : 0.f;
+  if (cnt == 0) return;                     // nothing was binned here (out already holds zeros / overflow adds)
+  for (int i = threadIdx.x; i < S; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  // this part's share, in units of 8 entries
+  const uint32_t n8 = (cnt + 7u) >> 3;
+  const uint32_t per = (n8 + parts - 1) / parts;
+  const uint32_t g_begin = part * per, g_end = g_begin + per < n8 ? g_begin + per : n8;
+  const uint16_t* bi = bin_idx + (int64_t)bin * cap;
+  const float* bw = bin_w + (int64_t)bin * cap;
+  for (uint32_t g = g_begin + threadIdx.x; g < g_end; g += blockDim.x) {
+    const uint32_t e0 = g * 8u;
+    if (e0 + 8u <= cnt) {        // cap is a multiple of 8: bin regions are 16-byte aligned
+      const uint4 iv = *reinterpret_cast<const uint4*>(bi + e0);
+      if (HOMO) {
+        plan_count8(reinterpret_cast<uint32_t*>(acc), iv.x, iv.y, iv.z, iv.w);
+      } else {
+        const float4 wa = *reinterpret_cast<const float4*>(bw + e0), wb = *reinterpret_cast<const float4*>(bw + e0 + 4);
+        plan_add4<HOMO>(acc, make_uint2(iv.x, iv.y), wa, scale);
+        plan_add4<HOMO>(acc, make_uint2(iv.z, iv.w), wb, scale);
+      }
+    } else {
+      for (uint32_t e = e0; e < cnt; ++e) {
+        if (HOMO) atomicAdd(reinterpret_cast<uint32_t*>(acc) + bi[e], 1u);
+        else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + bi[e], fixed_from_f32(bw[e], scale));
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t j0 = (int64_t)bin << slice_shift;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    if (j0 + i >= k) break;
+    float v;
+    if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
+    else v = (float)((double)(long long)reinterpret_cast<unsigned long long*>(acc)[i] * inv_scale);
+    if (v != 0.f) atomicAdd(out + j0 + i, v);     // contiguous float atomics; one add per output unless parts > 1
+  }
+}
+
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+// ---------------------------------------------------------------- binned route (no plan)
+static inline int64_t binned_cap_align(int64_t cap) { return (cap + 7) & ~7ll; }
+
+int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity) {
+  const int64_t n_bins = n_slices_of(k, slice_shift);
+  const int64_t cap = binned_cap_align(bin_capacity);
+  return 256 + be_align_up(m * 4, 256) + 2 * be_align_up(n_bins * 4, 256) + be_align_up(n_bins * cap * 2, 256) +
+         be_align_up(n_bins * cap * 4, 256);
+}
+
+int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                             int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                             int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
+                             int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(wdtype == BE_F32, BE_ERR_UNSUPPORTED, "the binned route supports f32 weights / outputs");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights && indices && spikes && out, BE_ERR_INVALID, "null pointer");
+  const int n_bins = n_slices_of(k, slice_shift);
+  BE_REQUIRE(n_bins <= kMaxBins, BE_ERR_RANGE, "too many bins for the binned route");
+  const int64_t cap = binned_cap_align(bin_capacity);
+  BE_REQUIRE(cap >= 8 && cap < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
+  BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
+  const int64_t S = 1ll << slice_shift;
+  const size_t lds = (size_t)S * (homo ? 4 : 8);
+  BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
+  BE_REQUIRE(workspace != nullptr &&
+                 workspace_bytes >= be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity),
+             BE_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned char* wsb = static_cast<unsigned char*>(workspace);
+  uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(wsb + 256 + be_align_up(m * 4, 256));
+  uint32_t* valid = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cursor) + be_align_up((int64_t)n_bins * 4, 256));
+  uint16_t* bin_idx = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(valid) + be_align_up((int64_t)n_bins * 4, 256));
+  float* bin_w = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_idx) + be_align_up((int64_t)n_bins * cap * 2, 256));
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, cursor,
+                       valid, n_bins, count);
+    BE_LAUNCH_CHECK();
+  } else {
+    BE_HIP(be_fill_async(out, 0, (size_t)k * 4, st));
+    BE_HIP(be_fill_async(cursor, 0, (size_t)n_bins * 4, st));
+    BE_HIP(be_fill_async(valid, 0xff, (size_t)n_bins * 4, st));
+    BE_HIP(be_fill_async(count, 0, 4, st));
+  }
+  ActiveList al;
+  int rc = be_resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, /*zero_first=*/false, &al);
+  if (rc != BE_OK) return rc;
+  const int prof = be_prof_begin(st);
+  if (homo)
+    hipLaunchKernelGGL((k_bin_rows<float, true>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
+                       al.ids, al.count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
+  else
+    hipLaunchKernelGGL((k_bin_rows<float, false>), dim3(256), dim3(1024), 0, st, static_cast<const float*>(weights), indices, rp,
+                       al.ids, al.count, slice_shift, n_bins, (uint32_t)cap, cursor, valid, bin_idx, bin_w, static_cast<float*>(out));
+  BE_LAUNCH_CHECK();
+  // n_bins * parts ~ 256: every workgroup fills a CU (128 KB of LDS) and its slice is merged into the output with float
+  // atomics, one per non-zero accumulator, so more parts than CUs only add merge traffic (39 bins: 13 parts took 55 us, 6 take 30)
+  int parts = 256 / (n_bins > 0 ? n_bins : 1);
+  parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+  const float scale = ldexpf(1.0f, scale_exp - 32);
+  const double inv_scale = ldexp(1.0, -scale_exp);
+  if (homo) {
+    auto kern = k_bin_accumulate<true>;
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap,
+                       slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(weights), static_cast<float*>(out));
+  } else {
+    auto kern = k_bin_accumulate<false>;
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap,
+                       slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(nullptr), static_cast<float*>(out));
+  }
+  be_prof_end(prof, st);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+}  // extern "C"
