@@ -70,13 +70,24 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
   if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
   if (tid == 0) { s_next = blockIdx.x; s_carry_len = 0; }
   __syncthreads();
+  // fixed-length rows that fit a batch (at most 1024 per batch: one thread per row)
+  const bool fixed_rows = rp.p == nullptr && rp.fixed > 0 && rp.fixed <= (int64_t)kBatch;
+  const uint32_t fixed_nch = fixed_rows ? (uint32_t)((rp.fixed + 63) >> 6) : 1u;
+  const uint32_t fixed_per_batch = fixed_rows ? (kChunks / fixed_nch < 1024u ? kChunks / fixed_nch : 1024u) : 0u;
 
   for (;;) {
     // ---- form a batch: thread t looks at this workgroup's t-th next row (loads in parallel), a block scan of
     //      the rows' chunk counts picks the longest prefix that fits one batch; a row longer than a batch is
     //      processed alone, one batch-sized piece at a time (carry)
     for (int b = tid; b < n_bins; b += blockDim.x) { hist[b] = 0; fill[b] = 0; }
-    if (s_carry_len) {               // uniform: shared state
+    if (fixed_rows) {                // rows of one length (FixedNumPerPre): the batch is arithmetic — no scan, no search
+      const uint64_t nx = s_next;
+      const uint64_t left = nx < n_active ? (n_active - nx + gridDim.x - 1) / gridDim.x : 0;
+      const uint32_t nr = left < fixed_per_batch ? (uint32_t)left : fixed_per_batch;
+      if ((uint32_t)tid < nr) s_begin[tid] = (int64_t)active[nx + (uint64_t)tid * gridDim.x] * rp.fixed;
+      __syncthreads();
+      if (tid == 0) { s_next = nx + (uint64_t)nr * gridDim.x; s_nrows = nr; s_nchunks = nr * fixed_nch; }
+    } else if (s_carry_len) {        // uniform: shared state
       __syncthreads();
       if (tid == 0) {
         const uint32_t take = s_carry_len < kBatch ? s_carry_len : kBatch;
@@ -117,6 +128,7 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
       }
       __syncthreads();
     }
+    if (fixed_rows) __syncthreads();                         // publish s_nrows / s_nchunks of the arithmetic path
     const uint32_t nrows = s_nrows;
     if (nrows == 0) break;
 
@@ -126,7 +138,15 @@ __global__ void __launch_bounds__(1024) k_bin_rows(const W* __restrict__ weights
     uint32_t my_n = 0;
     {
       const uint32_t cid = (uint32_t)wave * SLOTS + (uint32_t)lane;
-      if (lane < SLOTS && cid < s_nchunks) {
+      if (fixed_rows) {
+        if (lane < SLOTS && cid < s_nchunks) {
+          const uint32_t pc = cid / fixed_nch;
+          const uint32_t j0 = (cid - pc * fixed_nch) << 6;
+          my_e0 = s_begin[pc] + j0;
+          const uint32_t left = (uint32_t)rp.fixed - j0;
+          my_n = left < 64u ? left : 64u;
+        }
+      } else if (lane < SLOTS && cid < s_nchunks) {
         uint32_t lo = 0, hi = nrows;                        // first piece with cstart > cid
         while (lo < hi) {
           const uint32_t mid = (lo + hi) >> 1;
