@@ -1,5 +1,7 @@
 """Index-structure conversions between CSR, COO and CSC (reference ``brainevent/_misc.py:871-1085`` and ``:1516-1700``:
-``csr_to_coo_index``, ``coo_to_csc_index``, ``coo2csr``, ``csr_to_csc_index``, ``csc_to_csr_index``).
+``csr_to_coo_index``, ``coo_to_csc_index``, ``coo2csr``, ``csr_to_csc_index``, ``csc_to_csr_index``) and the
+fixed-connection-number companions (``:1135-1153``, ``:1255-1320``: ``fixed_conn_num_csr_indptr``,
+``fixed_conn_num_csc_structure``, ``fixed_conn_num_to_csc``).
 
 One-off preprocessing, done on the device with stable sorts (entries that share a column keep their row order, as the
 reference's ``argsort(..., stable=True)``); numpy in -> numpy out, device tensors in -> device tensors out.  Coordinates
@@ -12,7 +14,8 @@ import torch
 
 from . import _array as A
 
-__all__ = ['csr_to_coo_index', 'coo_to_csc_index', 'coo2csr', 'csr_to_csc_index', 'csc_to_csr_index']
+__all__ = ['csr_to_coo_index', 'coo_to_csc_index', 'coo2csr', 'csr_to_csc_index', 'csc_to_csr_index',
+           'fixed_conn_num_csr_indptr', 'fixed_conn_num_csc_structure', 'fixed_conn_num_to_csc']
 
 
 def _offset_dtype(nnz: int) -> torch.dtype:
@@ -79,3 +82,44 @@ def csr_to_csc_index(csr_indptr, csr_indices, *, shape: Tuple[int, int], include
 def csc_to_csr_index(csc_indptr, csc_indices, *, shape: Tuple[int, int], include_perm: bool = True):
     """Inverse companion: the CSC arrays of ``W (n_rows, n_cols)`` are the CSR arrays of ``W.T``."""
     return csr_to_csc_index(csc_indptr, csc_indices, shape=(int(shape[1]), int(shape[0])), include_perm=include_perm)
+
+
+def fixed_conn_num_csr_indptr(indices):
+    """The implicit CSR ``indptr`` of fixed-number connectivity ``indices (n_pre, n_conn)``: ``arange(n_pre + 1) * n_conn``,
+    int32 until the entry count needs int64 (reference ``_misc.py:1135-1153``)."""
+    assert indices.ndim == 2, f'Indices must be 2D, got {indices.ndim}D.'
+    n_pre, n_conn = int(indices.shape[0]), int(indices.shape[1])
+    dt = _offset_dtype(n_pre * n_conn)
+    if isinstance(indices, np.ndarray):
+        return np.arange(n_pre + 1, dtype=np.int64 if dt == torch.int64 else np.int32) * n_conn
+    return torch.arange(n_pre + 1, dtype=dt, device=indices.device) * n_conn
+
+
+def fixed_conn_num_csc_structure(indices, *, shape: Tuple[int, int]):
+    """``(csc_indptr, csc_indices, perm)`` of row-major fixed-number connectivity: for every post neuron the pre neurons
+    that target it (stable: pre order kept), and the permutation that reorders the flattened weights into CSC order
+    (reference ``_misc.py:1255-1296``).  Offsets and ``perm`` follow the entry count's dtype, coordinates are int32."""
+    assert indices.ndim == 2, f'Indices must be 2D, got {indices.ndim}D.'
+    n_pre, n_post = int(shape[0]), int(shape[1])
+    assert int(indices.shape[0]) == n_pre, (
+        f'Pre size mismatch: indices.shape[0] ({indices.shape[0]}) != shape[0] ({n_pre})')
+    as_np = A.wants_numpy(indices)
+    idx = A.to_device(indices)
+    ptr, rows, perm = csr_to_csc_index(fixed_conn_num_csr_indptr(idx), idx.reshape(-1), shape=(n_pre, n_post))
+    return _finish(as_np, ptr, rows.to(torch.int32), perm)
+
+
+def fixed_conn_num_to_csc(weights, indices, *, shape: Tuple[int, int]):
+    """``(csc_data, csc_indices, csc_indptr)``: the CSC mirror of fixed-number weights and connectivity; a size-1 weight
+    stays size-1 (reference ``_misc.py:1299-1320``)."""
+    as_np = A.wants_numpy(weights, indices)
+    w = A.to_device(weights)
+    if w.ndim == 0:
+        w = w.reshape(1)
+    if w.ndim == 1:
+        assert w.numel() == 1, f'When weights is 1D, it should be a scalar (size 1), got {w.numel()}.'
+    elif w.ndim != 2:
+        raise ValueError(f'weight dim should be 2, 1, or 0, but got {w.ndim}')
+    ptr, rows, perm = fixed_conn_num_csc_structure(A.to_device(indices), shape=shape)
+    data = w.reshape(1) if w.ndim == 1 else w.reshape(-1)[perm.long()]
+    return _finish(as_np, data, rows, ptr)

@@ -156,6 +156,41 @@ def test_index_structure_conversions_match_scipy():
         be.csr_to_csc_index(np.array([0, 1]), np.array([0]), shape=(1, 1), method='bogus')
 
 
+def test_fixed_conn_num_csc_helpers_match_scipy():
+    """fixed_conn_num_csr_indptr / _csc_structure / _to_csc (reference ``_misc.py:1135-1320``) against scipy's CSR -> CSC,
+    and the CSC mirror drives the same products as the fixed-number container."""
+    import scipy.sparse as sp
+    import brainevent_amd as be
+    rng = np.random.default_rng(8)
+    n_pre, n_post, K = 60, 45, 7
+    indices = rng.integers(0, n_post, (n_pre, K)).astype(np.int32)
+    w = rng.uniform(0.1, 1.0, (n_pre, K)).astype(np.float32)
+    ptr = be.fixed_conn_num_csr_indptr(indices)
+    assert ptr.dtype == np.int32 and np.array_equal(ptr, np.arange(n_pre + 1) * K)
+    cptr, crows, perm = be.fixed_conn_num_csc_structure(indices, shape=(n_pre, n_post))
+    assert crows.dtype == np.int32 and cptr[0] == 0 and cptr[-1] == n_pre * K
+    # every column lists its pre neurons in pre order (stable), and perm reorders the flat weights
+    flat_rows = np.repeat(np.arange(n_pre), K)
+    np.testing.assert_array_equal(flat_rows[perm], crows)
+    np.testing.assert_array_equal(indices.reshape(-1)[perm], np.repeat(np.arange(n_post), np.diff(cptr)))
+    assert all(np.all(np.diff(crows[cptr[j]:cptr[j + 1]]) >= 0) for j in range(n_post))
+    data, rows2, ptr2 = be.fixed_conn_num_to_csc(w, indices, shape=(n_pre, n_post))
+    np.testing.assert_array_equal(rows2, crows); np.testing.assert_array_equal(ptr2, cptr)
+    dense = np.zeros((n_pre, n_post), np.float64)
+    np.add.at(dense, (flat_rows, indices.reshape(-1)), w.reshape(-1))
+    np.testing.assert_allclose(sp.csc_matrix((data, rows2, ptr2), shape=(n_pre, n_post)).toarray(), dense, rtol=1e-6)
+    h_data, _, _ = be.fixed_conn_num_to_csc(np.float32(2.0), indices, shape=(n_pre, n_post))      # homogeneous stays size 1
+    assert h_data.shape == (1,) and h_data[0] == 2.0
+    v = rng.random(n_pre) < 0.4
+    csc = be.CSC((data, rows2, ptr2), shape=(n_pre, n_post))
+    fcn = be.FixedNumPerPre((w, indices), shape=(n_pre, n_post))
+    np.testing.assert_allclose(be.BinaryArray(v) @ csc, be.BinaryArray(v) @ fcn, rtol=1e-5, atol=1e-6)
+    t = be.fixed_conn_num_csc_structure(torch.from_numpy(indices).cuda(), shape=(n_pre, n_post))
+    assert all(isinstance(x, torch.Tensor) and x.is_cuda for x in t)
+    with pytest.raises(AssertionError):
+        be.fixed_conn_num_csc_structure(indices, shape=(n_pre + 1, n_post))
+
+
 def test_indexed_products_equal_the_reindexed_matrix():
     """binary_csrmv/mm_indexed (reference ``_csr/binary_indexed.py``): the CSC view of a CSR matrix with the weights left
     in CSR order and reached through the permutation — same numbers as the products on the CSR matrix itself."""
