@@ -24,7 +24,8 @@ from ._graph import GraphedStep, capture_step
 from ._hybrid import HybridConfig, get_hybrid_config, hybrid_task_capacity
 from ._op import OpKernel
 XLACustomKernel = OpKernel      # the operator object under the reference's name (no XLA underneath)
-from ._jitc import (JITCMatrix, JITCScalarR, JITCScalarC, JITCUniformR, JITCUniformC, JITCNormalR, JITCNormalC,
+from ._data import DataRepresentation
+from ._jitc import (JITCScalarMatrix, JITCUniformMatrix, JITCNormalMatrix, JITCMatrix, JITCScalarR, JITCScalarC, JITCUniformR, JITCUniformC, JITCNormalR, JITCNormalC,
                     binary_jitsmv, binary_jitsmm, binary_jitumv, binary_jitumm, binary_jitnmv, binary_jitnmm,
                     binary_jitsmv_p, binary_jitsmm_p, binary_jitumv_p, binary_jitumm_p, binary_jitnmv_p, binary_jitnmm_p,
                     binary_jitsmv_p_call, binary_jitsmm_p_call, binary_jitumv_p_call, binary_jitumm_p_call,

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import _array as A
+from ._data import DataRepresentation
 from ._error import MathError
 from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
@@ -649,7 +650,7 @@ PLAN_MIN_SEGMENT = 18       # entries per (row, slice) from which the planned la
 PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply
 
 
-class CompressedSparseData:
+class CompressedSparseData(DataRepresentation):
     """Common base of :class:`CSR` and :class:`CSC` (reference ``_csr/main.py:182-277``)."""
     _compressed_format = 'csr'
 
@@ -674,7 +675,7 @@ class CompressedSparseData:
             _check_compressed_structure(self.indices, self.indptr, shape, format=fmt, check_values=True)
         self.shape = shape
         self.backend = backend
-        self.buffers: Dict = dict(buffers) if buffers else {}
+        self._init_buffers(buffers)
 
     @classmethod
     def _from_parts(cls, data, indices, indptr, *, shape, backend=None, buffers=None, numpy_result=None):

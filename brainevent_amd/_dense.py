@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _array as A
+from ._data import DataRepresentation
 from ._lib import check, fn
 from ._op import OpKernel
 
@@ -121,7 +122,7 @@ def binary_densemm(weights, spikes, *, transpose, backend: Optional[str] = None)
     return A.to_result(binary_densemm_p_call(w, s, transpose=transpose, backend=backend)[0], as_np)
 
 
-class Dense:
+class Dense(DataRepresentation):
     """Explicit dense matrix with the representation contract of the sparse families (reference
     ``brainevent/_dense/main.py:60-490``, minus units, pytree plumbing and plasticity): ``data``, ``shape``,
     ``backend``, ``buffers``, ``with_data``, ``todense``, ``T`` / ``transpose`` and event-driven ``@``.
@@ -138,7 +139,7 @@ class Dense:
             raise ValueError(f"shape {tuple(shape)} does not match the data shape {tuple(self.data.shape)}.")
         self.shape = (int(self.data.shape[0]), int(self.data.shape[1]))
         self.backend = backend
-        self.buffers = dict(buffers) if buffers else {}
+        self._init_buffers(buffers)
 
     dtype = property(lambda self: self.data.dtype)
     ndim = property(lambda self: 2)

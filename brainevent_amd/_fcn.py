@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import _array as A
+from ._data import DataRepresentation
 from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, _csrmm_generic
 from . import _csr as _csr_mod
 from ._event import BinaryArray, is_event, event_operand
@@ -169,7 +170,7 @@ def _contains_invalid_indices(indices, *, upper_bound: int):
                          f'But found indices with min {lo} and max {hi}.')
 
 
-class FixedNumConn:
+class FixedNumConn(DataRepresentation):
     """Base of the two ELL containers (reference ``_fcn/main.py:199-460``)."""
 
     def __init__(self, data, indices=None, *, shape, backend: Optional[str] = None, buffers: Optional[Dict] = None,
@@ -187,7 +188,7 @@ class FixedNumConn:
             raise ValueError(f"Data shape {tuple(self.data.shape)} must match indices shape "
                              f"{tuple(self.indices.shape)}. But got {tuple(self.data.shape)} != {tuple(self.indices.shape)}")
         self.backend = backend
-        self.buffers: Dict = dict(buffers) if buffers else {}
+        self._init_buffers(buffers)
         if check_indices:
             _contains_invalid_indices(self.indices, upper_bound=upper)
 

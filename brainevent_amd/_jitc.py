@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _array as A
+from ._data import DataRepresentation
 from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
 from ._op import OpKernel
@@ -305,7 +306,7 @@ def _validate_prob(prob) -> float:
     return p
 
 
-class JITCMatrix:
+class JITCMatrix(DataRepresentation):
     """Common base of the six JIT-connectivity containers."""
     _family = 's'
     _is_row = True          # R classes: logical orientation == generator orientation; C classes: transposed
@@ -320,7 +321,7 @@ class JITCMatrix:
         self.shape = (int(shape[0]), int(shape[1]))
         self.corder = bool(corder)
         self.backend = backend
-        self.buffers: Dict = dict(buffers) if buffers else {}
+        self._init_buffers(buffers)
 
     @property
     def dtype(self):
@@ -513,6 +514,10 @@ class _NormalInit(JITCMatrix):
 
     wloc = property(lambda self: self._weights[0])
     wscale = property(lambda self: self._weights[1])
+
+
+# the reference's names for the per-family bases (``_jit_scalar/main.py:190``, ``_jit_uniform/main.py:78``, ``_jit_normal/main.py:78``)
+JITCScalarMatrix, JITCUniformMatrix, JITCNormalMatrix = _ScalarInit, _UniformInit, _NormalInit
 
 
 class JITCScalarR(_ScalarInit):

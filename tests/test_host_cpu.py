@@ -264,3 +264,31 @@ def test_scatter_plan_auto_geometry():
     assert geo(100_000, 100_000, 10000, False, delta_ok=False) == (U16, 51)
     # more than 1024 slices: u16
     assert geo(10_000_000, 30_000_000, 1000, False)[0] == U16
+
+
+def test_data_representation_buffer_contract():
+    """DataRepresentation (reference ``_data.py:35-60``): named buffers have to be registered before they are set; the
+    structure operations are declared on the base and refused there; every container family derives from it."""
+    import brainevent_amd as be
+
+    class X(be.DataRepresentation):
+        def __init__(self, buffers=None):
+            self._init_buffers(buffers)
+
+    x = X({'a': 1})
+    assert x.buffers == {'a': 1}
+    x.register_buffer('b')
+    assert x.buffers['b'] is None
+    x.set_buffer('b', 3)
+    assert x.buffers == {'a': 1, 'b': 3}
+    with pytest.raises(ValueError):
+        x.set_buffer('c', 1)
+    with pytest.raises(AssertionError):
+        X(buffers=[1])
+    for op in (x.tocsr, x.tocsc, x.tocoo, x.todense, X.fromdense, x.transpose):
+        with pytest.raises(NotImplementedError):
+            op()
+    for cls in (be.CSR, be.CSC, be.FixedNumPerPre, be.FixedNumPerPost, be.JITCScalarR, be.JITCUniformC, be.JITCNormalR, be.Dense):
+        assert issubclass(cls, be.DataRepresentation)
+    assert issubclass(be.JITCScalarR, be.JITCScalarMatrix) and issubclass(be.JITCScalarC, be.JITCScalarMatrix)
+    assert issubclass(be.JITCUniformR, be.JITCUniformMatrix) and issubclass(be.JITCNormalC, be.JITCNormalMatrix)
