@@ -640,6 +640,25 @@ def binary_csrmm_indexed(data, indices, indptr, perm, B, *, shape, workspace=Non
     return A.to_result(res, as_np)
 
 
+def _binary_csrmv_indexed_hip(data, indices, indptr, perm, vector, *, shape, transpose, workspace=None):
+    return _binary_csrmv_hip(_indexed_weights(data, perm), indices, indptr, vector, shape=shape, transpose=transpose,
+                             workspace=workspace)
+
+
+def _binary_csrmm_indexed_hip(data, indices, indptr, perm, B, *, shape, transpose, workspace=None):
+    return _binary_csrmm_hip(_indexed_weights(data, perm), indices, indptr, B, shape=shape, transpose=transpose,
+                             workspace=workspace)
+
+
+#: operator objects of the indexed products (reference ``_csr/binary_indexed.py``: ``binary_csrmv_indexed_p`` / ``binary_csrmm_indexed_p``)
+binary_csrmv_indexed_p = OpKernel('binary_csrmv_indexed')
+binary_csrmv_indexed_p.def_kernel('hip', 'gpu', _binary_csrmv_indexed_hip, asdefault=True)
+binary_csrmv_indexed_p.def_tags('csr', 'binary', 'indexed')
+binary_csrmm_indexed_p = OpKernel('binary_csrmm_indexed')
+binary_csrmm_indexed_p.def_kernel('hip', 'gpu', _binary_csrmm_indexed_hip, asdefault=True)
+binary_csrmm_indexed_p.def_tags('csr', 'binary', 'indexed')
+
+
 # =====================================================================================================
 # containers
 # =====================================================================================================

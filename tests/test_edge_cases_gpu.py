@@ -212,6 +212,13 @@ def test_indexed_products_equal_the_reindexed_matrix():
         B = rng.random((k, 4)) < 0.4
         np.testing.assert_allclose(be.binary_csrmm_indexed(w, cidx, cptr, perm, B, shape=(k, m), transpose=True),
                                    O.binary_csrmm(w, idx, ptr, B, (m, k), False), rtol=1e-5, atol=1e-5)
+        # the operator objects (device operands, backend resolution as for every other operator)
+        dw, di, dp, dperm = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (w, cidx, cptr, perm))
+        got = be.binary_csrmv_indexed_p(dw, di, dp, dperm, torch.from_numpy(sk).cuda(), shape=(k, m), transpose=True)
+        np.testing.assert_allclose(got.cpu().numpy(), O.binary_csrmv(w, idx, ptr, sk, (m, k), False), rtol=1e-5, atol=1e-5)
+        got = be.binary_csrmm_indexed_p(dw, di, dp, dperm, torch.from_numpy(B).cuda(), shape=(k, m), transpose=True)
+        np.testing.assert_allclose(got.cpu().numpy(), O.binary_csrmm(w, idx, ptr, B, (m, k), False), rtol=1e-5, atol=1e-5)
+    assert 'indexed' in be.binary_csrmv_indexed_p.tags and be.binary_csrmv_indexed_p.available_backends('gpu') == ['hip']
 
 
 def test_tocsc_tocsr_keep_the_matrix():
