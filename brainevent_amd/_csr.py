@@ -72,6 +72,7 @@ class ScatterPlan:
         self.scale_exp = int(scale_exp)
         self.weight_dtype = weight_dtype
         self.nnz = 0                      # stored entries (set by build): sizes the number of parts
+        self.block_hint_override: Optional[int] = None
         self._ws: Dict = {}
 
     # -- sizing ---------------------------------------------------------------------------------
@@ -99,6 +100,15 @@ class ScatterPlan:
             parts = max(1, 256 // n_min)
             n = max(n_min, 256 // parts)
         return max(1, min(cap, (int(k) + n - 1) // n))
+
+    @property
+    def block_hint(self) -> int:
+        """Average entries per (row, slice) block (a speed hint for the step kernel; 0 = unknown)."""
+        if self.block_hint_override is not None:
+            return int(self.block_hint_override)
+        if not self.nnz:
+            return 0
+        return max(1, min(1 << 20, int(round(self.nnz / max(1, self.m * self.n_slices)))))
 
     def default_parts(self) -> int:
         """Workgroups per slice.  One 1024-thread workgroup per CU at most (~256 in total), but not more than the matrix can
@@ -408,10 +418,11 @@ def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor
         parts = max(1, min(parts, 512 // (plan.n_slices * nb)))
     ws = plan.workspace(parts, nb)
     f = fn('be_binary_csrmm_t_plan', c_int,
-           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp, c_i64,
-            c_vp])
+           [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
+            c_i64, c_vp])
     check(f(A.ptr(weights), int(plan.homo), A.wcode(out_bm), A.ptr(plan.blob), A.ptr(plan.seg), A.ptr(spikes_bm), sd,
-            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, plan.slice_width, plan.layout, parts, plan.scale_exp, A.ptr(ws),
+            A.ptr(out_bm), plan.m, plan.k, nb, plan.slice_shift, plan.slice_width, plan.layout, plan.block_hint, parts,
+            plan.scale_exp, A.ptr(ws),
             ws.numel(),
             A.stream_ptr()), 'be_binary_csrmm_t_plan')
 

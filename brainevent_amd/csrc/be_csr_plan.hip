@@ -657,6 +657,66 @@ __device__ __forceinline__ void d8_consume(const SegGroupD8& g, unsigned long lo
   }
 }
 
+// ---- short blocks: a quarter wave per block.  With ~20 entries per block (N = 1M, K = 1000) only 5 of 64 lanes work in
+// the one-block-per-wave path and the kernel is bound by its instruction count (~60 wave instructions per block).  Here the
+// four 16-lane rows of a wave decode four blocks at once (the DPP row shifts scan within 16 lanes natively), the per-row
+// segment entries travel by ds_bpermute, and 16 blocks are in flight per wave (9 registers per group of four).
+__device__ __forceinline__ uint32_t row16_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  return v;
+}
+
+struct QGroupD8 {
+  uint32_t ng, base, d;
+  be_v4u w;
+  const unsigned char* blk;
+};
+
+__device__ __forceinline__ void d8q_issue(QGroupD8& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
+                                          const unsigned char* __restrict__ blob) {
+  const int row = i + (lane >> 4);
+  const uint32_t st = (uint32_t)__shfl((int)st_v, row & 63, 64);
+  const uint32_t y = (uint32_t)__shfl((int)n4_v, row & 63, 64);
+  g.ng = row < nvalid ? (y & 0xffffu) : 0u;
+  g.base = y >> 16;
+  g.blk = g.ng ? blob + ((uint64_t)st << 7) : blob;          // nothing to do: read the head of the blob (in bounds, cached)
+  const uint32_t l = (uint32_t)lane & 15u;
+  const uint32_t o = l < g.ng ? l : 0u;                       // clamped: loads stay unconditional (counted vmcnt waits)
+  const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
+  g.w = be_v4u{x.x, x.y, x.z, x.w};
+  g.d = reinterpret_cast<const uint32_t*>(g.blk + (uint64_t)g.ng * 16u)[o];
+}
+
+__device__ __forceinline__ void d8q_consume(const QGroupD8& g, unsigned long long* acc, int lane, float scale) {
+  const uint32_t l = (uint32_t)lane & 15u;
+  const uint32_t d0 = l < g.ng ? g.d : 0u;
+  const uint32_t t0 = d8_sum4(d0);
+  const uint32_t incl0 = row16_incl_scan_u32(t0);
+  if (l < g.ng) d8_add4(acc, g.base + incl0 - t0, d0, g.w, scale);
+  if (__ballot(g.ng > 16u) != 0ull) {                         // blocks above 64 entries: further passes of 16 lane-groups
+    uint32_t carry = g.base + (uint32_t)__shfl((int)incl0, (lane & 48) | 15, 64);
+    for (uint32_t o0 = 16; __ballot(o0 < g.ng) != 0ull; o0 += 16) {
+      const uint32_t o = o0 + l;
+      const bool in = o < g.ng;
+      uint32_t d = 0u;
+      be_v4u wv = {0u, 0u, 0u, 0u};
+      if (in) {
+        d = reinterpret_cast<const uint32_t*>(g.blk + (uint64_t)g.ng * 16u)[o];
+        const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
+        wv = be_v4u{x.x, x.y, x.z, x.w};
+      }
+      const uint32_t t = d8_sum4(d);
+      const uint32_t incl = row16_incl_scan_u32(t);
+      if (in) d8_add4(acc, carry + incl - t, d, wv, scale);
+      carry += (uint32_t)__shfl((int)incl, (lane & 48) | 15, 64);
+    }
+  }
+}
+
+template <bool QUARTER>
 __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                              const uint32_t* __restrict__ active,
                                                              const uint32_t* __restrict__ n_active_p, int n_slices,
@@ -703,13 +763,30 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
       const bool v_nn = a < n_active;
       const uint32_t r_nn = active[a < last ? a : last];
       a += a_step;
-      SegGroupD8 gA, gB;
-      d8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
-      for (int i = 0; i < nvalid; i += 8) {
-        d8_issue(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
-        d8_consume(gA, acc, lane, scale, blob);
-        d8_issue(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
-        d8_consume(gB, acc, lane, scale, blob);
+      if constexpr (QUARTER) {
+        QGroupD8 g0, g1, g2, g3;
+        d8q_issue(g0, 0, nvalid, st_v, n4_v, lane, blob);
+        d8q_issue(g1, 4, nvalid, st_v, n4_v, lane, blob);
+        d8q_issue(g2, 8, nvalid, st_v, n4_v, lane, blob);
+        for (int i = 0; i < nvalid; i += 16) {
+          d8q_issue(g3, i + 12, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume(g0, acc, lane, scale);
+          d8q_issue(g0, i + 16, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume(g1, acc, lane, scale);
+          d8q_issue(g1, i + 20, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume(g2, acc, lane, scale);
+          d8q_issue(g2, i + 24, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume(g3, acc, lane, scale);
+        }
+      } else {
+        SegGroupD8 gA, gB;
+        d8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
+        for (int i = 0; i < nvalid; i += 8) {
+          d8_issue(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
+          d8_consume(gA, acc, lane, scale, blob);
+          d8_issue(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
+          d8_consume(gB, acc, lane, scale, blob);
+        }
       }
       st_v = sgn.x;
       n4_v = v_n ? sgn.y : 0u;
@@ -1033,6 +1110,7 @@ extern "C" {
 // ---------------------------------------------------------------- scatter plan
 // slices are `slice_width` output neurons wide (0 = the LDS capacity 2^slice_shift); a width below the capacity lets
 // the caller balance the slices (k = 1M: 64 slices of 15625 instead of 61 full ones and a sliver)
+constexpr int kD8QuarterMaxBlock = 48;  // average entries per block up to which the quarter-wave d8 kernel is used
 constexpr int kD8MaxWidth = 20000;     // d8 blocks need no pad slot and no power-of-two capacity: 20000 x 8 B = 156 KiB of LDS
 constexpr int kH8MaxWidth = 40000;     // h8: the same LDS in 4-byte counters
 static inline bool width_ok(int slice_shift, int slice_width, int layout = BE_PLAN_U16) {
@@ -1176,8 +1254,8 @@ int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_s
 
 int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int64_t n_batch,
-                           int slice_shift, int slice_width, int layout, int parts, int scale_exp, void* workspace,
-                           int64_t workspace_bytes, be_stream_t stream) {
+                           int slice_shift, int slice_width, int layout, int block_hint, int parts, int scale_exp,
+                           void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll && k <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
   BE_REQUIRE(layout == BE_PLAN_U16 || (layout == BE_PLAN_D8 && !homo) || (layout == BE_PLAN_H8 && homo), BE_ERR_INVALID,
              "bad plan layout");
@@ -1246,7 +1324,8 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride, (int)S);
   } else if (layout == BE_PLAN_D8) {
-    auto kern = k_plan_accumulate_d8;
+    // short blocks (average <= 48 entries): a quarter wave per block
+    auto kern = (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) ? k_plan_accumulate_d8<true> : k_plan_accumulate_d8<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, (int)S, parts, scale, static_cast<unsigned long long*>(partial), astride);
@@ -1271,10 +1350,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
 
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
-                           int slice_width, int layout, int parts, int scale_exp, void* workspace, int64_t workspace_bytes,
-                           be_stream_t stream) {
+                           int slice_width, int layout, int block_hint, int parts, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream) {
   return be_binary_csrmm_t_plan(weights, homo, wdtype, blob, seg, spikes, spike_dtype, out, m, k, 1, slice_shift, slice_width,
-                                layout, parts, scale_exp, workspace, workspace_bytes, stream);
+                                layout, block_hint, parts, scale_exp, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -171,6 +171,8 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
  *               round(w * 2^scale_exp) in a 64-bit integer (order independent, bitwise reproducible).  The largest
  *               column sum of |w| times 2^scale_exp must stay below 2^62 (a row may list a column several times, so
  *               "rows x max|w|" is NOT a bound); sums that exceed it wrap silently.
+ *   block_hint : average entries per (row, slice) block of the plan, or 0 (unknown).  A speed hint only: short blocks
+ *               (<= 48 entries, BE_PLAN_D8) are decoded by a quarter wave each instead of a wave each.
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
  *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) bytes.
  *               Its first 4 * n_batch bytes (the spike counters) must be ZERO on entry; they are zero again when the
@@ -181,12 +183,12 @@ int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_b
                                                int parts, int homo);
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
-                           int slice_width, int layout, int parts, int scale_exp, void* workspace,
+                           int slice_width, int layout, int block_hint, int parts, int scale_exp, void* workspace,
                            int64_t workspace_bytes, be_stream_t stream);
 int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m, int64_t k, int64_t n_batch,
-                           int slice_shift, int slice_width, int layout, int parts, int scale_exp, void* workspace,
-                           int64_t workspace_bytes, be_stream_t stream);
+                           int slice_shift, int slice_width, int layout, int block_hint, int parts, int scale_exp,
+                           void* workspace, int64_t workspace_bytes, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * binned scatter: the event-driven transpose=True product for a matrix WITHOUT a plan (raw CSR / fixed-length rows),

@@ -577,6 +577,36 @@ def test_h8_layout_randomized(be, oracle, seed):
     np.testing.assert_array_equal(got, be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan16))
 
 
+@pytest.mark.parametrize('k', [900, 30000, 120000])
+def test_d8_quarter_wave_kernel_equals_full_wave(be, oracle, k):
+    """The d8 step kernel has two decoders — a wave per block, and a quarter wave per block for plans of short blocks
+    (``block_hint`` <= 48) — over the same blob.  Same bits from both on rows of 0 ... 5000 entries (blocks from empty to
+    many 16-lane passes), vectors and batches; the hint only selects the kernel."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(k)
+    m = 700
+    lens = np.where(rng.random(m) < 0.1, rng.integers(200, 5000, m), rng.integers(0, 40, m))
+    lens[::17] = 0
+    w, idx, ptr = rand_csr(rng, m, k, lens)
+    w = rng.normal(0, 1, w.shape).astype(np.float32)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='d8')
+    # deterministic comparison on fixed vectors
+    vs = [np.random.default_rng(s).random(m) < f for s, f in ((1, 0.05), (2, 0.6), (3, 1.1), (4, -1.0))]
+    B = np.stack([np.random.default_rng(9).random(m) < 0.3 for _ in range(3)], axis=1)
+    ref = None
+    for hint in (1, 48, 49, 100000):
+        plan.block_hint_override = hint
+        got = [np.asarray(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)) for v in vs]
+        got.append(np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)))
+        if ref is None:
+            ref = got
+            for v, g in zip(vs, got):
+                np.testing.assert_allclose(g, oracle.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-5, atol=1e-5)
+        else:
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+
+
 def test_d8_layout_falls_back_when_it_does_not_apply(be):
     from brainevent_amd._csr import ScatterPlan
     rng = np.random.default_rng(4)
