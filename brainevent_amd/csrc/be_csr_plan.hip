@@ -271,7 +271,40 @@ __device__ __forceinline__ void seg_consume(const SegGroup& g, typename PlanAcc<
 // gridDim.x is a multiple of 8; tasks L >= n_slices * parts are idle.
 // Each wave keeps two groups of 4 segments in flight (register double buffer) and prefetches the segment
 // pointers of its next 64 rows and the row ids of the 64 after those.
-template <bool HOMO>
+// ---- counted entries, short blocks: LPB lanes per block (8 columns per lane), 64 / LPB blocks per load instruction.
+// With 31 entries per block (N = 1M, K = 1000, one shared weight) the wave-per-block path keeps 4 of 64 lanes busy.
+struct SubGroup {
+  uint32_t n;                   // lane-groups of 8 columns in this lane's block
+  be_v4u c;
+  const unsigned char* blk;
+};
+template <int LPB>
+__device__ __forceinline__ void sub_issue(SubGroup& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
+                                          const unsigned char* __restrict__ blob) {
+  const int row = i + lane / LPB;
+  const uint32_t st = (uint32_t)__shfl((int)st_v, row & 63, 64);
+  const uint32_t n = (uint32_t)__shfl((int)n4_v, row & 63, 64);
+  g.n = row < nvalid ? n : 0u;
+  g.blk = g.n ? blob + ((uint64_t)st << 7) : blob;
+  const uint32_t l = (uint32_t)(lane % LPB);
+  const uint4 x = reinterpret_cast<const uint4*>(g.blk)[l < g.n ? l : 0u];     // clamped: unconditional load
+  g.c = be_v4u{x.x, x.y, x.z, x.w};
+}
+template <int LPB>
+__device__ __forceinline__ void sub_consume(const SubGroup& g, uint32_t* acc, int lane) {
+  const uint32_t l = (uint32_t)(lane % LPB);
+  if (l < g.n) plan_count8(acc, g.c.x, g.c.y, g.c.z, g.c.w);
+  if (__ballot(g.n > (uint32_t)LPB) != 0ull) {            // longer blocks: further passes of LPB lane-groups
+    for (uint32_t o = LPB + l; __ballot(o < g.n) != 0ull; o += LPB) {
+      if (o < g.n) {
+        const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
+        plan_count8(acc, x.x, x.y, x.z, x.w);
+      }
+    }
+  }
+}
+
+template <bool HOMO, int LPB = 0>
 __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                           const uint32_t* __restrict__ active,
                                                           const uint32_t* __restrict__ n_active_p, int n_slices,
@@ -329,13 +362,31 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
       const uint32_t r_nn = active[a < last ? a : last];
       a += a_step;
 
-      SegGroup gA, gB;
-      seg_issue<HOMO>(gA, 0, nvalid, st_v, n4_v, lane, blob);
-      for (int i = 0; i < nvalid; i += 8) {
-        seg_issue<HOMO>(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
-        seg_consume<HOMO>(gA, acc, lane, scale, blob);
-        seg_issue<HOMO>(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
-        seg_consume<HOMO>(gB, acc, lane, scale, blob);
+      if constexpr (HOMO && LPB > 0) {
+        constexpr int BPI = 64 / LPB;                       // blocks per instruction; four groups in flight
+        SubGroup g0, g1, g2, g3;
+        sub_issue<LPB>(g0, 0, nvalid, st_v, n4_v, lane, blob);
+        sub_issue<LPB>(g1, BPI, nvalid, st_v, n4_v, lane, blob);
+        sub_issue<LPB>(g2, 2 * BPI, nvalid, st_v, n4_v, lane, blob);
+        for (int i = 0; i < nvalid; i += 4 * BPI) {
+          sub_issue<LPB>(g3, i + 3 * BPI, nvalid, st_v, n4_v, lane, blob);
+          sub_consume<LPB>(g0, reinterpret_cast<uint32_t*>(acc), lane);
+          sub_issue<LPB>(g0, i + 4 * BPI, nvalid, st_v, n4_v, lane, blob);
+          sub_consume<LPB>(g1, reinterpret_cast<uint32_t*>(acc), lane);
+          sub_issue<LPB>(g1, i + 5 * BPI, nvalid, st_v, n4_v, lane, blob);
+          sub_consume<LPB>(g2, reinterpret_cast<uint32_t*>(acc), lane);
+          sub_issue<LPB>(g2, i + 6 * BPI, nvalid, st_v, n4_v, lane, blob);
+          sub_consume<LPB>(g3, reinterpret_cast<uint32_t*>(acc), lane);
+        }
+      } else {
+        SegGroup gA, gB;
+        seg_issue<HOMO>(gA, 0, nvalid, st_v, n4_v, lane, blob);
+        for (int i = 0; i < nvalid; i += 8) {
+          seg_issue<HOMO>(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
+          seg_consume<HOMO>(gA, acc, lane, scale, blob);
+          seg_issue<HOMO>(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
+          seg_consume<HOMO>(gB, acc, lane, scale, blob);
+        }
       }
       st_v = sgn.x;
       n4_v = v_n ? sgn.y : 0u;
@@ -1319,7 +1370,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, (int)S, parts, static_cast<uint32_t*>(partial), astride);
   } else if (homo) {
-    auto kern = k_plan_accumulate<true>;
+    // short blocks: 4 lanes (<= 32 entries on average) or 16 lanes (<= 128) per block instead of a wave
+    auto kern = (block_hint > 0 && block_hint <= 32)    ? k_plan_accumulate<true, 4>
+                : (block_hint > 0 && block_hint <= 128) ? k_plan_accumulate<true, 16>
+                                                        : k_plan_accumulate<true, 0>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride, (int)S);
@@ -1330,7 +1384,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, (int)S, parts, scale, static_cast<unsigned long long*>(partial), astride);
   } else {
-    auto kern = k_plan_accumulate<false>;
+    auto kern = k_plan_accumulate<false, 0>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),

@@ -607,6 +607,34 @@ def test_d8_quarter_wave_kernel_equals_full_wave(be, oracle, k):
                 np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('k', [50000, 200000])
+def test_counted_sub_wave_decoders_equal_full_wave(be, oracle, k):
+    """Counted entries (one shared weight, uint16 layout): 4 or 16 lanes per block for plans of short blocks, a wave per
+    block otherwise — the hint only selects the decoder; rows of 0 ... 5000 entries, vectors and batches."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(k + 1)
+    m = 700
+    lens = np.where(rng.random(m) < 0.1, rng.integers(200, 5000, m), rng.integers(0, 40, m))
+    lens[::17] = 0
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=True)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='u16')
+    assert plan.n_slices > 1
+    vs = [np.random.default_rng(s).random(m) < f for s, f in ((1, 0.05), (2, 0.6), (3, 1.1), (4, -1.0))]
+    B = np.stack([np.random.default_rng(9).random(m) < 0.3 for _ in range(3)], axis=1)
+    ref = None
+    for hint in (1, 32, 33, 128, 129, 100000):
+        plan.block_hint_override = hint
+        got = [np.asarray(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)) for v in vs]
+        got.append(np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)))
+        if ref is None:
+            ref = got
+            for v, g in zip(vs, got):
+                np.testing.assert_allclose(g, oracle.binary_csrmv(w, idx, ptr, v, (m, k), True), rtol=1e-6, atol=1e-6)
+        else:
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+
+
 def test_d8_layout_falls_back_when_it_does_not_apply(be):
     from brainevent_amd._csr import ScatterPlan
     rng = np.random.default_rng(4)
