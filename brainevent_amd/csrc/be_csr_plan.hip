@@ -712,11 +712,21 @@ __device__ __forceinline__ void d8_consume(const SegGroupD8& g, unsigned long lo
 // the one-block-per-wave path and the kernel is bound by its instruction count (~60 wave instructions per block).  Here the
 // four 16-lane rows of a wave decode four blocks at once (the DPP row shifts scan within 16 lanes natively), the per-row
 // segment entries travel by ds_bpermute, and 16 blocks are in flight per wave (9 registers per group of four).
-__device__ __forceinline__ uint32_t row16_incl_scan_u32(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+template <int LPB>
+__device__ __forceinline__ uint32_t sub_incl_scan_u32(uint32_t v, uint32_t l /* lane % LPB */) {
+  if (LPB == 16) {          // a DPP row: the shifts stop at the row boundary by themselves
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  } else {                  // half a row: mask what would cross the 8-lane boundary
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += l >= 1u ? t : 0u;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += l >= 2u ? t : 0u;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += l >= 4u ? t : 0u;
+  }
   return v;
 }
 
@@ -726,30 +736,32 @@ struct QGroupD8 {
   const unsigned char* blk;
 };
 
+template <int LPB>
 __device__ __forceinline__ void d8q_issue(QGroupD8& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
                                           const unsigned char* __restrict__ blob) {
-  const int row = i + (lane >> 4);
+  const int row = i + lane / LPB;
   const uint32_t st = (uint32_t)__shfl((int)st_v, row & 63, 64);
   const uint32_t y = (uint32_t)__shfl((int)n4_v, row & 63, 64);
   g.ng = row < nvalid ? (y & 0xffffu) : 0u;
   g.base = y >> 16;
   g.blk = g.ng ? blob + ((uint64_t)st << 7) : blob;          // nothing to do: read the head of the blob (in bounds, cached)
-  const uint32_t l = (uint32_t)lane & 15u;
+  const uint32_t l = (uint32_t)(lane % LPB);
   const uint32_t o = l < g.ng ? l : 0u;                       // clamped: loads stay unconditional (counted vmcnt waits)
   const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
   g.w = be_v4u{x.x, x.y, x.z, x.w};
   g.d = reinterpret_cast<const uint32_t*>(g.blk + (uint64_t)g.ng * 16u)[o];
 }
 
+template <int LPB>
 __device__ __forceinline__ void d8q_consume(const QGroupD8& g, unsigned long long* acc, int lane, float scale) {
-  const uint32_t l = (uint32_t)lane & 15u;
+  const uint32_t l = (uint32_t)(lane % LPB);
   const uint32_t d0 = l < g.ng ? g.d : 0u;
   const uint32_t t0 = d8_sum4(d0);
-  const uint32_t incl0 = row16_incl_scan_u32(t0);
+  const uint32_t incl0 = sub_incl_scan_u32<LPB>(t0, l);
   if (l < g.ng) d8_add4(acc, g.base + incl0 - t0, d0, g.w, scale);
-  if (__ballot(g.ng > 16u) != 0ull) {                         // blocks above 64 entries: further passes of 16 lane-groups
-    uint32_t carry = g.base + (uint32_t)__shfl((int)incl0, (lane & 48) | 15, 64);
-    for (uint32_t o0 = 16; __ballot(o0 < g.ng) != 0ull; o0 += 16) {
+  if (__ballot(g.ng > (uint32_t)LPB) != 0ull) {               // longer blocks: further passes of LPB lane-groups
+    uint32_t carry = g.base + (uint32_t)__shfl((int)incl0, (lane & ~(LPB - 1)) | (LPB - 1), 64);
+    for (uint32_t o0 = LPB; __ballot(o0 < g.ng) != 0ull; o0 += LPB) {
       const uint32_t o = o0 + l;
       const bool in = o < g.ng;
       uint32_t d = 0u;
@@ -760,14 +772,14 @@ __device__ __forceinline__ void d8q_consume(const QGroupD8& g, unsigned long lon
         wv = be_v4u{x.x, x.y, x.z, x.w};
       }
       const uint32_t t = d8_sum4(d);
-      const uint32_t incl = row16_incl_scan_u32(t);
+      const uint32_t incl = sub_incl_scan_u32<LPB>(t, l);
       if (in) d8_add4(acc, carry + incl - t, d, wv, scale);
-      carry += (uint32_t)__shfl((int)incl, (lane & 48) | 15, 64);
+      carry += (uint32_t)__shfl((int)incl, (lane & ~(LPB - 1)) | (LPB - 1), 64);
     }
   }
 }
 
-template <bool QUARTER>
+template <int LPB /* 0: a wave per block; 8 / 16: lanes per block */>
 __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                              const uint32_t* __restrict__ active,
                                                              const uint32_t* __restrict__ n_active_p, int n_slices,
@@ -814,20 +826,21 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
       const bool v_nn = a < n_active;
       const uint32_t r_nn = active[a < last ? a : last];
       a += a_step;
-      if constexpr (QUARTER) {
+      if constexpr (LPB > 0) {
+        constexpr int BPI = 64 / LPB;                       // blocks per instruction; four groups in flight
         QGroupD8 g0, g1, g2, g3;
-        d8q_issue(g0, 0, nvalid, st_v, n4_v, lane, blob);
-        d8q_issue(g1, 4, nvalid, st_v, n4_v, lane, blob);
-        d8q_issue(g2, 8, nvalid, st_v, n4_v, lane, blob);
-        for (int i = 0; i < nvalid; i += 16) {
-          d8q_issue(g3, i + 12, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume(g0, acc, lane, scale);
-          d8q_issue(g0, i + 16, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume(g1, acc, lane, scale);
-          d8q_issue(g1, i + 20, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume(g2, acc, lane, scale);
-          d8q_issue(g2, i + 24, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume(g3, acc, lane, scale);
+        d8q_issue<LPB>(g0, 0, nvalid, st_v, n4_v, lane, blob);
+        d8q_issue<LPB>(g1, BPI, nvalid, st_v, n4_v, lane, blob);
+        d8q_issue<LPB>(g2, 2 * BPI, nvalid, st_v, n4_v, lane, blob);
+        for (int i = 0; i < nvalid; i += 4 * BPI) {
+          d8q_issue<LPB>(g3, i + 3 * BPI, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume<LPB>(g0, acc, lane, scale);
+          d8q_issue<LPB>(g0, i + 4 * BPI, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume<LPB>(g1, acc, lane, scale);
+          d8q_issue<LPB>(g1, i + 5 * BPI, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume<LPB>(g2, acc, lane, scale);
+          d8q_issue<LPB>(g2, i + 6 * BPI, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume<LPB>(g3, acc, lane, scale);
         }
       } else {
         SegGroupD8 gA, gB;
@@ -1161,7 +1174,8 @@ extern "C" {
 // ---------------------------------------------------------------- scatter plan
 // slices are `slice_width` output neurons wide (0 = the LDS capacity 2^slice_shift); a width below the capacity lets
 // the caller balance the slices (k = 1M: 64 slices of 15625 instead of 61 full ones and a sliver)
-constexpr int kD8QuarterMaxBlock = 48;  // average entries per block up to which the quarter-wave d8 kernel is used
+constexpr int kD8QuarterMaxBlock = 48;  // average entries per block up to which 16 lanes per block decode the d8 layout
+constexpr int kD8EighthMaxBlock = 24;   // ... and 8 lanes per block
 constexpr int kD8MaxWidth = 20000;     // d8 blocks need no pad slot and no power-of-two capacity: 20000 x 8 B = 156 KiB of LDS
 constexpr int kH8MaxWidth = 40000;     // h8: the same LDS in 4-byte counters
 static inline bool width_ok(int slice_shift, int slice_width, int layout = BE_PLAN_U16) {
@@ -1378,8 +1392,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride, (int)S);
   } else if (layout == BE_PLAN_D8) {
-    // short blocks (average <= 48 entries): a quarter wave per block
-    auto kern = (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) ? k_plan_accumulate_d8<true> : k_plan_accumulate_d8<false>;
+    // short blocks: 8 lanes (<= 24 entries on average) or 16 lanes (<= 48) per block instead of a wave
+    auto kern = (block_hint > 0 && block_hint <= kD8EighthMaxBlock)    ? k_plan_accumulate_d8<8>
+                : (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) ? k_plan_accumulate_d8<16>
+                                                                        : k_plan_accumulate_d8<0>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
                        al.ids, al.count, n_slices, (int)S, parts, scale, static_cast<unsigned long long*>(partial), astride);

@@ -594,7 +594,7 @@ def test_d8_quarter_wave_kernel_equals_full_wave(be, oracle, k):
     vs = [np.random.default_rng(s).random(m) < f for s, f in ((1, 0.05), (2, 0.6), (3, 1.1), (4, -1.0))]
     B = np.stack([np.random.default_rng(9).random(m) < 0.3 for _ in range(3)], axis=1)
     ref = None
-    for hint in (1, 48, 49, 100000):
+    for hint in (1, 24, 25, 48, 49, 100000):          # 8 lanes, 16 lanes, a wave per block
         plan.block_hint_override = hint
         got = [np.asarray(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)) for v in vs]
         got.append(np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)))
