@@ -72,6 +72,8 @@ class ScatterPlan:
         self.scale_exp = int(scale_exp)
         self.weight_dtype = weight_dtype
         self.nnz = 0                      # stored entries (set by build): sizes the number of parts
+        self.row_len = -1                 # fixed row length when the plan was built without an indptr
+        self.stamp = None                 # weights_stamp() of the weights the blocks were filled from
         self.block_hint_override: Optional[int] = None
         self._ws: Dict = {}
 
@@ -201,7 +203,9 @@ class ScatterPlan:
             f = fn('be_binary_csrmm_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int])
             ws = A.workspace(f(self.m, self.k, n_batch, self.slice_shift, self.slice_width, parts, int(self.homo)))
             ws[:4 * max(n_batch, 64)].zero_()   # spike counters: zero on entry, re-armed by every call
-            self._ws = {key: ws}
+            # never evicted: a captured HIP graph keeps the raw pointer of the workspace its launches were recorded with,
+            # so a workspace that has been handed out must outlive every later call with another (parts, n_batch)
+            self._ws[key] = ws
         return ws
 
     # -- construction ---------------------------------------------------------------------------
@@ -264,24 +268,60 @@ class ScatterPlan:
         check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, slice_width, int(homo), lay, A.ptr(seg),
                     A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
         blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
-        maxabs = torch.zeros(2, dtype=torch.int32, device=dev)      # f32 bits of max |w| and of the smallest non-zero |w|
-        f_fill = fn('be_scatter_plan_fill', c_int,
-                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp])
-        check(f_fill(A.ptr(weights), int(homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, m, k,
-                     slice_shift, slice_width, lay, A.ptr(seg), A.ptr(blob), A.ptr(maxabs), st), 'be_scatter_plan_fill')
-        scale_exp = 0
-        if not homo:
-            mm = maxabs.cpu().numpy().view(np.uint32)
-            if int(mm[0]) >= 0x7F800000:
-                raise MathError("ScatterPlan: weights contain inf/nan; use the direct route (workspace=None).")
-            wmax, wmin = (float(x) for x in mm.view(np.float32))
-            scale_exp = _fixed_point_exponent(weights, indices, k)
-            if int(mm[1]) != 0xFFFFFFFF and not _fixed_point_resolves(weights, indices, k, scale_exp, wmin):
-                raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
-                                f"64-bit fixed-point sums resolve for {m} rows; use the direct route.")
-        plan = cls(m, k, homo, slice_shift, seg, blob, scale_exp, weights.dtype, slice_width, lay)
+        plan = cls(m, k, homo, slice_shift, seg, blob, 0, weights.dtype, slice_width, lay)
         plan.nnz = nnz
+        plan.row_len = int(row_len)
+        plan._fill(weights, indices, indptr)
         return plan
+
+    def _fill(self, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], keep_exp: bool = False):
+        """Write the blocks (``be_scatter_plan_fill``) and derive the fixed-point exponent of heterogeneous weights.  The
+        segment table — block starts and lengths — depends on the structure only, so the same call refreshes the weights of
+        an existing plan (:meth:`refresh_weights`)."""
+        is64 = int(indptr is not None and indptr.dtype == torch.int64)
+        maxabs = torch.zeros(2, dtype=torch.int32, device=self.seg.device)   # f32 bits of max |w| / smallest non-zero |w|
+        name = 'be_scatter_plan_refresh_weights' if keep_exp else 'be_scatter_plan_fill'
+        f_fill = fn(name, c_int,
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp])
+        check(f_fill(A.ptr(weights), int(self.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, self.row_len,
+                     self.m, self.k, self.slice_shift, self.slice_width, self.layout, A.ptr(self.seg), A.ptr(self.blob),
+                     A.ptr(maxabs), A.stream_ptr()), name)
+        self.stamp = weights_stamp(weights)
+        if self.homo:
+            return
+        mm = maxabs.cpu().numpy().view(np.uint32)
+        if int(mm[0]) >= 0x7F800000:
+            raise MathError("ScatterPlan: weights contain inf/nan; use the direct route (workspace=None).")
+        wmax, wmin = (float(x) for x in mm.view(np.float32))
+        need = _fixed_point_exponent(weights, indices, self.k)
+        # a refresh keeps the exponent it was built with while that still cannot overflow (it is a launch argument: a
+        # captured graph replays with the old one) — unless the new weights need the finer resolution
+        exps = [self.scale_exp, need] if keep_exp and self.scale_exp <= need else [need]
+        for e in exps:
+            if int(mm[1]) == 0xFFFFFFFF or _fixed_point_resolves(weights, indices, self.k, e, wmin):
+                self.scale_exp = e
+                return
+        raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
+                        f"64-bit fixed-point sums resolve for {self.m} rows; use the direct route.")
+
+    def refresh_weights(self, weights, indices, indptr) -> None:
+        """Re-encode the weights of an unchanged structure into the existing blocks (the reference's cached workspace holds
+        task ranges only, ``_csr/main.py:58-88``, so in-place weight updates are legal there; here the blocks embed the
+        weights and have to follow them).  Raises ``MathError`` like :meth:`build` when the new weights do not qualify."""
+        weights = A.to_device(weights).reshape(-1)
+        assert (weights.numel() == 1) == self.homo, "refresh_weights cannot switch between one weight and per-entry weights"
+        assert weights.numel() == 1 or weights.numel() == self.nnz, "refresh_weights: the structure must be unchanged"
+        self._fill(weights, A.to_device(indices).reshape(-1), None if indptr is None else A.to_device(indptr), keep_exp=True)
+
+    def is_stale(self, weights: torch.Tensor) -> bool:
+        """Heterogeneous plans embed the weights: true when ``weights`` was modified in place or replaced since the fill
+        (one shared weight is read by the reduce kernel on every call and cannot go stale)."""
+        return (not self.homo) and self.stamp != weights_stamp(weights)
+
+
+def weights_stamp(t: torch.Tensor):
+    """Identity + in-place modification counter of a weight tensor (what a cached workspace was derived from)."""
+    return (t.data_ptr(), t._version, t.numel())
 
 
 def _fixed_point_exponent(weights: torch.Tensor, indices: torch.Tensor, k: int) -> int:
@@ -298,6 +338,19 @@ def _fixed_point_exponent(weights: torch.Tensor, indices: torch.Tensor, k: int) 
     bound = float(colsum.max().item()) * 1.001 if colsum.numel() else 0.0     # f32 accumulation slack
     eb = math.frexp(bound)[1] if bound > 0 else 0                              # bound < 2^eb
     return max(-90, min(150, 62 - eb))                                         # 2^(e-32) must be a normal f32
+
+
+def fresh_scatter_workspace(ws, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor]):
+    """``ws`` brought up to date with ``weights``: a cached :class:`ScatterPlan` / :class:`BinnedScatter` is re-derived when
+    the weight tensor was modified in place (``data.mul_``, ``data.copy_`` — plasticity) or replaced since it was built;
+    ``None`` (the direct route) when the new weights do not qualify for the fixed-point routes."""
+    if ws is None or not ws.is_stale(weights):
+        return ws
+    try:
+        ws.refresh_weights(weights, indices, indptr)
+    except MathError:
+        return None
+    return ws
 
 
 def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str:
@@ -377,19 +430,38 @@ class BinnedScatter:
         expect = max_active_fraction * nnz / max(self.n_slices, 1)
         self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
         self.scale_exp = 0
-        if not self.homo:
-            wmax, wmin = _abs_range(weights)
-            if not math.isfinite(wmax):
-                raise MathError("BinnedScatter: weights contain inf/nan; use the direct route (workspace=None).")
-            if indices is None:     # no structure: bound a column by all the weights there are
-                e = math.frexp(wmax)[1] if wmax > 0 else 0
-                self.scale_exp = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(nnz + 1))))))
-            else:
-                self.scale_exp = _fixed_point_exponent(weights, indices, k)
-            if math.isfinite(wmin) and not _fixed_point_resolves(weights, indices, k, self.scale_exp, wmin):
-                raise MathError("BinnedScatter: dynamic range of the weights exceeds what the fixed-point sums resolve.")
+        self.nnz = int(nnz)
+        self._derive_exponent(weights, indices)
         f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
         self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))
+
+    def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False) -> None:
+        self.stamp = weights_stamp(weights)
+        if self.homo:
+            return
+        wmax, wmin = _abs_range(weights)
+        if not math.isfinite(wmax):
+            raise MathError("BinnedScatter: weights contain inf/nan; use the direct route (workspace=None).")
+        if indices is None:     # no structure: bound a column by all the weights there are
+            e = math.frexp(wmax)[1] if wmax > 0 else 0
+            need = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(self.nnz + 1))))))
+        else:
+            need = _fixed_point_exponent(weights, indices, self.k)
+        exps = [self.scale_exp, need] if keep_exp and self.scale_exp <= need else [need]
+        for e in exps:
+            if not math.isfinite(wmin) or _fixed_point_resolves(weights, indices, self.k, e, wmin):
+                self.scale_exp = e
+                return
+        raise MathError("BinnedScatter: dynamic range of the weights exceeds what the fixed-point sums resolve.")
+
+    def refresh_weights(self, weights, indices, indptr=None) -> None:
+        """The bins are refilled from the matrix on every call; only the fixed-point exponent derives from the weights."""
+        weights = A.to_device(weights).reshape(-1)
+        assert (weights.numel() == 1) == self.homo, "refresh_weights cannot switch between one weight and per-entry weights"
+        self._derive_exponent(weights, None if indices is None else A.to_device(indices).reshape(-1), keep_exp=True)
+
+    def is_stale(self, weights: torch.Tensor) -> bool:
+        return (not self.homo) and self.stamp != weights_stamp(weights)
 
     @staticmethod
     def applicable(weights: torch.Tensor, k: int) -> bool:
@@ -775,7 +847,9 @@ class CompressedSparseData(DataRepresentation):
         """Plan for the scatter direction, built on first use and cached in ``buffers``
         (reference ``_ensure_binary_workspace_and_get``, ``_csr/main.py:148-161``)."""
         if 'scatter_plan' in self.buffers:
-            return self.buffers['scatter_plan']
+            plan = self.buffers['scatter_plan'] = fresh_scatter_workspace(self.buffers['scatter_plan'], self.data, self.indices,
+                                                                          self.indptr)
+            return plan
         m, k = self._plan_shape()
         plan = None
         if self.nse >= PLAN_MIN_NNZ and m > 0 and k > 0:
@@ -798,6 +872,16 @@ class CompressedSparseData(DataRepresentation):
             self.build_mirror()
         return self
 
+    def refresh_weights(self):
+        """Bring the cached workspaces up to date after ``self.data`` was modified in place.  The products check this by
+        themselves on every call (``data._version``); call it explicitly between replays of a captured HIP graph, whose
+        launches cannot."""
+        if 'scatter_plan' in self.buffers:
+            self._scatter_workspace()
+        if 'mirror' in self.buffers:
+            self._fresh_mirror()
+        return self
+
     # -- transposed mirror: makes the unfavourable (gather) direction event-driven -----------------------------
     def build_mirror(self):
         """Materialise the transposed structure once (the reference's ``_weight_indices`` / ``csr_to_csc_index`` route,
@@ -815,7 +899,8 @@ class CompressedSparseData(DataRepresentation):
         t_indptr, t_indices, order = csr_to_csc_index(self.indptr, self.indices, shape=(m, k))   # secondary ids = rows here
         t_indptr = t_indptr.to(self.indptr.dtype)
         t_data = self.data if self.data.numel() == 1 else self.data[order.long()].contiguous()
-        mirror = {'data': t_data, 'indices': t_indices, 'indptr': t_indptr, 'shape': (k, m), 'plan': None}
+        mirror = {'data': t_data, 'indices': t_indices, 'indptr': t_indptr, 'shape': (k, m), 'plan': None,
+                  'order': None if self.data.numel() == 1 else order.to(torch.int32), 'stamp': weights_stamp(self.data)}
         route = choose_scatter_route(nse, k, m, t_data)
         try:
             if route == 'plan':
@@ -827,9 +912,19 @@ class CompressedSparseData(DataRepresentation):
         self.buffers['mirror'] = mirror
         return mirror
 
+    def _fresh_mirror(self):
+        """The mirror holds a permuted copy of the weights: re-gather it when ``self.data`` changed since."""
+        mr = self.buffers.get('mirror')
+        if mr is None or mr['order'] is None or mr['stamp'] == weights_stamp(self.data):
+            return mr
+        torch.index_select(self.data.reshape(-1), 0, mr['order'], out=mr['data'])      # in place: captured graphs keep the pointer
+        mr['stamp'] = weights_stamp(self.data)
+        mr['plan'] = fresh_scatter_workspace(mr['plan'], mr['data'], mr['indices'], mr['indptr'])
+        return mr
+
     def _gather_via_mirror(self, v):
         """Event-driven evaluation of the gather direction through the mirror, or ``None`` if there is no mirror."""
-        mr = self.buffers.get('mirror')
+        mr = self._fresh_mirror()
         if mr is None:
             return None
         if v.ndim == 1:

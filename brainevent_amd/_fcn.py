@@ -213,8 +213,10 @@ class FixedNumConn(DataRepresentation):
 
     # -- per-matrix workspace -----------------------------------------------------------------------
     def _scatter_workspace(self):
-        if 'scatter_plan' in self.buffers:
-            return self.buffers['scatter_plan']
+        if 'scatter_plan' in self.buffers:     # re-derived when ``self.data`` was modified in place since
+            plan = self.buffers['scatter_plan'] = _csr_mod.fresh_scatter_workspace(self.buffers['scatter_plan'], self.data,
+                                                                                   self.indices, None)
+            return plan
         n_rows, n_cols = self._a_shape
         plan = None
         route = _csr_mod.choose_scatter_route(self.nse, n_rows, n_cols, self.data)
@@ -230,6 +232,13 @@ class FixedNumConn(DataRepresentation):
 
     def prepare(self):
         self._scatter_workspace()
+        return self
+
+    def refresh_weights(self):
+        """Bring the cached workspace up to date after ``self.data`` was modified in place (the products check it on every
+        call; needed explicitly only between replays of a captured HIP graph)."""
+        if 'scatter_plan' in self.buffers:
+            self._scatter_workspace()
         return self
 
     # -- dispatch (reference ``_binary_matvec`` / ``_binary_matmat`` / ``_dispatch``) -----------------

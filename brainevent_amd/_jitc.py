@@ -32,7 +32,7 @@ __all__ = [
     'binary_jitsmv', 'binary_jitsmm', 'binary_jitumv', 'binary_jitumm', 'binary_jitnmv', 'binary_jitnmm',
     'binary_jitsmv_p', 'binary_jitsmm_p', 'binary_jitumv_p', 'binary_jitumm_p', 'binary_jitnmv_p', 'binary_jitnmm_p',
     'binary_jitsmv_p_call', 'binary_jitsmm_p_call', 'binary_jitumv_p_call', 'binary_jitumm_p_call',
-    'binary_jitnmv_p_call', 'binary_jitnmm_p_call', 'JITCScatterShard', 'jit_scatter_class_columns',
+    'binary_jitnmv_p_call', 'binary_jitnmm_p_call', 'JITCScatterShard', 'jit_scatter_class_columns', 'jit_edge_weights',
 ]
 
 c_i64, c_int, c_vp, c_dbl, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_uint32
@@ -294,6 +294,22 @@ def binary_jitnmm(w_loc, w_scale, prob, B, seed: Optional[int] = None, *, shape,
 # =====================================================================================================
 # containers
 # =====================================================================================================
+def jit_edge_weights(family: str, a, b, seed, rows, cols):
+    """f32 weights the edges ``(rows[i], cols[i])`` carry — RNG-orientation coordinates — evaluated by the device hashes the
+    products use (``be_jit_edge_weights``; reference ``brainevent/_numba_random.py:424-486``).  ``family``: ``'s'`` scalar
+    (``a`` = weight), ``'u'`` uniform (``a, b`` = low, high), ``'n'`` normal (``a, b`` = loc, scale)."""
+    as_np = A.wants_numpy(rows, cols)
+    r, c = A.to_device(rows, torch.int32).reshape(-1), A.to_device(cols, torch.int32).reshape(-1)
+    assert r.numel() == c.numel(), "rows and cols must have the same length"
+    w0, w1, _ = _jit_params(family, a, b)
+    mode = _FAMILY[family]
+    out = torch.empty(r.numel(), dtype=torch.float32, device=r.device)
+    f = fn('be_jit_edge_weights', c_int, [c_int, c_dbl, c_dbl, c_u32, c_vp, c_vp, c_i64, c_vp, c_vp])
+    check(f(mode, w0, w1, _initialize_seed(seed) & 0xFFFFFFFF, A.ptr(r), A.ptr(c), r.numel(), A.ptr(out), A.stream_ptr()),
+          'be_jit_edge_weights')
+    return A.to_result(out, as_np)
+
+
 def _validate_prob(prob) -> float:
     p = np.asarray(prob.cpu() if isinstance(prob, torch.Tensor) else prob)
     if p.size != 1:

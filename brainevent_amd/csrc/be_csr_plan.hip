@@ -532,12 +532,16 @@ __host__ __device__ __forceinline__ uint32_t h8_block_units(uint32_t ng) { retur
 
 template <bool H8>
 __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
-                                                        uint32_t slice_width, int n_slices, uint2* __restrict__ seg) {
+                                                        uint32_t slice_width, int n_slices, uint2* __restrict__ seg,
+                                                        unsigned long long* __restrict__ too_long) {
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t tot[kD8MaxSlices], base_s[kD8MaxSlices];
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
     for (int s = threadIdx.x; s < n_slices; s += blockDim.x) { tot[s] = 0; base_s[s] = 0; }
-    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1));   // ends with a barrier
+    const int64_t rb = rp.at(r), re = rp.at(r + 1);
+    // a row the LDS sort cannot hold: reported to the host, which fails the build (d8_sort_row would cut it)
+    if (threadIdx.x == 0 && re - rb > (int64_t)kD8MaxRow) atomicMax(too_long, (unsigned long long)(re - rb));
+    const int len = d8_sort_row(d8_keys, indices, rb, re);   // ends with a barrier
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
       const D8Item it = d8_item<H8>(d8_keys, i, slice_width);
       atomicAdd(&tot[it.s], 1u + it.esc);
@@ -1216,6 +1220,11 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
   RowPtr rp{indptr, indptr_is_i64, row_len};
   const int64_t n = (int64_t)n_slices * m;
   uint2* sg = static_cast<uint2*>(seg);
+  uint64_t* sums = static_cast<uint64_t*>(scratch);
+  const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
+  BE_REQUIRE(n_blocks < (1ll << 31), BE_ERR_RANGE, "plan index too large");
+  unsigned long long* too_long = reinterpret_cast<unsigned long long*>(sums + n_blocks + 1);   // longest over-long row
+  BE_HIP(be_fill_async(too_long, 0, 8, st));
   if (layout == BE_PLAN_D8 || layout == BE_PLAN_H8) {
     BE_REQUIRE((layout == BE_PLAN_H8) == (homo != 0), BE_ERR_INVALID, "d8 is the heterogeneous layout, h8 the homogeneous one");
     BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 / h8 layout: rows of at most 16384 entries");
@@ -1223,23 +1232,23 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
     auto kern = layout == BE_PLAN_H8 ? k_plan_d8_count<true> : k_plan_d8_count<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
     hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
-                       (uint32_t)width_of(slice_shift, slice_width), n_slices, sg);
+                       (uint32_t)width_of(slice_shift, slice_width), n_slices, sg, too_long);
   } else {
     BE_REQUIRE(layout == BE_PLAN_U16, BE_ERR_INVALID, "unknown plan layout");
     hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m,
                        (uint32_t)width_of(slice_shift, slice_width), n_slices, homo, sg);
   }
   BE_LAUNCH_CHECK();
-  uint64_t* sums = static_cast<uint64_t*>(scratch);
-  const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
-  BE_REQUIRE(n_blocks < (1ll << 31), BE_ERR_RANGE, "plan index too large");
   hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, st, sg, n, sums);
   BE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, n_blocks);
   BE_LAUNCH_CHECK();
-  uint64_t total_units = 0;
-  BE_HIP(hipMemcpyAsync(&total_units, sums + n_blocks, 8, hipMemcpyDeviceToHost, st));
+  uint64_t back[2] = {0, 0};        // { total block units, longest row above the d8 / h8 limit }
+  BE_HIP(hipMemcpyAsync(back, sums + n_blocks, 16, hipMemcpyDeviceToHost, st));
   BE_HIP(hipStreamSynchronize(st));
+  BE_REQUIRE(back[1] == 0, BE_ERR_RANGE,
+             "d8 / h8 layout: a row has " + std::to_string(back[1]) + " entries (at most 16384); use BE_PLAN_U16");
+  const uint64_t total_units = back[0];
   BE_REQUIRE(total_units < (1ull << 32), BE_ERR_RANGE, "matrix too large for a 32-bit block index (512 GiB)");
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_blocks), dim3(256), 0, st, sg, n, sums);
   BE_LAUNCH_CHECK();
@@ -1306,12 +1315,26 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   return BE_OK;
 }
 
+int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                                    int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
+                                    int slice_width, int layout, const void* seg, void* blob, uint32_t* maxabs_bits,
+                                    be_stream_t stream) {
+  // block starts and lengths (seg) depend on the structure only: re-running the fill over the same seg / blob rewrites
+  // every block with the new weights (the d8 fill re-sorts the rows; positions inside a u16 block may differ from the
+  // first fill, which integer accumulation does not see)
+  return be_scatter_plan_fill(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, m, k, slice_shift, slice_width,
+                              layout, seg, blob, maxabs_bits, stream);
+}
+
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
                                                int parts, int homo) {
   const int64_t n_slices = n_slices_of(k, slice_shift, slice_width);
   const int64_t acc_bytes = homo ? 4 : 8;
+  // a task's partial sums are cap_of() accumulators wide; the layout is not an argument here, so size for the widest
+  // rounding any layout applies to the width (h8 / homo u16: up to the next multiple of 4)
+  const int64_t task = std::max<int64_t>(1ll << slice_shift, (width_of(slice_shift, slice_width) + 3) & ~3ll);
   return counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
-         be_align_up(n_batch * n_slices * parts * std::max<int64_t>(1ll << slice_shift, slice_width + 1) * acc_bytes, 256);
+         be_align_up(n_batch * n_slices * parts * task * acc_bytes, 256);
 }
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo) {
   return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, slice_width, parts, homo);
@@ -1338,6 +1361,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   BE_REQUIRE(workspace != nullptr &&
                  workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo),
              BE_ERR_WORKSPACE, "workspace too small");
+  // what the launch below actually writes (independent of the sizing function above)
+  BE_REQUIRE(workspace_bytes >= counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
+                                    n_batch * (int64_t)n_slices_of(k, slice_shift, slice_width) * parts * S * (homo ? 4 : 8),
+             BE_ERR_WORKSPACE, "workspace too small for this layout's partial sums");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);

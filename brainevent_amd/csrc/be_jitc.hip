@@ -617,6 +617,14 @@ int jit_mm_run(const JitP& p, const uint32_t* mask, int64_t rows, int nc, int ga
   return BE_OK;
 }
 
+// weights of explicitly listed edges (rows / cols in the RNG orientation): the device hashes exposed as an op
+template <int MODE>
+__global__ void __launch_bounds__(256) k_jit_edge_weights(JitP p, const int32_t* __restrict__ rows,
+                                                          const int32_t* __restrict__ cols, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = edge_weight<MODE, float>(p, (uint32_t)rows[i], (uint32_t)cols[i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -777,6 +785,26 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
   return BE_OK;
 }
 
+
+// ---------------------------------------------------------------- per-edge weights
+int be_jit_edge_weights(int mode, double w0, double w1, uint32_t seed, const int32_t* rows, const int32_t* cols, int64_t n,
+                        float* out, be_stream_t stream) {
+  BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
+  BE_REQUIRE(n >= 0, BE_ERR_INVALID, "negative count");
+  if (n == 0) return BE_OK;
+  BE_REQUIRE(rows && cols && out, BE_ERR_INVALID, "null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  JitP p{};
+  p.seed = seed;
+  p.w0 = w0;
+  p.w1 = w1;
+  const dim3 grid(gcap(n, 256, 8192)), block(256);
+  if (mode == MODE_UNIFORM) hipLaunchKernelGGL(k_jit_edge_weights<MODE_UNIFORM>, grid, block, 0, st, p, rows, cols, n, out);
+  else if (mode == MODE_NORMAL) hipLaunchKernelGGL(k_jit_edge_weights<MODE_NORMAL>, grid, block, 0, st, p, rows, cols, n, out);
+  else hipLaunchKernelGGL(k_jit_edge_weights<MODE_SCALAR>, grid, block, 0, st, p, rows, cols, n, out);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
 
 // ---------------------------------------------------------------- materialisation (generator matrix -> CSR)
 // replaces: brainevent/_jit_scalar/csr.cu count + fill (and the uniform / normal twins).

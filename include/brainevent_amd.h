@@ -137,8 +137,8 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *     homo  : [ uint16 local column x 8*ng ]                          with ng = ceil(count / 8)
  * pads carry local column 2^slice_shift (a dummy accumulator) and weight 0.
  *     seg[(r * n_slices + s)] = { uint32 block start in 128-B units, uint32 ng }     (8 bytes per entry)
- * layout BE_PLAN_D8 (heterogeneous weights, at most 1024 slices, rows of at most 16384 entries — a caller contract for
- * CSR rows: longer rows are truncated, never written out of bounds): 5 bytes per entry —
+ * layout BE_PLAN_D8 (heterogeneous weights, at most 1024 slices, rows of at most 16384 entries — be_scatter_plan_count
+ * checks every row on the device and returns BE_ERR_RANGE for a longer one): 5 bytes per entry —
  *     block: [ f32 weight x 4*ng ][ uint8 delta x 4*ng ], entries sorted by column, column = previous column + delta
  *     (first delta 0), gaps above 255 bridged by escape entries (weight 0, delta 255), tail pads (weight 0, delta 0);
  *     seg = { block start in 128-B units, ng | (local column of the first entry << 16) }.
@@ -153,6 +153,10 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *   step 3  be_scatter_plan_fill  : fills blob; writes the f32 bit patterns of max |w| and of the smallest non-zero |w|
  *           to maxabs_bits[0] and maxabs_bits[1] (device uint32[2]) so that the caller can pick the fixed-point exponent
  *           and refuse matrices whose dynamic range the 64-bit fixed-point sums cannot resolve.
+ *   later   be_scatter_plan_refresh_weights : same arguments as the fill, over the SAME seg / blob, after the weights of
+ *           an unchanged structure were updated (plasticity).  The reference's cached workspace holds task ranges only
+ *           (brainevent/_csr/main.py:58-88, :148-161), so weight updates never invalidate it; here the blocks embed the
+ *           weights, and this call is what keeps them current.  Re-derive scale_exp from the new maxabs / column sums.
  * ---------------------------------------------------------------------------------------------- */
 #define BE_PLAN_U16 0 /* uint16 local columns (both weight kinds) */
 #define BE_PLAN_D8 1  /* sorted columns as uint8 deltas (heterogeneous weights) */
@@ -164,6 +168,10 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
 int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                          int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
                          int layout, const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream);
+int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                                    int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
+                                    int slice_width, int layout, const void* seg, void* blob, uint32_t* maxabs_bits,
+                                    be_stream_t stream);
 
 /* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
  *   weights : device pointer to weights[0] (homo only; may be NULL for hetero)
@@ -274,6 +282,13 @@ int64_t be_binary_jitmm_workspace_bytes(int64_t shape1, int64_t in_len, int64_t 
 int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes_bm,
                     int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,
                     int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+
+/* weights of explicitly listed edges: out[i] = the weight edge (rows[i], cols[i]) carries if the walk generates it —
+ * rows / cols in the RNG orientation (the generator row and the walk coordinate).  mode / w0 / w1 as above.  These are the
+ * per-edge hashes of the reference, brainevent/_numba_random.py:424-430 (uniform01), :433-486 (normal01), evaluated by
+ * the device code the products use; the reference pins them with exact values (brainevent/_numba_random_test.py:58-93). */
+int be_jit_edge_weights(int mode, double w0, double w1, uint32_t seed, const int32_t* rows, const int32_t* cols, int64_t n,
+                        float* out, be_stream_t stream);
 
 /* materialisation of the generator matrix as CSR (rows = walk owners; stride 32 = the mv matrix, 4 = the mm matrix)
  * replaces: the count + fill kernels of brainevent/_jit_scalar/csr.cu (and the uniform / normal twins).

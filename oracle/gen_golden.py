@@ -27,9 +27,33 @@ def load_ref_util():
     return mod
 
 
+def load_ref_normal_util(ru):
+    """brainevent/_jit_normal/_test_util.py is numpy-only in its body but imports the uniform golden model through the
+    package path (`from brainevent._jit_uniform._test_util import ...`).  The package itself cannot be imported here (jax /
+    brainunit absent), so the already-loaded uniform util is registered under the module name the file asks for — nothing
+    of the reference is rewritten or stubbed, the two files it consists of are executed as they are."""
+    import types
+    for name in ('brainevent', 'brainevent._jit_uniform'):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = []
+            sys.modules[name] = pkg
+    sys.modules['brainevent._jit_uniform._test_util'] = ru
+    path = os.path.join(REF, 'brainevent', '_jit_normal', '_test_util.py')
+    spec = importlib.util.spec_from_file_location('_ref_jit_normal_test_util', path)
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        for name in ('brainevent._jit_uniform._test_util', 'brainevent._jit_uniform', 'brainevent'):
+            sys.modules.pop(name, None)
+    return mod
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ru = load_ref_util()
+    rn = load_ref_normal_util(ru)
 
     # ---- 1a. scalar RNG values on a grid -------------------------------------------------------------
     grid = [0, 1, 2, 7, 42, 123, 0xFFFFFFFF, 0x80000000, 0x6d2b79f5, 99991]
@@ -49,7 +73,6 @@ def main():
         for cl in (2, 3, 10, 20, 2000):
             q, s2 = ru.stationary_initial_q(st, cl)
             scal['initial_q'].append([st, cl, int(q), int(s2)])
-    json.dump(scal, open(os.path.join(OUT, 'light_rng_scalars.json'), 'w'))
 
     # ---- 1b. edge lists ------------------------------------------------------------------------------
     edges = {}
@@ -77,6 +100,32 @@ def main():
                                                    transpose=transpose, corder=corder, matrix_mode=mm)
                     dense[f'{shape[0]}x{shape[1]}_t{int(transpose)}_c{int(corder)}_{mm}'] = d
     np.savez_compressed(os.path.join(OUT, 'jitu_dense.npz'), **dense)
+
+    # ---- 1d. dense normal matrices from the reference's normal golden model (_jit_normal/_test_util.py:50-80) and a
+    #          grid of its hash_normal01 values (:10-47) — central region and both tails ------------------------------
+    dense_n = {}
+    for shape in ((13, 17), (20, 30)):
+        for transpose in (False, True):
+            for corder in (False, True):
+                for mm in ('mv', 'mm'):
+                    d = rn.dense_normal_reference(np.float32(0.25), np.float32(1.5), 0.2, 123, shape=shape,
+                                                  transpose=transpose, corder=corder, matrix_mode=mm)
+                    dense_n[f'{shape[0]}x{shape[1]}_t{int(transpose)}_c{int(corder)}_{mm}'] = d
+    np.savez_compressed(os.path.join(OUT, 'jitn_dense.npz'), **dense_n)
+    nrm = [[s, r, c, float(rn.hash_normal01(s, r, c))] for s in (0, 42, 123) for r in range(0, 40, 3) for c in range(0, 40, 3)]
+    us = np.array([float(ru.hash_uniform01(s, r, c)) for s, r, c, _ in nrm])
+    assert (us < 0.02425).any() and (us > 0.97575).any(), "the normal01 grid must reach both Acklam tails"
+    scal['normal01'] = nrm
+    # the reference's own exact-value tests of the two hashes (data: inputs + expected outputs)
+    scal['uniform01_reference_test'] = {
+        'src': 'brainevent/_numba_random_test.py:58-70', 'compare': 'exact float32',
+        'cases': [[42, 0, 0, 0.2929498553276062], [42, 3, 7, 0.548724353313446], [123, 19, 29, 0.5329357385635376],
+                  [0, 1, 2, 0.31099069118499756], [0xFFFFFFFF, 65535, 123456, 0.8090267777442932]]}
+    scal['normal01_reference_test'] = {
+        'src': 'brainevent/_numba_random_test.py:81-93', 'compare': 'rtol 1e-6, atol 1e-6',
+        'cases': [[42, 0, 0, -0.5447874069213867], [42, 3, 7, 0.12243907153606415], [123, 19, 29, 0.08265165984630585],
+                  [0, 1, 2, -0.4930441081523895], [0xFFFFFFFF, 65535, 123456, 0.8743151426315308]]}
+    json.dump(scal, open(os.path.join(OUT, 'light_rng_scalars.json'), 'w'))
 
     # ---- 2. known-answer tests transcribed from the reference's tests / docstrings -----------------------
     kat = [

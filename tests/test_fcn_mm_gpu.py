@@ -190,3 +190,50 @@ def test_fixed_num_conversions(be):
     np.testing.assert_array_equal(post.tocsc().todense(), dense)
     with pytest.raises(ValueError):
         be.FixedNumPerPre.fromdense(dense[0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's own forward tests of the ELL ops, restated: brainevent/_fcn/binary_test.py:202-236 (matvec) and :292-313
+# (matmat) compare the op with `dense_from_fixed_conn(weights, indices) @ binarised events` (`_mv_reference` /
+# `_mm_reference`, :157-190) at rtol = atol = 1e-3, for shapes (20, 40), (50, 30) [CPU] / (400, 200) [GPU],
+# n_conn = max(1, int(n * 0.1)), weights [1.5] or N(0, 1), bool events (rand < 0.5) or floats where(raw > 0.4, raw, 0),
+# indices drawn with or without replacement.  The dense product below is built independently of the oracle's loops.
+# ---------------------------------------------------------------------------------------------------
+def fcn_reference_case(rng, shape, homo, replace):
+    m, n = shape
+    n_conn = max(1, int(n * 0.1))
+    if replace:
+        idx = rng.integers(0, n, (m, n_conn)).astype(np.int32)
+    else:
+        idx = np.stack([rng.choice(n, size=n_conn, replace=False) for _ in range(m)]).astype(np.int32)
+    w = np.asarray([1.5], np.float32) if homo else rng.normal(0.0, 1.0, idx.shape).astype(np.float32)
+    dense = np.zeros(shape, np.float64)
+    np.add.at(dense, (np.repeat(np.arange(m), n_conn), idx.reshape(-1)),
+              np.broadcast_to(w.astype(np.float64).reshape(-1), (idx.size,)) if homo else w.astype(np.float64).reshape(-1))
+    return w, idx, dense
+
+
+def fcn_reference_events(rng, shape, as_bool):
+    if as_bool:
+        return rng.random(shape) < 0.5
+    raw = rng.random(shape).astype(np.float32)
+    return np.where(raw > 0.4, raw, np.float32(0.0))
+
+
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('transpose', [True, False])
+@pytest.mark.parametrize('as_bool', [True, False])
+@pytest.mark.parametrize('shape', [(20, 40), (50, 30), (400, 200)])
+@pytest.mark.parametrize('replace', [True, False])
+def test_fcn_forward_matches_the_reference_dense_recipe(be, homo, transpose, as_bool, shape, replace):
+    rng = np.random.default_rng(0x5EED)
+    w, idx, dense = fcn_reference_case(rng, shape, homo, replace)
+    m, n = shape
+    ev = fcn_reference_events(rng, m if transpose else n, as_bool)
+    y = be.binary_fcnmv(w, idx, ev, shape=shape, transpose=transpose)
+    b = (ev > 0).astype(np.float64)
+    np.testing.assert_allclose(y, b @ dense if transpose else dense @ b, rtol=1e-3, atol=1e-3)
+    M = fcn_reference_events(rng, (m if transpose else n, 10), as_bool)
+    Y = be.binary_fcnmm(w, idx, M, shape=shape, transpose=transpose)
+    Bm = (M > 0).astype(np.float64)
+    np.testing.assert_allclose(Y, dense.T @ Bm if transpose else dense @ Bm, rtol=1e-3, atol=1e-3)

@@ -40,6 +40,60 @@ def test_jitumm_matches_reference_dense_golden(be, transpose, corder):
 
 
 @pytest.mark.parametrize('transpose,corder', COMBOS)
+@pytest.mark.parametrize('shape', [(13, 17), (20, 30)])
+def test_jitnmv_matches_reference_dense_golden(be, transpose, corder, shape):
+    # dense_normal_reference of the reference's golden model (brainevent/_jit_normal/_test_util.py:50-80), tolerance of its
+    # own test (brainevent/_jit_normal/binary_test.py:108-160)
+    dense = np.load(os.path.join(G, 'jitn_dense.npz'))
+    D = dense[f'{shape[0]}x{shape[1]}_t{int(transpose)}_c{int(corder)}_mv'].astype(np.float64)   # [out_len, in_len]
+    rng = np.random.default_rng(5)
+    for kind in ('bool', 'float'):
+        v = spikes_of(rng, D.shape[1], 0.5, kind)
+        got = be.binary_jitnmv(np.float32(0.25), np.float32(1.5), 0.2, v, 123, shape=shape, transpose=transpose, corder=corder)
+        act = (v > 0) if kind == 'float' else v
+        np.testing.assert_allclose(got, D @ act.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('transpose,corder', COMBOS)
+def test_jitnmm_matches_reference_dense_golden(be, transpose, corder):
+    shape = (13, 17)
+    dense = np.load(os.path.join(G, 'jitn_dense.npz'))
+    D = dense[f'13x17_t{int(transpose)}_c{int(corder)}_mm'].astype(np.float64)
+    rng = np.random.default_rng(6)
+    B = rng.random((D.shape[1], 5)) < 0.5
+    got = be.binary_jitnmm(np.float32(0.25), np.float32(1.5), 0.2, B, 123, shape=shape, transpose=transpose, corder=corder)
+    np.testing.assert_allclose(got, D @ B.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+def test_device_hashes_match_the_reference_exact_value_tests(be):
+    """The device's per-edge hashes (``be_jit_edge_weights``) against the values the reference's own tests pin:
+    ``brainevent/_numba_random_test.py:58-70`` (uniform01, exact float32) and ``:81-93`` (normal01, rtol = atol = 1e-6),
+    plus the grid generated from the reference's numpy golden model (both Acklam tails; logf / sqrtf differ by ULPs
+    there: rtol 2e-6)."""
+    import json
+    from brainevent_amd._jitc import jit_edge_weights
+    sc = json.load(open(os.path.join(G, 'light_rng_scalars.json')))
+    for key, fam, a, b in (('uniform01_reference_test', 'u', 0.0, 1.0), ('normal01_reference_test', 'n', 0.0, 1.0)):
+        cases = sc[key]['cases']
+        seeds = sorted({c[0] for c in cases})
+        for seed in seeds:
+            sub = [c for c in cases if c[0] == seed]
+            got = jit_edge_weights(fam, a, b, seed, np.array([c[1] for c in sub], np.int32), np.array([c[2] for c in sub], np.int32))
+            want = np.array([c[3] for c in sub], np.float32)
+            if fam == 'u':
+                np.testing.assert_array_equal(got, want)
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    for seed in (0, 42, 123):
+        sub = [c for c in sc['normal01'] if c[0] == seed]
+        got = jit_edge_weights('n', 0.0, 1.0, seed, np.array([c[1] for c in sub], np.int32), np.array([c[2] for c in sub], np.int32))
+        np.testing.assert_allclose(got, np.array([c[3] for c in sub], np.float32), rtol=2e-6, atol=1e-6)
+        sub = [c for c in sc['uniform01'] if c[0] == seed]
+        got = jit_edge_weights('u', 0.0, 1.0, seed, np.array([c[1] for c in sub], np.int32), np.array([c[2] for c in sub], np.int32))
+        np.testing.assert_array_equal(got, np.array([c[3] for c in sub], np.float32))
+
+
+@pytest.mark.parametrize('transpose,corder', COMBOS)
 @pytest.mark.parametrize('family', ['s', 'u', 'n'])
 @pytest.mark.parametrize('shape,prob', [((40, 70), 0.1), ((100, 50), 0.3), ((3, 5), 0.5), ((64, 257), 1.0)])
 def test_jitmv_matches_oracle(be, oracle, family, transpose, corder, shape, prob):

@@ -36,11 +36,41 @@ def test_light_rng_scalars(scalars):
         assert O.default_chunk_size(n) == y
 
 
-def test_light_rng_normal01_properties():
-    # brainevent/_numba_random_test.py:60-100 pins normal01 statistically; here: finite, symmetric-ish, N(0,1) moments
-    z = np.array([O.lr_normal01(7, r, c) for r in range(60) for c in range(60)], dtype=np.float64)
-    assert np.isfinite(z).all() and abs(z.mean()) < 0.06 and abs(z.std() - 1.0) < 0.06
-    assert O.lr_normal01(1, 2, 3) == O.lr_normal01(1, 2, 3)
+def test_light_rng_hashes_match_the_reference_exact_value_tests(scalars):
+    """The reference pins both per-edge hashes with exact values (``brainevent/_numba_random_test.py:58-70`` uniform01,
+    exact float32; ``:81-93`` normal01, rtol = atol = 1e-6); the cases are transcribed as data in tests/golden/."""
+    t = scalars['uniform01_reference_test']
+    assert t['src'] == 'brainevent/_numba_random_test.py:58-70'
+    for seed, row, col, expect in t['cases']:
+        assert np.float32(O.lr_uniform01(seed, row, col)) == np.float32(expect), (seed, row, col)
+    t = scalars['normal01_reference_test']
+    assert t['src'] == 'brainevent/_numba_random_test.py:81-93'
+    for seed, row, col, expect in t['cases']:
+        np.testing.assert_allclose(np.float32(O.lr_normal01(seed, row, col)), np.float32(expect), rtol=1e-6, atol=1e-6)
+
+
+def test_light_rng_normal01_matches_reference_golden_model(scalars):
+    """A grid of ``hash_normal01`` values generated from the reference's own numpy golden model
+    (``brainevent/_jit_normal/_test_util.py:10-47``, both Acklam tails included): the restatement is bit-identical."""
+    for s, r, c, y in scalars['normal01']:
+        assert float(O.lr_normal01(s, r, c)) == y, (s, r, c)
+    z = np.array([y for *_, y in scalars['normal01']])
+    assert np.isfinite(z).all() and (z < -1.9).any() and (z > 1.9).any()
+
+
+def test_normal_dense_matches_reference_golden_model():
+    """``dense_normal_reference`` (``brainevent/_jit_normal/_test_util.py:50-80``) for every (transpose, corder, mv/mm)."""
+    dense = np.load(os.path.join(G, 'jitn_dense.npz'))
+    assert len(dense.files) == 16
+    for key in dense.files:
+        shp, t, c, mm = key.split('_')
+        shape = tuple(int(x) for x in shp.split('x'))
+        transpose, corder = bool(int(t[1])), bool(int(c[1]))
+        Gm = O.jit_generator_matrix('n', np.float32(0.25), np.float32(1.5), 0.2, 123, shape=shape, transpose=transpose,
+                                    corder=corder, matrix_mode=mm, dtype=np.float32)
+        D = Gm if corder else Gm.T
+        assert D.shape == dense[key].shape
+        np.testing.assert_array_equal(D, dense[key], err_msg=key)
 
 
 def test_edges_match_reference_golden_model():
@@ -150,3 +180,25 @@ def test_c_oracle_parallel_variant_equals_serial():
         a = oracle_c.csrmv_t_f32_parallel(w, idx, ptr, v, (m, k), 4)
         b = oracle_c.csrmv_f32(w, idx, ptr, v, (m, k), True)
         np.testing.assert_array_equal(a, b)
+
+
+def test_fcn_oracle_matches_the_reference_dense_recipe():
+    """The reference's forward tests of the ELL ops (``brainevent/_fcn/binary_test.py:202-236``, ``:292-313``) compare
+    them with ``dense_from_fixed_conn @ binarised events`` at rtol = atol = 1e-3; the oracle's loops (restating
+    ``_fcn/binary.py:156-253``, ``:677-766``) pass the same check."""
+    from test_fcn_mm_gpu import fcn_reference_case, fcn_reference_events
+    for shape in ((20, 40), (50, 30)):
+        for homo in (True, False):
+            for replace in (True, False):
+                rng = np.random.default_rng(0x5EED)
+                w, idx, dense = fcn_reference_case(rng, shape, homo, replace)
+                for transpose in (True, False):
+                    for as_bool in (True, False):
+                        ev = fcn_reference_events(rng, shape[0] if transpose else shape[1], as_bool)
+                        b = (ev > 0).astype(np.float64)
+                        y = O.binary_fcnmv(w, idx, ev, shape, transpose)
+                        np.testing.assert_allclose(y, b @ dense if transpose else dense @ b, rtol=1e-3, atol=1e-3)
+                        M = fcn_reference_events(rng, (shape[0] if transpose else shape[1], 10), as_bool)
+                        Y = O.binary_fcnmm(w, idx, M, shape, transpose)
+                        Bm = (M > 0).astype(np.float64)
+                        np.testing.assert_allclose(Y, dense.T @ Bm if transpose else dense @ Bm, rtol=1e-3, atol=1e-3)

@@ -1,0 +1,190 @@
+"""Contracts of the per-matrix scatter workspace (the role of the reference's cached task workspace,
+``brainevent/_csr/main.py:58-88``, ``:148-161``): sizing of the partial sums, in-place weight updates, workspace lifetime
+under graph capture, and the C ABI's own checks of what the Python layer normally guards.
+
+Oracle: ``oracle/oracle_np.py`` (numpy restatement of ``_csr/binary.py:387-489`` / ``_fcn/binary.py:156-253``).
+Tolerance: f32 accumulated currents rtol = atol = 1e-5; homogeneous counts exact.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-5
+
+
+def _fixed_rows(rng, m, k, row, homo):
+    idx = rng.integers(0, k, m * row).astype(np.int32)
+    ptr = (np.arange(m + 1) * row).astype(np.int32)
+    w = np.ones(1, np.float32) if homo else rng.uniform(0.1, 1.0, m * row).astype(np.float32)
+    return w, idx, ptr
+
+
+@pytest.mark.parametrize('width', [32769, 32770, 32771, 39998])
+def test_h8_partial_sums_fit_the_sized_workspace(be, oracle, width):
+    """h8 slices wider than 2^15 whose width is not a multiple of 4: a task's partial sums are (width + 3) & ~3 counters
+    wide, which the workspace query has to cover (it used to size for width + 1).  A canary behind the workspace the
+    query asked for must survive the call."""
+    from brainevent_amd._csr import ScatterPlan, _plan_call
+    from brainevent_amd import _array as A
+    from brainevent_amd._lib import fn
+    rng = np.random.default_rng(width)
+    m, k, row, parts = 300, 2 * width, 700, 10
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo=True)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_width=width, layout='h8')
+    assert plan.layout == ScatterPlan.LAYOUT_H8 and plan.slice_width == width and plan.n_slices == 2
+    f = fn('be_binary_csrmm_t_plan_workspace_bytes', ctypes.c_int64,
+           [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int])
+    nbytes = int(f(m, k, 1, plan.slice_shift, plan.slice_width, parts, 1))
+    big = torch.full((nbytes + 4096,), 0xAB, dtype=torch.uint8, device='cuda')
+    big[:1024].zero_()                                   # spike counters: zero on entry
+    plan._ws[(parts, 1)] = big[:nbytes]
+    v = rng.random(m) < 0.5
+    spikes, sd = A.spikes_to_device(v)
+    out = torch.empty(k, dtype=torch.float32, device='cuda')
+    _plan_call(plan, A.to_device(w), spikes, sd, out, parts=parts)
+    torch.cuda.synchronize()
+    assert bool((big[nbytes:] == 0xAB).all()), "the planned step wrote past the workspace the library asked for"
+    ref = np.zeros(k, np.int64)
+    np.add.at(ref, idx.reshape(m, row)[v].reshape(-1), 1)
+    np.testing.assert_array_equal(out.cpu().numpy().astype(np.int64), ref)
+
+
+def test_plan_follows_in_place_weight_updates(be, oracle, monkeypatch):
+    """The plan embeds heterogeneous weights; the containers notice ``data`` modified in place (``_version``) and refresh the
+    blocks — the reference's workspace is weight independent (``_csr/main.py:58-88``), so the same code is legal there."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(3)
+    m, k, row = 500, 30000, 300
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo=False)
+    data = torch.tensor(w, device='cuda')
+    csr = be.CSR((data, torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')), shape=(m, k))
+    v = rng.random(m) < 0.2
+    spk = be.BinaryArray(torch.tensor(v, device='cuda'))
+    y0 = (spk @ csr).cpu().numpy()
+    plan = csr.buffers['scatter_plan']
+    assert isinstance(plan, C.ScatterPlan) and not plan.is_stale(csr.data)
+    np.testing.assert_allclose(y0, oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True), rtol=RTOL, atol=ATOL)
+    blob_ptr, e0 = plan.blob.data_ptr(), plan.scale_exp
+    # plasticity-style update: scale some weights, overwrite others
+    data.mul_(0.5)
+    data[::3] = torch.tensor(rng.uniform(-1, 1, len(w[::3])).astype(np.float32), device='cuda')
+    w1 = data.cpu().numpy()
+    assert plan.is_stale(csr.data)
+    y1 = (spk @ csr).cpu().numpy()
+    assert csr.buffers['scatter_plan'] is plan and plan.blob.data_ptr() == blob_ptr, "refresh must reuse the blocks"
+    assert plan.scale_exp == e0, "the exponent is kept while it still cannot overflow (captured graphs hold it)"
+    np.testing.assert_allclose(y1, oracle.binary_csrmv(w1.astype(np.float64), idx, ptr, v, (m, k), True), rtol=RTOL, atol=ATOL)
+    # much larger weights: the kept exponent would overflow, a new one is derived
+    data.mul_(1e6)
+    y2 = (spk @ csr).cpu().numpy()
+    assert plan.scale_exp < e0
+    np.testing.assert_allclose(y2, oracle.binary_csrmv(data.cpu().numpy().astype(np.float64), idx, ptr, v, (m, k), True),
+                               rtol=RTOL, atol=ATOL * 1e6)
+    # weights the fixed-point sums cannot hold: the container falls back to the direct route instead of a wrong answer
+    data[0] = float('inf')
+    y3 = (spk @ csr).cpu().numpy()
+    assert csr.buffers['scatter_plan'] is None
+    ref3 = oracle.binary_csrmv(data.cpu().numpy().astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(y3, ref3, rtol=RTOL, atol=ATOL * 1e6)
+
+
+def test_mirror_and_fixed_num_follow_in_place_weight_updates(be, oracle, monkeypatch):
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(4)
+    m, k, row = 400, 20000, 256
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo=False)
+    data = torch.tensor(w, device='cuda')
+    csr = be.CSR((data, torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')), shape=(m, k)).prepare(mirror=True)
+    v2 = rng.random(k) < 0.05
+    g0 = (csr @ be.BinaryArray(torch.tensor(v2, device='cuda'))).cpu().numpy()
+    np.testing.assert_allclose(g0, oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v2, (m, k), False), rtol=RTOL, atol=ATOL)
+    data.add_(0.25)
+    g1 = (csr @ be.BinaryArray(torch.tensor(v2, device='cuda'))).cpu().numpy()
+    np.testing.assert_allclose(g1, oracle.binary_csrmv((w + np.float32(0.25)).astype(np.float64), idx, ptr, v2, (m, k), False),
+                               rtol=RTOL, atol=ATOL)
+    # FixedNumPerPre: same contract
+    fdata = torch.tensor(w.reshape(m, row), device='cuda')
+    fcn = be.FixedNumPerPre((fdata, torch.tensor(idx.reshape(m, row), device='cuda')), shape=(m, k))
+    v = rng.random(m) < 0.3
+    spk = be.BinaryArray(torch.tensor(v, device='cuda'))
+    f0 = (spk @ fcn).cpu().numpy()
+    assert isinstance(fcn.buffers['scatter_plan'], C.ScatterPlan)
+    np.testing.assert_allclose(f0, oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True), rtol=RTOL, atol=ATOL)
+    fdata.mul_(-2.0)
+    f1 = (spk @ fcn).cpu().numpy()
+    np.testing.assert_allclose(f1, oracle.binary_csrmv((w * np.float32(-2)).astype(np.float64), idx, ptr, v, (m, k), True),
+                               rtol=RTOL, atol=ATOL)
+
+
+def test_binned_route_follows_in_place_weight_updates(be, oracle):
+    from brainevent_amd._csr import BinnedScatter
+    rng = np.random.default_rng(5)
+    m, k, row = 300, 200000, 64
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo=False)
+    data = torch.tensor(w, device='cuda')
+    tidx, tptr = torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')
+    ws = BinnedScatter(data, m, k, m * row, indices=tidx)
+    v = rng.random(m) < 0.3
+    e0 = ws.scale_exp
+    data.mul_(1e5)
+    assert ws.is_stale(data)
+    from brainevent_amd._csr import fresh_scatter_workspace
+    assert fresh_scatter_workspace(ws, data, tidx, tptr) is ws and ws.scale_exp < e0
+    got = be.binary_csrmv(data, tidx, tptr, torch.tensor(v, device='cuda'), shape=(m, k), transpose=True, workspace=ws)
+    ref = oracle.binary_csrmv(data.cpu().numpy().astype(np.float64), idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=ATOL * 1e5)
+
+
+def test_plan_keeps_every_workspace_it_handed_out(be):
+    """A captured graph keeps the raw pointer of the workspace it was recorded with: a later call with another
+    (parts, n_batch) must not free it."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(6)
+    m, k, row = 200, 5000, 100
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo=True)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=10)
+    a = plan.workspace(3, 1)
+    b = plan.workspace(2, 4)
+    c = plan.workspace(3, 1)
+    assert a.data_ptr() == c.data_ptr() and a.data_ptr() != b.data_ptr()
+    assert len(plan._ws) == 2
+
+
+def test_c_abi_refuses_rows_the_delta_layouts_cannot_sort(be):
+    """``be_scatter_plan_count`` with BE_PLAN_D8 / BE_PLAN_H8 and a real indptr checks the row lengths on the device:
+    a 20000-entry row is BE_ERR_RANGE at the boundary, not a silently truncated row."""
+    from brainevent_amd._lib import fn, lib
+    c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+    rng = np.random.default_rng(8)
+    m, k = 64, 100000
+    lens = np.full(m, 50, np.int64)
+    lens[17] = 20000
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device='cuda')
+    idx = torch.tensor(rng.integers(0, k, int(lens.sum())).astype(np.int32), device='cuda')
+    f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
+    f_cnt = fn('be_scatter_plan_count', c_int,
+               [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])
+    for layout, homo, shift in ((1, 0, 14), (2, 1, 15)):
+        width = 1 << shift
+        n_slices = -(-k // width)
+        seg = torch.zeros(n_slices * m * 2, dtype=torch.int32, device='cuda')
+        scratch = torch.empty(int(f_scr(m, k, shift, width)), dtype=torch.uint8, device='cuda')
+        blob_bytes = c_i64(-1)
+        rc = f_cnt(idx.data_ptr(), ptr.data_ptr(), 0, -1, m, k, shift, width, homo, layout, seg.data_ptr(), scratch.data_ptr(),
+                   scratch.numel(), ctypes.byref(blob_bytes), None)
+        assert rc == -4, rc                                     # BE_ERR_RANGE
+        assert b'20000' in lib().be_last_error()
+        # the uint16 layout takes the same matrix
+        rc = f_cnt(idx.data_ptr(), ptr.data_ptr(), 0, -1, m, k, shift, width, homo, 0, seg.data_ptr(), scratch.data_ptr(),
+                   scratch.numel(), ctypes.byref(blob_bytes), None)
+        assert rc == 0 and blob_bytes.value > 0
+    # and the Python layer still routes such a matrix to the uint16 layout by itself
+    from brainevent_amd._csr import ScatterPlan
+    plan = ScatterPlan.build(np.ones(1, np.float32), idx, ptr, shape=(m, k))
+    assert plan.layout == ScatterPlan.LAYOUT_U16
