@@ -10,13 +10,17 @@ One "step" = one  spk @ csr  (spike compaction + LDS-accumulating scatter + part
 fresh spike vector (a batch of 100 pre-generated vectors is cycled, as brainevent/_csr/initialize.py:115-125
 does).  Inputs are resident in HBM when the timed region starts.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): the matrix is partitioned by
-post-neuron slice; every step each rank contributes the spikes of its 1/G of the pre population and one
-all-gather rebuilds the full spike vector on every rank (the only exchange of the path); outputs are
-disjoint, no reduction.  Default is weak scaling: every rank owns a full C2-sized post slice
-(n_pre x n_post_per_gpu), so per-GPU work is fixed; `--scaling strong` splits the 1M posts across ranks.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): ONE global matrix — the named N = 1M problem,
+the same seed on every rank — is partitioned by post-neuron slice: rank g keeps the synapses that land in its 1/G of
+the outputs (generated in row blocks and cut on the fly, so no rank ever holds more than its shard).  Every step each
+rank contributes the spikes of its 1/G of the pre population and one all-gather rebuilds the full spike vector on every
+rank (the only exchange of the path); outputs are disjoint, no reduction.  That is STRONG scaling (`"scaling": "strong"`,
+the default: total work is fixed as N grows).  `--scaling weak` keeps a full C2-sized post slice per rank instead
+(1M pre x N·1M post: a different, N times larger problem — per-GPU work fixed).
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  With the default arguments on one GPU the line also carries `secondary`: the other
+single-GPU BASELINE.json configs (C3 JITC scatter, C4 FixedNumPerPre N = 10M K = 1000, C5 batched dense fp16), each with
+its own value / ms_per_step / kernel_ms / roofline, timed after the headline.
 """
 import argparse
 import ctypes
@@ -32,42 +36,49 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_SOURCE = 'profiles/traffic.json (rocprofv3 --pmc, separate pass, guide corrections applied; not this run)'
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--n', '--neurons', dest='n', type=int, default=1_000_000, help='pre = post population per GPU shard '
+    ap.add_argument('--n', '--neurons', dest='n', type=int, default=1_000_000, help='pre = post population '
                     '(--neurons: the spelling to use under torch.distributed.run, whose own parser trips over --n)')
     ap.add_argument('--conn', type=float, default=0.01)
     ap.add_argument('--fire', type=float, default=0.01)
     ap.add_argument('--homo', action='store_true', help='homogeneous weight (4 B/update) instead of hetero f32')
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help='N > 1: strong = the named problem cut into N post slices (default); weak = N times the problem')
+    ap.add_argument('--emulate-world', type=int, default=0, help='one process: hold the shard rank 0 of a W-way strong split '
+                    'would hold and run the exchange path with a one-rank group (what one rank of W does per step)')
     ap.add_argument('--jit-shard', type=int, default=1, help='jitc workload: run rank 0 of an N-way walk-class partition')
     ap.add_argument('--exchange', choices=['bits', 'bytes'], default='bits', help='payload of the per-step spike all-gather (N > 1)')
     ap.add_argument('--exchange-ahead', type=int, default=0, help='N > 1: 1 = post the all-gather of step t+1 before scattering '
-                    'step t (synaptic delay >= 2 steps); default 0 = exchange and scatter strictly in sequence (on one rank the '
-                    'pipelined schedule measured 16 us/step slower: the cross-stream waits cost more than the local copy hides)')
-    ap.add_argument('--route', choices=['plan', 'direct'], default='plan')
+                    'step t (synaptic delay >= 2 steps); default 0 = exchange and scatter strictly in sequence')
+    ap.add_argument('--route', choices=['plan', 'direct', 'auto'], default='plan')
     ap.add_argument('--parts', type=int, default=0)
     ap.add_argument('--shift', type=int, default=0)
     ap.add_argument('--width', type=int, default=0, help='columns per slice of the scatter plan (0 = balanced automatically)')
     ap.add_argument('--layout', choices=['u16', 'd8', 'h8'], default=None, help='block layout of the scatter plan (default: '
                     'the delta layout that applies)')
     ap.add_argument('--workload', choices=['csr', 'jitc', 'fcn', 'dense'], default='csr',
-                    help='csr = the headline C2 config; the others are the secondary BASELINE.json configs (single GPU)')
+                    help='csr = the headline C2 config; the others are the secondary BASELINE.json configs')
     ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
     ap.add_argument('--batch', type=int, default=32, help='dense: batch rows')
-    ap.add_argument('--k', type=int, default=1000, help='fcn: synapses per pre neuron (stored on this GPU)')
-    ap.add_argument('--n-post', type=int, default=0, help='fcn: post population on this GPU (default: n); with --k 125 '
-                    '--n-post 1250000 this is one rank of the 8-way post-sliced N=10M, K=1000 config')
+    ap.add_argument('--k', type=int, default=1000, help='fcn: synapses per pre neuron')
+    ap.add_argument('--n-post', type=int, default=0, help='fcn: post population (default: n)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configs after the headline')
+    ap.add_argument('--secondary-steps', type=int, default=60)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# =====================================================================================================================
+# synthetic inputs
+# =====================================================================================================================
 def gen_csr_on_device(n_pre, n_post, n_conn, homo, seed, dev):
     """Reference generator family, on the device, in row blocks (nnz can exceed 2^31)."""
     g = torch.Generator(device=dev)
@@ -85,6 +96,47 @@ def gen_csr_on_device(n_pre, n_post, n_conn, homo, seed, dev):
     return weights, indices, indptr
 
 
+def gen_csr_shard_on_device(n_pre, n_post_total, n_conn, homo, seed, dev, world, rank):
+    """Post slice `rank` of `world` of the SAME global matrix :func:`gen_csr_on_device` draws (same seed, same generator
+    calls in the same order on every rank): each row block is generated, cut to the columns [lo, hi) with local ids, and
+    appended — a rank never holds more than its shard plus one block.  Rows of the shard are ragged
+    (Binomial(n_conn, 1/world) entries).  Returns (weights, indices, indptr int64, (n_pre, hi - lo), global nnz)."""
+    from brainevent_amd._dist import post_slice_bounds
+    lo, hi = post_slice_bounds(n_post_total, world, rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rows_blk = max(1, (1 << 28) // max(n_conn, 1))
+    idx_parts, w_parts, cnt_parts = [], [], []
+    for r0 in range(0, n_pre, rows_blk):
+        r1 = min(n_pre, r0 + rows_blk)
+        blk = torch.randint(0, n_post_total, ((r1 - r0) * n_conn,), dtype=torch.int32, device=dev, generator=g)
+        wb = None if homo else torch.empty((r1 - r0) * n_conn, dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=g)
+        keep = (blk >= lo) & (blk < hi)
+        cnt_parts.append(keep.view(r1 - r0, n_conn).sum(dim=1))
+        idx_parts.append((blk[keep] - lo).to(torch.int32))
+        if not homo:
+            w_parts.append(wb[keep])
+        del blk, wb, keep
+    indices = torch.cat(idx_parts)
+    weights = torch.ones(1, dtype=torch.float32, device=dev) if homo else torch.cat(w_parts)
+    del idx_parts, w_parts
+    indptr = torch.zeros(n_pre + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.cat(cnt_parts), 0, out=indptr[1:])
+    return weights, indices, indptr, (n_pre, hi - lo), n_pre * n_conn
+
+
+def gen_fixed_num_on_device(n, K, n_post, homo, dev, g):
+    idx = torch.empty((n, K), dtype=torch.int32, device=dev)
+    for lo in range(0, n, 200_000):
+        hi = min(n, lo + 200_000)
+        idx[lo:hi] = torch.randint(0, n_post, (hi - lo, K), dtype=torch.int32, device=dev, generator=g)
+    w = torch.ones(1, device=dev) if homo else torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
+    return w, idx
+
+
+# =====================================================================================================================
+# CPU baseline (the oracle's C port of the reference's numba loop; rank 0, N = 1 only)
+# =====================================================================================================================
 def cpu_baseline(args, n_post, n_conn):
     """The oracle's C restatement of the reference's serial numba scatter loop
     (brainevent/_csr/binary.py:446-451), 1 thread, on a bounded row sample of the same workload:
@@ -141,112 +193,238 @@ def cpu_baseline(args, n_post, n_conn):
     return res
 
 
-def time_steps(step, steps, warmup):
-    import ctypes as ct
+# =====================================================================================================================
+# timing
+# =====================================================================================================================
+def time_steps(step, steps, warmup, fence=None):
+    """W untimed steps, then exactly K steps bracketed by `fence` (synchronize [+ barrier]) on both sides.
+    Returns (wall seconds of the K steps, per-step dominant-kernel ms [HIP events inside the C ABI, on the op's stream],
+    per-step whole-step ms [HIP events recorded between the steps on the same stream], last output)."""
     from brainevent_amd import _lib
+    fence = fence or torch.cuda.synchronize
+    out = None
     for i in range(warmup):
         out = step(i)
-    prof_enable = _lib.fn('be_profile_enable', ct.c_int, [ct.c_int])
-    prof_read = _lib.fn('be_profile_read', ct.c_int, [ct.c_void_p, ct.c_int])
+    prof_enable = _lib.fn('be_profile_enable', ctypes.c_int, [ctypes.c_int])
+    prof_read = _lib.fn('be_profile_read', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
     _lib.check(prof_enable(steps), 'be_profile_enable')
-    torch.cuda.synchronize()
+    # torch.cuda.Event records on torch's current stream — the stream every be_* call of the step is issued on
+    # (brainevent_amd._array.stream_ptr), so consecutive events bracket the whole step (compaction + kernels + reduce)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    fence()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):
         out = step(warmup + i)
-    torch.cuda.synchronize()
+        marks[i + 1].record()
+    fence()
     elapsed = time.perf_counter() - t0
-    ms = (ct.c_float * steps)()
-    n_rec = prof_read(ct.cast(ms, ct.c_void_p), steps)
+    ms = (ctypes.c_float * steps)()
+    n_rec = prof_read(ctypes.cast(ms, ctypes.c_void_p), steps)
     prof_enable(0)
-    return elapsed, (float(np.mean(ms[:n_rec])) if n_rec > 0 else None), out
+    kern = np.array(ms[:n_rec], dtype=np.float64) if n_rec > 0 else None
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)], dtype=np.float64)
+    return elapsed, kern, step_ms, out
 
 
-def secondary(args):
-    """Secondary single-GPU workloads (BASELINE.json configs[2..4]); same JSON shape, own metric strings."""
+def _stats(a):
+    return None if a is None or len(a) == 0 else {'mean': round(float(np.mean(a)), 5), 'median': round(float(np.median(a)), 5)}
+
+
+def hbm_roofline(alg_bytes, kern_ms, traffic=None, kernel=None, extra=None):
+    """The roofline object of an HBM-bound kernel.  `achieved` / `frac` are SURVEY.md §8(d)'s algorithmic bytes over the
+    kernel's measured duration — unless the layout stores fewer bytes than §8(d) counts and that figure would exceed the
+    peak: then `achieved` / `frac` are the real (PMC) traffic rate and the algorithmic rate is reported as `effective_GBps`
+    (a fraction of an HBM peak above 1 is not a bandwidth)."""
+    if not kern_ms:
+        return None
+    sec = kern_ms * 1e-3
+    alg_rate = alg_bytes / sec / 1e9
+    roof = {'bound': 'hbm', 'achieved': round(alg_rate, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(alg_rate / HBM_PEAK_GBS, 4), 'traffic': traffic, 'basis': 'algorithmic bytes (SURVEY 8d)'}
+    if traffic:
+        roof['traffic_GBps'] = round(traffic / sec / 1e9, 1)
+        roof['traffic_source'] = TRAFFIC_SOURCE
+    if alg_rate > HBM_PEAK_GBS:
+        roof['effective_GBps'] = round(alg_rate, 1)
+        if traffic:
+            roof.update(achieved=round(traffic / sec / 1e9, 1), frac=round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4),
+                        basis='measured HBM traffic: the layout stores fewer bytes per update than SURVEY 8d counts')
+        else:
+            roof.update(achieved=None, frac=None, basis='algorithmic rate exceeds the peak (compressed layout) and no PMC '
+                                                        'traffic figure exists for this configuration: see effective_GBps')
+    if kernel:
+        roof['kernel'] = kernel
+    roof['kernel_ms'] = round(kern_ms, 5)
+    roof['algorithmic_bytes_per_launch'] = int(alg_bytes)
+    if extra:
+        roof.update(extra)
+    return roof
+
+
+def plan_traffic(args, plan, world):
+    """PMC bytes per launch of the dominant kernel, looked up (they come from a separate rocprofv3 --pmc pass)."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not (os.path.exists(tpath) and plan is not None and args.conn == 0.01 and args.fire == 0.01 and world == 1):
+        return None
+    try:
+        tj = json.load(open(tpath))
+        lay = {1: 'd8', 2: 'h8'}.get(getattr(plan, 'layout', 0), 'u16')
+        return tj.get(f"{'homo' if args.homo else 'hetero'}_{lay}_n{args.n}", {}).get('hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
+# =====================================================================================================================
+# secondary single-GPU workloads (BASELINE.json configs[2..4]); same JSON shape, own metric strings
+# =====================================================================================================================
+def run_jitc(args, dev, g):
     import brainevent_amd as be
+    n_batch = 20
+    n = args.n if args.n != 1_000_000 else 4_000_000
+    prob = args.conn if args.conn != 0.01 else 0.001
+    M = be.JITCScalarR((np.float32(1.0), prob, 42), shape=(n, n), corder=not args.jit_gather)
+    spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
+    target = M.scatter_shard(args.jit_shard, 0) if args.jit_shard > 1 else M     # rank 0's walk classes of an N-way split
+    step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ target
+    elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup)
+    kern_ms = float(np.mean(kern)) if kern is not None else None
+    upd = float(out.double().sum().item())          # weight 1: the sum is the number of delivered edges
+    value = upd * args.steps / elapsed / 1e9 if not args.jit_gather else n * n * prob * args.steps / elapsed / 1e9
+    metric = 'synaptic updates/sec (Geff/s), BinaryArray @ JITCScalarR ' + ('gather: generated edges/s' if args.jit_gather else 'scatter')
+    cfg = {'workload': f'BinaryArray({args.fire:g}) @ JITCScalarR w=1 prob={prob:g} seed=42 {n}x{n}, '
+                       f"{'gather (corder=False matrix)' if args.jit_gather else 'scatter (corder=True matrix)'}",
+           'edges_last_step': upd}
+    if args.jit_shard > 1:
+        cfg['shard'] = f'walk classes of rank 0 of {args.jit_shard} (no stored state; outputs of the ranks are disjoint)'
+    roof = None
+    if kern_ms:
+        # no stored matrix: HBM is not the bound; report the bandwidth a stored CSR would have needed (8 B/update)
+        roof = {'bound': 'valu+lds (no HBM matrix traffic)', 'achieved': None, 'peak': None, 'unit': 'GB/s', 'frac': None,
+                'traffic': None, 'kernel_ms': round(kern_ms, 5),
+                'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
+    return _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+
+
+def run_fcn(args, dev, g):
+    import brainevent_amd as be
+    n_batch = 20
+    n = args.n if args.n != 1_000_000 else 10_000_000
+    K = args.k
+    n_post = args.n_post or n
+    w, idx = gen_fixed_num_on_device(n, K, n_post, args.homo, dev, g)
+    conn = be.FixedNumPerPre((w, idx), shape=(n, n_post), check_indices=False)
+    conn.prepare()
+    spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
+    act = spikes.sum(dim=1).cpu().numpy()
+    step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ conn
+    elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup)
+    kern_ms = float(np.mean(kern)) if kern is not None else None
+    upd = sum(int(act[(args.warmup + i) % n_batch]) for i in range(args.steps)) * K
+    value = upd / elapsed / 1e9
+    metric = 'synaptic updates/sec (Geff/s), BinaryArray @ FixedNumPerPre scatter'
+    ws = conn.buffers.get('scatter_plan')
+    cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} {n} pre x {n_post} post "
+                       f"{'homo' if args.homo else 'hetero'} f32, 1 GPU",
+           'route': type(ws).__name__ if ws is not None else 'direct (global atomics)'}
+    alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n_post
+    # the step is several kernels of similar weight on this route: the whole-step HIP-event time is the honest divisor
+    whole = float(np.median(step_ms))
+    roof = hbm_roofline(alg, whole, kernel='whole step (HIP events): compaction + ' + cfg['route'] + ' kernels',
+                        extra={'dominant_kernel_ms': round(kern_ms, 5) if kern_ms else None})
+    del conn, w, idx
+    return _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+
+
+def run_dense(args, dev, g):
+    import brainevent_amd as be
+    n_batch = 20
+    n = args.n if args.n != 1_000_000 else 65536
+    W = torch.empty((n, n), dtype=torch.float16, device=dev).normal_(0, 1, generator=g)
+    spikes = torch.rand((n_batch, args.batch, n), device=dev, generator=g) < args.fire
+    step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ W
+    elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup)
+    kern_ms = float(np.mean(kern)) if kern is not None else None
+    pairs = float(spikes.sum().item()) / n_batch
+    value = pairs * n * args.steps / elapsed / 1e9
+    metric = 'synaptic updates/sec (Geff/s), batched BinaryArray @ dense fp16'
+    union = float(spikes.any(dim=1).sum().item()) / n_batch
+    cfg = {'workload': f'BinaryArray({args.fire:g}) [{args.batch},{n}] @ dense fp16 [{n},{n}]', 'union_rows': union,
+           'active_pairs': pairs}
+    roof = hbm_roofline(union * n * 2 + args.batch * n * 2, kern_ms, kernel='k_densemm_mfma') if kern_ms else None
+    del W
+    return _line(metric, value, args, elapsed, 'f16', cfg, roof, kern, step_ms)
+
+
+def _line(metric, value, args, elapsed, dtype, cfg, roof, kern, step_ms):
+    return {'metric': metric, 'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': dtype, 'data': 'synthetic', 'config': cfg, 'roofline': roof,
+            'kernel_ms': _stats(kern), 'step_ms_hip_events': _stats(step_ms)}
+
+
+SECONDARY = {'jitc': run_jitc, 'fcn': run_fcn, 'dense': run_dense}
+
+
+def secondary(args, workload=None):
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
-    n_batch = 20
-    cfg, roof = {}, None
-    if args.workload == 'jitc':
-        n = args.n if args.n != 1_000_000 else 4_000_000
-        prob = args.conn if args.conn != 0.01 else 0.001
-        M = be.JITCScalarR((np.float32(1.0), prob, 42), shape=(n, n), corder=not args.jit_gather)
-        spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
-        target = M.scatter_shard(args.jit_shard, 0) if args.jit_shard > 1 else M     # rank 0's walk classes of an N-way split
-        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ target
-        elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
-        upd = float(out.double().sum().item())          # weight 1: the sum is the number of delivered edges
-        value = upd * args.steps / elapsed / 1e9 if not args.jit_gather else n * n * prob * args.steps / elapsed / 1e9
-        metric = 'synaptic updates/sec (Geff/s), BinaryArray @ JITCScalarR ' + ('gather: generated edges/s' if args.jit_gather else 'scatter')
-        cfg = {'workload': f'BinaryArray({args.fire:g}) @ JITCScalarR w=1 prob={prob:g} seed=42 {n}x{n}, '
-                           f"{'gather (corder=False matrix)' if args.jit_gather else 'scatter (corder=True matrix)'}",
-               'edges_last_step': upd}
-        if args.jit_shard > 1:
-            cfg['shard'] = f'walk classes of rank 0 of {args.jit_shard} (no stored state; outputs of the ranks are disjoint)'
-        if kern_ms:
-            # no stored matrix: HBM is not the bound; report the bandwidth a stored CSR would have needed (8 B/update)
-            roof = {'bound': 'valu+lds (no HBM matrix traffic)', 'achieved': None, 'peak': None, 'unit': 'GB/s', 'frac': None,
-                    'traffic': None, 'kernel_ms': round(kern_ms, 5),
-                    'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
-    elif args.workload == 'fcn':
-        n = args.n if args.n != 1_000_000 else 10_000_000
-        K = args.k
-        n_post = args.n_post or n
-        idx = torch.empty((n, K), dtype=torch.int32, device=dev)
-        for lo in range(0, n, 200_000):
-            hi = min(n, lo + 200_000)
-            idx[lo:hi] = torch.randint(0, n_post, (hi - lo, K), dtype=torch.int32, device=dev, generator=g)
-        w = torch.ones(1, device=dev) if args.homo else torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
-        conn = be.FixedNumPerPre((w, idx), shape=(n, n_post), check_indices=False)
-        conn.prepare()
-        spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
-        act = spikes.sum(dim=1).cpu().numpy()
-        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ conn
-        elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
-        upd = sum(int(act[(args.warmup + i) % n_batch]) for i in range(args.steps)) * K
-        value = upd / elapsed / 1e9
-        metric = 'synaptic updates/sec (Geff/s), BinaryArray @ FixedNumPerPre scatter'
-        cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} {n} pre x {n_post} post "
-                           f"{'homo' if args.homo else 'hetero'} f32, 1 GPU",
-               'route': type(conn.buffers.get('scatter_plan')).__name__ if conn.buffers.get('scatter_plan') is not None
-               else 'direct (global atomics)'}
-        if kern_ms:
-            alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n_post
-            roof = {'bound': 'hbm', 'achieved': round(alg / (kern_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel_ms': round(kern_ms, 5)}
-    else:   # dense
-        n = args.n if args.n != 1_000_000 else 65536
-        W = torch.empty((n, n), dtype=torch.float16, device=dev).normal_(0, 1, generator=g)
-        spikes = torch.rand((n_batch, args.batch, n), device=dev, generator=g) < args.fire
-        step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ W
-        elapsed, kern_ms, out = time_steps(step, args.steps, args.warmup)
-        pairs = float(spikes.sum().item()) / n_batch
-        value = pairs * n * args.steps / elapsed / 1e9
-        metric = 'synaptic updates/sec (Geff/s), batched BinaryArray @ dense fp16'
-        union = float(spikes.any(dim=1).sum().item()) / n_batch
-        cfg = {'workload': f'BinaryArray({args.fire:g}) [{args.batch},{n}] @ dense fp16 [{n},{n}]', 'union_rows': union,
-               'active_pairs': pairs}
-        if kern_ms:
-            alg = union * n * 2 + args.batch * n * 2
-            roof = {'bound': 'hbm', 'achieved': round(alg / (kern_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel_ms': round(kern_ms, 5),
-                    'algorithmic_bytes_per_launch': int(alg)}
-    line = {'metric': metric, 'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16' if args.workload == 'dense' else 'f32', 'data': 'synthetic', 'config': cfg, 'roofline': roof}
-    print(json.dumps(line), flush=True)
+    return SECONDARY[workload or args.workload](args, dev, g)
+
+
+def secondary_configs(base):
+    """C3 / C4 / C5 of BASELINE.json after the headline (one GPU): compact entries for the `secondary` object."""
+    out = {}
+    for name, wl, extra in (('C3', 'jitc', []), ('C4', 'fcn', []), ('C4_homo', 'fcn', ['--homo']), ('C5', 'dense', [])):
+        a = parse(['--workload', wl, '--steps', str(base.secondary_steps), '--warmup', '10'] + extra)
+        try:
+            ln = secondary(a, wl)
+            out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'kernel_ms',
+                                            'step_ms_hip_events', 'roofline')}
+            out[name]['config'] = ln['config']
+        except Exception as e:       # a secondary leg must never sink the headline
+            out[name] = {'error': repr(e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+# =====================================================================================================================
+# headline
+# =====================================================================================================================
+def reference_for_shard(weights, indices, indptr, spk, n_post, homo):
+    """Size-independent check of one step (SURVEY.md §8d "parity at scale"): exact integer histogram of the active rows'
+    columns (homogeneous weight) or a float64 index_add of their (column, weight) pairs, on the device."""
+    rows = torch.nonzero(spk).flatten()
+    ptr = indptr.to(torch.int64)
+    ref = torch.zeros(n_post, dtype=torch.int64 if homo else torch.float64, device=indices.device)
+    for c0 in range(0, rows.numel(), 2000):
+        r = rows[c0:c0 + 2000]
+        b, e = ptr[r], ptr[r + 1]
+        ln = e - b
+        tot = int(ln.sum().item())
+        if tot == 0:
+            continue
+        off = torch.repeat_interleave(b - torch.cumsum(ln, 0) + ln, ln) + torch.arange(tot, device=indices.device)
+        cols = indices[off].long()
+        if homo:
+            ref += torch.bincount(cols, minlength=n_post)
+        else:
+            ref.index_add_(0, cols, weights[off].double())
+    return ref
 
 
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    multi = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'
+    force_dist = os.environ.get('BENCH_FORCE_DIST') == '1' or args.emulate_world > 1
+    multi = world > 1 or force_dist
     is_fcn = args.workload == 'fcn'
     if args.workload != 'csr' and not (is_fcn and multi):
-        return secondary(args)       # jitc / dense, and fcn on one GPU without the exchange
+        print(json.dumps(secondary(args)), flush=True)       # jitc / dense, and fcn on one GPU without the exchange
+        return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world and world > 1:
@@ -257,9 +435,9 @@ def main():
     torch.cuda.set_device(local_rank % n_dev)          # (rehearsals put several ranks on one card; the driver has one GPU per rank)
     dev = torch.device('cuda', local_rank % n_dev)
     dist = None
-    # BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, all-gather, max-reduce) with a single rank:
-    # the only way to exercise it on a one-GPU box
-    use_dist = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'
+    # BENCH_FORCE_DIST=1 / --emulate-world W run the multi-rank code path (process group, all-gather, max-reduce) with a
+    # single rank: the only way to exercise it on a one-GPU box
+    use_dist = multi
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -273,49 +451,47 @@ def main():
             dist.init_process_group(backend)
 
     import brainevent_amd as be
-    from brainevent_amd import _csr as C, _lib
+    from brainevent_amd import _csr as C
 
+    # the partition this process holds: rank `p_rank` of `p_world` post slices (emulation: rank 0 of W on one process)
+    p_world, p_rank = (args.emulate_world, 0) if args.emulate_world > 1 else (world, rank)
     plan, plan_bytes = None, 0
     t_setup = time.perf_counter()
-    if is_fcn:
-        # C4: FixedNumPerPre K = 1000, N = 10M, post-sliced (strong scaling: the problem is fixed, a rank holds the K / world
-        # synapses per row that land in its N / world outputs).  The shard of a uniform random matrix is generated directly:
-        # K / world targets per row, uniform over the rank's slice (the exact shard is ragged around that, §4 of DESIGN.md).
+    if is_fcn:          # C4: FixedNumPerPre N = 10M, K = 1000 — as a global matrix it is a CSR with rows of K entries
         n_pre = args.n if args.n != 1_000_000 else 10_000_000
         n_post_total = args.n_post or n_pre
-        n_post = n_post_total // world
-        n_conn = max(1, args.k // world)
+        n_conn_global = args.k
         args.scaling = 'strong'
-        g0 = torch.Generator(device=dev)
-        g0.manual_seed(4321 + rank)
-        idx = torch.empty((n_pre, n_conn), dtype=torch.int32, device=dev)
-        for lo in range(0, n_pre, 200_000):
-            hi = min(n_pre, lo + 200_000)
-            idx[lo:hi] = torch.randint(0, n_post, (hi - lo, n_conn), dtype=torch.int32, device=dev, generator=g0)
-        wts = torch.ones(1, device=dev) if args.homo else torch.empty((n_pre, n_conn), device=dev).uniform_(0, 1, generator=g0)
-        csr = be.FixedNumPerPre((wts, idx), shape=(n_pre, n_post), check_indices=False).prepare()
-        ws_obj = csr.buffers.get('scatter_plan')
-        args.route = type(ws_obj).__name__ if ws_obj is not None else 'direct'
-        if isinstance(ws_obj, C.ScatterPlan):
-            plan, plan_bytes = ws_obj, ws_obj.nbytes()
     else:
         n_pre = args.n
-        n_post_total = args.n * world if args.scaling == 'weak' else args.n
-        n_post = n_post_total // world                     # this rank's post slice
-        n_conn = max(1, int(n_post * args.conn))           # stored synapses per (row, shard)
-        weights, indices, indptr = gen_csr_on_device(n_pre, n_post, n_conn, args.homo, 1234 + rank, dev)
-        csr = be.CSR((weights, indices, indptr), shape=(n_pre, n_post), check_structure=False)
-    if not is_fcn and args.route == 'plan':
+        n_post_total = args.n * p_world if args.scaling == 'weak' else args.n
+        n_conn_global = max(1, int(n_post_total * args.conn))
+    if p_world == 1:
+        n_post, n_conn = n_post_total, n_conn_global
+        weights, indices, indptr = gen_csr_on_device(n_pre, n_post, n_conn, args.homo, 1234, dev)
+        shape = (n_pre, n_post)
+    else:
+        weights, indices, indptr, shape, _ = gen_csr_shard_on_device(n_pre, n_post_total, n_conn_global, args.homo, 1234, dev,
+                                                                      p_world, p_rank)
+        n_post = shape[1]
+        n_conn = n_conn_global / p_world               # mean stored synapses per (row, shard); the rows are ragged
+    nnz_local = int(indices.numel())
+    csr = be.CSR((weights, indices, indptr), shape=shape, check_structure=False)
+    if args.route == 'plan' and not is_fcn:
         # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
-        csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=(n_pre, n_post),
+        csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=shape,
                                                           slice_shift=args.shift or None, slice_width=args.width or None,
                                                           layout=args.layout or None)
-        plan = csr.buffers['scatter_plan']
-        plan_bytes = plan.nbytes()
         if args.parts:
-            plan.default_parts = lambda: args.parts
-    elif not is_fcn:                      # --route direct: global atomics
+            csr.buffers['scatter_plan'].default_parts = lambda: args.parts
+    elif args.route == 'direct':                      # global atomics
         csr.buffers['scatter_plan'] = None
+    else:                                             # the container's own choice (plan / binned / direct)
+        csr.prepare()
+    ws_obj = csr.buffers.get('scatter_plan')
+    route = type(ws_obj).__name__ if ws_obj is not None else 'direct'
+    if isinstance(ws_obj, C.ScatterPlan):
+        plan, plan_bytes = ws_obj, ws_obj.nbytes()
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
@@ -323,20 +499,21 @@ def main():
     n_batch = 100
     g = torch.Generator(device=dev)
     g.manual_seed(999 + rank)
-    n_local = n_pre // world
+    n_local = n_pre
     if use_dist:
         from brainevent_amd._dist import SpikeExchange
         # one all-gather per step (RCCL over xGMI); bit-packed by default: 1/8 of the bytes, consumed packed
         exchange = SpikeExchange(n_pre, packed=(args.exchange == 'bits'), device=dev)
         n_local = exchange.hi - exchange.lo
     local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
+    row_len = (indptr[1:] - indptr[:-1]).to(torch.int64)
     if use_dist:
-        counts = torch.empty(n_batch, dtype=torch.int64, device=dev)
-        for b in range(n_batch):
-            counts[b] = exchange.gather(local_spikes[b]).sum()
-        active_per_vec = counts.cpu().numpy()
+        full = [exchange.gather(local_spikes[b]).clone() for b in range(n_batch)]
     else:
-        active_per_vec = local_spikes.sum(dim=1).cpu().numpy()
+        full = [local_spikes[b] for b in range(n_batch)]
+    # exact work per spike vector on THIS rank: stored synapses of the active rows
+    upd_per_vec = torch.stack([row_len[f].sum() for f in full]).cpu().numpy()
+    active_per_vec = torch.stack([f.sum() for f in full]).cpu().numpy()
 
     ahead = use_dist and args.exchange == 'bits' and args.exchange_ahead
     ticket = [exchange.post(local_spikes[0])] if ahead else None
@@ -360,33 +537,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out = step(i)
-    prof_enable = _lib.fn('be_profile_enable', ctypes.c_int, [ctypes.c_int])
-    prof_read = _lib.fn('be_profile_read', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
-    _lib.check(prof_enable(args.steps), 'be_profile_enable')
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup, fence)
     if ahead:
         ticket[0][1].wait()      # the exchange posted by the last step (never consumed)
-    ms = (ctypes.c_float * args.steps)()
-    n_rec = prof_read(ctypes.cast(ms, ctypes.c_void_p), args.steps)
-    prof_enable(0)
-    kern_ms = float(np.mean(ms[:n_rec])) if n_rec > 0 else None
-    kern_ms_median = float(np.median(ms[:n_rec])) if n_rec > 0 else None
+    kern_ms = float(np.mean(kern)) if kern is not None else None
 
+    # one-step parity check of what was timed (every rank checks its own slice; rank 0 reports the worst)
+    last = (args.warmup + args.steps - 1) % n_batch
+    ref = reference_for_shard(weights, indices, indptr, full[last], n_post, args.homo)
+    if args.homo:
+        err = float((out.to(torch.float64) - ref.to(torch.float64) * float(weights[0])).abs().max().item())
+    else:
+        err = float(((out.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
+    stats = torch.tensor([elapsed, err], dtype=torch.float64, device=dev)
+    nnz_sum = torch.tensor([float(nnz_local), float(upd_per_vec[[(args.warmup + i) % n_batch for i in range(args.steps)]].sum())],
+                           dtype=torch.float64, device=dev)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # exact work done in the timed steps (all ranks see the same full spike vector)
-    upd_per_rank = sum(int(active_per_vec[(args.warmup + i) % n_batch]) for i in range(args.steps)) * n_conn
-    total_upd = upd_per_rank * world
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nnz_sum, op=dist.ReduceOp.SUM)
+    elapsed, err = float(stats[0].item()), float(stats[1].item())
+    total_nnz, total_upd = float(nnz_sum[0].item()), float(nnz_sum[1].item())
     value = total_upd / elapsed / 1e9
     checksum = float(out.double().sum().item())
 
@@ -407,60 +577,59 @@ def main():
         except Exception:
             copy_gbps = None
     if rank == 0:
+        timed = [(args.warmup + i) % n_batch for i in range(args.steps)]
         bytes_per_upd = 4 if args.homo else 8           # int32 index (+ f32 weight)
-        mean_active = float(np.mean([active_per_vec[(args.warmup + i) % n_batch] for i in range(args.steps)]))
-        alg_bytes = bytes_per_upd * mean_active * n_conn + n_pre * 1 + n_post * 4 + 16 * mean_active
-        roof = None
-        if kern_ms:
-            achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    # PMC figures exist for the default workload only (density 1 %, firing 1 %), per block layout
-                    lay = {1: 'd8', 2: 'h8'}.get(getattr(plan, 'layout', 0) if args.route == 'plan' else 0, 'u16')
-                    key = f"{'homo' if args.homo else 'hetero'}_{lay}_n{args.n}"
-                    if args.conn == 0.01 and args.fire == 0.01 and args.route == 'plan' and world == 1:
-                        traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
-                except Exception:
-                    traffic = None
-            plan_kernel = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate')
-            kernel_name = {'plan': plan_kernel, 'ScatterPlan': plan_kernel,
-                           'BinnedScatter': 'k_bin_rows'}.get(args.route, 'k_csrmv_t_direct')
-            roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    # the same run's device-copy ceiling (bytes read + written per second of a 2 GiB
-                    # device-to-device copy) next to the nominal peak, and the kernel's real traffic rate against it
-                    'device_copy_GBps': copy_gbps,
-                    'traffic_GBps': (round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None),
-                    'kernel': kernel_name,
-                    'kernel_ms': round(kern_ms, 5), 'kernel_ms_median': round(kern_ms_median, 5),
-                    'algorithmic_bytes_per_launch': int(alg_bytes)}
+        mean_active = float(np.mean(active_per_vec[timed]))
+        mean_upd = float(np.mean(upd_per_vec[timed]))
+        alg_bytes = bytes_per_upd * mean_upd + n_pre * 1 + n_post * 4 + 16 * mean_active
+        plan_kernel = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate')
+        kernel_name = {'ScatterPlan': plan_kernel, 'BinnedScatter': 'k_bin_rows'}.get(route, 'k_csrmv_t_direct')
+        roof = hbm_roofline(alg_bytes, kern_ms, traffic=plan_traffic(args, plan, p_world), kernel=kernel_name,
+                            extra={'kernel_ms_median': round(float(np.median(kern)), 5) if kern is not None else None,
+                                   # the same run's device-copy ceiling (bytes read + written per second
+                                   # of a 2 GiB device-to-device copy) next to the nominal peak
+                                   'device_copy_GBps': copy_gbps})
+        what = 'FixedNumPerPre' if is_fcn else 'CSR'
+        scaling = args.scaling      # how `--gpus N` partitions: strong = this same problem cut into N post slices
         line = {
-            'metric': 'synaptic updates/sec (Geff/s), BinaryArray @ ' + ('FixedNumPerPre scatter' if is_fcn else 'CSR scatter'),
+            'metric': f'synaptic updates/sec (Geff/s), BinaryArray @ {what} scatter'
+                      + (f' [{scaling} scaling over {max(world, args.emulate_world)} post slices]'
+                         if world > 1 or args.emulate_world > 1 else ''),
             'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': args.scaling,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': (f"BinaryArray({args.fire:g} fire) @ FixedNumPerPre K={args.k} f32 "
-                                    f"{'homo' if args.homo else 'hetero'}, {n_pre} pre x {n_post_total} post "
-                                    f"({n_conn} synapses/row/shard), route={args.route}" if is_fcn else
-                                    f"BinaryArray({args.fire:g} fire) @ CSR f32 {'homo' if args.homo else 'hetero'}, "
-                                    f"{n_pre} pre x {n_post_total} post, {args.conn:g} density "
-                                    f"({n_conn} synapses/row/shard), route={args.route}"),
-                       'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn,
-                       'parallelism': f'post-slice x{world}' + (f' + spike all-gather ({args.exchange}' + (', posted one step ahead' if ahead else '') + ')' if use_dist else ''),
+            'config': {'workload': (f"BinaryArray({args.fire:g} fire) @ {what} f32 {'homo' if args.homo else 'hetero'}, "
+                                    f"{n_pre} pre x {n_post_total} post, {n_conn_global} synapses/row "
+                                    f"({n_conn_global / n_post_total:g} density), route={route}"),
+                       'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn_global,
+                       'synapses_per_row_per_shard': n_conn, 'stored_synapses_total': total_nnz,
+                       'parallelism': f'post-slice x{p_world}' + (f' + spike all-gather ({args.exchange}'
+                                                                  + (', posted one step ahead' if ahead else '') + ')' if use_dist else '')
+                                      + (f' [one process emulating rank 0 of {args.emulate_world}]' if args.emulate_world > 1 else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
                        'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '
                                        f"layout {({1: 'd8 (5 B/entry)', 2: 'h8 (1 B/entry)'}.get(plan.layout, 'u16'))}" if plan is not None else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},
+            'step_ms_hip_events': _stats(step_ms),
+            'parity_check': {'what': 'last timed step vs ' + ('exact integer histogram of the active rows\' columns (max abs diff)'
+                                                              if args.homo else 'float64 index_add of the active rows\' entries (max rel err)')
+                                     + ', every rank on its own slice, worst rank reported',
+                             'error': err, 'ok': bool(err == 0.0 if args.homo else err <= 1e-5),
+                             'stored_synapses_all_ranks': total_nnz,
+                             'expected_stored_synapses': float(n_pre) * n_conn_global if args.emulate_world <= 1 else None},
             'roofline': roof,
         }
-        if world == 1 and not args.no_cpu:
+        default_cfg = (args.n == 1_000_000 and args.conn == 0.01 and args.fire == 0.01 and not args.homo and args.route == 'plan')
+        if world == 1 and not force_dist and not args.no_cpu:
             try:
-                line['cpu_baseline'] = cpu_baseline(args, n_post, n_conn)
+                line['cpu_baseline'] = cpu_baseline(args, n_post, int(n_conn_global))
             except Exception as e:   # the CPU leg must never sink the GPU number
                 line['cpu_baseline'] = {'error': repr(e)}
+        if world == 1 and not force_dist and not args.no_secondary and default_cfg and args.workload == 'csr':
+            del csr, plan, ws_obj, weights, indices, indptr, ref, out, full, local_spikes, row_len
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            line['secondary'] = secondary_configs(args)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -92,6 +92,14 @@ def shard_fixed_num_by_post(data: torch.Tensor, indices: torch.Tensor, shape, wo
     return shard_csr_by_post(flat_data, indices.reshape(-1), indptr, shape, world, rank)
 
 
+def _active(spikes: torch.Tensor) -> torch.Tensor:
+    """The one spike predicate of the path (``_array.spikes_to_device``; reference ``_csr/binary.py`` ``v > 0.`` for floats,
+    ``include/cuda_common.h:120-131``): bool as is, floating point ``> 0``, integers ``!= 0``."""
+    if spikes.dtype == torch.bool:
+        return spikes
+    return spikes > 0 if spikes.dtype.is_floating_point else spikes != 0
+
+
 def _pack_bits(spikes: torch.Tensor) -> torch.Tensor:
     """bool[n] -> uint8[ceil(n/8)], bit i%8 of byte i/8 (little-endian bit order)."""
     n = spikes.numel()
@@ -166,7 +174,7 @@ class SpikeExchange:
                        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p])
                 check(f(A.ptr(sp), sd, n_local, A.ptr(local_words), A.stream_ptr()), 'be_pack_spikes')
         else:           # CPU tensors (gloo tests): same words through tensor arithmetic
-            by = _pack_bits(local_spikes != 0)
+            by = _pack_bits(_active(local_spikes))
             buf = local_words.view(torch.uint8)
             buf.zero_()
             buf[:by.numel()] = by
@@ -228,7 +236,7 @@ class SpikeExchange:
         if local_spikes.dtype == torch.bool:
             payload = local_spikes.view(torch.uint8)            # zero-copy: bool storage is one 0/1 byte per spike
         else:
-            payload = (local_spikes != 0).to(torch.uint8)
+            payload = _active(local_spikes).to(torch.uint8)
         if self.uniform:
             self.dist.all_gather_into_tensor(self._full, payload.contiguous(), group=self.group)
             return self._full.view(torch.bool)

@@ -1,0 +1,184 @@
+"""Parity at the sizes BASELINE.json names (SURVEY.md §8d "parity at scale"): the CPU oracle cannot hold these inputs,
+so each configuration is checked on the device through size-independent properties —
+
+  C2  BinaryArray @ CSR f32, 1M x 1M, 10 000 per row, int64 indptr, 1 % firing:
+        homogeneous weight 1 -> counts == exact integer histogram of the active rows' columns;
+        heterogeneous        -> within 1e-5 relative of a float64 index_add of the same (column, weight) pairs,
+                                 sum of the outputs == sum of the active rows' weight row-sums (1e-6 relative),
+                                 bitwise repeatable, equal to the direct (global-atomic) route within 1e-5;
+  C3  BinaryArray @ JITCScalarR 4M x 4M, prob 1e-3: on-the-fly scatter == scatter over the materialised CSR (exact);
+  C4  BinaryArray @ FixedNumPerPre N = 10M, K = 1000: histogram / index_add as C2; one of eight post slices
+        (`shard_fixed_num_by_post`) behind the spike exchange (one-rank RCCL group) == its slice of the histogram;
+  C5  batched BinaryArray [32, 65536] @ dense fp16 65536^2: MFMA path == vector path (batches of 4 rows) on the same
+        inputs within fp16 rounding, a column sample within 2e-3 of a float64 product, row checksums vs float64.
+
+Set BE_FULL_SIZE=0 to skip them (development runs); the driver's `pytest -m gpu` runs them.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('BE_FULL_SIZE', '1') == '0', reason='BE_FULL_SIZE=0')]
+
+
+def _free():
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
+def _active_entries(indices, spk, n_conn):
+    rows = torch.nonzero(spk).flatten()
+    pos = (rows[:, None] * n_conn + torch.arange(n_conn, device=spk.device)[None, :]).flatten()
+    return pos, indices[pos].to(torch.int64)
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_c2_csr_1m_by_1m_full_size(be, homo):
+    from brainevent_amd import _csr as C
+    from bench import gen_csr_on_device
+    n, n_conn = 1_000_000, 10_000
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    w, idx, ptr = gen_csr_on_device(n, n, n_conn, homo, 77, dev)
+    assert ptr.dtype == torch.int64 and idx.numel() == 10_000_000_000      # the plan is built from an int64 indptr
+    csr = be.CSR((w, idx, ptr), shape=(n, n), check_structure=False).prepare()
+    plan = csr.buffers['scatter_plan']
+    assert isinstance(plan, C.ScatterPlan)
+    assert plan.layout == (C.ScatterPlan.LAYOUT_H8 if homo else C.ScatterPlan.LAYOUT_D8)
+    for step in range(2):
+        spk = torch.rand(n, device=dev, generator=g) < 0.01
+        out = be.BinaryArray(spk) @ csr
+        assert torch.equal(out, be.BinaryArray(spk) @ csr), 'planned route is not bitwise repeatable'
+        pos, cols = _active_entries(idx, spk, n_conn)
+        if homo:
+            assert torch.equal(out.to(torch.int64), torch.bincount(cols, minlength=n))
+        else:
+            ref = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, cols, w[pos].double())
+            rel = ((out.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+            assert rel <= 1e-5, rel
+            rowsum = w[pos].double().sum().item()
+            assert abs(out.double().sum().item() - rowsum) <= 1e-6 * rowsum
+            if step == 0:
+                direct = be.binary_csrmv(w, idx, ptr, spk, shape=(n, n), transpose=True)      # workspace=None: global atomics
+                rel_d = ((direct.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+                assert rel_d <= 1e-5, rel_d
+            del ref
+        del pos, cols, out
+    del csr, plan, w, idx, ptr
+    _free()
+
+
+def test_c3_jitc_4m_on_the_fly_equals_materialised(be):
+    n, prob, seed = 4_000_000, 0.001, 42
+    M = be.JITCScalarR((np.float32(1.0), prob, seed), shape=(n, n), corder=True)
+    S = M.materialize('mv')          # native form (CSR for this orientation): no re-encoding of 1.6e10 entries
+    assert abs(S.nse / (n * n * prob) - 1.0) < 1e-3
+    g = torch.Generator(device='cuda'); g.manual_seed(1)
+    for step in range(2):
+        spk = torch.rand(n, device='cuda', generator=g) < 0.01
+        a = be.BinaryArray(spk) @ M          # on the fly (LDS residue-class scatter)
+        b = be.BinaryArray(spk) @ S          # stored matrix (plan / binned / direct route, whichever applies)
+        assert torch.equal(a, b), (step, (a - b).abs().max().item())
+        assert 0.9 < a.sum().item() / (n * 0.01 * n * prob) < 1.1
+    del S, M
+    _free()
+
+
+@pytest.fixture(scope='module')
+def one_rank_group():
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_c4_fixed_num_10m_full_size_and_one_of_eight_shard(be, one_rank_group):
+    from brainevent_amd import _csr as C, _dist as D
+    from bench import gen_fixed_num_on_device
+    n, K = 10_000_000, 1000
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    _, idx = gen_fixed_num_on_device(n, K, n, True, dev, g)
+
+    def histogram(rows, weights=None):
+        ref = torch.zeros(n, dtype=torch.int64 if weights is None else torch.float64, device=dev)
+        for lo in range(0, rows.numel(), 20_000):
+            r = rows[lo:lo + 20_000]
+            if weights is None:
+                ref += torch.bincount(idx[r].flatten().long(), minlength=n)
+            else:
+                ref.index_add_(0, idx[r].flatten().long(), weights[r].flatten().double())
+        return ref
+
+    # homogeneous weight: exact counts, on one GPU and as rank 3 of an 8-way post split behind the exchange
+    w1 = torch.ones(1, device=dev)
+    conn = be.FixedNumPerPre((w1, idx), shape=(n, n), check_indices=False).prepare()
+    assert conn.buffers['scatter_plan'] is not None, 'C4 must not fall to the direct (global-atomic) route'
+    spk = torch.rand(n, device=dev, generator=g) < 0.01
+    rows = torch.nonzero(spk).flatten()
+    ref = histogram(rows)
+    assert torch.equal((be.BinaryArray(spk) @ conn).to(torch.int64), ref)
+    del conn
+    sw, si, sp, sshape = D.shard_fixed_num_by_post(w1, idx, (n, n), 8, 3)
+    lo, hi = D.post_slice_bounds(n, 8, 3)
+    assert sshape == (n, hi - lo) and abs(si.numel() / (n * K / 8) - 1) < 1e-3
+    shard = be.CSR((sw, si, sp), shape=sshape, check_structure=False).prepare()
+    assert shard.buffers['scatter_plan'] is not None
+    for packed in (True, False):
+        ds = D.DistributedScatter(shard, n, packed=packed, device=dev)
+        assert (ds.exchange.lo, ds.exchange.hi) == (0, n)          # a one-rank group contributes the whole pre population
+        assert torch.equal(ds.step(spk).to(torch.int64), ref[lo:hi]), 'shard output != its slice of the histogram'
+    del shard, sw, si, sp, ds, ref
+    _free()
+    # heterogeneous weights
+    w = torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
+    conn = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False).prepare()
+    assert conn.buffers['scatter_plan'] is not None
+    spk = torch.rand(n, device=dev, generator=g) < 0.01
+    rows = torch.nonzero(spk).flatten()
+    out = be.BinaryArray(spk) @ conn
+    ref = histogram(rows, w)
+    rel = ((out.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+    assert rel <= 1e-5, rel
+    assert torch.equal(out, be.BinaryArray(spk) @ conn), 'fixed-point route is not bitwise repeatable'
+    del conn, w, idx, out, ref
+    _free()
+
+
+def test_c5_dense_fp16_64k_batch32(be):
+    n, B = 65536, 32
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    W = torch.empty((n, n), dtype=torch.float16, device=dev).normal_(0, 1, generator=g)
+    for fire in (0.01, 0.5):
+        S = torch.rand((B, n), device=dev, generator=g) < fire
+        out = be.BinaryArray(S) @ W                                   # >= 8 batch rows, fp16: the MFMA kernel
+        assert out.shape == (B, n) and out.dtype == torch.float16
+        # the vector kernel (fewer than 8 batch rows) on the same inputs: both accumulate in f32 and round once to fp16
+        vec = torch.cat([be.BinaryArray(S[b:b + 4]) @ W for b in (0, 12, 28)])
+        mf = torch.cat([out[b:b + 4] for b in (0, 12, 28)]).float()
+        scale = float(np.sqrt(fire * n))                              # std of an output: sum of fire * n N(0, 1) weights
+        assert (mf - vec.float()).abs().max().item() <= 2e-3 * 6 * scale
+        # column sample against float64
+        cols = torch.randint(0, n, (512,), device=dev, generator=g)
+        ref = S.double() @ W[:, cols].double()
+        err = (out[:, cols].double() - ref).abs().max().item()
+        assert err <= 2e-3 * 6 * scale, (fire, err)
+        # row checksums: sum_j out[b, j] against float64 (each output carries one fp16 rounding: random-walk bound)
+        rowsum_w = torch.zeros(n, dtype=torch.float64, device=dev)
+        for lo in range(0, n, 8192):
+            rowsum_w[lo:lo + 8192] = W[lo:lo + 8192].double().sum(dim=1)
+        chk = S.double() @ rowsum_w
+        got = out.double().sum(dim=1)
+        tol = 8 * 2.0 ** -11 * 4 * scale * np.sqrt(n)
+        assert (got - chk).abs().max().item() <= tol, ((got - chk).abs().max().item(), tol)
+        del S, out, vec, mf, ref
+    del W
+    _free()
