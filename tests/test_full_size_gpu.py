@@ -128,7 +128,8 @@ def test_c4_fixed_num_10m_full_size_and_one_of_eight_shard(be, one_rank_group):
     del conn
     sw, si, sp, sshape = D.shard_fixed_num_by_post(w1, idx, (n, n), 8, 3)
     lo, hi = D.post_slice_bounds(n, 8, 3)
-    assert sshape == (n, hi - lo) and abs(si.numel() / (n * K / 8) - 1) < 1e-3
+    # (torch.randint draws `u32 % n`: targets below 2^32 mod 1e7 are 0.23 % more likely, so a slice is not exactly 1/8)
+    assert sshape == (n, hi - lo) and abs(si.numel() / (n * K / 8) - 1) < 5e-3
     shard = be.CSR((sw, si, sp), shape=sshape, check_structure=False).prepare()
     assert shard.buffers['scatter_plan'] is not None
     for packed in (True, False):
