@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     obj_dir = LIB_DIR / 'obj'
     obj_dir.mkdir(exist_ok=True)
     flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
-             '-Wno-unused-result', f'-I{HEADER.parent}']
+             '-Wno-unused-result', f'-I{HEADER.parent}'] + os.environ.get('BE_HIPCC_FLAGS', '').split()
     hipcc = hipcc_path()
     hdr_t = max([p.stat().st_mtime for p in CSRC_DIR.glob('*.h')] + [HEADER.stat().st_mtime])
     procs = []

@@ -188,3 +188,29 @@ def test_c_abi_refuses_rows_the_delta_layouts_cannot_sort(be):
     from brainevent_amd._csr import ScatterPlan
     plan = ScatterPlan.build(np.ones(1, np.float32), idx, ptr, shape=(m, k))
     assert plan.layout == ScatterPlan.LAYOUT_U16
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_binned_route_is_bitwise_reproducible_with_one_workgroup_per_slice(be, oracle, homo):
+    """include/brainevent_amd.h, binned scatter, "Reproducibility": more than 128 slices and no overflowing region ->
+    integer sums converted once, identical bits on every call; an overflowing region switches that run to float atomics
+    (still within tolerance)."""
+    from brainevent_amd._csr import BinnedScatter
+    rng = np.random.default_rng(21)
+    m, k, row = 3000, 5_000_000, 400                   # 306 slices of 2^14 (153 of 2^15 counted)
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo)
+    if not homo:
+        w = rng.normal(0, 1, w.shape).astype(np.float32)
+    wd, idd, ptd = torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')
+    v = torch.tensor(rng.random(m) < 0.3, device='cuda')
+    ws = BinnedScatter(wd, m, k, idx.size, max_active_fraction=0.5, indices=idd)
+    assert ws.n_slices > 128
+    outs = [be.binary_csrmv(wd, idd, ptd, v, shape=(m, k), transpose=True, workspace=ws) for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), 'binned route with one workgroup per slice must be bitwise reproducible'
+    ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v.cpu().numpy(), (m, k), True)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    # regions sized far too small: overflowing runs are delivered by float atomics — correct, order dependent in the last bit
+    tiny = BinnedScatter(wd, m, k, idx.size, max_active_fraction=1e-4, indices=idd)
+    got = be.binary_csrmv(wd, idd, ptd, v, shape=(m, k), transpose=True, workspace=tiny)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
