@@ -151,8 +151,14 @@ class ScatterPlan:
         A matrix that the single-launch kernel takes whole (one slice, <= 1M entries) stays one slice."""
         if int(k) <= cap and 0 < nnz <= (1 << 20):
             return max(1, int(k))
+        # fewer outputs than stored rows (a post slice of a multi-GPU partition: 1M x 125k) move the optimum to fewer, wider
+        # slices: more active rows per output column make the per-block cost weigh more against the partial sums (cost
+        # model in DESIGN.md: n^2 ~ k * acc / active rows).  Measured on the 1-of-8 shard of C2 (tools/exp_shard_geometry.py):
+        # 25 slices 37 us weighted / 17.6 counted, 13 slices 28 / 15.8, 7-8 slices 27 / 20.5.
+        m_rows = nnz / row if row > 0 and nnz > 0 else float(k)
+        target = max(1, int(round(cls.TARGET_SLICES * min(1.0, int(k) / max(m_rows, 1.0)) ** (1.0 / 3.0))))
         n_need = max(1, int(math.ceil(row / (0.82 * (cls.HOMO_PASS if homo else cls.HETERO_PASS)))),
-                     min(cls.TARGET_SLICES, int(row // cls.TARGET_MIN_BLOCK)))
+                     min(target, int(row // cls.TARGET_MIN_BLOCK)))
         return cls.balanced_width_cap(k, max(16, min(cap, -(-int(k) // n_need))))
 
     @classmethod
@@ -287,22 +293,10 @@ class ScatterPlan:
                      self.m, self.k, self.slice_shift, self.slice_width, self.layout, A.ptr(self.seg), A.ptr(self.blob),
                      A.ptr(maxabs), A.stream_ptr()), name)
         self.stamp = weights_stamp(weights)
-        if self.homo:
-            return
-        mm = maxabs.cpu().numpy().view(np.uint32)
-        if int(mm[0]) >= 0x7F800000:
-            raise MathError("ScatterPlan: weights contain inf/nan; use the direct route (workspace=None).")
-        wmax, wmin = (float(x) for x in mm.view(np.float32))
-        need = _fixed_point_exponent(weights, indices, self.k)
-        # a refresh keeps the exponent it was built with while that still cannot overflow (it is a launch argument: a
-        # captured graph replays with the old one) — unless the new weights need the finer resolution
-        exps = [self.scale_exp, need] if keep_exp and self.scale_exp <= need else [need]
-        for e in exps:
-            if int(mm[1]) == 0xFFFFFFFF or _fixed_point_resolves(weights, indices, self.k, e, wmin):
-                self.scale_exp = e
-                return
-        raise MathError(f"ScatterPlan: dynamic range of the weights ({wmin:g} .. {wmax:g}) exceeds what the "
-                        f"64-bit fixed-point sums resolve for {self.m} rows; use the direct route.")
+        if not self.homo:
+            # a refresh keeps the exponent it was built with while that still cannot overflow (it is a launch argument: a
+            # captured graph replays with the old one) — unless the new weights need the finer resolution
+            self.scale_exp = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp if keep_exp else None)
 
     def refresh_weights(self, weights, indices, indptr) -> None:
         """Re-encode the weights of an unchanged structure into the existing blocks (the reference's cached workspace holds
@@ -324,20 +318,33 @@ def weights_stamp(t: torch.Tensor):
     return (t.data_ptr(), t._version, t.numel())
 
 
-def _fixed_point_exponent(weights: torch.Tensor, indices: torch.Tensor, k: int) -> int:
-    """Largest exponent ``e`` for which no output can overflow: ``max_j sum_{entries of column j} |w| * 2^e < 2^62``.
+def fixed_point_exponent(weights: torch.Tensor, indices: Optional[torch.Tensor], k: int, keep: Optional[int] = None) -> int:
+    """Fixed-point exponent ``e`` of a weight array (``be_fixed_point_exponent``, chosen inside the library so that a
+    non-Python binder can set up the same workspaces).
 
-    The bound is the largest *column* sum of ``|w|`` — every row active at once — and not ``rows * max|w|``: a row may
-    list a column several times (the reference sums duplicates), so a column can receive more addends than there are
-    rows.  One chunked ``index_add`` over the entries, build time only (~0.5 s at 1e10 entries)."""
-    flat_w, flat_i = weights.reshape(-1), indices.reshape(-1)
-    colsum = torch.zeros(int(k), dtype=torch.float32, device=flat_w.device)
-    chunk = 1 << 26
-    for lo in range(0, flat_i.numel(), chunk):
-        colsum.index_add_(0, flat_i[lo:lo + chunk].long(), flat_w[lo:lo + chunk].abs().float())
-    bound = float(colsum.max().item()) * 1.001 if colsum.numel() else 0.0     # f32 accumulation slack
-    eb = math.frexp(bound)[1] if bound > 0 else 0                              # bound < 2^eb
-    return max(-90, min(150, 62 - eb))                                         # 2^(e-32) must be a normal f32
+    Overflow bound: the largest ``e`` with ``max_j sum_{entries of column j} |w| * 2^e < 2^62`` — the largest *column* sum
+    with every row active, not ``rows * max|w|``: a row may list a column several times (the reference sums duplicates), so
+    a column can receive more addends than there are rows.  Without ``indices`` all the weights bound a column.
+    Accuracy gate: a sum of ``n`` weights carries an absolute error below ``n * 2^-e``; ``e`` is accepted when the largest
+    weight *of every non-empty output column* keeps ``ScatterPlan.MIN_WEIGHT_BITS`` bits (cheap sufficient test first: the
+    globally smallest non-zero ``|w|`` does; otherwise — e.g. U[0,1) weights: 1e10 samples contain values down to 2^-32 —
+    one scatter-max pass over the entries decides).  ``keep``: an exponent to keep if it still cannot overflow (a refresh
+    of weights: captured graphs hold it as a launch argument).  Raises ``MathError`` for inf / nan weights or a dynamic range
+    the 64-bit sums cannot resolve.  One or two passes of global atomics over the entries, build time only (~1 s at 1e10)."""
+    flat_w = weights.reshape(-1)
+    f_scr = fn('be_fixed_point_scratch_bytes', c_i64, [c_i64])
+    scratch = A.workspace(f_scr(int(k)))
+    out = c_int(0)
+    f = fn('be_fixed_point_exponent', c_int,
+           [c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, ctypes.POINTER(c_int), c_vp])
+    rc = f(A.ptr(flat_w), A.wcode(flat_w), A.ptr(None if indices is None else indices.reshape(-1)), flat_w.numel(), int(k),
+           ScatterPlan.MIN_WEIGHT_BITS, -(1 << 31) if keep is None else int(keep), A.ptr(scratch), scratch.numel(),
+           ctypes.byref(out), A.stream_ptr())
+    if rc == -4:            # BE_ERR_RANGE: not representable
+        from ._lib import lib
+        raise MathError((lib().be_last_error() or b'').decode())
+    check(rc, 'be_fixed_point_exponent')
+    return int(out.value)
 
 
 def fresh_scatter_workspace(ws, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor]):
@@ -375,43 +382,6 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
     return 'direct'
 
 
-def _abs_range(weights: torch.Tensor, chunk: int = 1 << 27):
-    """``(max |w|, smallest non-zero |w| or inf)`` in chunks (1e10 weights: no 40 GB temporaries; nan -> max is nan)."""
-    flat = weights.reshape(-1)
-    wmax, wmin = 0.0, math.inf
-    for lo in range(0, flat.numel(), chunk):
-        a = flat[lo:lo + chunk].abs().float()
-        mx = float(a.max().item())
-        wmax = mx if (mx != mx or mx > wmax) else wmax
-        if wmax != wmax:
-            return wmax, wmin
-        wmin = min(wmin, float(torch.where(a > 0, a, torch.full_like(a, math.inf)).min().item()))
-    return wmax, wmin
-
-
-def _fixed_point_resolves(weights: torch.Tensor, indices: Optional[torch.Tensor], k: int, scale_exp: int,
-                          wmin: float) -> bool:
-    """Accuracy gate of the fixed-point routes.  A sum of ``n`` weights carries an absolute error below
-    ``n * 2^-scale_exp``; the routes are used when that is below ``2^-MIN_WEIGHT_BITS`` of the largest weight
-    *of every output column* (so each output is good to ~1e-5 of its column's weight scale, the tolerance of the
-    path).  Cheap sufficient test first: the globally smallest non-zero ``|w|`` keeps ``MIN_WEIGHT_BITS`` bits.
-    Otherwise (e.g. U[0,1) weights: 1e10 samples contain values down to 2^-32) the per-column maxima decide:
-    one chunked scatter-max over the entries, build time only."""
-    thr = 2.0 ** (ScatterPlan.MIN_WEIGHT_BITS - scale_exp)
-    if wmin >= thr:
-        return True
-    if indices is None:
-        return False
-    flat_w, flat_i = weights.reshape(-1), indices.reshape(-1)
-    colmax = torch.zeros(int(k), dtype=torch.float32, device=flat_w.device)
-    chunk = 1 << 26
-    for lo in range(0, flat_i.numel(), chunk):
-        colmax.scatter_reduce_(0, flat_i[lo:lo + chunk].long(), flat_w[lo:lo + chunk].abs().float(), 'amax',
-                               include_self=True)
-    live = colmax[colmax > 0]              # columns without a non-zero weight are exact zeros
-    return bool((live >= thr).all().item()) if live.numel() else True
-
-
 class BinnedScatter:
     """Workspace of the *binned* scatter route: no per-matrix layout, only per-slice bins that are refilled every call
     (``be_binary_csrmv_t_binned``).  Used when a matrix is large but a :class:`ScatterPlan` does not pay — fewer than
@@ -437,22 +407,8 @@ class BinnedScatter:
 
     def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False) -> None:
         self.stamp = weights_stamp(weights)
-        if self.homo:
-            return
-        wmax, wmin = _abs_range(weights)
-        if not math.isfinite(wmax):
-            raise MathError("BinnedScatter: weights contain inf/nan; use the direct route (workspace=None).")
-        if indices is None:     # no structure: bound a column by all the weights there are
-            e = math.frexp(wmax)[1] if wmax > 0 else 0
-            need = max(-90, min(150, 62 - e - max(1, int(math.ceil(math.log2(self.nnz + 1))))))
-        else:
-            need = _fixed_point_exponent(weights, indices, self.k)
-        exps = [self.scale_exp, need] if keep_exp and self.scale_exp <= need else [need]
-        for e in exps:
-            if not math.isfinite(wmin) or _fixed_point_resolves(weights, indices, self.k, e, wmin):
-                self.scale_exp = e
-                return
-        raise MathError("BinnedScatter: dynamic range of the weights exceeds what the fixed-point sums resolve.")
+        if not self.homo:
+            self.scale_exp = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp if keep_exp else None)
 
     def refresh_weights(self, weights, indices, indptr=None) -> None:
         """The bins are refilled from the matrix on every call; only the fixed-point exponent derives from the weights."""

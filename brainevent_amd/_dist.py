@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 __all__ = ['post_slice_bounds', 'pre_slice_bounds', 'word_aligned_bounds', 'shard_csr_by_post', 'shard_fixed_num_by_post', 'SpikeExchange',
-           'DistributedScatter']
+           'NativeSpikeExchange', 'DistributedScatter']
 
 
 def post_slice_bounds(n_post: int, world: int, rank: int) -> Tuple[int, int]:
@@ -244,6 +244,69 @@ class SpikeExchange:
             payload = torch.cat([payload, torch.zeros(self._pad - payload.numel(), dtype=torch.uint8, device=payload.device)])
         self.dist.all_gather(self._chunks, payload.contiguous(), group=self.group)
         return torch.cat([c[:b[1] - b[0]].view(torch.bool) for c, b in zip(self._chunks, self.bounds)])
+
+
+class NativeSpikeExchange:
+    """The bit-packed exchange through the C ABI alone (``be_exchange_*``: the library loads RCCL itself; no
+    ``torch.distributed`` on the data path) — what a binder that is not PyTorch uses.  Rank 0 calls :meth:`unique_id` and
+    ships the bytes to the other processes by whatever means it has; every process then constructs the exchange (a
+    collective: ``ncclCommInitRank``) on its current device.  Same slices as ``SpikeExchange(packed=True)``."""
+
+    def __init__(self, n_pre: int, world: int, rank: int, unique_id: bytes, device=None):
+        import ctypes
+        from ._lib import fn, check
+        self._ct = ctypes
+        self.n_pre, self.world, self.rank = int(n_pre), int(world), int(rank)
+        self.device = device
+        self._h = ctypes.c_void_p(0)
+        buf = ctypes.create_string_buffer(bytes(unique_id), len(unique_id))
+        f = fn('be_exchange_init', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                  ctypes.POINTER(ctypes.c_void_p)])
+        check(f(buf, self.world, self.rank, self.n_pre, ctypes.byref(self._h)), 'be_exchange_init')
+        lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+        f = fn('be_exchange_slice', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                                   ctypes.POINTER(ctypes.c_int64)])
+        check(f(self._h, self.rank, ctypes.byref(lo), ctypes.byref(hi)), 'be_exchange_slice')
+        self.lo, self.hi = int(lo.value), int(hi.value)
+        assert (self.lo, self.hi) == word_aligned_bounds(self.n_pre, self.world, self.rank)
+        n_words = int(fn('be_exchange_full_words', ctypes.c_int64, [ctypes.c_void_p])(self._h))
+        self._full_words = torch.zeros(max(n_words, 1), dtype=torch.int32, device=device)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from ._lib import fn, check
+        n = int(fn('be_exchange_unique_id_bytes', ctypes.c_int, [])())
+        buf = ctypes.create_string_buffer(n)
+        check(fn('be_exchange_get_unique_id', ctypes.c_int, [ctypes.c_void_p])(buf), 'be_exchange_get_unique_id')
+        return buf.raw
+
+    def gather_events(self, local_spikes: torch.Tensor):
+        """This rank's spikes ``[hi - lo]`` -> the full spike vector as a bit-packed event container."""
+        from . import _array as A
+        from ._event import BitPackedBinary
+        from ._lib import fn, check
+        assert local_spikes.numel() == self.hi - self.lo
+        sp, sd = A.spikes_to_device(local_spikes)
+        ct = self._ct
+        f = fn('be_exchange_allgather_bits', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p])
+        check(f(self._h, A.ptr(sp), sd, A.ptr(self._full_words), A.stream_ptr()), 'be_exchange_allgather_bits')
+        return BitPackedBinary.from_packed(self._full_words, self.n_pre)
+
+    def gather(self, local_spikes: torch.Tensor) -> torch.Tensor:
+        return self.gather_events(local_spikes).value
+
+    def close(self) -> None:
+        if self._h:
+            from ._lib import fn
+            fn('be_exchange_destroy', self._ct.c_int, [self._ct.c_void_p])(self._h)
+            self._h = self._ct.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DistributedScatter:

@@ -81,7 +81,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         log, _ = p.communicate()
         if p.returncode != 0:
             raise KernelCompilationError(f"hipcc failed on {src.name}:\n{log}")
-    cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', *map(str, objs), '-o', str(out)]
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', *map(str, objs), '-ldl', '-o', str(out)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise KernelCompilationError(f"link failed:\n{r.stdout}")

@@ -14,6 +14,12 @@ const char* be_last_error(void) { return g_last_error.c_str(); }
 
 const char* be_build_arch(void) { return "gfx950"; }
 
+int be_profile_enable(int max_records);
+
+/* releases what the library holds on to between calls (the profiling events); exchange handles are released by
+ * be_exchange_destroy.  Every other buffer belongs to the caller. */
+int be_shutdown(void) { return be_profile_enable(0); }
+
 int be_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);

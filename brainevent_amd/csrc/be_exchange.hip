@@ -1,0 +1,159 @@
+// be_exchange.hip — the one collective of the multi-GPU path behind the C ABI: a bit-packed all-gather of the spike vector
+// over RCCL (xGMI), one process per GPU.  SURVEY.md §8(e): rank g owns a post slice of the matrix and produces the spikes
+// of its 1/G of the pre population; one all-gather rebuilds the full vector on every rank; the scatter is local.
+// The reference has no distributed path; a JAX-side binder (not torch) reaches the exchange through these entry points:
+// rank 0 obtains an id (be_exchange_get_unique_id), the binder ships its 128 bytes to the other processes by its own
+// means, every process calls be_exchange_init.  RCCL is loaded at run time (dlopen "librccl.so"): the library itself keeps
+// no link-time dependency on it, and a process that has already loaded RCCL (PyTorch ships one) shares that copy.
+#include "be_common.h"
+#include <dlfcn.h>
+#include <cstring>
+#include <cstdlib>
+#include <mutex>
+
+namespace {
+
+struct NcclUniqueId { char internal[128]; };           // ncclUniqueId of rccl.h (NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* NcclComm;
+constexpr int kNcclUint32 = 3;                          // ncclDataType_t: ncclUint32
+
+struct Rccl {
+  void* handle = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {getenv("BE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) return;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+  });
+  return (r.handle && r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy) ? &r : nullptr;
+}
+
+struct Exchange {
+  NcclComm comm;
+  int world, rank;
+  int64_t n_pre, words_per_rank;      // every rank owns the same whole number of 32-bit words (the last may hold fewer spikes)
+  uint32_t* local_words;              // device: this rank's packed slice (words_per_rank)
+};
+
+#define BE_RCCL(call)                                                                                     \
+  do {                                                                                                    \
+    const int rc__ = (call);                                                                              \
+    if (rc__ != 0) {                                                                                      \
+      be_set_error(std::string(__func__) + ": " #call " -> " + (R->GetErrorString ? R->GetErrorString(rc__) : "RCCL error")); \
+      return BE_ERR_HIP;                                                                                  \
+    }                                                                                                     \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
+
+int be_exchange_unique_id_bytes(void) { return (int)sizeof(NcclUniqueId); }
+
+int be_exchange_get_unique_id(void* id_host) {
+  BE_REQUIRE(id_host != nullptr, BE_ERR_INVALID, "null pointer");
+  Rccl* R = rccl();
+  BE_REQUIRE(R != nullptr, BE_ERR_UNSUPPORTED, "librccl.so could not be loaded (set BE_RCCL_LIB)");
+  BE_RCCL(R->GetUniqueId(static_cast<NcclUniqueId*>(id_host)));
+  return BE_OK;
+}
+
+int be_exchange_init(const void* id_host, int world, int rank, int64_t n_pre, void** exchange_host_out) {
+  BE_REQUIRE(id_host && exchange_host_out, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(world >= 1 && rank >= 0 && rank < world && n_pre >= 0, BE_ERR_INVALID, "bad world / rank / n_pre");
+  Rccl* R = rccl();
+  BE_REQUIRE(R != nullptr, BE_ERR_UNSUPPORTED, "librccl.so could not be loaded (set BE_RCCL_LIB)");
+  Exchange* ex = new Exchange();
+  ex->world = world;
+  ex->rank = rank;
+  ex->n_pre = n_pre;
+  ex->words_per_rank = (((n_pre + 31) / 32) + world - 1) / world;
+  ex->local_words = nullptr;
+  NcclUniqueId id;
+  memcpy(&id, id_host, sizeof(id));
+  const int rc = R->CommInitRank(&ex->comm, world, id, rank);
+  if (rc != 0) {
+    be_set_error(std::string("be_exchange_init: ncclCommInitRank -> ") + (R->GetErrorString ? R->GetErrorString(rc) : "RCCL error"));
+    delete ex;
+    return BE_ERR_HIP;
+  }
+  if (hipMalloc(&ex->local_words, (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * 4) != hipSuccess) {
+    be_set_error("be_exchange_init: hipMalloc failed");
+    R->CommDestroy(ex->comm);
+    delete ex;
+    return BE_ERR_HIP;
+  }
+  *exchange_host_out = ex;
+  return BE_OK;
+}
+
+int be_exchange_slice(const void* exchange, int rank, int64_t* lo_host, int64_t* hi_host) {
+  BE_REQUIRE(exchange && lo_host && hi_host, BE_ERR_INVALID, "null pointer");
+  const Exchange* ex = static_cast<const Exchange*>(exchange);
+  BE_REQUIRE(rank >= 0 && rank < ex->world, BE_ERR_INVALID, "rank out of range");
+  const int64_t lo = (int64_t)rank * ex->words_per_rank * 32, hi = lo + ex->words_per_rank * 32;
+  *lo_host = lo < ex->n_pre ? lo : ex->n_pre;
+  *hi_host = hi < ex->n_pre ? hi : ex->n_pre;
+  return BE_OK;
+}
+
+int64_t be_exchange_full_words(const void* exchange) {
+  if (!exchange) return 0;
+  const Exchange* ex = static_cast<const Exchange*>(exchange);
+  return ex->words_per_rank * ex->world;
+}
+
+int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spike_dtype, uint32_t* full_bits,
+                               be_stream_t stream) {
+  BE_REQUIRE(exchange && full_bits, BE_ERR_INVALID, "null pointer");
+  Exchange* ex = static_cast<Exchange*>(exchange);
+  Rccl* R = rccl();
+  BE_REQUIRE(R != nullptr, BE_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t lo = (int64_t)ex->rank * ex->words_per_rank * 32;
+  int64_t n_local = ex->n_pre - lo;
+  n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
+  BE_REQUIRE(n_local == 0 || local_spikes != nullptr, BE_ERR_INVALID, "null pointer");
+  const int64_t used = (n_local + 31) / 32;
+  if (used < ex->words_per_rank)      // words of the slice that hold no spike of the population
+    BE_HIP(be_fill_async(ex->local_words + used, 0, (size_t)(ex->words_per_rank - used) * 4, st));
+  if (n_local > 0) {
+    const int rc = be_pack_spikes(local_spikes, spike_dtype, n_local, ex->local_words, stream);
+    if (rc != BE_OK) return rc;
+  }
+  if (ex->words_per_rank > 0)
+    BE_RCCL(R->AllGather(ex->local_words, full_bits, (size_t)ex->words_per_rank, kNcclUint32, ex->comm, st));
+  return BE_OK;
+}
+
+int be_exchange_destroy(void* exchange) {
+  if (!exchange) return BE_OK;
+  Exchange* ex = static_cast<Exchange*>(exchange);
+  Rccl* R = rccl();
+  if (ex->local_words) (void)hipFree(ex->local_words);
+  if (R) (void)R->CommDestroy(ex->comm);
+  delete ex;
+  return BE_OK;
+}
+
+}  // extern "C"

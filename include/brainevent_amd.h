@@ -73,6 +73,8 @@ const char* be_build_arch(void);      /* "gfx950" */
  * records copied to ms_host (kernel durations in milliseconds, in call order) and rearms. */
 int be_profile_enable(int max_records);
 int be_profile_read(float* ms_host, int capacity);
+/* releases the little the library keeps between calls (profiling events); exchange handles have be_exchange_destroy */
+int be_shutdown(void);
 
 /* ------------------------------------------------------------------------------------------------
  * event vector helpers (replace: brainevent/_jit_scalar/binary_jitsmv.cu:107-125 `_pack_bool_kern`
@@ -91,6 +93,28 @@ int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* 
 /* batch-major spikes_bm[n_batch, n] -> active_ids[b * active_stride + ...] and counts[b] */
 int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch, uint32_t* active_ids,
                               int64_t active_stride, uint32_t* counts, be_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * spike exchange of the multi-GPU partition (the reference has no distributed path): one process per
+ * GPU, rank g owns a post slice of the matrix and the spikes of its 1/G of the pre population; ONE all-gather of the
+ * bit-packed slices (RCCL over xGMI) rebuilds the full spike vector on every rank, which the scatter entry points consume
+ * as it is (BE_SPIKE_BITS).  Every rank owns the same whole number of 32-bit words: slice of rank r =
+ * [r * w * 32, (r + 1) * w * 32) clipped to n_pre, w = ceil(ceil(n_pre / 32) / world) (be_exchange_slice).
+ *   rank 0: be_exchange_get_unique_id(id)  ->  the binder ships the be_exchange_unique_id_bytes() bytes to every process
+ *   all   : be_exchange_init(id, world, rank, n_pre, &ex)        (collective: ncclCommInitRank; current HIP device)
+ *   step  : be_exchange_allgather_bits(ex, local_spikes, dtype, full_bits, stream)   full_bits: be_exchange_full_words(ex) words
+ *   end   : be_exchange_destroy(ex)
+ * The handle owns the communicator and one device buffer of w words.  RCCL is loaded with dlopen("librccl.so") on first use
+ * (override: environment variable BE_RCCL_LIB); BE_ERR_UNSUPPORTED if it cannot be loaded.
+ * ---------------------------------------------------------------------------------------------- */
+int be_exchange_unique_id_bytes(void);
+int be_exchange_get_unique_id(void* id_host);
+int be_exchange_init(const void* id_host, int world, int rank, int64_t n_pre, void** exchange_host_out);
+int be_exchange_slice(const void* exchange, int rank, int64_t* lo_host, int64_t* hi_host);
+int64_t be_exchange_full_words(const void* exchange);
+int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spike_dtype, uint32_t* full_bits,
+                               be_stream_t stream);
+int be_exchange_destroy(void* exchange);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch convention (all *mm entry points): spikes_bm is batch-major [n_batch, len] and out_bm is
@@ -172,6 +196,21 @@ int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, c
                                     int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
                                     int slice_width, int layout, const void* seg, void* blob, uint32_t* maxabs_bits,
                                     be_stream_t stream);
+
+/* Fixed-point exponent of a weight array — the `scale_exp` of the planned and the binned step — chosen by the library:
+ *   overflow bound : the largest e with (largest column sum of |w|) * 2^e < 2^62 (every row active; a row may list a column
+ *                    several times, so "rows x max|w|" is NOT a bound).  indices == NULL: all the weights bound a column.
+ *   accuracy gate  : e is accepted when the largest weight of every non-empty output column keeps `min_weight_bits` bits
+ *                    (16 gives ~1e-5 of the column's weight scale, the tolerance of the path).
+ *   keep_exp       : an exponent to keep when it still cannot overflow (weights refreshed under a captured graph, where
+ *                    scale_exp is a recorded launch argument), or INT_MIN.
+ * SYNCHRONOUS (reads statistics back).  Returns BE_ERR_RANGE — use the direct route — for inf / nan weights or a dynamic
+ * range 64-bit sums cannot resolve.  scratch >= be_fixed_point_scratch_bytes(k).  No reference counterpart: its GPU kernels
+ * add floats with global atomics (brainevent/_csr/binary_csrmv_hybrid.cu:199-234). */
+int64_t be_fixed_point_scratch_bytes(int64_t k);
+int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indices, int64_t nnz, int64_t k,
+                            int min_weight_bits, int keep_exp, void* scratch, int64_t scratch_bytes, int* scale_exp_host,
+                            be_stream_t stream);
 
 /* planned scatter step: out[n_batch, k] (dtype wdtype, fully written) from spikes[n_batch, m].
  *   weights : device pointer to weights[0] (homo only; may be NULL for hetero)

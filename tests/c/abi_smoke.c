@@ -1,0 +1,142 @@
+/* abi_smoke.c — the INTEGRATION.md call sequence from plain C (gcc, no C++, no torch, no Python): what a non-Python
+ * binder of the reference (its FFI replaces `jax.ffi.ffi_call("<module>.<fn>")`, brainevent/_op/kernix_runtime.py:161-189)
+ * would do with include/brainevent_amd.h.
+ *   1. direct route:   be_binary_csrmv_t_hetero_f32_bool            (no preprocessing, global atomics)
+ *   2. planned route:  be_scatter_plan_count -> _fill -> be_fixed_point_exponent -> be_binary_csrmv_t_plan
+ *   3. weight refresh: be_scatter_plan_refresh_weights, then step 2's call again
+ *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
+ * Every result is compared with the serial loop of the reference's CPU kernel (brainevent/_csr/binary.py:446-451 /
+ * :466-472), restated inline in double precision; tolerance 1e-5 relative (the tolerance of the path).
+ * Build:  gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/c/abi_smoke.c \
+ *             -L brainevent_amd/lib -lbrainevent_amd -L /opt/rocm/lib -lamdhip64 -lm -o abi_smoke
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "brainevent_amd.h"
+
+#define CHECK_BE(call)                                                                      \
+  do {                                                                                      \
+    int rc_ = (call);                                                                       \
+    if (rc_ != BE_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, be_last_error()); return 1; } \
+  } while (0)
+#define CHECK_HIP(call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } \
+  } while (0)
+
+static uint32_t rng_state = 12345u;
+static uint32_t rnd(void) { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+
+static void *dev_copy(const void *host, size_t bytes) {
+  void *d = NULL;
+  if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return NULL;
+  if (bytes && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
+  return d;
+}
+
+static int compare(const char *what, const float *got, const double *ref, int64_t n) {
+  double worst = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double err = fabs((double)got[i] - ref[i]) / (fabs(ref[i]) > 1e-3 ? fabs(ref[i]) : 1e-3);
+    if (err > worst) worst = err;
+  }
+  printf("%-28s max rel err %.3g %s\n", what, worst, worst <= 1e-5 ? "ok" : "FAIL");
+  return worst <= 1e-5 ? 0 : 1;
+}
+
+int main(void) {
+  const int64_t m = 3000, k = 50000, row = 400, nnz = m * row;
+  if (be_device_count() < 1) { fprintf(stderr, "no HIP device: %s\n", be_last_error()); return 2; }
+  printf("libbrainevent_amd %d for %s\n", be_version(), be_build_arch());
+
+  int32_t *idx = malloc(nnz * 4), *ptr = malloc((m + 1) * 4);
+  float *w = malloc(nnz * 4), *got = malloc((k > m ? k : m) * 4);
+  uint8_t *spk = malloc(m), *spk_k = malloc(k);
+  double *ref = malloc((k > m ? k : m) * 8);
+  for (int64_t i = 0; i <= m; ++i) ptr[i] = (int32_t)(i * row);
+  for (int64_t j = 0; j < nnz; ++j) { idx[j] = (int32_t)(rnd() % k); w[j] = (float)(rnd() % 100000) / 100000.f - 0.3f; }
+  for (int64_t i = 0; i < m; ++i) spk[i] = (rnd() % 100) < 10;
+  for (int64_t i = 0; i < k; ++i) spk_k[i] = (rnd() % 100) < 10;
+
+  void *d_idx = dev_copy(idx, nnz * 4), *d_ptr = dev_copy(ptr, (m + 1) * 4), *d_w = dev_copy(w, nnz * 4);
+  void *d_spk = dev_copy(spk, m), *d_spk_k = dev_copy(spk_k, k), *d_out = dev_copy(NULL, (k > m ? k : m) * 4);
+  if (!d_idx || !d_ptr || !d_w || !d_spk || !d_spk_k || !d_out) { fprintf(stderr, "hipMalloc / hipMemcpy failed\n"); return 1; }
+  int fails = 0;
+
+  /* reference loop, transpose=True: posts[indices[j]] += weights[j] for every active row */
+  memset(ref, 0, k * 8);
+  for (int64_t i = 0; i < m; ++i)
+    if (spk[i]) for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ref[idx[j]] += (double)w[j];
+
+  /* 1. direct route */
+  int64_t ws_bytes = be_binary_csrmv_t_workspace_bytes(m, k, BE_F32);
+  void *d_ws = dev_copy(NULL, ws_bytes);
+  CHECK_BE(be_binary_csrmv_t_hetero_f32_bool(d_w, d_idx, d_ptr, 0, d_spk, d_out, m, k, d_ws, ws_bytes, NULL));
+  CHECK_HIP(hipMemcpy(got, d_out, k * 4, hipMemcpyDeviceToHost));
+  fails += compare("direct scatter", got, ref, k);
+
+  /* 2. planned route */
+  const int shift = 14, width = 0, layout = BE_PLAN_D8, parts = 4;
+  const int64_t n_slices = (k + (1 << shift) - 1) >> shift;
+  void *d_seg = dev_copy(NULL, m * n_slices * 8);
+  int64_t scr_bytes = be_scatter_plan_scratch_bytes(m, k, shift, width), blob_bytes = 0;
+  void *d_scr = dev_copy(NULL, scr_bytes);
+  CHECK_BE(be_scatter_plan_count(d_idx, d_ptr, 0, -1, m, k, shift, width, 0, layout, d_seg, d_scr, scr_bytes, &blob_bytes, NULL));
+  void *d_blob = dev_copy(NULL, blob_bytes + 128), *d_maxabs = dev_copy(NULL, 8);
+  CHECK_BE(be_scatter_plan_fill(d_w, 0, BE_F32, d_idx, d_ptr, 0, -1, m, k, shift, width, layout, d_seg, d_blob, d_maxabs, NULL));
+  int64_t fp_bytes = be_fixed_point_scratch_bytes(k);
+  void *d_fp = dev_copy(NULL, fp_bytes);
+  int scale_exp = 0;
+  CHECK_BE(be_fixed_point_exponent(d_w, BE_F32, d_idx, nnz, k, 16, INT_MIN, d_fp, fp_bytes, &scale_exp, NULL));
+  int64_t pws_bytes = be_binary_csrmv_t_plan_workspace_bytes(m, k, shift, width, parts, 0);
+  void *d_pws = dev_copy(NULL, pws_bytes);
+  CHECK_HIP(hipMemset(d_pws, 0, 256));                    /* spike counters: zero on entry, zero again on exit */
+  const int block_hint = (int)(nnz / (m * n_slices));
+  for (int rep = 0; rep < 2; ++rep) {                     /* twice on one workspace: the counters are re-armed by the call */
+    CHECK_BE(be_binary_csrmv_t_plan(NULL, 0, BE_F32, d_blob, d_seg, d_spk, BE_SPIKE_BOOL, d_out, m, k, shift, width, layout,
+                                    block_hint, parts, scale_exp, d_pws, pws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, k * 4, hipMemcpyDeviceToHost));
+    fails += compare(rep ? "planned scatter (again)" : "planned scatter", got, ref, k);
+  }
+  printf("plan: %lld slices, blob %lld bytes, scale_exp %d\n", (long long)n_slices, (long long)blob_bytes, scale_exp);
+
+  /* 3. weights updated in place (plasticity): refresh the blocks of the unchanged structure */
+  for (int64_t j = 0; j < nnz; ++j) w[j] = w[j] * 0.5f + 0.01f;
+  CHECK_HIP(hipMemcpy(d_w, w, nnz * 4, hipMemcpyHostToDevice));
+  CHECK_BE(be_scatter_plan_refresh_weights(d_w, 0, BE_F32, d_idx, d_ptr, 0, -1, m, k, shift, width, layout, d_seg, d_blob, d_maxabs, NULL));
+  CHECK_BE(be_fixed_point_exponent(d_w, BE_F32, d_idx, nnz, k, 16, scale_exp, d_fp, fp_bytes, &scale_exp, NULL));
+  memset(ref, 0, k * 8);
+  for (int64_t i = 0; i < m; ++i)
+    if (spk[i]) for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ref[idx[j]] += (double)w[j];
+  CHECK_BE(be_binary_csrmv_t_plan(NULL, 0, BE_F32, d_blob, d_seg, d_spk, BE_SPIKE_BOOL, d_out, m, k, shift, width, layout,
+                                  block_hint, parts, scale_exp, d_pws, pws_bytes, NULL));
+  CHECK_HIP(hipMemcpy(got, d_out, k * 4, hipMemcpyDeviceToHost));
+  fails += compare("planned, refreshed weights", got, ref, k);
+
+  /* 4. gather direction: out[i] = sum_j w[j] * e(spikes[indices[j]]) */
+  for (int64_t i = 0; i < m; ++i) {
+    double s = 0;
+    for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) if (spk_k[idx[j]]) s += (double)w[j];
+    ref[i] = s;
+  }
+  int64_t gws_bytes = be_binary_csrmv_nt_workspace_bytes(m, k);
+  void *d_gws = dev_copy(NULL, gws_bytes);
+  CHECK_BE(be_binary_csrmv_nt_hetero_f32_bool(d_w, d_idx, d_ptr, 0, d_spk_k, d_out, m, k, d_gws, gws_bytes, NULL));
+  CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
+  fails += compare("gather", got, ref, m);
+
+  /* error convention: status code + message, never an abort */
+  if (be_binary_csrmv_t_plan(NULL, 0, BE_F32, d_blob, d_seg, d_spk, BE_SPIKE_BOOL, d_out, m, k, shift, width, layout, block_hint,
+                             parts, scale_exp, d_pws, 16, NULL) != BE_ERR_WORKSPACE) { printf("missing BE_ERR_WORKSPACE\n"); ++fails; }
+  be_shutdown();
+  printf(fails ? "abi_smoke: %d FAILED\n" : "abi_smoke: all ok\n", fails);
+  return fails ? 1 : 0;
+}

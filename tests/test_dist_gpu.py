@@ -70,3 +70,33 @@ def test_jitc_shard_behind_the_exchange(one_rank_group):
     s = rng.random(n) < 0.1
     got = ds.step(torch.from_numpy(s).to(dev))
     np.testing.assert_array_equal(got.cpu().numpy(), be.BinaryArray(s) @ M)
+
+
+def test_native_exchange_through_the_c_abi():
+    """``be_exchange_*`` (RCCL loaded by the library, one-rank communicator — all a one-GPU box can run): the gathered words
+    are the bit-packed full vector, consumed packed by the planned scatter; slices follow ``word_aligned_bounds``."""
+    import brainevent_amd as be
+    from brainevent_amd import _dist as D
+    from brainevent_amd._csr import ScatterPlan
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(5)
+    dev = torch.device('cuda', 0)
+    n_pre, n_post = 70001, 30011                        # n_pre not a multiple of 32: the last word is partial
+    uid = D.NativeSpikeExchange.unique_id()
+    assert len(uid) == 128
+    ex = D.NativeSpikeExchange(n_pre, 1, 0, uid, device=dev)
+    assert (ex.lo, ex.hi) == (0, n_pre)
+    lens = rng.integers(0, 40, n_pre)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, n_post, ptr[-1]).astype(np.int32)
+    w = rng.random(ptr[-1]).astype(np.float32)
+    csr = be.CSR((torch.from_numpy(w).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(ptr).to(dev)), shape=(n_pre, n_post))
+    csr.buffers['scatter_plan'] = ScatterPlan.build(csr.data, csr.indices, csr.indptr, shape=(n_pre, n_post))
+    for kind in ('bool', 'float'):
+        s = rng.random(n_pre) < 0.05
+        local = torch.from_numpy(s if kind == 'bool' else np.where(s, 1.5, -1.0).astype(np.float32)).to(dev)
+        ev = ex.gather_events(local)
+        np.testing.assert_array_equal(ev.value.cpu().numpy(), s)
+        out = ev @ csr
+        np.testing.assert_allclose(out.cpu().numpy(), O.binary_csrmv(w, idx, ptr, s, (n_pre, n_post), True), rtol=1e-5, atol=1e-5)
+    ex.close()

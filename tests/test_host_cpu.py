@@ -253,6 +253,8 @@ def test_scatter_plan_auto_geometry():
     # mid-size outputs: ~24 slices (25 x 10 parts) instead of the few the LDS capacity would allow, blocks of >= 32 entries
     assert geo(100_000, 100_000, 1000, True) == (U16, 25) and geo(100_000, 100_000, 1000, False) == (D8, 25)
     assert geo(100_000, 100_000, 300, True) == (U16, 9)
+    # a post slice of an 8-way partition (1M stored rows x 125k outputs): ~24 * (k / m)^(1/3) slices
+    assert geo(1_000_000, 125_000, 1250, False) == (D8, 12) and geo(1_000_000, 125_000, 1250, True) == (U16, 12)
     # short rows: h8 has nothing to gain (blocks of a line or two)
     assert geo(1_000_000, 1_000_000, 1000, True) == (U16, 32)
     assert geo(1_000_000, 1_000_000, 1000, False) == (D8, 51)
