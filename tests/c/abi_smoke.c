@@ -6,7 +6,7 @@
  *   3. weight refresh: be_scatter_plan_refresh_weights, then step 2's call again
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
  * Every result is compared with the serial loop of the reference's CPU kernel (brainevent/_csr/binary.py:446-451 /
- * :466-472), restated inline in double precision; tolerance 1e-5 relative (the tolerance of the path).
+ * :466-472), restated inline in double precision; tolerance rtol = atol = 1e-5 (the tolerance of the path).
  * Build:  gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/c/abi_smoke.c \
  *             -L brainevent_amd/lib -lbrainevent_amd -L /opt/rocm/lib -lamdhip64 -lm -o abi_smoke
  */
@@ -38,18 +38,20 @@ static uint32_t rnd(void) { rng_state = rng_state * 1664525u + 1013904223u; retu
 static void *dev_copy(const void *host, size_t bytes) {
   void *d = NULL;
   if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return NULL;
-  if (bytes && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
+  if (host && bytes && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
   return d;
 }
 
+/* tolerance of the path: |got - ref| <= 1e-5 + 1e-5 |ref| (f32 accumulated currents; the direct route adds f32 atomically
+ * in arrival order, so mixed-sign rows carry the cancellation error of an f32 sum — the planned route is exact to the ulp) */
 static int compare(const char *what, const float *got, const double *ref, int64_t n) {
   double worst = 0;
   for (int64_t i = 0; i < n; ++i) {
-    const double err = fabs((double)got[i] - ref[i]) / (fabs(ref[i]) > 1e-3 ? fabs(ref[i]) : 1e-3);
+    const double err = fabs((double)got[i] - ref[i]) / (1e-5 + 1e-5 * fabs(ref[i]));
     if (err > worst) worst = err;
   }
-  printf("%-28s max rel err %.3g %s\n", what, worst, worst <= 1e-5 ? "ok" : "FAIL");
-  return worst <= 1e-5 ? 0 : 1;
+  printf("%-28s worst error / tolerance %.3g %s\n", what, worst, worst <= 1.0 ? "ok" : "FAIL");
+  return worst <= 1.0 ? 0 : 1;
 }
 
 int main(void) {
