@@ -73,6 +73,7 @@ class ScatterPlan:
         self.weight_dtype = weight_dtype
         self.nnz = 0                      # stored entries (set by build): sizes the number of parts
         self.row_len = -1                 # fixed row length when the plan was built without an indptr
+        self.split_f64 = False            # per-entry f64 weights stored as two f32 entries each
         self.stamp = None                 # weights_stamp() of the weights the blocks were filled from
         self.block_hint_override: Optional[int] = None
         self._ws: Dict = {}
@@ -230,6 +231,13 @@ class ScatterPlan:
         indices = A.to_device(indices).reshape(-1)
         assert indices.dtype == torch.int32
         homo = weights.numel() == 1
+        out_dtype = weights.dtype
+        if indptr is not None:
+            indptr = A.to_device(indptr)
+        split = weights.dtype == torch.float64 and not homo
+        src_stamp = weights_stamp(weights)
+        if split:       # per-entry f64 weights: every entry becomes two f32 entries (see _split_f64)
+            weights, indices, indptr, row_len = _split_f64(weights, indices, indptr, row_len)
         if layout not in (None, 'u16', 'd8', 'h8'):
             raise ValueError(f"layout must be 'u16', 'd8', 'h8' or None, got {layout!r}.")
         if layout == ('h8', 'd8')[homo]:
@@ -239,12 +247,10 @@ class ScatterPlan:
         dev = A.device()
         st = A.stream_ptr()
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
-        if indptr is not None:
-            indptr = A.to_device(indptr)
-        # block layout: the sorted-delta layouts (d8 / h8) apply to non-f64 weights, rows the LDS sort holds and <= 1024
-        # slices; without explicit choices auto_geometry picks by the measured regime
+        # block layout: the sorted-delta layouts (d8 / h8) apply to rows the LDS sort holds and <= 1024 slices; without
+        # explicit choices auto_geometry picks by the measured regime
         nnz = int(indices.numel())
-        d8_ok = weights.dtype != torch.float64 and layout != 'u16'
+        d8_ok = layout != 'u16'
         if d8_ok:
             max_row = int(row_len) if indptr is None else (int((indptr[1:] - indptr[:-1]).max().item()) if m > 0 else 0)
             d8_ok = max_row <= cls.D8_MAX_ROW
@@ -274,10 +280,12 @@ class ScatterPlan:
         check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, slice_width, int(homo), lay, A.ptr(seg),
                     A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
         blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
-        plan = cls(m, k, homo, slice_shift, seg, blob, 0, weights.dtype, slice_width, lay)
+        plan = cls(m, k, homo, slice_shift, seg, blob, 0, out_dtype, slice_width, lay)
         plan.nnz = nnz
         plan.row_len = int(row_len)
+        plan.split_f64 = split
         plan._fill(weights, indices, indptr)
+        plan.stamp = src_stamp
         return plan
 
     def _fill(self, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], keep_exp: bool = False):
@@ -303,14 +311,35 @@ class ScatterPlan:
         task ranges only, ``_csr/main.py:58-88``, so in-place weight updates are legal there; here the blocks embed the
         weights and have to follow them).  Raises ``MathError`` like :meth:`build` when the new weights do not qualify."""
         weights = A.to_device(weights).reshape(-1)
+        indices = A.to_device(indices).reshape(-1)
+        indptr = None if indptr is None else A.to_device(indptr)
         assert (weights.numel() == 1) == self.homo, "refresh_weights cannot switch between one weight and per-entry weights"
+        src_stamp = weights_stamp(weights)
+        if self.split_f64:
+            assert weights.dtype == torch.float64
+            weights, indices, indptr, _ = _split_f64(weights, indices, indptr, self.row_len // 2 if indptr is None else -1)
         assert weights.numel() == 1 or weights.numel() == self.nnz, "refresh_weights: the structure must be unchanged"
-        self._fill(weights, A.to_device(indices).reshape(-1), None if indptr is None else A.to_device(indptr), keep_exp=True)
+        self._fill(weights, indices, indptr, keep_exp=True)
+        self.stamp = src_stamp
 
     def is_stale(self, weights: torch.Tensor) -> bool:
         """Heterogeneous plans embed the weights: true when ``weights`` was modified in place or replaced since the fill
         (one shared weight is read by the reduce kernel on every call and cannot go stale)."""
         return (not self.homo) and self.stamp != weights_stamp(weights)
+
+
+def _split_f64(weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], row_len: int):
+    """Per-entry f64 weights for the f32 block layouts: ``w = hi + lo`` with ``hi = f32(w)``, ``lo = f32(w - hi)`` — two f32
+    entries on the same column, 48 significant bits of ``w`` between them.  Each is converted to 64-bit fixed point exactly
+    (``fixed_from_f32``), the integer sums are order independent, and the f64 output is their sum scaled once: accumulated
+    currents are good to ~2^-48 of the column's weight scale, inside the 1e-10 bar of the f64 tests.  The reference's f64
+    variants (``binary_csrmv_hybrid.cu:789-821``) add doubles with atomics; this chip's global atomics run at 21 G/s."""
+    hi = weights.float()
+    lo = (weights - hi.double()).float()
+    w2 = torch.stack([hi, lo], dim=1).reshape(-1)
+    idx2 = indices.repeat_interleave(2)
+    ptr2 = None if indptr is None else indptr * 2
+    return w2, idx2, ptr2, (2 * int(row_len) if indptr is None else -1)
 
 
 def weights_stamp(t: torch.Tensor):
@@ -367,10 +396,12 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
     binned, us/step): homo 62: 33 / 66, 31: 48 / 74, 20: 81 / 93, 16: 122 / 109, 8: 310 / 137; hetero 40: 40 / 69,
     20: 82 / 99, 12: 165 / 123, 8: 295 / 153.  The planned layout pays per block, the binned route per entry: they cross
     at about 18 entries per block."""
-    if nse < PLAN_MIN_NNZ or m <= 0 or k <= 0 or weights.dtype == torch.float64:
+    if nse < PLAN_MIN_NNZ or m <= 0 or k <= 0:
         return 'direct'
     homo = weights.numel() == 1
     shift = ScatterPlan.default_shift(k, homo)
+    if weights.dtype == torch.float64 and not homo:
+        nse = 2 * nse                     # stored as two f32 entries each (_split_f64)
     n_slices = -(-k // ScatterPlan.auto_geometry(m, k, nse, homo, shift)[1])
     per_block = nse / (m * n_slices)
     if n_slices <= 4096 and per_block >= PLAN_MIN_SEGMENT:
@@ -421,8 +452,8 @@ class BinnedScatter:
 
     @staticmethod
     def applicable(weights: torch.Tensor, k: int) -> bool:
-        if weights.dtype != torch.float32:
-            return False
+        if weights.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            return False                  # f64: the bins carry f32 weights (per-entry f64 weights take the planned route)
         shift = ScatterPlan.default_shift(k, weights.numel() == 1)
         return ((k + (1 << shift) - 1) >> shift) <= 2048
 
@@ -435,6 +466,16 @@ def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes,
     check(f(A.ptr(weights), int(ws.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes), sd,
             A.ptr(out), ws.m, ws.k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(),
             A.stream_ptr()), 'be_binary_csrmv_t_binned')
+
+
+def binned_batch(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes_bm, sd, out_bm) -> None:
+    """One binned step per batch row on the shared bins (stream ordered) — the reference's batched scatter is a host loop over
+    the columns too (``binary_csrmm_hybrid.cu:16-57``).  An id list is a single vector by construction."""
+    if sd == A.BE_SPIKE_IDS:
+        _binned_call(ws, weights, indices, indptr, row_len, spikes_bm, sd, out_bm)
+        return
+    for b in range(int(out_bm.shape[0])):
+        _binned_call(ws, weights, indices, indptr, row_len, spikes_bm[b], sd, out_bm[b])
 
 
 def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor, sd: int, out_bm: torch.Tensor,
@@ -494,9 +535,9 @@ def _csr_batched(weights, indices, indptr, spikes_bm, sd, *, shape, transpose, w
             assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
             _plan_call(workspace, weights, spikes_bm, sd, out)
             return out
-        if isinstance(workspace, BinnedScatter) and nb == 1:
+        if isinstance(workspace, BinnedScatter):
             assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
-            _binned_call(workspace, weights, indices, indptr, -1, spikes_bm, sd, out)
+            binned_batch(workspace, weights, indices, indptr, -1, spikes_bm, sd, out)
             return out
         f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
         ws = A.workspace(f_ws(m, k, nb, A.wcode(weights)))

@@ -22,7 +22,7 @@ import torch
 
 from . import _array as A
 from ._data import DataRepresentation
-from ._csr import ScatterPlan, BinnedScatter, _plan_call, _binned_call, _csrmm_generic
+from ._csr import ScatterPlan, BinnedScatter, _plan_call, binned_batch, _csrmm_generic
 from . import _csr as _csr_mod
 from ._event import BinaryArray, is_event, event_operand
 from ._lib import check, fn
@@ -56,8 +56,8 @@ def _fcn_batched(weights, indices, spikes_bm, sd, *, shape, transpose, workspace
         if isinstance(workspace, ScatterPlan):
             _plan_call(workspace, weights, spikes_bm, sd, out)
             return out
-        if isinstance(workspace, BinnedScatter) and nb == 1:
-            _binned_call(workspace, weights, indices, None, n_conn, spikes_bm, sd, out)
+        if isinstance(workspace, BinnedScatter):
+            binned_batch(workspace, weights, indices, None, n_conn, spikes_bm, sd, out)
             return out
         f_ws = fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
         ws = A.workspace(f_ws(n_rows, n_cols, nb, A.wcode(weights)))

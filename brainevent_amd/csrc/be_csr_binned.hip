@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restr
                                                          const uint32_t* __restrict__ bin_cursor,
                                                          const uint32_t* __restrict__ bin_valid, uint32_t cap, int slice_shift,
                                                          int parts, int64_t k, float scale, double inv_scale,
-                                                         const float* __restrict__ w0p, float* __restrict__ out) {
+                                                         const void* __restrict__ w0p, int wdtype, float* __restrict__ out) {
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
@@ -361,7 +361,12 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restr
     cnts[x] = c < cap ? c : cap;
     any |= cnts[x];
   }
-  const float w0 = HOMO ? w0p[0] : 0.f;
+  float w0 = 0.f;
+  if (HOMO) {
+    if (wdtype == BE_F16) w0 = __half2float(static_cast<const __half*>(w0p)[0]);
+    else if (wdtype == BE_BF16) w0 = __bfloat162float(static_cast<const __hip_bfloat16*>(w0p)[0]);
+    else w0 = static_cast<const float*>(w0p)[0];
+  }
   if (any == 0) return;                     // nothing was binned here (out already holds zeros / overflow adds)
   for (int i = threadIdx.x; i < S; i += blockDim.x) acc[i] = 0;
   __syncthreads();
@@ -422,6 +427,13 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restr
   }
 }
 
+// f16 / bf16 outputs: the bins accumulate into an f32 image of the output (the overflow path adds f32 atomically), rounded once
+template <typename W>
+__global__ void __launch_bounds__(256) k_bin_round(const float* __restrict__ src, W* __restrict__ dst, int64_t k) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) WTraits<W>::store(dst, i, src[i]);
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -445,7 +457,7 @@ int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice
   const int64_t n_bins = n_slices_of(k, slice_shift);
   const int64_t cap = binned_cap_x(bin_capacity) * kBinRegions;
   return 256 + be_align_up(m * 4, 256) + 2 * be_align_up(n_bins * kBinRegions * 4, 256) + be_align_up(n_bins * cap * 2, 256) +
-         be_align_up(n_bins * cap * 4, 256);
+         be_align_up(n_bins * cap * 4, 256) + be_align_up(k * 4, 256);      // the tail: f32 image of an f16 / bf16 output
 }
 
 int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
@@ -453,7 +465,8 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
                              int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
                              int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
-  BE_REQUIRE(wdtype == BE_F32, BE_ERR_UNSUPPORTED, "the binned route supports f32 weights / outputs");
+  BE_REQUIRE(wdtype == BE_F32 || wdtype == BE_F16 || wdtype == BE_BF16, BE_ERR_UNSUPPORTED,
+             "the binned route supports f32 / f16 / bf16 weights (its bins carry f32; f64 weights take the planned route)");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(weights && indices && spikes && out, BE_ERR_INVALID, "null pointer");
@@ -477,6 +490,9 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   uint32_t* valid = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cursor) + be_align_up((int64_t)n_bins * kBinRegions * 4, 256));
   uint16_t* bin_idx = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(valid) + be_align_up((int64_t)n_bins * kBinRegions * 4, 256));
   float* bin_w = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_idx) + be_align_up((int64_t)n_bins * cap * 2, 256));
+  float* out32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_w) + be_align_up((int64_t)n_bins * cap * 4, 256));
+  void* out_user = out;
+  if (wdtype != BE_F32) out = out32;                 // accumulate in f32, round once at the end
   RowPtr rp{indptr, indptr_is_i64, row_len};
   if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, cursor,
@@ -496,7 +512,10 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   // the other has its loads or its copy-out in flight, measured slower at C4 — 533 vs 422 us weighted, 284 vs 204 counted:
   // twice the batches pay twice the barriers and fixed latencies, and the runs are half as long.)
   {
-    const void* kern = homo ? (const void*)k_bin_rows<float, true, 16> : (const void*)k_bin_rows<float, false, 16>;
+    const void* kern = nullptr;
+#define BE_BIN_KERN(WT) kern = homo ? (const void*)k_bin_rows<WT, true, 16> : (const void*)k_bin_rows<WT, false, 16>
+    if (wdtype == BE_F16) BE_BIN_KERN(__half); else if (wdtype == BE_BF16) BE_BIN_KERN(__hip_bfloat16); else BE_BIN_KERN(float);
+#undef BE_BIN_KERN
     hipFuncAttributes fa;
     BE_HIP(hipFuncGetAttributes(&fa, kern));
     // the batch payload lives in dynamic LDS next to the kernel's static bookkeeping: every run is padded to 4 entries
@@ -509,11 +528,13 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
     const uint32_t payload_entries = (uint32_t)((chunks * 64 + 3ll * n_bins + 7) & ~7ll);
     const size_t dyn = (size_t)payload_entries * per_entry;
     BE_HIP(be_allow_lds(kern, (int)dyn));
-#define BE_BIN_ROWS(HOMO_, NW_, GRID_)                                                                                          \
-  hipLaunchKernelGGL((k_bin_rows<float, HOMO_, NW_>), dim3(GRID_), dim3(NW_ * 64), dyn, st, static_cast<const float*>(weights),  \
-                     indices, rp, al.ids, al.count, slice_shift, n_bins, (uint32_t)cap_x, cursor, valid, bin_idx, bin_w,        \
+#define BE_BIN_ROWS(WT, HOMO_)                                                                                              \
+  hipLaunchKernelGGL((k_bin_rows<WT, HOMO_, 16>), dim3(256), dim3(1024), dyn, st, static_cast<const WT*>(weights), indices, rp, \
+                     al.ids, al.count, slice_shift, n_bins, (uint32_t)cap_x, cursor, valid, bin_idx, bin_w,                    \
                      static_cast<float*>(out), (uint32_t)chunks, payload_entries)
-    if (homo) BE_BIN_ROWS(true, 16, 256); else BE_BIN_ROWS(false, 16, 256);
+#define BE_BIN_ROWS_W(WT) do { if (homo) BE_BIN_ROWS(WT, true); else BE_BIN_ROWS(WT, false); } while (0)
+    if (wdtype == BE_F16) BE_BIN_ROWS_W(__half); else if (wdtype == BE_BF16) BE_BIN_ROWS_W(__hip_bfloat16); else BE_BIN_ROWS_W(float);
+#undef BE_BIN_ROWS_W
 #undef BE_BIN_ROWS
   }
   BE_LAUNCH_CHECK();
@@ -527,14 +548,20 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
     auto kern = k_bin_accumulate<true>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
-                       slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(weights), static_cast<float*>(out));
+                       slice_shift, parts, k, scale, inv_scale, weights, wdtype, static_cast<float*>(out));
   } else {
     auto kern = k_bin_accumulate<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
-                       slice_shift, parts, k, scale, inv_scale, static_cast<const float*>(nullptr), static_cast<float*>(out));
+                       slice_shift, parts, k, scale, inv_scale, static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out));
   }
   be_prof_end(prof, st);
+  BE_LAUNCH_CHECK();
+  if (wdtype == BE_F16)
+    hipLaunchKernelGGL(k_bin_round<__half>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st, out32, static_cast<__half*>(out_user), k);
+  else if (wdtype == BE_BF16)
+    hipLaunchKernelGGL(k_bin_round<__hip_bfloat16>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st, out32,
+                       static_cast<__hip_bfloat16*>(out_user), k);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }

@@ -871,6 +871,18 @@ def test_csr_type_zoo_randomized(be, oracle, monkeypatch, seed):
     conv = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if on_device else (lambda a: a)
     csr = be.CSR((conv(w), conv(idx_in), conv(ptr)), shape=(m, k))
     assert csr.indices.dtype == torch.int32
+    # no weight dtype is left to the global-atomic route once a matrix is worth a workspace (>= PLAN_MIN_NNZ entries and at
+    # least PLAN_MIN_SEGMENT_NO_BINNED entries per (row, slice) block, or the binned route applies)
+    nse = int(idx.size)
+    if nse >= C.PLAN_MIN_NNZ and m > 0 and k > 0:
+        route = C.choose_scatter_route(nse, m, k, csr.data)
+        n_sl = -(-k // C.ScatterPlan.auto_geometry(m, k, nse * (2 if (wdt == np.float64 and not homo) else 1), homo,
+                                                    C.ScatterPlan.default_shift(k, homo))[1])
+        per_block = nse * (2 if (wdt == np.float64 and not homo) else 1) / (m * n_sl)
+        if per_block >= C.PLAN_MIN_SEGMENT_NO_BINNED or C.BinnedScatter.applicable(csr.data, k):
+            assert route != 'direct', (wdt, homo, per_block)
+            csr.prepare()
+            assert csr.buffers['scatter_plan'] is not None
     tol = {np.float32: 1e-5, np.float64: 1e-10, np.float16: 2e-2}[wdt]
     sdt = [np.bool_, np.uint8, np.int8, np.int32, np.float32, np.float64, np.float16][int(rng.integers(0, 7))]
 

@@ -214,3 +214,74 @@ def test_binned_route_is_bitwise_reproducible_with_one_workgroup_per_slice(be, o
     tiny = BinnedScatter(wd, m, k, idx.size, max_active_fraction=1e-4, indices=idd)
     got = be.binary_csrmv(wd, idd, ptd, v, shape=(m, k), transpose=True, workspace=tiny)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the dtype / shape matrix of the reference's scatter variants (f64 / f16 / bf16 weights, batched operands:
+# brainevent/_csr/binary_csrmv_hybrid.cu:789-821, binary_csrmm_hybrid.cu:469-530) on the fast routes
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('homo', [True, False])
+@pytest.mark.parametrize('layout', [None, 'u16'])
+def test_f64_weights_take_the_planned_route(be, oracle, monkeypatch, homo, layout):
+    """Per-entry f64 weights are stored as two f32 entries (hi + lo), summed exactly as 64-bit integers and scaled once in
+    f64: 1e-10 relative, the bar of the f64 tests; one f64 weight is a count times the weight in f64."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(31)
+    m, k, row = 700, 40000, 300
+    idx = rng.integers(0, k, m * row).astype(np.int32)
+    ptr = (np.arange(m + 1) * row).astype(np.int64)
+    w = np.asarray([0.37], np.float64) if homo else rng.normal(0, 1, m * row) * np.exp(rng.uniform(-3, 3, m * row))
+    data = torch.tensor(w, device='cuda')
+    tidx, tptr = torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')
+    if layout is None:
+        csr = be.CSR((data, tidx, tptr), shape=(m, k)).prepare()
+        plan = csr.buffers['scatter_plan']
+    else:
+        csr = be.CSR((data, tidx, tptr), shape=(m, k))
+        plan = csr.buffers['scatter_plan'] = C.ScatterPlan.build(data, tidx, tptr, shape=(m, k), layout=layout)
+    assert isinstance(plan, C.ScatterPlan) and plan.split_f64 == (not homo)
+    for fire in (0.1, 1.0):
+        v = rng.random(m) < fire
+        got = be.BinaryArray(torch.tensor(v, device='cuda')) @ csr
+        assert got.dtype == torch.float64
+        ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), True)
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-10, atol=1e-10 * max(1.0, float(np.abs(ref).max())))
+    B = rng.random((3, m)) < 0.3                               # batched
+    gotB = be.BinaryArray(torch.tensor(B, device='cuda')) @ csr
+    refB = np.stack([oracle.binary_csrmv(w, idx, ptr, B[b], (m, k), True) for b in range(3)])
+    np.testing.assert_allclose(gotB.cpu().numpy(), refB, rtol=1e-10, atol=1e-10 * max(1.0, float(np.abs(refB).max())))
+    if not homo:                                               # in-place update of f64 weights: the split blocks follow
+        data.mul_(-0.5)
+        v = rng.random(m) < 0.5
+        got = be.BinaryArray(torch.tensor(v, device='cuda')) @ csr
+        assert csr.buffers['scatter_plan'] is plan
+        np.testing.assert_allclose(got.cpu().numpy(), oracle.binary_csrmv(w * -0.5, idx, ptr, v, (m, k), True), rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('homo', [True, False])
+def test_binned_route_half_precision_and_batches(be, oracle, monkeypatch, dtype, homo):
+    """Sparse rows over many outputs (the binned route) with f16 / bf16 weights and with a batch of spike vectors: the bins carry
+    f32, sums are exact integers, the output is rounded once."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(32)
+    n_pre, n_post, K = 3000, 400_000, 24                   # 24 entries over 25 slices: the binned route
+    idx = rng.integers(0, n_post, (n_pre, K)).astype(np.int32)
+    w32 = np.asarray([0.75], np.float32) if homo else rng.uniform(0.1, 1.0, (n_pre, K)).astype(np.float32)
+    data = torch.tensor(w32, device='cuda').to(dtype)
+    wref = data.float().cpu().numpy().astype(np.float64)
+    conn = be.FixedNumPerPre((data, torch.tensor(idx, device='cuda')), shape=(n_pre, n_post))
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    v = rng.random(n_pre) < 0.2
+    got = be.BinaryArray(torch.tensor(v, device='cuda')) @ conn
+    assert isinstance(conn.buffers['scatter_plan'], C.BinnedScatter) and got.dtype == dtype
+    ptr = (np.arange(n_pre + 1) * K).astype(np.int64)
+    ref = oracle.binary_csrmv(wref.reshape(-1), idx.reshape(-1), ptr, v, (n_pre, n_post), True)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol)
+    B = rng.random((4, n_pre)) < 0.2
+    gotB = be.BinaryArray(torch.tensor(B, device='cuda')) @ conn
+    refB = np.stack([oracle.binary_csrmv(wref.reshape(-1), idx.reshape(-1), ptr, B[b], (n_pre, n_post), True) for b in range(4)])
+    assert gotB.shape == (4, n_post)
+    np.testing.assert_allclose(gotB.float().cpu().numpy(), refB, rtol=tol, atol=tol)
