@@ -35,6 +35,14 @@ __device__ __forceinline__ uint32_t lr_next(uint32_t x) {
   x ^= x << 13; x ^= x >> 17; x ^= x << 5;
   return x == 0u ? 0x6d2b79f5u : x;
 }
+// the same step for a state known to be non-zero: xorshift32 (13, 17, 5) is a bijection of the non-zero 32-bit words, so
+// a walk that starts from lr_init (never zero) never reaches zero and the reference's zero fix-up cannot fire — the hot
+// loops drop its compare + select (2 of ~15 vector instructions per generated edge; the gather kernel is VALU-bound:
+// SQ_ACTIVE_INST_VALU x 4 waves per SIMD = 1.15 of SQ_WAVE_CYCLES at C3)
+__device__ __forceinline__ uint32_t lr_next_nz(uint32_t x) {
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+  return x;
+}
 __device__ __forceinline__ uint32_t lr_bounded(uint32_t r, uint32_t bound) { return __umulhi(r, bound); }
 __device__ __forceinline__ uint32_t lr_init(uint32_t seed, uint32_t row, uint32_t chunk, uint32_t lane) {
   uint32_t x = seed ^ 0xd1b54a35u;
@@ -155,7 +163,7 @@ __global__ void __launch_bounds__(1024) k_jit_mv_gather(JitP p, const uint32_t* 
           if (MODE == MODE_SCALAR) acc += 1;
           else acc += (AccT)edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)(bit0 + 32ll * q));
         }
-        state = lr_next(state);
+        state = lr_next_nz(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
       }
     }
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
           if (MODE == MODE_SCALAR) atomicAdd(&acc[q - qb], (AccT)1);
           else atomicAdd(&acc[q - qb], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + S * q), fx_scale));
         }
-        state = lr_next(state);
+        state = lr_next_nz(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
       }
     }
@@ -336,7 +344,7 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
 #pragma unroll
             for (int c = 0; c < 32; ++c) acc[c] += ((mk >> c) & 1u) ? w : A(0);
           }
-          state = lr_next(state);
+          state = lr_next_nz(state);
           q = q + 1u + lr_bounded(state, p.cl - 1u);
           lj = (uint64_t)l + (uint64_t)p.stride * q;
         }
@@ -387,7 +395,7 @@ __global__ void __launch_bounds__(256) k_jit_csr_count(JitP p, int64_t n_rows, u
     uint32_t cnt = 0;
     while ((int64_t)lj < width) {
       ++cnt;
-      state = lr_next(state);
+      state = lr_next_nz(state);
       q = q + 1u + lr_bounded(state, p.cl - 1u);
       lj = (uint64_t)l + (uint64_t)p.stride * q;
     }
@@ -418,7 +426,7 @@ __global__ void __launch_bounds__(256) k_jit_csr_fill(JitP p, int64_t n_rows, co
     uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
     while ((int64_t)lj < width) {
       ++cnt;
-      state = lr_next(state);
+      state = lr_next_nz(state);
       q = q + 1u + lr_bounded(state, p.cl - 1u);
       lj = (uint64_t)l + (uint64_t)p.stride * q;
     }
@@ -431,7 +439,7 @@ __global__ void __launch_bounds__(256) k_jit_csr_fill(JitP p, int64_t n_rows, co
       indices[pos] = (int32_t)j;
       if (MODE != MODE_SCALAR) weights[pos] = edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)j);
       ++pos;
-      state = lr_next(state);
+      state = lr_next_nz(state);
       q = q + 1u + lr_bounded(state, p.cl - 1u);
       lj = (uint64_t)l + (uint64_t)p.stride * q;
     }
