@@ -388,6 +388,22 @@ def secondary_configs(base):
             out[name] = {'error': repr(e)}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    # what ONE rank of the 8-way strong split does per step, measured on this GPU (shard rank 0 of 8 of the same global matrix
+    # + the exchange path on a one-rank RCCL group): the single-GPU evidence for the multi-GPU projection in DESIGN.md section 4
+    for name, extra in (('C2_rank_of_8', []), ('C4_rank_of_8', ['--workload', 'fcn'])):
+        a = parse(['--emulate-world', '8', '--steps', '100', '--warmup', '20', '--no-cpu', '--no-secondary'] + extra)
+        try:
+            ln = run_scatter(a)
+            out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'step_ms_hip_events',
+                                            'parity_check', 'roofline')}
+            out[name]['config'] = {k: ln['config'][k] for k in ('workload', 'parallelism', 'n_post_per_gpu', 'synapses_per_row_per_shard',
+                                                                'plan_slices', 'setup_s')}
+            out[name]['note'] = ('value = updates THIS rank delivers per second; an 8-rank job delivers 8x that if every rank keeps this step '
+                                 'time with 8 real ranks in the all-gather')
+        except Exception as e:
+            out[name] = {'error': repr(e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     return out
 
 
@@ -416,15 +432,14 @@ def reference_for_shard(weights, indices, indptr, spk, n_post, homo):
     return ref
 
 
-def main():
-    args = parse()
+def run_scatter(args):
+    """The scatter workload (csr, or fcn behind the exchange) on this process's rank; returns the JSON line on rank 0."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     force_dist = os.environ.get('BENCH_FORCE_DIST') == '1' or args.emulate_world > 1
     multi = world > 1 or force_dist
     is_fcn = args.workload == 'fcn'
     if args.workload != 'csr' and not (is_fcn and multi):
-        print(json.dumps(secondary(args)), flush=True)       # jitc / dense, and fcn on one GPU without the exchange
-        return
+        return secondary(args)       # jitc / dense, and fcn on one GPU without the exchange
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world and world > 1:
@@ -561,7 +576,8 @@ def main():
     checksum = float(out.double().sum().item())
 
     copy_gbps = None
-    if rank == 0:
+    line = None
+    if rank == 0 and args.emulate_world <= 1:
         try:
             src = torch.empty(1 << 29, dtype=torch.float32, device=dev)       # 2 GiB
             dst = torch.empty_like(src)
@@ -626,14 +642,22 @@ def main():
             except Exception as e:   # the CPU leg must never sink the GPU number
                 line['cpu_baseline'] = {'error': repr(e)}
         if world == 1 and not force_dist and not args.no_secondary and default_cfg and args.workload == 'csr':
-            del csr, plan, ws_obj, weights, indices, indptr, ref, out, full, local_spikes, row_len
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
-            line['secondary'] = secondary_configs(args)
-        print(json.dumps(line), flush=True)
+            line['secondary'] = 'pending'      # filled in by main() once this call's process group and buffers are gone
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return line
+
+
+def main():
+    args = parse()
+    line = run_scatter(args)
+    if line is not None and line.get('secondary') == 'pending':
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        line['secondary'] = secondary_configs(args)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

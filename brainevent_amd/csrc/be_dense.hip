@@ -15,7 +15,7 @@
 //                    registers; partial sums per row part are reduced in a fixed order (deterministic).
 //   transpose=False: one wave per weight row streams it with 16 B loads against the mask vector
 //                    (or gathers only the active columns when fewer than 1/16 of them are active).
-// The MFMA kernel for the fp16/bf16 batched case lives in be_dense_mfma.hip.
+// The MFMA kernels for the batched fp16 / bf16 case (k_densemm_mfma, k_densemm_nt_mfma) follow the vector kernels below.
 #include "be_common.h"
 #include <algorithm>
 #include <type_traits>

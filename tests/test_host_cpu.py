@@ -213,26 +213,6 @@ def test_operator_call_function_contract():
         assert prim._call_fn is getattr(be, name + '_p_call')
 
 
-def test_hybrid_workspace_sizing_contract(monkeypatch):
-    """``HybridConfig`` / ``hybrid_task_capacity`` (reference ``_csr/hybrid_config.py:77-88``, ``:298-324``): SURVEY.md §8 a4's
-    example — C2 rows of 10 000 entries are all "heavy" and need ceil(10000 / 4096) = 3 tasks each."""
-    import brainevent_amd as be
-    cfg = be.get_hybrid_config()
-    assert (cfg.block_size, cfg.fixed_scatter_blocks, cfg.tpr_threshold, cfg.task_nnz) == (256, 2048, 128, 4096)
-    indptr = np.arange(1001, dtype=np.int64) * 10000
-    assert be.hybrid_task_capacity(indptr) == 3000
-    assert be.hybrid_task_capacity(np.array([0, 128, 257, 257, 10000])) == 0 + 1 + 0 + 3     # 128 is not "> 128"
-    with pytest.raises(ValueError):
-        be.hybrid_task_capacity(np.array([0, 5, 3]))
-    with pytest.raises(ValueError):
-        be.hybrid_task_capacity(np.zeros((2, 2)))
-    be.get_hybrid_config.cache_clear()
-    monkeypatch.setenv('BRAINEVENT_CSR_HYBRID_CONFIG', '{"tpr_threshold": 10, "task_nnz": 100}')
-    assert be.hybrid_task_capacity(np.array([0, 11, 250])) == 1 + 3
-    monkeypatch.delenv('BRAINEVENT_CSR_HYBRID_CONFIG')
-    be.get_hybrid_config.cache_clear()
-
-
 def test_scatter_plan_auto_geometry():
     """Layout / slice-width rules of a plan built without explicit choices (measured: tools/exp_layouts.py)."""
     from brainevent_amd._csr import ScatterPlan as P
