@@ -55,6 +55,9 @@ def parse(argv=None):
                     'would hold and run the exchange path with a one-rank group (what one rank of W does per step)')
     ap.add_argument('--jit-shard', type=int, default=1, help='jitc workload: run rank 0 of an N-way walk-class partition')
     ap.add_argument('--exchange', choices=['bits', 'bytes'], default='bits', help='payload of the per-step spike all-gather (N > 1)')
+    ap.add_argument('--exchange-impl', choices=['native', 'torch'], default='native', help='native = the library\'s own RCCL '
+                    'all-gather (be_exchange_*: one C call per step); torch = torch.distributed.all_gather_into_tensor '
+                    '(about 30 us of host time per call: a 1-of-8 shard step is host-bound behind it)')
     ap.add_argument('--exchange-ahead', type=int, default=0, help='N > 1: 1 = post the all-gather of step t+1 before scattering '
                     'step t (synaptic delay >= 2 steps); default 0 = exchange and scatter strictly in sequence')
     ap.add_argument('--route', choices=['plan', 'direct', 'auto'], default='plan')
@@ -515,10 +518,17 @@ def run_scatter(args):
     g = torch.Generator(device=dev)
     g.manual_seed(999 + rank)
     n_local = n_pre
+    native = False
     if use_dist:
-        from brainevent_amd._dist import SpikeExchange
+        from brainevent_amd._dist import SpikeExchange, NativeSpikeExchange
         # one all-gather per step (RCCL over xGMI); bit-packed by default: 1/8 of the bytes, consumed packed
-        exchange = SpikeExchange(n_pre, packed=(args.exchange == 'bits'), device=dev)
+        native = (args.exchange_impl == 'native' and args.exchange == 'bits' and os.environ.get('BENCH_BACKEND', 'nccl') == 'nccl')
+        if native:      # the library's own communicator; the id travels over the (already initialised) process group
+            box = [NativeSpikeExchange.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            exchange = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
+        else:
+            exchange = SpikeExchange(n_pre, packed=(args.exchange == 'bits'), device=dev)
         n_local = exchange.hi - exchange.lo
     local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
     row_len = (indptr[1:] - indptr[:-1]).to(torch.int64)
@@ -553,8 +563,8 @@ def run_scatter(args):
             torch.cuda.synchronize()
 
     elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup, fence)
-    if ahead:
-        ticket[0][1].wait()      # the exchange posted by the last step (never consumed)
+    if ahead:      # the exchange posted by the last step (never consumed)
+        exchange.wait_events(ticket[0]) if native else ticket[0][1].wait()
     kern_ms = float(np.mean(kern)) if kern is not None else None
 
     # one-step parity check of what was timed (every rank checks its own slice; rank 0 reports the worst)
@@ -619,7 +629,8 @@ def run_scatter(args):
                                     f"({n_conn_global / n_post_total:g} density), route={route}"),
                        'n_pre': n_pre, 'n_post': n_post_total, 'n_post_per_gpu': n_post, 'n_conn': n_conn_global,
                        'synapses_per_row_per_shard': n_conn, 'stored_synapses_total': total_nnz,
-                       'parallelism': f'post-slice x{p_world}' + (f' + spike all-gather ({args.exchange}'
+                       'parallelism': f'post-slice x{p_world}' + (f' + spike all-gather ({args.exchange}, '
+                                                                  + ('be_exchange_* / RCCL' if native else 'torch.distributed')
                                                                   + (', posted one step ahead' if ahead else '') + ')' if use_dist else '')
                                       + (f' [one process emulating rank 0 of {args.emulate_world}]' if args.emulate_world > 1 else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
@@ -644,6 +655,8 @@ def run_scatter(args):
         if world == 1 and not force_dist and not args.no_secondary and default_cfg and args.workload == 'csr':
             line['secondary'] = 'pending'      # filled in by main() once this call's process group and buffers are gone
     if use_dist:
+        if native:
+            exchange.close()
         dist.barrier()
         dist.destroy_process_group()
     return line

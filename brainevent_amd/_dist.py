@@ -296,6 +296,36 @@ class NativeSpikeExchange:
     def gather(self, local_spikes: torch.Tensor) -> torch.Tensor:
         return self.gather_events(local_spikes).value
 
+    # -- pipelined exchange: post step t + 1's spikes on a side stream, then work on step t ----------------------------
+    def post(self, local_spikes: torch.Tensor):
+        """Start the exchange of this rank's spikes on the exchange's own stream and return a ticket for :meth:`wait_events`
+        (same contract as ``SpikeExchange.post``: legitimate when synaptic delays are at least two steps; two buffers
+        alternate, at most one ticket in flight while another is consumed)."""
+        from . import _array as A
+        from ._lib import fn, check
+        assert local_spikes.numel() == self.hi - self.lo
+        if not hasattr(self, '_slots'):
+            self._slots = [self._full_words, torch.zeros_like(self._full_words)]
+            self._side = torch.cuda.Stream(device=self._full_words.device)
+            self._next = 0
+        slot = self._next
+        self._next ^= 1
+        sp, sd = A.spikes_to_device(local_spikes)
+        self._side.wait_stream(torch.cuda.current_stream())      # the spikes were produced on the caller's stream
+        ct = self._ct
+        f = fn('be_exchange_allgather_bits', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p])
+        with torch.cuda.stream(self._side):
+            check(f(self._h, A.ptr(sp), sd, A.ptr(self._slots[slot]), A.stream_ptr()), 'be_exchange_allgather_bits')
+            done = torch.cuda.Event()
+            done.record()
+        return slot, done, sp
+
+    def wait_events(self, ticket):
+        from ._event import BitPackedBinary
+        slot, done, _ = ticket
+        torch.cuda.current_stream().wait_event(done)
+        return BitPackedBinary.from_packed(self._slots[slot], self.n_pre)
+
     def close(self) -> None:
         if self._h:
             from ._lib import fn

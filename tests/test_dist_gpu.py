@@ -99,4 +99,12 @@ def test_native_exchange_through_the_c_abi():
         np.testing.assert_array_equal(ev.value.cpu().numpy(), s)
         out = ev @ csr
         np.testing.assert_allclose(out.cpu().numpy(), O.binary_csrmv(w, idx, ptr, s, (n_pre, n_post), True), rtol=1e-5, atol=1e-5)
+    # pipelined schedule on the exchange's own stream: post step t + 1, consume step t
+    spikes = [rng.random(n_pre) < 0.1 for _ in range(4)]
+    ticket = ex.post(torch.from_numpy(spikes[0]).to(dev))
+    for t in range(4):
+        nxt = ex.post(torch.from_numpy(spikes[t + 1]).to(dev)) if t + 1 < 4 else None
+        out = ex.wait_events(ticket) @ csr
+        np.testing.assert_allclose(out.cpu().numpy(), O.binary_csrmv(w, idx, ptr, spikes[t], (n_pre, n_post), True), rtol=1e-5, atol=1e-5)
+        ticket = nxt
     ex.close()

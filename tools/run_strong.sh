@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/strong_${1:-x}; mkdir -p $O
 cd $R
 for cfg in "c2:" "c2h:--homo" "c4:--workload fcn" "c4h:--workload fcn --homo"; do
   name=${cfg%%:*}; args=${cfg#*:}
-  timeout -k 10 200 python bench.py --emulate-world 8 $args --steps 100 --warmup 20 --no-cpu > $O/$name.log 2>&1
+  timeout -k 10 200 python bench.py --emulate-world 8 $args $BENCH_EXTRA --steps 100 --warmup 20 --no-cpu > $O/$name.log 2>&1
   python - "$O/$name.log" "$name" <<'PY'
 import json, sys
 l = [x for x in open(sys.argv[1]) if x.startswith('{')]
