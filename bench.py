@@ -523,11 +523,28 @@ def run_scatter(args):
         from brainevent_amd._dist import SpikeExchange, NativeSpikeExchange
         # one all-gather per step (RCCL over xGMI); bit-packed by default: 1/8 of the bytes, consumed packed
         native = (args.exchange_impl == 'native' and args.exchange == 'bits' and os.environ.get('BENCH_BACKEND', 'nccl') == 'nccl')
+        exchange = None
         if native:      # the library's own communicator; the id travels over the (already initialised) process group
-            box = [NativeSpikeExchange.unique_id() if rank == 0 else None]
+            box = [None]
+            try:
+                box = [NativeSpikeExchange.unique_id() if rank == 0 else None]
+            except Exception as e:
+                print(f'[bench] rank {rank}: native exchange unavailable ({e!r})', file=sys.stderr, flush=True)
             dist.broadcast_object_list(box, src=0)
-            exchange = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
-        else:
+            ok = 0.0
+            if box[0] is not None:
+                try:
+                    exchange = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
+                    ok = 1.0
+                except Exception as e:
+                    print(f'[bench] rank {rank}: be_exchange_init failed ({e!r})', file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
+            if flag.item() < 1.0:
+                if exchange is not None:
+                    exchange.close()
+                exchange, native = None, False
+        if exchange is None:
             exchange = SpikeExchange(n_pre, packed=(args.exchange == 'bits'), device=dev)
         n_local = exchange.hi - exchange.lo
     local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
