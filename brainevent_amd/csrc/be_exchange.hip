@@ -8,8 +8,10 @@
 #include "be_common.h"
 #include <dlfcn.h>
 #include <cstring>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 
 namespace {
 
@@ -30,7 +32,22 @@ Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {getenv("BE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // a copy of RCCL the process has already mapped (PyTorch ships its own under torch/lib) is reused: two copies in one
+    // process would each run their own bootstrap
+    std::string mapped;
+    if (FILE* maps = fopen("/proc/self/maps", "r")) {
+      char line[4096];
+      while (mapped.empty() && fgets(line, sizeof(line), maps)) {
+        const char* path = strchr(line, '/');
+        if (path && strstr(path, "librccl.so")) {
+          mapped = path;
+          while (!mapped.empty() && (mapped.back() == '\n' || mapped.back() == ' ')) mapped.pop_back();
+        }
+      }
+      fclose(maps);
+    }
+    const char* names[] = {getenv("BE_RCCL_LIB"), mapped.empty() ? nullptr : mapped.c_str(), "librccl.so", "librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
       if (!n || !*n) continue;
       r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
