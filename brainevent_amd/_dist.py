@@ -246,6 +246,13 @@ class SpikeExchange:
         return torch.cat([c[:b[1] - b[0]].view(torch.bool) for c, b in zip(self._chunks, self.bounds)])
 
 
+def _device_view_i32(ptr: int, n: int, device) -> torch.Tensor:
+    """int32 tensor over ``n`` words of device memory the library owns (``__cuda_array_interface__``; no copy, no ownership)."""
+    class _Raw:
+        __cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<i4', 'data': (int(ptr), False), 'version': 2}
+    return torch.as_tensor(_Raw(), device=device)
+
+
 class NativeSpikeExchange:
     """The bit-packed exchange through the C ABI alone (``be_exchange_*``: the library loads RCCL itself; no
     ``torch.distributed`` on the data path) — what a binder that is not PyTorch uses.  Rank 0 calls :meth:`unique_id` and
@@ -296,35 +303,39 @@ class NativeSpikeExchange:
     def gather(self, local_spikes: torch.Tensor) -> torch.Tensor:
         return self.gather_events(local_spikes).value
 
-    # -- pipelined exchange: post step t + 1's spikes on a side stream, then work on step t ----------------------------
+    # -- pipelined exchange: post step t + 1's spikes on the library's own stream, then work on step t ------------------
     def post(self, local_spikes: torch.Tensor):
-        """Start the exchange of this rank's spikes on the exchange's own stream and return a ticket for :meth:`wait_events`
-        (same contract as ``SpikeExchange.post``: legitimate when synaptic delays are at least two steps; two buffers
-        alternate, at most one ticket in flight while another is consumed)."""
+        """Start the exchange of this rank's spikes (``be_exchange_post``: the library's stream waits for the caller's, packs,
+        gathers, records an event) and return a ticket for :meth:`wait_events` — same contract as ``SpikeExchange.post``:
+        legitimate when synaptic delays are at least two steps; two buffers alternate, at most one ticket in flight while
+        another is consumed."""
         from . import _array as A
         from ._lib import fn, check
         assert local_spikes.numel() == self.hi - self.lo
-        if not hasattr(self, '_slots'):
-            self._slots = [self._full_words, torch.zeros_like(self._full_words)]
-            self._side = torch.cuda.Stream(device=self._full_words.device)
-            self._next = 0
-        slot = self._next
-        self._next ^= 1
+        slot = getattr(self, '_next', 0)
+        self._next = slot ^ 1
         sp, sd = A.spikes_to_device(local_spikes)
-        self._side.wait_stream(torch.cuda.current_stream())      # the spikes were produced on the caller's stream
         ct = self._ct
-        f = fn('be_exchange_allgather_bits', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p])
-        with torch.cuda.stream(self._side):
-            check(f(self._h, A.ptr(sp), sd, A.ptr(self._slots[slot]), A.stream_ptr()), 'be_exchange_allgather_bits')
-            done = torch.cuda.Event()
-            done.record()
-        return slot, done, sp
+        f = fn('be_exchange_post', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p])
+        check(f(self._h, A.ptr(sp), sd, slot, A.stream_ptr()), 'be_exchange_post')
+        return slot, sp                      # (the spikes stay referenced until the ticket is consumed)
 
     def wait_events(self, ticket):
+        from . import _array as A
         from ._event import BitPackedBinary
-        slot, done, _ = ticket
-        torch.cuda.current_stream().wait_event(done)
-        return BitPackedBinary.from_packed(self._slots[slot], self.n_pre)
+        from ._lib import fn, check
+        slot = ticket[0]
+        ct = self._ct
+        out = ct.c_void_p(0)
+        f = fn('be_exchange_wait', ct.c_int, [ct.c_void_p, ct.c_int, ct.POINTER(ct.c_void_p), ct.c_void_p])
+        check(f(self._h, slot, ct.byref(out), A.stream_ptr()), 'be_exchange_wait')
+        if not hasattr(self, '_views'):
+            self._views = {}
+        view = self._views.get(slot)
+        if view is None or view.data_ptr() != out.value:       # wrap the library's buffer once (no copy)
+            n_words = self._full_words.numel()
+            view = self._views[slot] = _device_view_i32(out.value, n_words, self._full_words.device)
+        return BitPackedBinary.from_packed(view, self.n_pre)
 
     def close(self) -> None:
         if self._h:

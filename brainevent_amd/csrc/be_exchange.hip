@@ -68,6 +68,11 @@ struct Exchange {
   int world, rank;
   int64_t n_pre, words_per_rank;      // every rank owns the same whole number of 32-bit words (the last may hold fewer spikes)
   uint32_t* local_words;              // device: this rank's packed slice (words_per_rank)
+  // pipelined exchange (be_exchange_post / _wait): the library's own stream, two result buffers, their events
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
+  uint32_t* post_local[2] = {nullptr, nullptr};
+  uint32_t* post_full[2] = {nullptr, nullptr};
 };
 
 #define BE_RCCL(call)                                                                                     \
@@ -163,10 +168,68 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
   return BE_OK;
 }
 
+// Pipelined form: the all-gather of step t + 1 runs on the exchange's own stream while the caller's stream scatters step t
+// (legitimate when synaptic delays are at least two steps: the spikes a step delivers were emitted before the previous
+// step started).  post: the side stream waits for what `producer_stream` has queued so far (the spikes), packs and gathers into
+// the exchange's buffer `slot` (0 / 1, alternate them) and records the slot's event.  wait: `consumer_stream` waits for that
+// event; *full_bits_out is the slot's device buffer (be_exchange_full_words words), valid until the slot is posted again.
+int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream) {
+  BE_REQUIRE(exchange, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(slot == 0 || slot == 1, BE_ERR_INVALID, "slot must be 0 or 1");
+  Exchange* ex = static_cast<Exchange*>(exchange);
+  Rccl* R = rccl();
+  BE_REQUIRE(R != nullptr, BE_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+  if (!ex->side) {
+    BE_HIP(hipStreamCreateWithFlags(&ex->side, hipStreamNonBlocking));
+    BE_HIP(hipEventCreateWithFlags(&ex->ev_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+      BE_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming));
+      BE_HIP(hipMalloc(&ex->post_local[i], (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * 4));
+      BE_HIP(hipMalloc(&ex->post_full[i], (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * ex->world * 4));
+    }
+  }
+  BE_HIP(hipEventRecord(ex->ev_in, static_cast<hipStream_t>(producer_stream)));
+  BE_HIP(hipStreamWaitEvent(ex->side, ex->ev_in, 0));
+  const int64_t lo = (int64_t)ex->rank * ex->words_per_rank * 32;
+  int64_t n_local = ex->n_pre - lo;
+  n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
+  BE_REQUIRE(n_local == 0 || local_spikes != nullptr, BE_ERR_INVALID, "null pointer");
+  const int64_t used = (n_local + 31) / 32;
+  if (used < ex->words_per_rank) BE_HIP(be_fill_async(ex->post_local[slot] + used, 0, (size_t)(ex->words_per_rank - used) * 4, ex->side));
+  if (n_local > 0) {
+    const int rc = be_pack_spikes(local_spikes, spike_dtype, n_local, ex->post_local[slot], ex->side);
+    if (rc != BE_OK) return rc;
+  }
+  if (ex->words_per_rank > 0)
+    BE_RCCL(R->AllGather(ex->post_local[slot], ex->post_full[slot], (size_t)ex->words_per_rank, kNcclUint32, ex->comm, ex->side));
+  BE_HIP(hipEventRecord(ex->ev_done[slot], ex->side));
+  return BE_OK;
+}
+
+int be_exchange_wait(void* exchange, int slot, const uint32_t** full_bits_out, be_stream_t consumer_stream) {
+  BE_REQUIRE(exchange && full_bits_out, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(slot == 0 || slot == 1, BE_ERR_INVALID, "slot must be 0 or 1");
+  Exchange* ex = static_cast<Exchange*>(exchange);
+  BE_REQUIRE(ex->side != nullptr, BE_ERR_INVALID, "nothing was posted");
+  BE_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), ex->ev_done[slot], 0));
+  *full_bits_out = ex->post_full[slot];
+  return BE_OK;
+}
+
 int be_exchange_destroy(void* exchange) {
   if (!exchange) return BE_OK;
   Exchange* ex = static_cast<Exchange*>(exchange);
   Rccl* R = rccl();
+  if (ex->side) {
+    (void)hipStreamSynchronize(ex->side);
+    for (int i = 0; i < 2; ++i) {
+      if (ex->ev_done[i]) (void)hipEventDestroy(ex->ev_done[i]);
+      if (ex->post_local[i]) (void)hipFree(ex->post_local[i]);
+      if (ex->post_full[i]) (void)hipFree(ex->post_full[i]);
+    }
+    if (ex->ev_in) (void)hipEventDestroy(ex->ev_in);
+    (void)hipStreamDestroy(ex->side);
+  }
   if (ex->local_words) (void)hipFree(ex->local_words);
   if (R) (void)R->CommDestroy(ex->comm);
   delete ex;

@@ -114,6 +114,11 @@ int be_exchange_slice(const void* exchange, int rank, int64_t* lo_host, int64_t*
 int64_t be_exchange_full_words(const void* exchange);
 int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spike_dtype, uint32_t* full_bits,
                                be_stream_t stream);
+/* pipelined form (synaptic delays >= 2 steps): post step t + 1's exchange on the library's own stream — it waits for what
+ * producer_stream has queued so far, i.e. the spikes — then scatter step t; wait makes consumer_stream wait for the posted
+ * slot (0 / 1, alternate them) and returns its device buffer, valid until that slot is posted again. */
+int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream);
+int be_exchange_wait(void* exchange, int slot, const uint32_t** full_bits_out, be_stream_t consumer_stream);
 int be_exchange_destroy(void* exchange);
 
 /* ------------------------------------------------------------------------------------------------
