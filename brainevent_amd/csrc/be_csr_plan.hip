@@ -189,6 +189,96 @@ __global__ void __launch_bounds__(256) k_plan_fill(const W* __restrict__ weights
 }
 
 // =================================================================================================
+// fused step: the accumulate kernel lists the active rows of ITS part itself (no compaction launch, no active list in
+// memory, one dependent round trip less).  Rows are dealt to the parts in stripes of 1024 (32 words of the bit-packed
+// vector / 1024 spike bytes): part p owns stripes p, p + parts, ... — a different split of the rows than the interleaved
+// list positions of the unfused path, which integer sums do not see.  Every workgroup of a part builds the same list, in
+// ascending row order (block scans, no atomics), into LDS behind its accumulators; a list that does not fit LDS goes to
+// the part's region of the workspace instead (all workgroups of the part write identical values there).
+// FUSED: 0 = list from the workspace (compaction kernel or the caller's ids), 1 = bit-packed spikes, 2 = 1-byte spikes.
+// =================================================================================================
+template <int FUSED>
+__device__ __forceinline__ uint32_t fused_word(const void* __restrict__ spikes, int64_t gw, int64_t m) {
+  uint32_t w = 0;
+  if (FUSED == 1) {
+    w = static_cast<const uint32_t*>(spikes)[gw];
+  } else {
+    const uint8_t* sp = static_cast<const uint8_t*>(spikes) + gw * 32;
+    if (gw * 32 + 32 <= m) {
+      const uint4 a = reinterpret_cast<const uint4*>(sp)[0], b = reinterpret_cast<const uint4*>(sp)[1];
+      const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (((v[q] >> (8 * e)) & 0xffu) != 0u ? 1u : 0u) << (4 * q + e);
+    } else {
+      for (int e = 0; e < 32 && gw * 32 + e < m; ++e) w |= (sp[e] != 0 ? 1u : 0u) << e;
+    }
+  }
+  const int64_t left = m - gw * 32;                        // spikes of the population in this word
+  return left >= 32 ? w : (left > 0 ? (w & ((1u << (uint32_t)left) - 1u)) : 0u);
+}
+
+// inclusive scan over the 1024 threads + the block total with ONE barrier: consecutive calls alternate between two
+// arrays of wave totals, so a call never overwrites totals a slower thread of the previous call may still be reading
+__device__ __forceinline__ uint32_t block_scan_total_1024(uint32_t v, uint32_t* wave_tot /* [16] of this call */, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, t = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t x = wave_tot[w];
+    t += x;
+    if (w < wave) base += x;
+  }
+  *total = t;
+  return base + incl;
+}
+
+template <int FUSED>
+__device__ __forceinline__ uint32_t build_part_list(const void* __restrict__ spikes, int64_t m, int part, int parts,
+                                                    uint32_t* lds_list, uint32_t lds_cap, uint32_t* glob_list,
+                                                    uint32_t* wave_tot /* [32] */, const uint32_t** list_out) {
+  const int64_t n_words = (m + 31) >> 5;
+  const int64_t n_stripes = (n_words + 31) >> 5;
+  const int64_t my_words = part < n_stripes ? ((n_stripes - part + parts - 1) / parts) * 32 : 0;
+  uint32_t* dst = lds_list;
+  uint32_t base = 0;
+  int buf = 0;
+  for (int64_t u0 = 0; u0 < my_words; u0 += 1024) {
+    const int64_t u = u0 + threadIdx.x;
+    const int64_t gw = ((u >> 5) * parts + part) * 32 + (u & 31);
+    uint32_t w = (u < my_words && gw < n_words) ? fused_word<FUSED>(spikes, gw, m) : 0u;
+    const uint32_t v = __popc(w);
+    uint32_t it_total;
+    uint32_t pos = base + block_scan_total_1024(v, wave_tot + 16 * buf, &it_total) - v;
+    buf ^= 1;
+    if (dst == lds_list && base + it_total > lds_cap) {     // uniform: the list outgrows LDS -> start over into the workspace
+      dst = glob_list;
+      base = 0;
+      u0 = -1024;
+      continue;
+    }
+    while (w) {
+      const uint32_t b = __ffs(w) - 1u;
+      dst[pos++] = (uint32_t)(gw * 32) + b;
+      w &= w - 1u;
+    }
+    base += it_total;
+  }
+  __syncthreads();
+  *list_out = dst;
+  return base;
+}
+
+// =================================================================================================
 // planned scatter step
 // =================================================================================================
 // One group = up to 4 row segments whose first 64 lane-groups are in flight together.
@@ -304,13 +394,16 @@ __device__ __forceinline__ void sub_consume(const SubGroup& g, uint32_t* acc, in
   }
 }
 
-template <bool HOMO, int LPB = 0>
+template <bool HOMO, int LPB = 0, int FUSED = 0>
 __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
-                                                          const uint32_t* __restrict__ active,
+                                                          const uint32_t* active,
                                                           const uint32_t* __restrict__ n_active_p, int n_slices,
                                                           int slice_shift, int parts, float scale,
                                                           typename PlanAcc<HOMO>::type* __restrict__ partial,
-                                                          int64_t active_stride, int stride) {
+                                                          int64_t active_stride, int stride,
+                                                          const void* __restrict__ fused_spikes, int64_t fused_m, int64_t fused_stride,
+                                                          uint32_t list_off, uint32_t lds_cap, uint32_t* __restrict__ glob_lists,
+                                                          int64_t glob_region) {
   // `stride` = accumulators a task hands to the reduce (slice width rounded up to 16 bytes): the LDS holds 2^slice_shift
   // slots + the pad slot whatever the width, but only the slice's own columns travel through memory
   using acc_t = typename PlanAcc<HOMO>::type;
@@ -323,7 +416,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
   if (L >= n_tasks) return;
   const int part = L / n_slices;
   const int slice = L - part * n_slices;
-  active += (int64_t)blockIdx.y * active_stride;
+  if constexpr (FUSED == 0) active += (int64_t)blockIdx.y * active_stride;
   partial += ((int64_t)blockIdx.y * n_tasks + L) * stride;
   {
     uint4* z = reinterpret_cast<uint4*>(smem_raw);
@@ -332,12 +425,20 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
   }
   __syncthreads();
 
-  const uint32_t n_active = n_active_p[blockIdx.y];
+  __shared__ uint32_t fused_wtot[32];
+  uint32_t n_active;
+  if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
+    n_active = build_part_list<FUSED>(static_cast<const unsigned char*>(fused_spikes) + (int64_t)blockIdx.y * fused_stride, fused_m,
+                                      part, parts, reinterpret_cast<uint32_t*>(smem_raw + list_off), lds_cap,
+                                      glob_lists + ((int64_t)blockIdx.y * parts + part) * glob_region, fused_wtot, &active);
+  } else {
+    n_active = n_active_p[blockIdx.y];
+  }
   const uint2* sp = seg + slice;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   // list position of this lane's row in batch b of this wave
-  const uint64_t a0 = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
-  const uint64_t a_step = (uint64_t)parts * nw * 64;
+  const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a_step = FUSED ? (uint64_t)nw * 64 : (uint64_t)parts * nw * 64;
 
   // pointer pipeline: rows of batch b+2 | bounds of batch b+1 | work on batch b.  All pointer loads are
   // unconditional (clamped index, result masked) for the same counted-vmcnt reason as above.
@@ -783,12 +884,15 @@ __device__ __forceinline__ void d8q_consume(const QGroupD8& g, unsigned long lon
   }
 }
 
-template <int LPB /* 0: a wave per block; 8 / 16: lanes per block */>
+template <int LPB /* 0: a wave per block; 8 / 16: lanes per block */, int FUSED = 0>
 __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
-                                                             const uint32_t* __restrict__ active,
+                                                             const uint32_t* active,
                                                              const uint32_t* __restrict__ n_active_p, int n_slices,
                                                              int cap, int parts, float scale,
-                                                             unsigned long long* __restrict__ partial, int64_t active_stride) {
+                                                             unsigned long long* __restrict__ partial, int64_t active_stride,
+                                                          const void* __restrict__ fused_spikes, int64_t fused_m, int64_t fused_stride,
+                                                          uint32_t list_off, uint32_t lds_cap, uint32_t* __restrict__ glob_lists,
+                                                          int64_t glob_region) {
   using acc_t = unsigned long long;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
@@ -799,7 +903,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
   if (L >= n_tasks) return;
   const int part = L / n_slices;
   const int slice = L - part * n_slices;
-  active += (int64_t)blockIdx.y * active_stride;
+  if constexpr (FUSED == 0) active += (int64_t)blockIdx.y * active_stride;
   partial += ((int64_t)blockIdx.y * n_tasks + L) * S;
   {
     uint4* z = reinterpret_cast<uint4*>(smem_raw);
@@ -807,11 +911,19 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
     for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
-  const uint32_t n_active = n_active_p[blockIdx.y];
+  __shared__ uint32_t fused_wtot[32];
+  uint32_t n_active;
+  if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
+    n_active = build_part_list<FUSED>(static_cast<const unsigned char*>(fused_spikes) + (int64_t)blockIdx.y * fused_stride, fused_m,
+                                      part, parts, reinterpret_cast<uint32_t*>(smem_raw + list_off), lds_cap,
+                                      glob_lists + ((int64_t)blockIdx.y * parts + part) * glob_region, fused_wtot, &active);
+  } else {
+    n_active = n_active_p[blockIdx.y];
+  }
   const uint2* sp = seg + slice;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const uint64_t a0 = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
-  const uint64_t a_step = (uint64_t)parts * nw * 64;
+  const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a_step = FUSED ? (uint64_t)nw * 64 : (uint64_t)parts * nw * 64;
   if (n_active > 0) {
     const uint64_t last = n_active - 1;
     uint64_t a = a0;
@@ -990,11 +1102,15 @@ __device__ __forceinline__ void h8_consume(const SegGroupH8& g, uint32_t* acc, i
   }
 }
 
+template <int FUSED = 0>
 __global__ void __launch_bounds__(1024) k_plan_accumulate_h8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
-                                                             const uint32_t* __restrict__ active,
+                                                             const uint32_t* active,
                                                              const uint32_t* __restrict__ n_active_p, int n_slices,
                                                              int cap, int parts, uint32_t* __restrict__ partial,
-                                                             int64_t active_stride) {
+                                                             int64_t active_stride,
+                                                          const void* __restrict__ fused_spikes, int64_t fused_m, int64_t fused_stride,
+                                                          uint32_t list_off, uint32_t lds_cap, uint32_t* __restrict__ glob_lists,
+                                                          int64_t glob_region) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem_raw);
   const int S = cap;                     // multiple of 4; >= slice width
@@ -1004,7 +1120,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_h8(const unsigned char
   if (L >= n_tasks) return;
   const int part = L / n_slices;
   const int slice = L - part * n_slices;
-  active += (int64_t)blockIdx.y * active_stride;
+  if constexpr (FUSED == 0) active += (int64_t)blockIdx.y * active_stride;
   partial += ((int64_t)blockIdx.y * n_tasks + L) * S;
   {
     uint4* z = reinterpret_cast<uint4*>(smem_raw);
@@ -1012,11 +1128,19 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_h8(const unsigned char
     for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
-  const uint32_t n_active = n_active_p[blockIdx.y];
+  __shared__ uint32_t fused_wtot[32];
+  uint32_t n_active;
+  if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
+    n_active = build_part_list<FUSED>(static_cast<const unsigned char*>(fused_spikes) + (int64_t)blockIdx.y * fused_stride, fused_m,
+                                      part, parts, reinterpret_cast<uint32_t*>(smem_raw + list_off), lds_cap,
+                                      glob_lists + ((int64_t)blockIdx.y * parts + part) * glob_region, fused_wtot, &active);
+  } else {
+    n_active = n_active_p[blockIdx.y];
+  }
   const uint2* sp = seg + slice;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const uint64_t a0 = (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
-  const uint64_t a_step = (uint64_t)parts * nw * 64;
+  const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a_step = FUSED ? (uint64_t)nw * 64 : (uint64_t)parts * nw * 64;
   if (n_active > 0) {
     const uint64_t last = n_active - 1;
     uint64_t a = a0;
@@ -1198,6 +1322,14 @@ static inline int64_t lds_slots_of(int slice_shift, int slice_width, int layout,
   return layout == BE_PLAN_U16 ? (1ll << slice_shift) : cap_of(slice_shift, slice_width, layout, homo);
 }
 
+#define COMMA ,
+constexpr size_t kFusedMinList = 2048;   // LDS room (row ids) from which the step lists its active rows in the kernel
+// rows a part can own: its stripes of 1024 rows (the overflow destination of a part's list in the workspace)
+static inline int64_t fused_region_of(int64_t m, int parts) {
+  const int64_t n_stripes = (((m + 31) >> 5) + 31) >> 5;
+  return ((n_stripes + parts - 1) / parts) * 1024;
+}
+
 int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int slice_width) {
   const int64_t n = (int64_t)n_slices_of(k, slice_shift, slice_width) * m;
   const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
@@ -1326,6 +1458,10 @@ int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, c
                               layout, seg, blob, maxabs_bits, stream);
 }
 
+// active-list area per batch row: the compacted list (m ids) or, in the fused step, one region per part (its stripes of
+// 1024 rows: at most 64 x 1024 ids more than m in all)
+static inline int64_t plan_active_stride(int64_t m) { return active_stride_of(m + 64 * 1024 + 1024); }
+
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
                                                int parts, int homo) {
   const int64_t n_slices = n_slices_of(k, slice_shift, slice_width);
@@ -1333,7 +1469,7 @@ int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_b
   // a task's partial sums are cap_of() accumulators wide; the layout is not an argument here, so size for the widest
   // rounding any layout applies to the width (h8 / homo u16: up to the next multiple of 4)
   const int64_t task = std::max<int64_t>(1ll << slice_shift, (width_of(slice_shift, slice_width) + 3) & ~3ll);
-  return counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
+  return counts_bytes(n_batch) + n_batch * plan_active_stride(m) * 4 +
          be_align_up(n_batch * n_slices * parts * task * acc_bytes, 256);
 }
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo) {
@@ -1362,14 +1498,14 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
                  workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo),
              BE_ERR_WORKSPACE, "workspace too small");
   // what the launch below actually writes (independent of the sizing function above)
-  BE_REQUIRE(workspace_bytes >= counts_bytes(n_batch) + n_batch * active_stride_of(m) * 4 +
+  BE_REQUIRE(workspace_bytes >= counts_bytes(n_batch) + n_batch * plan_active_stride(m) * 4 +
                                     n_batch * (int64_t)n_slices_of(k, slice_shift, slice_width) * parts * S * (homo ? 4 : 8),
              BE_ERR_WORKSPACE, "workspace too small for this layout's partial sums");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + counts_bytes(n_batch));
-  const int64_t astride = active_stride_of(m);
+  const int64_t astride = plan_active_stride(m);
   void* partial = wsb + counts_bytes(n_batch) + n_batch * astride * 4;
   const int n_slices = n_slices_of(k, slice_shift, slice_width);
   if (n_slices == 1 && parts == 1 && n_batch == 1 && wdtype != BE_F64 &&
@@ -1395,44 +1531,67 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     be_prof_end(prof1, st);
     return rc1;
   }
-  // the per-batch counters at the head of the workspace are zero on entry (caller contract) and are zeroed
-  // again by k_plan_reduce once the accumulate kernel has consumed them: saves a 5 us memset node per step
-  ActiveList al;
-  int rc = be_resolve_active(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false, &al);
-  if (rc != BE_OK) return rc;
+  // Fused step: when the accumulators leave room in LDS and the spikes are bit-packed or 1-byte, every workgroup lists the
+  // active rows of its part itself (build_part_list): no compaction launch, no active list through memory.  Otherwise the
+  // spikes are compacted into the workspace first (or the caller's id list is used).  The per-batch counters at the head
+  // of the workspace are zero on entry (caller contract) and are zeroed again by k_plan_reduce: no memset node per step.
+  static const int fused_off = [] { const char* e = getenv("BE_PLAN_FUSED"); return e && e[0] == '0'; }();
+  const size_t lds_room = 160 * 1024 - 1024 - lds;                    // bytes of LDS the accumulators leave
+  int fused = 0;
+  if (!fused_off && lds + 1024 <= 160 * 1024 && lds_room >= kFusedMinList * 4) {
+    if (spike_dtype == BE_SPIKE_BITS) fused = 1;
+    else if (spike_dtype == BE_SPIKE_BOOL && (reinterpret_cast<uintptr_t>(spikes) & 15) == 0 && (n_batch == 1 || m % 16 == 0)) fused = 2;
+  }
+  const uint32_t lds_cap = fused ? (uint32_t)std::min<size_t>(lds_room / 4, 32768) : 0u;
+  const uint32_t list_off = (uint32_t)lds;
+  const size_t lds_dyn = lds + (size_t)lds_cap * 4;
+  const int64_t fused_stride = spike_dtype == BE_SPIKE_BITS ? ((m + 31) / 32) * 4 : m;       // bytes per batch row of spikes
+  const int64_t glob_region = fused_region_of(m, parts);
+  ActiveList al{active, count};
+  if (!fused) {
+    int rc = be_resolve_active(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false, &al);
+    if (rc != BE_OK) return rc;
+  }
   const float scale = ldexpf(1.0f, scale_exp - 32);   // see fixed_from_f32
   const double inv_scale = ldexp(1.0, -scale_exp);
   const int n_tasks = n_slices * parts;
   const dim3 grid((unsigned)((n_tasks + 7) / 8 * 8), (unsigned)n_batch), block(1024);
   const int prof = be_prof_begin(st);
+#define BE_FUSED_ARGS spikes, m, fused_stride, list_off, lds_cap, active, glob_region
+#define BE_PLAN_LAUNCH(KERN, ...)                                                                              \
+  do {                                                                                                         \
+    auto kern__ = KERN;                                                                                        \
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern__), (int)lds_dyn));                                 \
+    hipLaunchKernelGGL(kern__, grid, block, lds_dyn, st, static_cast<const unsigned char*>(blob),              \
+                       static_cast<const uint2*>(seg), al.ids, al.count, __VA_ARGS__, BE_FUSED_ARGS);          \
+  } while (0)
+#define BE_PLAN_BY_FUSED(TMPL_A, TMPL_B, ...)                                                                 \
+  do {                                                                                                         \
+    if (fused == 1) BE_PLAN_LAUNCH((TMPL_A 1 TMPL_B), __VA_ARGS__);                                           \
+    else if (fused == 2) BE_PLAN_LAUNCH((TMPL_A 2 TMPL_B), __VA_ARGS__);                                      \
+    else BE_PLAN_LAUNCH((TMPL_A 0 TMPL_B), __VA_ARGS__);                                                      \
+  } while (0)
   if (layout == BE_PLAN_H8) {
-    auto kern = k_plan_accumulate_h8;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       al.ids, al.count, n_slices, (int)S, parts, static_cast<uint32_t*>(partial), astride);
+    BE_PLAN_BY_FUSED(k_plan_accumulate_h8<, >, n_slices, (int)S, parts, static_cast<uint32_t*>(partial), astride);
   } else if (homo) {
     // short blocks: 4 lanes (<= 32 entries on average) or 16 lanes (<= 128) per block instead of a wave
-    auto kern = (block_hint > 0 && block_hint <= 32)    ? k_plan_accumulate<true, 4>
-                : (block_hint > 0 && block_hint <= 128) ? k_plan_accumulate<true, 16>
-                                                        : k_plan_accumulate<true, 0>;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<uint32_t*>(partial), astride, (int)S);
+    uint32_t* pp = static_cast<uint32_t*>(partial);
+    if (block_hint > 0 && block_hint <= 32) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 4 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= 128) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 16 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
+    else BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 0 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
   } else if (layout == BE_PLAN_D8) {
     // short blocks: 8 lanes (<= 24 entries on average) or 16 lanes (<= 48) per block instead of a wave
-    auto kern = (block_hint > 0 && block_hint <= kD8EighthMaxBlock)    ? k_plan_accumulate_d8<8>
-                : (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) ? k_plan_accumulate_d8<16>
-                                                                        : k_plan_accumulate_d8<0>;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       al.ids, al.count, n_slices, (int)S, parts, scale, static_cast<unsigned long long*>(partial), astride);
+    unsigned long long* pp = static_cast<unsigned long long*>(partial);
+    if (block_hint > 0 && block_hint <= kD8EighthMaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate_d8<8 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
+    else if (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate_d8<16 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
+    else BE_PLAN_BY_FUSED(k_plan_accumulate_d8<0 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
   } else {
-    auto kern = k_plan_accumulate<false, 0>;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const unsigned char*>(blob), static_cast<const uint2*>(seg),
-                       al.ids, al.count, n_slices, slice_shift, parts, scale, static_cast<unsigned long long*>(partial),
-                       astride, (int)S);
+    BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 0 COMMA, >, n_slices, slice_shift, parts, scale,
+                     static_cast<unsigned long long*>(partial), astride, (int)S);
   }
+#undef BE_PLAN_BY_FUSED
+#undef BE_PLAN_LAUNCH
+#undef BE_FUSED_ARGS
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   const int rgrid = grid_for(k, 256, n_batch >= 8 ? 256 : 2048);

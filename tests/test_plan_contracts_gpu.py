@@ -285,3 +285,34 @@ def test_binned_route_half_precision_and_batches(be, oracle, monkeypatch, dtype,
     refB = np.stack([oracle.binary_csrmv(wref.reshape(-1), idx.reshape(-1), ptr, B[b], (n_pre, n_post), True) for b in range(4)])
     assert gotB.shape == (4, n_post)
     np.testing.assert_allclose(gotB.float().cpu().numpy(), refB, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('packed', [False, True])
+@pytest.mark.parametrize('layout,homo', [('d8', False), ('u16', False), ('u16', True), ('h8', True)])
+def test_fused_step_lists_its_rows_in_the_kernel_and_spills_to_the_workspace(be, oracle, layout, homo, packed):
+    """The planned step lists the active rows of each part inside the accumulate kernel when LDS has room behind the
+    accumulators (be_csr_plan.hip: build_part_list).  Dense firing over many rows makes a part's list outgrow that room:
+    it is then written to the part's region of the workspace.  Bit-packed and 1-byte spikes, every layout, a row count that
+    is not a multiple of the 1024-row stripes; results against the oracle, bitwise equal between the two spike encodings."""
+    from brainevent_amd._csr import ScatterPlan, _plan_call
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(77)
+    m, row = 200_123, 6
+    width = 18000 if layout != 'u16' else (16000 if not homo else 30000)
+    k = 2 * width
+    w, idx, ptr = _fixed_rows(rng, m, k, row, homo)
+    if not homo:
+        w = rng.normal(0, 1, w.shape).astype(np.float32)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_width=width, layout=layout)
+    outs = []
+    for fire in (1.0, 0.5, 0.001):
+        v = rng.random(m) < fire
+        ev = be.BinaryArray(torch.tensor(v, device='cuda'))
+        spikes, sd = A.spikes_to_device(A.PackedSpikes(ev.bitpack().packed[0], m) if packed else ev.value)
+        assert sd == (A.BE_SPIKE_BITS if packed else A.BE_SPIKE_BOOL)
+        out = torch.empty(k, dtype=torch.float32, device='cuda')
+        _plan_call(plan, A.to_device(w), spikes, sd, out, parts=4)
+        ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), True)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL * max(1.0, float(np.abs(ref).max())))
+        outs.append(out.clone())
+    assert len(outs) == 3
