@@ -746,10 +746,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 // one lane-group: 4 deltas (one dword) + 4 weights; `before` = column of the entry preceding this lane-group
 __device__ __forceinline__ void d8_add4(unsigned long long* acc, uint32_t before, uint32_t d, const be_v4u& wv, float scale) {
   const uint32_t c0 = before + (d & 0xffu), c1 = c0 + ((d >> 8) & 0xffu), c2 = c1 + ((d >> 16) & 0xffu), c3 = c2 + (d >> 24);
+#ifdef BE_ABL_NOATOMIC      // ablation builds: everything but the LDS atomics (operands kept alive)
+  const unsigned long long v0 = fixed_from_f32(__uint_as_float(wv.x), scale), v1 = fixed_from_f32(__uint_as_float(wv.y), scale),
+                           v2 = fixed_from_f32(__uint_as_float(wv.z), scale), v3 = fixed_from_f32(__uint_as_float(wv.w), scale);
+  asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#else
   atomicAdd(&acc[c0], fixed_from_f32(__uint_as_float(wv.x), scale));
   atomicAdd(&acc[c1], fixed_from_f32(__uint_as_float(wv.y), scale));
   atomicAdd(&acc[c2], fixed_from_f32(__uint_as_float(wv.z), scale));
   atomicAdd(&acc[c3], fixed_from_f32(__uint_as_float(wv.w), scale));
+#endif
 }
 __device__ __forceinline__ uint32_t d8_sum4(uint32_t d) { return (d & 0xffu) + ((d >> 8) & 0xffu) + ((d >> 16) & 0xffu) + (d >> 24); }
 
@@ -884,6 +890,14 @@ __device__ __forceinline__ void d8q_consume(const QGroupD8& g, unsigned long lon
   }
 }
 
+// phase stamps of k_plan_accumulate_d8 (diagnostic builds only: BE_HIPCC_FLAGS=-DBE_PLAN_PROF; tools/plan_phase_prof.py)
+#ifdef BE_PLAN_PROF
+__device__ unsigned long long g_plan_prof[256 * 8];
+#define PLAN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); g_plan_prof[blockIdx.x * 8 + (i)] += t__ - plan_t; plan_t = t__; } } while (0)
+#else
+#define PLAN_STAMP(i) do { } while (0)
+#endif
+
 template <int LPB /* 0: a wave per block; 8 / 16: lanes per block */, int FUSED = 0>
 __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                              const uint32_t* active,
@@ -897,6 +911,9 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   const int S = cap;                     // even; >= slice width (the d8 layout needs no pad slot)
+#ifdef BE_PLAN_PROF
+  unsigned long long plan_t = __builtin_amdgcn_s_memtime();
+#endif
   const int per_xcd = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int n_tasks = n_slices * parts;
@@ -911,6 +928,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
     for (int i = threadIdx.x; i < n16; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
+  PLAN_STAMP(0);     // LDS zeroed
   __shared__ uint32_t fused_wtot[32];
   uint32_t n_active;
   if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
@@ -920,6 +938,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
   } else {
     n_active = n_active_p[blockIdx.y];
   }
+  PLAN_STAMP(1);     // spike count / list known
   const uint2* sp = seg + slice;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
@@ -936,6 +955,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
     v_n = a < n_active;
     r_n = active[a < last ? a : last];
     a += a_step;
+    PLAN_STAMP(2);   // first row ids and segment entries landed (wave 0)
     while (__ballot(v_c) != 0ull) {
       const int nvalid = __popcll(__ballot(v_c));
       const uint2 sgn = sp[(uint64_t)r_n * n_slices];
@@ -975,13 +995,19 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
       r_n = r_nn;
     }
   }
+  PLAN_STAMP(3);     // wave 0 through its blocks
   __syncthreads();
+  PLAN_STAMP(4);     // every wave through
   {
     const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
     uint4* dst = reinterpret_cast<uint4*>(partial);
     const int n16 = (int)((size_t)S * sizeof(acc_t) / 16);
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
   }
+#ifdef BE_PLAN_PROF
+  __builtin_amdgcn_s_waitcnt(0);
+  PLAN_STAMP(5);     // partial sums stored
+#endif
 }
 
 // =================================================================================================
@@ -1297,6 +1323,14 @@ int launch_plan_single(const void* blob, const void* seg, const void* spikes, in
 // =================================================================================================
 // C ABI
 // =================================================================================================
+#ifdef BE_PLAN_PROF
+extern "C" int be_debug_plan_prof(unsigned long long* host, int reset) {
+  if (host) (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_plan_prof), sizeof(unsigned long long) * 256 * 8);
+  if (reset) { static unsigned long long z[256 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_plan_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
+
 extern "C" {
 
 // ---------------------------------------------------------------- scatter plan
