@@ -76,6 +76,7 @@ class ScatterPlan:
         self.split_f64 = False            # per-entry f64 weights stored as two f32 entries each
         self.stamp = None                 # weights_stamp() of the weights the blocks were filled from
         self.block_hint_override: Optional[int] = None
+        self.items_hint: Optional[int] = None      # d8: average stored items (entries + escapes) per block, from the table
         self._ws: Dict = {}
 
     # -- sizing ---------------------------------------------------------------------------------
@@ -106,9 +107,12 @@ class ScatterPlan:
 
     @property
     def block_hint(self) -> int:
-        """Average entries per (row, slice) block (a speed hint for the step kernel; 0 = unknown)."""
+        """Average entries per (row, slice) block — for the d8 layout including its escape entries — (a speed hint for the
+        step kernel: lanes per block, pre-gathered segment table; 0 = unknown)."""
         if self.block_hint_override is not None:
             return int(self.block_hint_override)
+        if self.items_hint is not None:
+            return self.items_hint
         if not self.nnz:
             return 0
         return max(1, min(1 << 20, int(round(self.nnz / max(1, self.m * self.n_slices)))))
@@ -134,6 +138,11 @@ class ScatterPlan:
     #: auto_geometry thresholds (stored rows per workgroup-part; entries per block; slice width with small partial sums)
     D8_MIN_ROWS_PER_PART, H8_MIN_ROWS_PER_PART, H8_MIN_BLOCK = 20000, 32768, 192
     D8_SMALL_WIDTH, H8_SMALL_WIDTH = 8192, 16384
+    #: widest average column gap (slice width / entries per block) the d8 layout is chosen for: a gap above 255 costs an
+    #: escape entry, and blocks of 16-40 entries in slices 14000-20000 columns wide carry 1.4-4 escapes per entry
+    #: (N = 350k ... 1M, K = 1000: d8 31 / 82 us against 26 / 55 us for uint16 columns decoded by 8 lanes per block;
+    #: N = 200k, gap 200: 23 / 23 us)
+    D8_MAX_GAP = 160
 
     #: slices a matrix is cut into when neither the LDS capacity nor the pass size asks for more, and the shortest
     #: average block that is worth it
@@ -197,7 +206,7 @@ class ScatterPlan:
         if homo:
             ok = row / n_d >= cls.H8_MIN_BLOCK and (busy >= cls.H8_MIN_ROWS_PER_PART or wd <= cls.H8_SMALL_WIDTH)
         else:
-            ok = busy >= cls.D8_MIN_ROWS_PER_PART or wd <= cls.D8_SMALL_WIDTH
+            ok = (busy >= cls.D8_MIN_ROWS_PER_PART or wd <= cls.D8_SMALL_WIDTH) and wd * n_d <= cls.D8_MAX_GAP * row
         return (delta, wd) if ok else (U16, w16)
 
     def nbytes(self) -> int:
@@ -282,6 +291,11 @@ class ScatterPlan:
         blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
         plan = cls(m, k, homo, slice_shift, seg, blob, 0, out_dtype, slice_width, lay)
         plan.nnz = nnz
+        if lay == cls.LAYOUT_D8 and nnz:
+            # lane-groups of 4 items per block (low 16 bits of the table's second word), over a strided sample of the blocks
+            n_blk = m * n_slices
+            ng = seg.view(n_blk, 2)[::max(1, n_blk >> 22), 1] & 0xffff
+            plan.items_hint = max(1, min(1 << 20, int(round(4.0 * ng.double().mean().item()))))
         plan.row_len = int(row_len)
         plan.split_f64 = split
         plan._fill(weights, indices, indptr)

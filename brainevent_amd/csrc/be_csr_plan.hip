@@ -279,6 +279,43 @@ __device__ __forceinline__ uint32_t build_part_list(const void* __restrict__ spi
 }
 
 // =================================================================================================
+// Pre-gathered segment table (short blocks).  With ~20 entries per block the step is bound by its segment-table gather:
+// one load instruction of a wave fetches the 8-byte entries of 64 different rows — 64 different 128-byte lines — and
+// compiling that gather out (made-up block addresses) cut the weighted kernel at N = 1M, K = 1000 from 65 to 17 us.
+// k_gather_seg runs between the compaction and the accumulate kernel: it reads the active rows' table rows (n_slices x
+// 8 B contiguous: coalesced) and writes them transposed, dense by LIST POSITION: dense[slice][position].  The accumulate
+// kernel then gives every part a contiguous range of positions and every wave 64 consecutive ones, reads its 64 entries as
+// one 512-byte load, and never loads a row id at all (FUSED = 3).
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_gather_seg(const uint2* __restrict__ seg, const uint32_t* __restrict__ active,
+                                                    const uint32_t* __restrict__ n_active_p, int n_slices, int64_t a_stride,
+                                                    uint2* __restrict__ dense) {
+  __shared__ uint2 tile[64][65];
+  const uint32_t n_active = *n_active_p;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t c = blockIdx.x; (uint64_t)c * 64 < n_active; c += gridDim.x) {
+    const uint32_t a0 = c * 64;
+    const uint32_t n_here = n_active - a0 < 64u ? n_active - a0 : 64u;
+    // a wave takes 16 of the 64 rows: their ids in one load, then 16 independent row reads in flight (two memory latencies
+    // per tile instead of 32)
+    const uint32_t i_mine = (uint32_t)wave * 16u + (uint32_t)(lane & 15);
+    const uint32_t rid = active[a0 + (i_mine < n_here ? i_mine : 0u)];
+    for (int s0 = 0; s0 < n_slices; s0 += 64) {
+      const int sl = s0 + lane < n_slices ? s0 + lane : n_slices - 1;
+      uint2 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = seg[(uint64_t)__builtin_amdgcn_readlane((int)rid, j) * n_slices + sl];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tile[wave * 16 + j][lane] = v[j];
+      __syncthreads();
+      for (int s = wave; s < 64 && s0 + s < n_slices; s += 4)      // wave: one slice; lanes: 64 consecutive positions
+        if ((uint32_t)lane < n_here) dense[(int64_t)(s0 + s) * a_stride + a0 + lane] = tile[lane][s];
+      __syncthreads();
+    }
+  }
+}
+
+// =================================================================================================
 // planned scatter step
 // =================================================================================================
 // One group = up to 4 row segments whose first 64 lane-groups are in flight together.
@@ -364,31 +401,62 @@ __device__ __forceinline__ void seg_consume(const SegGroup& g, typename PlanAcc<
 // ---- counted entries, short blocks: LPB lanes per block (8 columns per lane), 64 / LPB blocks per load instruction.
 // With 31 entries per block (N = 1M, K = 1000, one shared weight) the wave-per-block path keeps 4 of 64 lanes busy.
 struct SubGroup {
-  uint32_t n;                   // lane-groups of 8 columns in this lane's block
-  be_v4u c;
+  uint32_t n;                   // lane-groups in this lane's block (8 counted columns, or 4 weighted entries, per lane)
+  be_v4u c;                     // 8 uint16 columns (counted) / 4 weights
+  be_v2u iv;                    // weighted: 4 uint16 columns
   const unsigned char* blk;
 };
-template <int LPB>
+template <bool HOMO, int LPB>
 __device__ __forceinline__ void sub_issue(SubGroup& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
                                           const unsigned char* __restrict__ blob) {
   const int row = i + lane / LPB;
   const uint32_t st = (uint32_t)__shfl((int)st_v, row & 63, 64);
   const uint32_t n = (uint32_t)__shfl((int)n4_v, row & 63, 64);
   g.n = row < nvalid ? n : 0u;
-  g.blk = g.n ? blob + ((uint64_t)st << 7) : blob;
+  g.blk = g.n ? blob + ((uint64_t)st << 7) : blob;          // nothing to do: the head of the blob (in bounds, cached)
   const uint32_t l = (uint32_t)(lane % LPB);
-  const uint4 x = reinterpret_cast<const uint4*>(g.blk)[l < g.n ? l : 0u];     // clamped: unconditional load
+  const uint32_t o = l < g.n ? l : 0u;                       // clamped: the loads stay unconditional (counted vmcnt waits)
+  const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
   g.c = be_v4u{x.x, x.y, x.z, x.w};
+  if constexpr (!HOMO) {
+    const uint2 y = reinterpret_cast<const uint2*>(g.blk + (uint64_t)g.n * 16u)[o];
+    g.iv = be_v2u{y.x, y.y};
+  }
 }
-template <int LPB>
-__device__ __forceinline__ void sub_consume(const SubGroup& g, uint32_t* acc, int lane) {
+template <bool HOMO, int LPB>
+__device__ __forceinline__ void sub_consume(SubGroup& g, typename PlanAcc<HOMO>::type* acc, int lane, float scale) {
+  // an opaque use of the loaded registers in straight-line code: without it the compiler may sink a load into the `l < n`
+  // branch below, where its wait (vmcnt(0)) drains every load the pipeline has in flight
+  if constexpr (HOMO) asm volatile("" : "+v"(g.c.x), "+v"(g.c.y), "+v"(g.c.z), "+v"(g.c.w));
+  else asm volatile("" : "+v"(g.c.x), "+v"(g.c.y), "+v"(g.c.z), "+v"(g.c.w), "+v"(g.iv.x), "+v"(g.iv.y));
   const uint32_t l = (uint32_t)(lane % LPB);
-  if (l < g.n) plan_count8(acc, g.c.x, g.c.y, g.c.z, g.c.w);
-  if (__ballot(g.n > (uint32_t)LPB) != 0ull) {            // longer blocks: further passes of LPB lane-groups
-    for (uint32_t o = LPB + l; __ballot(o < g.n) != 0ull; o += LPB) {
-      if (o < g.n) {
-        const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
-        plan_count8(acc, x.x, x.y, x.z, x.w);
+  if (l < g.n) {                                             // the first LPB lane-groups; longer blocks: sub_tails
+    if constexpr (HOMO) {
+      plan_count8(reinterpret_cast<uint32_t*>(acc), g.c.x, g.c.y, g.c.z, g.c.w);
+    } else {
+      plan_add4<false>(acc, make_uint2(g.iv.x, g.iv.y),
+                       make_float4(__uint_as_float(g.c.x), __uint_as_float(g.c.y), __uint_as_float(g.c.z), __uint_as_float(g.c.w)), scale);
+    }
+  }
+}
+// The rare blocks longer than one sub-wave pass (n > LPB lane-groups), after the batch's pipelined loop, a wave per block.
+// The lanes-per-block variant is chosen so that these are ~0.1 % of the blocks (host: mean + 3 sigma fits one pass).
+template <bool HOMO, int LPB>
+__device__ __forceinline__ void sub_tails(uint32_t st_v, uint32_t n4_v, int nvalid, typename PlanAcc<HOMO>::type* acc, int lane,
+                                          float scale, const unsigned char* __restrict__ blob) {
+  unsigned long long longm = __ballot(lane < nvalid && n4_v > (uint32_t)LPB);
+  while (longm) {
+    const int src = __ffsll((long long)longm) - 1;
+    longm &= longm - 1;
+    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)st_v, src), n = (uint32_t)__builtin_amdgcn_readlane((int)n4_v, src);
+    const unsigned char* blk = blob + ((uint64_t)st << 7);
+    for (uint32_t o = LPB + lane; o < n; o += 64) {
+      const uint4 x = reinterpret_cast<const uint4*>(blk)[o];
+      if constexpr (HOMO) {
+        plan_count8(reinterpret_cast<uint32_t*>(acc), x.x, x.y, x.z, x.w);
+      } else {
+        const uint2 iv = reinterpret_cast<const uint2*>(blk + (uint64_t)n * 16u)[o];
+        plan_add4<false>(acc, iv, make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)), scale);
       }
     }
   }
@@ -427,58 +495,68 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
 
   __shared__ uint32_t fused_wtot[32];
   uint32_t n_active;
-  if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
+  if constexpr (FUSED == 1 || FUSED == 2) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
     n_active = build_part_list<FUSED>(static_cast<const unsigned char*>(fused_spikes) + (int64_t)blockIdx.y * fused_stride, fused_m,
                                       part, parts, reinterpret_cast<uint32_t*>(smem_raw + list_off), lds_cap,
                                       glob_lists + ((int64_t)blockIdx.y * parts + part) * glob_region, fused_wtot, &active);
   } else {
     n_active = n_active_p[blockIdx.y];
   }
-  const uint2* sp = seg + slice;
+  // FUSED == 3 (pre-gathered table): part p owns the list positions [p * npp, (p + 1) * npp), a wave 64 consecutive ones
+  uint32_t pos_lo = 0;
+  if constexpr (FUSED == 3) {
+    const uint32_t npp = (n_active + (uint32_t)parts - 1u) / (uint32_t)parts;
+    pos_lo = (uint32_t)part * npp;
+    const uint32_t hi = pos_lo + npp < n_active ? pos_lo + npp : n_active;
+    n_active = hi > pos_lo ? hi : pos_lo;            // from here on: one past this part's last position
+  }
+  // segment table: [row][slice] as built, or (FUSED == 3) the step's pre-gathered [slice][list position]
+  const uint2* sp = FUSED == 3 ? seg + (int64_t)slice * glob_region : seg + slice;
+  const uint64_t seg_rs = FUSED == 3 ? 1u : (uint64_t)n_slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   // list position of this lane's row in batch b of this wave
-  const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a0 = FUSED == 3 ? (uint64_t)pos_lo + (uint64_t)wave * 64 + lane
+                      : FUSED  ? (uint64_t)wave + (uint64_t)nw * lane
+                               : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
   const uint64_t a_step = FUSED ? (uint64_t)nw * 64 : (uint64_t)parts * nw * 64;
 
   // pointer pipeline: rows of batch b+2 | bounds of batch b+1 | work on batch b.  All pointer loads are
   // unconditional (clamped index, result masked) for the same counted-vmcnt reason as above.
-  if (n_active > 0) {
+  if (n_active > pos_lo) {
     const uint64_t last = n_active - 1;
     uint64_t a = a0;
     bool v_n = a < n_active;
-    uint32_t r_n = active[a < last ? a : last];
+    uint32_t r_n = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
     a += a_step;
-    uint2 sg = sp[(uint64_t)r_n * n_slices];
+    uint2 sg = sp[(uint64_t)r_n * seg_rs];
     uint32_t st_v = sg.x, n4_v = v_n ? sg.y : 0u;
     bool v_c = v_n;
     v_n = a < n_active;
-    r_n = active[a < last ? a : last];
+    r_n = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
     a += a_step;
 
     while (__ballot(v_c) != 0ull) {
       const int nvalid = __popcll(__ballot(v_c));   // valid lanes form a prefix: a grows with the lane
       // issue next batch's bounds and the batch-after-next's row ids before touching this batch's data
-      const uint2 sgn = sp[(uint64_t)r_n * n_slices];
+      const uint2 sgn = sp[(uint64_t)r_n * seg_rs];
       const bool v_nn = a < n_active;
-      const uint32_t r_nn = active[a < last ? a : last];
+      const uint32_t r_nn = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
       a += a_step;
 
-      if constexpr (HOMO && LPB > 0) {
-        constexpr int BPI = 64 / LPB;                       // blocks per instruction; four groups in flight
-        SubGroup g0, g1, g2, g3;
-        sub_issue<LPB>(g0, 0, nvalid, st_v, n4_v, lane, blob);
-        sub_issue<LPB>(g1, BPI, nvalid, st_v, n4_v, lane, blob);
-        sub_issue<LPB>(g2, 2 * BPI, nvalid, st_v, n4_v, lane, blob);
-        for (int i = 0; i < nvalid; i += 4 * BPI) {
-          sub_issue<LPB>(g3, i + 3 * BPI, nvalid, st_v, n4_v, lane, blob);
-          sub_consume<LPB>(g0, reinterpret_cast<uint32_t*>(acc), lane);
-          sub_issue<LPB>(g0, i + 4 * BPI, nvalid, st_v, n4_v, lane, blob);
-          sub_consume<LPB>(g1, reinterpret_cast<uint32_t*>(acc), lane);
-          sub_issue<LPB>(g1, i + 5 * BPI, nvalid, st_v, n4_v, lane, blob);
-          sub_consume<LPB>(g2, reinterpret_cast<uint32_t*>(acc), lane);
-          sub_issue<LPB>(g2, i + 6 * BPI, nvalid, st_v, n4_v, lane, blob);
-          sub_consume<LPB>(g3, reinterpret_cast<uint32_t*>(acc), lane);
+      if constexpr (LPB > 0) {
+        // straight-line over the batch's 64 / BPI groups, DEPTH groups ahead (see k_plan_accumulate_d8)
+        constexpr int BPI = 64 / LPB;                       // blocks per load instruction
+        constexpr int NGRP = 64 / BPI;
+        constexpr int DEPTH = NGRP < 4 ? NGRP : 4;
+        SubGroup g[NGRP];
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) sub_issue<HOMO, LPB>(g[q], q * BPI, nvalid, st_v, n4_v, lane, blob);
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) {
+          if (q + DEPTH < NGRP) sub_issue<HOMO, LPB>(g[q + DEPTH], (q + DEPTH) * BPI, nvalid, st_v, n4_v, lane, blob);
+          sub_consume<HOMO, LPB>(g[q], acc, lane, scale);
         }
+        sub_tails<HOMO, LPB>(st_v, n4_v, nvalid, acc, lane, scale, blob);
       } else {
         SegGroup gA, gB;
         seg_issue<HOMO>(gA, 0, nvalid, st_v, n4_v, lane, blob);
@@ -864,28 +942,46 @@ __device__ __forceinline__ void d8q_issue(QGroupD8& g, int i, int nvalid, uint32
 }
 
 template <int LPB>
-__device__ __forceinline__ void d8q_consume(const QGroupD8& g, unsigned long long* acc, int lane, float scale) {
+__device__ __forceinline__ void d8q_consume(QGroupD8& g, unsigned long long* acc, int lane, float scale) {
+  // an opaque use of the loaded registers in straight-line code: without it the compiler sinks the weight load into the
+  // `l < ng` branch below, where its wait (vmcnt(0)) drains every load the pipeline has in flight
+  asm volatile("" : "+v"(g.w.x), "+v"(g.w.y), "+v"(g.w.z), "+v"(g.w.w), "+v"(g.d));
   const uint32_t l = (uint32_t)(lane % LPB);
   const uint32_t d0 = l < g.ng ? g.d : 0u;
   const uint32_t t0 = d8_sum4(d0);
   const uint32_t incl0 = sub_incl_scan_u32<LPB>(t0, l);
   if (l < g.ng) d8_add4(acc, g.base + incl0 - t0, d0, g.w, scale);
-  if (__ballot(g.ng > (uint32_t)LPB) != 0ull) {               // longer blocks: further passes of LPB lane-groups
-    uint32_t carry = g.base + (uint32_t)__shfl((int)incl0, (lane & ~(LPB - 1)) | (LPB - 1), 64);
-    for (uint32_t o0 = LPB; __ballot(o0 < g.ng) != 0ull; o0 += LPB) {
-      const uint32_t o = o0 + l;
-      const bool in = o < g.ng;
+}
+
+// the rare blocks longer than one sub-wave pass (ng > LPB lane-groups), after the batch's pipelined loop, a wave per block
+// (see sub_tails).  The columns reached by the first LPB lane-groups are re-derived from their deltas.
+template <int LPB>
+__device__ __forceinline__ void d8q_tails(uint32_t st_v, uint32_t n4_v, int nvalid, unsigned long long* acc, int lane, float scale,
+                                          const unsigned char* __restrict__ blob) {
+  unsigned long long longm = __ballot(lane < nvalid && (n4_v & 0xffffu) > (uint32_t)LPB);
+  while (longm) {
+    const int src = __ffsll((long long)longm) - 1;
+    longm &= longm - 1;
+    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)st_v, src), y = (uint32_t)__builtin_amdgcn_readlane((int)n4_v, src);
+    const uint32_t ng = y & 0xffffu;
+    const unsigned char* blk = blob + ((uint64_t)st << 7);
+    const uint32_t* dp = reinterpret_cast<const uint32_t*>(blk + (uint64_t)ng * 16u);
+    const uint32_t d_head = lane < LPB ? dp[lane] : 0u;                 // deltas the pipelined pass has already applied
+    uint32_t carry = (y >> 16) + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(d8_sum4(d_head)), 63);
+    for (uint32_t o0 = LPB; o0 < ng; o0 += 64) {
+      const uint32_t o = o0 + lane;
+      const bool in = o < ng;
       uint32_t d = 0u;
       be_v4u wv = {0u, 0u, 0u, 0u};
       if (in) {
-        d = reinterpret_cast<const uint32_t*>(g.blk + (uint64_t)g.ng * 16u)[o];
-        const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
+        d = dp[o];
+        const uint4 x = reinterpret_cast<const uint4*>(blk)[o];
         wv = be_v4u{x.x, x.y, x.z, x.w};
       }
       const uint32_t t = d8_sum4(d);
-      const uint32_t incl = sub_incl_scan_u32<LPB>(t, l);
+      const uint32_t incl = wave_incl_scan_u32(t);
       if (in) d8_add4(acc, carry + incl - t, d, wv, scale);
-      carry += (uint32_t)__shfl((int)incl, (lane & ~(LPB - 1)) | (LPB - 1), 64);
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
   }
 }
@@ -931,53 +1027,65 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
   PLAN_STAMP(0);     // LDS zeroed
   __shared__ uint32_t fused_wtot[32];
   uint32_t n_active;
-  if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
+  if constexpr (FUSED == 1 || FUSED == 2) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
     n_active = build_part_list<FUSED>(static_cast<const unsigned char*>(fused_spikes) + (int64_t)blockIdx.y * fused_stride, fused_m,
                                       part, parts, reinterpret_cast<uint32_t*>(smem_raw + list_off), lds_cap,
                                       glob_lists + ((int64_t)blockIdx.y * parts + part) * glob_region, fused_wtot, &active);
   } else {
     n_active = n_active_p[blockIdx.y];
   }
+  // FUSED == 3 (pre-gathered table): part p owns the list positions [p * npp, (p + 1) * npp), a wave 64 consecutive ones
+  uint32_t pos_lo = 0;
+  if constexpr (FUSED == 3) {
+    const uint32_t npp = (n_active + (uint32_t)parts - 1u) / (uint32_t)parts;
+    pos_lo = (uint32_t)part * npp;
+    const uint32_t hi = pos_lo + npp < n_active ? pos_lo + npp : n_active;
+    n_active = hi > pos_lo ? hi : pos_lo;            // from here on: one past this part's last position
+  }
   PLAN_STAMP(1);     // spike count / list known
-  const uint2* sp = seg + slice;
+  // segment table: [row][slice] as built, or (FUSED == 3) the step's pre-gathered [slice][list position]
+  const uint2* sp = FUSED == 3 ? seg + (int64_t)slice * glob_region : seg + slice;
+  const uint64_t seg_rs = FUSED == 3 ? 1u : (uint64_t)n_slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a0 = FUSED == 3 ? (uint64_t)pos_lo + (uint64_t)wave * 64 + lane
+                      : FUSED  ? (uint64_t)wave + (uint64_t)nw * lane
+                               : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
   const uint64_t a_step = FUSED ? (uint64_t)nw * 64 : (uint64_t)parts * nw * 64;
-  if (n_active > 0) {
+  if (n_active > pos_lo) {
     const uint64_t last = n_active - 1;
     uint64_t a = a0;
     bool v_n = a < n_active;
-    uint32_t r_n = active[a < last ? a : last];
+    uint32_t r_n = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
     a += a_step;
-    uint2 sg = sp[(uint64_t)r_n * n_slices];
+    uint2 sg = sp[(uint64_t)r_n * seg_rs];
     uint32_t st_v = sg.x, n4_v = v_n ? sg.y : 0u;
     bool v_c = v_n;
     v_n = a < n_active;
-    r_n = active[a < last ? a : last];
+    r_n = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
     a += a_step;
     PLAN_STAMP(2);   // first row ids and segment entries landed (wave 0)
     while (__ballot(v_c) != 0ull) {
       const int nvalid = __popcll(__ballot(v_c));
-      const uint2 sgn = sp[(uint64_t)r_n * n_slices];
+      const uint2 sgn = sp[(uint64_t)r_n * seg_rs];
       const bool v_nn = a < n_active;
-      const uint32_t r_nn = active[a < last ? a : last];
+      const uint32_t r_nn = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
       a += a_step;
       if constexpr (LPB > 0) {
-        constexpr int BPI = 64 / LPB;                       // blocks per instruction; four groups in flight
-        QGroupD8 g0, g1, g2, g3;
-        d8q_issue<LPB>(g0, 0, nvalid, st_v, n4_v, lane, blob);
-        d8q_issue<LPB>(g1, BPI, nvalid, st_v, n4_v, lane, blob);
-        d8q_issue<LPB>(g2, 2 * BPI, nvalid, st_v, n4_v, lane, blob);
-        for (int i = 0; i < nvalid; i += 4 * BPI) {
-          d8q_issue<LPB>(g3, i + 3 * BPI, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume<LPB>(g0, acc, lane, scale);
-          d8q_issue<LPB>(g0, i + 4 * BPI, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume<LPB>(g1, acc, lane, scale);
-          d8q_issue<LPB>(g1, i + 5 * BPI, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume<LPB>(g2, acc, lane, scale);
-          d8q_issue<LPB>(g2, i + 6 * BPI, nvalid, st_v, n4_v, lane, blob);
-          d8q_consume<LPB>(g3, acc, lane, scale);
+        // The 64 rows of a batch are 64 / BPI groups; they are walked in STRAIGHT-LINE code, DEPTH groups ahead: hipcc's
+        // wait-count pass is exact without a back edge (the rotating four-group loop this replaces drained the queue to one
+        // group at the first consume of every iteration: s_waitcnt vmcnt(2) with eight loads outstanding).
+        constexpr int BPI = 64 / LPB;                       // blocks per load instruction
+        constexpr int NGRP = 64 / BPI;                      // groups of a 64-row batch
+        constexpr int DEPTH = 4;
+        QGroupD8 g[NGRP];
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) d8q_issue<LPB>(g[q], q * BPI, nvalid, st_v, n4_v, lane, blob);
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) {
+          if (q + DEPTH < NGRP) d8q_issue<LPB>(g[q + DEPTH], (q + DEPTH) * BPI, nvalid, st_v, n4_v, lane, blob);
+          d8q_consume<LPB>(g[q], acc, lane, scale);
         }
+        d8q_tails<LPB>(st_v, n4_v, nvalid, acc, lane, scale, blob);
       } else {
         SegGroupD8 gA, gB;
         d8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
@@ -1156,34 +1264,46 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_h8(const unsigned char
   __syncthreads();
   __shared__ uint32_t fused_wtot[32];
   uint32_t n_active;
-  if constexpr (FUSED != 0) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
+  if constexpr (FUSED == 1 || FUSED == 2) {       // list the active rows of this part in LDS behind the accumulators (or in the part's region)
     n_active = build_part_list<FUSED>(static_cast<const unsigned char*>(fused_spikes) + (int64_t)blockIdx.y * fused_stride, fused_m,
                                       part, parts, reinterpret_cast<uint32_t*>(smem_raw + list_off), lds_cap,
                                       glob_lists + ((int64_t)blockIdx.y * parts + part) * glob_region, fused_wtot, &active);
   } else {
     n_active = n_active_p[blockIdx.y];
   }
-  const uint2* sp = seg + slice;
+  // FUSED == 3 (pre-gathered table): part p owns the list positions [p * npp, (p + 1) * npp), a wave 64 consecutive ones
+  uint32_t pos_lo = 0;
+  if constexpr (FUSED == 3) {
+    const uint32_t npp = (n_active + (uint32_t)parts - 1u) / (uint32_t)parts;
+    pos_lo = (uint32_t)part * npp;
+    const uint32_t hi = pos_lo + npp < n_active ? pos_lo + npp : n_active;
+    n_active = hi > pos_lo ? hi : pos_lo;            // from here on: one past this part's last position
+  }
+  // segment table: [row][slice] as built, or (FUSED == 3) the step's pre-gathered [slice][list position]
+  const uint2* sp = FUSED == 3 ? seg + (int64_t)slice * glob_region : seg + slice;
+  const uint64_t seg_rs = FUSED == 3 ? 1u : (uint64_t)n_slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const uint64_t a0 = FUSED ? (uint64_t)wave + (uint64_t)nw * lane : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
+  const uint64_t a0 = FUSED == 3 ? (uint64_t)pos_lo + (uint64_t)wave * 64 + lane
+                      : FUSED  ? (uint64_t)wave + (uint64_t)nw * lane
+                               : (uint64_t)part + (uint64_t)parts * ((uint64_t)wave + (uint64_t)nw * lane);
   const uint64_t a_step = FUSED ? (uint64_t)nw * 64 : (uint64_t)parts * nw * 64;
-  if (n_active > 0) {
+  if (n_active > pos_lo) {
     const uint64_t last = n_active - 1;
     uint64_t a = a0;
     bool v_n = a < n_active;
-    uint32_t r_n = active[a < last ? a : last];
+    uint32_t r_n = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
     a += a_step;
-    uint2 sg = sp[(uint64_t)r_n * n_slices];
+    uint2 sg = sp[(uint64_t)r_n * seg_rs];
     uint32_t st_v = sg.x, n4_v = v_n ? sg.y : 0u;
     bool v_c = v_n;
     v_n = a < n_active;
-    r_n = active[a < last ? a : last];
+    r_n = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
     a += a_step;
     while (__ballot(v_c) != 0ull) {
       const int nvalid = __popcll(__ballot(v_c));
-      const uint2 sgn = sp[(uint64_t)r_n * n_slices];
+      const uint2 sgn = sp[(uint64_t)r_n * seg_rs];
       const bool v_nn = a < n_active;
-      const uint32_t r_nn = active[a < last ? a : last];
+      const uint32_t r_nn = FUSED == 3 ? (uint32_t)(a < last ? a : last) : active[a < last ? a : last];
       a += a_step;
       SegGroupH8 gA, gB;
       h8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
@@ -1336,8 +1456,18 @@ extern "C" {
 // ---------------------------------------------------------------- scatter plan
 // slices are `slice_width` output neurons wide (0 = the LDS capacity 2^slice_shift); a width below the capacity lets
 // the caller balance the slices (k = 1M: 64 slices of 15625 instead of 61 full ones and a sliver)
-constexpr int kD8QuarterMaxBlock = 48;  // average entries per block up to which 16 lanes per block decode the d8 layout
-constexpr int kD8EighthMaxBlock = 24;   // ... and 8 lanes per block
+// Lanes per block by the average block length: a sub-wave pass covers LPB lane-groups (4 entries each for d8, 8 for counted
+// u16); longer blocks wait for the serial tails pass, so a variant is used while mean + 3 sigma (Poisson) fits one pass.
+constexpr int kD8QuarterMaxBlock = 43;  // average entries per block up to which 16 lanes per block decode the d8 layout (64 per pass)
+constexpr int kD8EighthMaxBlock = 18;   // ... and 8 lanes per block (32 per pass)
+constexpr int kSub4MaxBlock = 18;       // counted u16: 4 lanes per block (32 per pass)
+constexpr int kSub8MaxBlock = 43;       // 8 lanes (64 per pass)
+constexpr int kSub16MaxBlock = 96;      // 16 lanes (128 per pass)
+constexpr int kSubW4MaxBlock = 7;       // weighted u16: 4 lanes per block (16 per pass)
+constexpr int kSubW8MaxBlock = 18;      // weighted u16: 8 lanes per block (32 per pass)
+constexpr int kSubW16MaxBlock = 43;     // 16 lanes (64 per pass)
+constexpr int kSubW32MaxBlock = 96;     // 32 lanes (128 per pass)
+constexpr int kSub32MaxBlock = 210;     // counted u16: 32 lanes (256 per pass)
 constexpr int kD8MaxWidth = 20000;     // d8 blocks need no pad slot and no power-of-two capacity: 20000 x 8 B = 156 KiB of LDS
 constexpr int kH8MaxWidth = 40000;     // h8: the same LDS in 4-byte counters
 static inline bool width_ok(int slice_shift, int slice_width, int layout = BE_PLAN_U16) {
@@ -1357,6 +1487,12 @@ static inline int64_t lds_slots_of(int slice_shift, int slice_width, int layout,
 }
 
 #define COMMA ,
+// The segment table of a step is pre-gathered (k_gather_seg) for short blocks in many slices: the two extra small launches
+// cost ~5 us, the gather they take out of the accumulate kernel grows with the slice count (FixedNumPerPre K = 1000, 1 %
+// firing, weighted / counted, us per step: 25 slices 26 -> 28 / 21 -> 25; 32 slices 30 -> 33 / 37 -> 35; 51 slices
+// 43 -> 38 / 60 -> 48; 64 slices 55 -> 46; 85 slices counted 172 -> 89; 128 slices weighted 125 -> 84).
+constexpr int kPreGatherMaxBlock = 64;   // average entries per block up to which ...
+constexpr int kPreGatherMinSlices = 40;  // ... and slices from which the segment table is pre-gathered
 constexpr size_t kFusedMinList = 2048;   // LDS room (row ids) from which the step lists its active rows in the kernel
 // rows a part can own: its stripes of 1024 rows (the overflow destination of a part's list in the workspace)
 static inline int64_t fused_region_of(int64_t m, int parts) {
@@ -1496,6 +1632,18 @@ int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, c
 // 1024 rows: at most 64 x 1024 ids more than m in all)
 static inline int64_t plan_active_stride(int64_t m) { return active_stride_of(m + 64 * 1024 + 1024); }
 
+// room for the pre-gathered segment table (k_gather_seg: n_slices x positions x 8 B, sized for every row active: 8 B per
+// block of the plan, which itself holds >= 128 B per block) of a single-vector step, as long as it stays below 8 GiB;
+// larger tables (and batches) gather from the plan's own table
+static inline int pregather_min_slices() {
+  static const int v = [] { const char* e = getenv("BE_PLAN_PREGATHER_SLICES"); return e ? atoi(e) : kPreGatherMinSlices; }();
+  return v > 2 ? v : 2;
+}
+static inline int64_t plan_dense_seg_bytes(int64_t m, int64_t n_slices, int64_t n_batch) {
+  const int64_t bytes = n_slices * plan_active_stride(m) * 8;
+  return (n_batch == 1 && n_slices >= pregather_min_slices() && bytes <= (8ll << 30)) ? be_align_up(bytes, 256) : 0;
+}
+
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
                                                int parts, int homo) {
   const int64_t n_slices = n_slices_of(k, slice_shift, slice_width);
@@ -1504,7 +1652,7 @@ int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_b
   // rounding any layout applies to the width (h8 / homo u16: up to the next multiple of 4)
   const int64_t task = std::max<int64_t>(1ll << slice_shift, (width_of(slice_shift, slice_width) + 3) & ~3ll);
   return counts_bytes(n_batch) + n_batch * plan_active_stride(m) * 4 +
-         be_align_up(n_batch * n_slices * parts * task * acc_bytes, 256);
+         be_align_up(n_batch * n_slices * parts * task * acc_bytes, 256) + plan_dense_seg_bytes(m, n_slices, n_batch);
 }
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo) {
   return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, slice_width, parts, homo);
@@ -1576,15 +1724,29 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     if (spike_dtype == BE_SPIKE_BITS) fused = 1;
     else if (spike_dtype == BE_SPIKE_BOOL && (reinterpret_cast<uintptr_t>(spikes) & 15) == 0 && (n_batch == 1 || m % 16 == 0)) fused = 2;
   }
-  const uint32_t lds_cap = fused ? (uint32_t)std::min<size_t>(lds_room / 4, 32768) : 0u;
+  // short blocks: the segment-table gather dominates the step -> pre-gather it (k_gather_seg, FUSED = 3) instead of fusing
+  // the compaction (a workgroup that lists its own rows would have to gather its table entries itself)
+  static const int pre_max_block = [] { const char* e = getenv("BE_PLAN_PREGATHER_MAX"); return e ? atoi(e) : kPreGatherMaxBlock; }();
+  const int64_t dense_bytes = plan_dense_seg_bytes(m, n_slices, n_batch);
+  if (dense_bytes > 0 && block_hint > 0 && block_hint <= pre_max_block) fused = 3;
+  const uint32_t lds_cap = (fused == 1 || fused == 2) ? (uint32_t)std::min<size_t>(lds_room / 4, 32768) : 0u;
   const uint32_t list_off = (uint32_t)lds;
   const size_t lds_dyn = lds + (size_t)lds_cap * 4;
   const int64_t fused_stride = spike_dtype == BE_SPIKE_BITS ? ((m + 31) / 32) * 4 : m;       // bytes per batch row of spikes
-  const int64_t glob_region = fused_region_of(m, parts);
+  const int64_t glob_region = fused == 3 ? astride : fused_region_of(m, parts);
   ActiveList al{active, count};
-  if (!fused) {
+  if (fused == 0 || fused == 3) {
     int rc = be_resolve_active(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false, &al);
     if (rc != BE_OK) return rc;
+  }
+  const void* seg_used = seg;
+  if (fused == 3) {       // dense[slice][list position] behind the partial sums
+    uint2* dense = reinterpret_cast<uint2*>(static_cast<unsigned char*>(partial) +
+                                            be_align_up((int64_t)n_slices * parts * S * (homo ? 4 : 8), 256));
+    hipLaunchKernelGGL(k_gather_seg, dim3(512), dim3(256), 0, st, static_cast<const uint2*>(seg), al.ids, al.count, n_slices,
+                       astride, dense);
+    BE_LAUNCH_CHECK();
+    seg_used = dense;
   }
   const float scale = ldexpf(1.0f, scale_exp - 32);   // see fixed_from_f32
   const double inv_scale = ldexp(1.0, -scale_exp);
@@ -1597,12 +1759,13 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     auto kern__ = KERN;                                                                                        \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern__), (int)lds_dyn));                                 \
     hipLaunchKernelGGL(kern__, grid, block, lds_dyn, st, static_cast<const unsigned char*>(blob),              \
-                       static_cast<const uint2*>(seg), al.ids, al.count, __VA_ARGS__, BE_FUSED_ARGS);          \
+                       static_cast<const uint2*>(seg_used), al.ids, al.count, __VA_ARGS__, BE_FUSED_ARGS);     \
   } while (0)
 #define BE_PLAN_BY_FUSED(TMPL_A, TMPL_B, ...)                                                                 \
   do {                                                                                                         \
     if (fused == 1) BE_PLAN_LAUNCH((TMPL_A 1 TMPL_B), __VA_ARGS__);                                           \
     else if (fused == 2) BE_PLAN_LAUNCH((TMPL_A 2 TMPL_B), __VA_ARGS__);                                      \
+    else if (fused == 3) BE_PLAN_LAUNCH((TMPL_A 3 TMPL_B), __VA_ARGS__);                                      \
     else BE_PLAN_LAUNCH((TMPL_A 0 TMPL_B), __VA_ARGS__);                                                      \
   } while (0)
   if (layout == BE_PLAN_H8) {
@@ -1610,8 +1773,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   } else if (homo) {
     // short blocks: 4 lanes (<= 32 entries on average) or 16 lanes (<= 128) per block instead of a wave
     uint32_t* pp = static_cast<uint32_t*>(partial);
-    if (block_hint > 0 && block_hint <= 32) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 4 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
-    else if (block_hint > 0 && block_hint <= 128) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 16 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
+    if (block_hint > 0 && block_hint <= kSub4MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 4 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= kSub8MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 8 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= kSub16MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 16 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= kSub32MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 32 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
     else BE_PLAN_BY_FUSED(k_plan_accumulate<true COMMA 0 COMMA, >, n_slices, slice_shift, parts, scale, pp, astride, (int)S);
   } else if (layout == BE_PLAN_D8) {
     // short blocks: 8 lanes (<= 24 entries on average) or 16 lanes (<= 48) per block instead of a wave
@@ -1620,8 +1785,12 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     else if (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate_d8<16 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
     else BE_PLAN_BY_FUSED(k_plan_accumulate_d8<0 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
   } else {
-    BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 0 COMMA, >, n_slices, slice_shift, parts, scale,
-                     static_cast<unsigned long long*>(partial), astride, (int)S);
+    unsigned long long* pw = static_cast<unsigned long long*>(partial);
+    if (block_hint > 0 && block_hint <= kSubW4MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 4 COMMA, >, n_slices, slice_shift, parts, scale, pw, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= kSubW8MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 8 COMMA, >, n_slices, slice_shift, parts, scale, pw, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= kSubW16MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 16 COMMA, >, n_slices, slice_shift, parts, scale, pw, astride, (int)S);
+    else if (block_hint > 0 && block_hint <= kSubW32MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 32 COMMA, >, n_slices, slice_shift, parts, scale, pw, astride, (int)S);
+    else BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 0 COMMA, >, n_slices, slice_shift, parts, scale, pw, astride, (int)S);
   }
 #undef BE_PLAN_BY_FUSED
 #undef BE_PLAN_LAUNCH

@@ -223,8 +223,12 @@ int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indi
  *               round(w * 2^scale_exp) in a 64-bit integer (order independent, bitwise reproducible).  The largest
  *               column sum of |w| times 2^scale_exp must stay below 2^62 (a row may list a column several times, so
  *               "rows x max|w|" is NOT a bound); sums that exceed it wrap silently.
- *   block_hint : average entries per (row, slice) block of the plan, or 0 (unknown).  A speed hint only: short blocks
- *               (<= 48 entries, BE_PLAN_D8) are decoded by a quarter wave each instead of a wave each.
+ *   block_hint : average stored items per (row, slice) block of the plan — nnz / (m * slices); for BE_PLAN_D8 the
+ *               entries plus its escape items, i.e. 4 x the average of the table's lane-group counts — or 0 (unknown).
+ *               A speed hint only, never a correctness input: short blocks are decoded by 4, 8 or 16 lanes each instead
+ *               of a wave each (the variant whose single pass holds the average + 3 sigma of a Poisson length; longer
+ *               blocks finish in a serial tail), and with >= 40 slices of blocks <= 64 items the step first gathers the
+ *               active rows' table entries into the workspace (two small launches more).
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
  *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) bytes.
  *               Its first 4 * n_batch bytes (the spike counters) must be ZERO on entry; they are zero again when the

@@ -237,7 +237,9 @@ def test_scatter_plan_auto_geometry():
     assert geo(1_000_000, 125_000, 1250, False) == (D8, 12) and geo(1_000_000, 125_000, 1250, True) == (U16, 12)
     # short rows: h8 has nothing to gain (blocks of a line or two)
     assert geo(1_000_000, 1_000_000, 1000, True) == (U16, 32)
-    assert geo(1_000_000, 1_000_000, 1000, False) == (D8, 51)
+    # ... and d8 would spend most of its items on escapes (column gaps of ~1000): uint16 columns, 8 lanes per block
+    assert geo(1_000_000, 1_000_000, 1000, False) == (U16, 64)
+    assert geo(350_000, 350_000, 1000, False) == (U16, 25) and geo(200_000, 200_000, 1000, False) == (U16, 25)
     assert geo(300_000, 300_000, 3000, True)[0] == U16
     # one slice, <= 1M entries: the single-launch kernel (d8 reaches 20000 columns), counted entries stay u16
     assert geo(4000, 4000, 80, False) == (D8, 1) and geo(4000, 18000, 80, False) == (D8, 1)

@@ -10,6 +10,7 @@ from brainevent_amd import _array as A
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev); g.manual_seed(0)
 K = int(os.environ.get('BE_EXP_K', 1000))
+PARTS = int(os.environ['BE_EXP_PARTS']) if os.environ.get('BE_EXP_PARTS') else None
 for n in [int(x) for x in os.environ.get('BE_EXP_NS', '100000,200000,350000,500000,1000000,1500000,2500000').split(',')]:
     idx = torch.randint(0, n, (n, K), dtype=torch.int32, device=dev, generator=g)
     spikes = [(torch.rand(n, device=dev, generator=g) < 0.01).to(torch.uint8) for _ in range(10)]
@@ -20,15 +21,17 @@ for n in [int(x) for x in os.environ.get('BE_EXP_NS', '100000,200000,350000,5000
         for layout in [l for l in ('u16', 'h8' if homo else 'd8', None) if str(l) in os.environ.get('BE_EXP_LAYOUTS', 'u16,d8,h8,None').split(',')]:
             width = 0 if layout is None else int(os.environ.get('BE_EXP_WIDTH16' if layout == 'u16' else 'BE_EXP_WIDTH', 0))
             plan = C.ScatterPlan.build(w, idx.reshape(-1), None, shape=(n, n), row_len=K, layout=layout, slice_width=width or None)
+            if os.environ.get('BE_EXP_HINT'):
+                plan.block_hint_override = int(os.environ['BE_EXP_HINT'])
             for i in range(5):
-                C._plan_call(plan, w, spikes[i], A.BE_SPIKE_BOOL, out)
+                C._plan_call(plan, w, spikes[i], A.BE_SPIKE_BOOL, out, parts=PARTS)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(40):
-                C._plan_call(plan, w, spikes[i % 10], A.BE_SPIKE_BOOL, out)
+                C._plan_call(plan, w, spikes[i % 10], A.BE_SPIKE_BOOL, out, parts=PARTS)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 40
-            res.append(f'{layout or "auto=" + ("u16", "d8", "h8")[plan.layout]} {plan.n_slices}x{plan.default_parts()} ({K / plan.n_slices:.0f}/block) {dt*1e6:.0f} us')
+            res.append(f'{layout or "auto=" + ("u16", "d8", "h8")[plan.layout]} {plan.n_slices}x{PARTS or plan.default_parts()} ({K / plan.n_slices:.0f}/block) {dt*1e6:.0f} us')
             del plan
             torch.cuda.empty_cache()
         print(f'N={n} K={K} {"homo" if homo else "hetero"}: ' + ' | '.join(res), flush=True)

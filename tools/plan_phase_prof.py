@@ -16,6 +16,8 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 idx = torch.randint(0, n, (n, K), dtype=torch.int32, device=dev, generator=g)
 w = torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
 plan = C.ScatterPlan.build(w, idx.reshape(-1), None, shape=(n, n), row_len=K)
+if os.environ.get('BE_PLAN_SEGT') == '1':      # experiment: slice-major segment table
+    plan.seg = plan.seg.view(n, plan.n_slices, 2).permute(1, 0, 2).contiguous().view(-1)
 spikes = [(torch.rand(n, device=dev, generator=g) < 0.01).to(torch.uint8) for _ in range(4)]
 out = torch.empty(n, dtype=torch.float32, device=dev)
 for i in range(5):
