@@ -533,11 +533,27 @@ def run_scatter(args):
             dist.broadcast_object_list(box, src=0)
             ok = 0.0
             if box[0] is not None:
-                try:
-                    exchange = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
-                    ok = 1.0
-                except Exception as e:
-                    print(f'[bench] rank {rank}: be_exchange_init failed ({e!r})', file=sys.stderr, flush=True)
+                # ncclCommInitRank blocks until every rank has joined: run it beside a watchdog so that a rendezvous that
+                # never completes (it has only ever been run with one rank) ends in the torch.distributed exchange
+                # instead of a hung job
+                import threading
+                res = {}
+
+                def _init():
+                    try:
+                        torch.cuda.set_device(dev)      # the current HIP device is per thread
+                        res['ex'] = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
+                    except Exception as e:          # noqa: BLE001 - reported below, every rank then falls back together
+                        res['err'] = e
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get('BENCH_NATIVE_INIT_TIMEOUT', 90)))
+                if th.is_alive():
+                    print(f'[bench] rank {rank}: be_exchange_init did not return in time', file=sys.stderr, flush=True)
+                elif 'ex' in res:
+                    exchange, ok = res['ex'], 1.0
+                else:
+                    print(f'[bench] rank {rank}: be_exchange_init failed ({res.get("err")!r})', file=sys.stderr, flush=True)
             flag = torch.tensor([ok], dtype=torch.float64, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
             if flag.item() < 1.0:
