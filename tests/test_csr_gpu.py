@@ -579,9 +579,10 @@ def test_h8_layout_randomized(be, oracle, seed):
 
 @pytest.mark.parametrize('k', [900, 30000, 120000])
 def test_d8_quarter_wave_kernel_equals_full_wave(be, oracle, k):
-    """The d8 step kernel has two decoders — a wave per block, and a quarter wave per block for plans of short blocks
-    (``block_hint`` <= 48) — over the same blob.  Same bits from both on rows of 0 ... 5000 entries (blocks from empty to
-    many 16-lane passes), vectors and batches; the hint only selects the kernel."""
+    """The d8 step kernel has three decoders — a wave per block, and 16 or 8 lanes per block for plans of short blocks
+    (``block_hint`` <= 43 / <= 18) — over the same blob.  Same bits from all on rows of 0 ... 5000 entries (blocks from empty
+    to many passes: the sub-wave decoders finish long blocks in their serial tail), vectors and batches; the hint only
+    selects the kernel."""
     from brainevent_amd._csr import ScatterPlan
     rng = np.random.default_rng(k)
     m = 700
@@ -594,7 +595,7 @@ def test_d8_quarter_wave_kernel_equals_full_wave(be, oracle, k):
     vs = [np.random.default_rng(s).random(m) < f for s, f in ((1, 0.05), (2, 0.6), (3, 1.1), (4, -1.0))]
     B = np.stack([np.random.default_rng(9).random(m) < 0.3 for _ in range(3)], axis=1)
     ref = None
-    for hint in (1, 24, 25, 48, 49, 100000):          # 8 lanes, 16 lanes, a wave per block
+    for hint in (1, 18, 19, 43, 44, 100000):          # 8 lanes, 16 lanes, a wave per block
         plan.block_hint_override = hint
         got = [np.asarray(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)) for v in vs]
         got.append(np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)))
@@ -609,8 +610,8 @@ def test_d8_quarter_wave_kernel_equals_full_wave(be, oracle, k):
 
 @pytest.mark.parametrize('k', [50000, 200000])
 def test_counted_sub_wave_decoders_equal_full_wave(be, oracle, k):
-    """Counted entries (one shared weight, uint16 layout): 4 or 16 lanes per block for plans of short blocks, a wave per
-    block otherwise — the hint only selects the decoder; rows of 0 ... 5000 entries, vectors and batches."""
+    """Counted entries (one shared weight, uint16 layout): 4, 8, 16 or 32 lanes per block for plans of short blocks, a wave
+    per block otherwise — the hint only selects the decoder; rows of 0 ... 5000 entries, vectors and batches."""
     from brainevent_amd._csr import ScatterPlan
     rng = np.random.default_rng(k + 1)
     m = 700
@@ -622,7 +623,7 @@ def test_counted_sub_wave_decoders_equal_full_wave(be, oracle, k):
     vs = [np.random.default_rng(s).random(m) < f for s, f in ((1, 0.05), (2, 0.6), (3, 1.1), (4, -1.0))]
     B = np.stack([np.random.default_rng(9).random(m) < 0.3 for _ in range(3)], axis=1)
     ref = None
-    for hint in (1, 32, 33, 128, 129, 100000):
+    for hint in (1, 18, 19, 43, 44, 96, 97, 210, 211, 100000):
         plan.block_hint_override = hint
         got = [np.asarray(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)) for v in vs]
         got.append(np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)))
@@ -633,6 +634,65 @@ def test_counted_sub_wave_decoders_equal_full_wave(be, oracle, k):
         else:
             for a, b in zip(ref, got):
                 np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('k,width', [(50000, None), (200000, None), (60000, 1000)])
+def test_weighted_sub_wave_decoders_equal_full_wave(be, oracle, k, width):
+    """Weighted entries in the uint16 layout: 4, 8, 16 or 32 lanes per block for plans of short blocks (long blocks finish in
+    the serial tail), a wave per block otherwise.  With 60 slices (``width`` 1000) and a hint <= 64 the step also runs on the
+    pre-gathered segment table (``k_gather_seg``).  Fixed-point sums: every variant returns the same bits."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(k + 2)
+    m = 900
+    lens = np.where(rng.random(m) < 0.1, rng.integers(200, 5000, m), rng.integers(0, 40, m))
+    lens[::17] = 0
+    w, idx, ptr = rand_csr(rng, m, k, lens)
+    w = rng.normal(0, 1, w.shape).astype(np.float32)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='u16', slice_width=width)
+    assert plan.n_slices > 1 and (width is None or plan.n_slices >= 40)
+    vs = [np.random.default_rng(s).random(m) < f for s, f in ((1, 0.05), (2, 0.6), (3, 1.1), (4, -1.0))]
+    vs.append(np.where(vs[1], 2.5, 0.0).astype(np.float32))          # float spikes: compacted list, not the fused step
+    B = np.stack([np.random.default_rng(9).random(m) < 0.3 for _ in range(3)], axis=1)
+    ref = None
+    for hint in (100000, 1, 7, 8, 18, 19, 43, 44, 64, 65, 96, 97):
+        plan.block_hint_override = hint
+        got = [np.asarray(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan)) for v in vs]
+        got.append(np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=plan)))
+        if ref is None:
+            ref = got
+            for v, g in zip(vs, got):
+                np.testing.assert_allclose(g, oracle.binary_csrmv(w, idx, ptr, v > 0, (m, k), True), rtol=1e-5, atol=1e-5)
+        else:
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+
+
+def test_pre_gathered_segment_table_counted_and_packed(be, oracle):
+    """>= 40 slices of short blocks: the active rows' segment entries are gathered into the workspace first (FUSED = 3).
+    Counted entries, every spike encoding (bool, float, bit-packed events), part counts that do and do not divide the list."""
+    from brainevent_amd._csr import ScatterPlan, _plan_call
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(77)
+    m, k = 3000, 48000
+    lens = rng.integers(0, 300, m)
+    w, idx, ptr = rand_csr(rng, m, k, lens, homo=True)
+    plan = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), layout='u16', slice_width=800)
+    assert plan.n_slices == 60 and plan.block_hint <= 64
+    for fire in (0.0, 0.01, 0.3, 1.0):
+        v = rng.random(m) < fire
+        ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), True)
+        np.testing.assert_array_equal(be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=plan), ref)
+        np.testing.assert_array_equal(be.binary_csrmv(w, idx, ptr, np.where(v, 0.5, -1.0).astype(np.float32), shape=(m, k),
+                                                      transpose=True, workspace=plan), ref)
+        for parts in (1, 3, 4, 7):
+            sp, sd = A.spikes_to_device(v)
+            out = torch.empty(k, dtype=torch.float32, device='cuda')
+            _plan_call(plan, A.to_device(w), sp, sd, out, parts=parts)
+            np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        csr = be.CSR((w, idx, ptr), shape=(m, k))
+        csr.buffers['scatter_plan'] = plan
+        got = be.BitPackedBinary(v) @ csr
+        np.testing.assert_array_equal(got.cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got), ref)
 
 
 def test_d8_layout_falls_back_when_it_does_not_apply(be):
