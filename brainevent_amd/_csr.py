@@ -94,11 +94,14 @@ class ScatterPlan:
         return ScatterPlan.balanced_width_cap(k, 1 << slice_shift)
 
     @staticmethod
-    def balanced_width_cap(k: int, cap: int) -> int:
+    def balanced_width_cap(k: int, cap: int, short_blocks: bool = False) -> int:
         """:meth:`balanced_width` for an accumulator capacity of ``cap`` columns (the d8 layout is not tied to powers of
-        two: 20000 eight-byte accumulators fill the LDS, k = 1M -> 51 slices of 19608 x 5 parts)."""
+        two: 20000 eight-byte accumulators fill the LDS, k = 1M -> 51 slices of 19608 x 5 parts).  ``short_blocks``: the
+        step pays per block, not per byte — as few slices as the capacity allows (a multiple of 8, one per XCD) instead of
+        a count that fills every CU (N = 1.5M, K = 1000 weighted: 128 x 2 parts 82 us, 96 x 2 71 us; N = 2.5M: 256 x 1
+        198 us, 160 x 1 158 us)."""
         n_min = (int(k) + cap - 1) // cap
-        if n_min >= 256:
+        if n_min >= 256 or (short_blocks and n_min > 8):
             n = (n_min + 7) // 8 * 8
         else:
             parts = max(1, 256 // n_min)
@@ -169,7 +172,8 @@ class ScatterPlan:
         target = max(1, int(round(cls.TARGET_SLICES * min(1.0, int(k) / max(m_rows, 1.0)) ** (1.0 / 3.0))))
         n_need = max(1, int(math.ceil(row / (0.82 * (cls.HOMO_PASS if homo else cls.HETERO_PASS)))),
                      min(target, int(row // cls.TARGET_MIN_BLOCK)))
-        return cls.balanced_width_cap(k, max(16, min(cap, -(-int(k) // n_need))))
+        cap_w = max(16, min(cap, -(-int(k) // n_need)))
+        return cls.balanced_width_cap(k, cap_w, short_blocks=row / -(-int(k) // cap_w) < cls.TARGET_MIN_BLOCK)
 
     @classmethod
     def auto_geometry(cls, m: int, k: int, nnz: int, homo: bool, slice_shift: int, delta_ok: bool = True,
@@ -407,9 +411,9 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
     """``'plan'``, ``'binned'`` or ``'direct'`` for a matrix of ``nse`` entries, ``m`` stored rows and ``k`` outputs.
 
     Measured on FixedNumPerPre K = 1000, 1 % firing (``tools/exp_plan_vs_binned.py``; entries per (row, slice) -> planned vs
-    binned, us/step): homo 62: 33 / 66, 31: 48 / 74, 20: 81 / 93, 16: 122 / 109, 8: 310 / 137; hetero 40: 40 / 69,
-    20: 82 / 99, 12: 165 / 123, 8: 295 / 153.  The planned layout pays per block, the binned route per entry: they cross
-    at about 18 entries per block."""
+    binned, us/step): homo 20: 51 / 87, 12: 87 / 119, 8: 169 / 148, 4: 845 / 198; hetero 16: 45 / 90, 10: 71 / 105,
+    6: 158 / 162, 4: 306 / 236.  The planned layout pays per block (and 128 bytes of memory per block), the binned route per
+    entry: they cross at 6-10 entries per block (round 1, before blocks were decoded by part of a wave each: 18)."""
     if nse < PLAN_MIN_NNZ or m <= 0 or k <= 0:
         return 'direct'
     homo = weights.numel() == 1
@@ -418,7 +422,7 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
         nse = 2 * nse                     # stored as two f32 entries each (_split_f64)
     n_slices = -(-k // ScatterPlan.auto_geometry(m, k, nse, homo, shift)[1])
     per_block = nse / (m * n_slices)
-    if n_slices <= 4096 and per_block >= PLAN_MIN_SEGMENT:
+    if n_slices <= 4096 and per_block >= (PLAN_MIN_SEGMENT_HOMO if homo else PLAN_MIN_SEGMENT):
         return 'plan'
     if BinnedScatter.applicable(weights, k):
         return 'binned'
@@ -759,7 +763,8 @@ binary_csrmm_indexed_p.def_tags('csr', 'binary', 'indexed')
 #: matrices with fewer stored elements than this use the direct kernel (plan build is not worth it)
 PLAN_MIN_NNZ = 1 << 15          # below this the direct kernel is used (nothing to gain from a layout)
 #: below this average number of entries per (row, slice) segment the plan degenerates into pointer chasing
-PLAN_MIN_SEGMENT = 18       # entries per (row, slice) from which the planned layout beats the binned route (measured: choose_scatter_route)
+PLAN_MIN_SEGMENT = 8        # entries per (row, slice) from which the planned layout beats the binned route (measured: choose_scatter_route)
+PLAN_MIN_SEGMENT_HOMO = 10  # ... for one shared weight (the binned route moves 2 B per counted entry)
 PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply
 
 

@@ -240,6 +240,14 @@ def test_scatter_plan_auto_geometry():
     # ... and d8 would spend most of its items on escapes (column gaps of ~1000): uint16 columns, 8 lanes per block
     assert geo(1_000_000, 1_000_000, 1000, False) == (U16, 64)
     assert geo(350_000, 350_000, 1000, False) == (U16, 25) and geo(200_000, 200_000, 1000, False) == (U16, 25)
+    # short blocks pay per block: as few slices as the LDS capacity allows (a multiple of 8), not a CU-filling count
+    assert geo(1_500_000, 1_500_000, 1000, False) == (U16, 96) and geo(2_500_000, 2_500_000, 1000, True) == (U16, 80)
+    # ... and below 8 (weighted) / 10 (counted) entries per block the binned route takes over
+    import torch
+    from brainevent_amd._csr import choose_scatter_route as route
+    w1, wn = torch.ones(1), torch.ones(2)
+    assert route(1_500_000 * 1000, 1_500_000, 1_500_000, wn) == 'plan' and route(2_500_000 * 1000, 2_500_000, 2_500_000, wn) == 'binned'
+    assert route(2_500_000 * 1000, 2_500_000, 2_500_000, w1) == 'plan' and route(4_000_000 * 1000, 4_000_000, 4_000_000, w1) == 'binned'
     assert geo(300_000, 300_000, 3000, True)[0] == U16
     # one slice, <= 1M entries: the single-launch kernel (d8 reaches 20000 columns), counted entries stay u16
     assert geo(4000, 4000, 80, False) == (D8, 1) and geo(4000, 18000, 80, False) == (D8, 1)

@@ -17,7 +17,7 @@ for n in [int(x) for x in os.environ.get('BE_EXP_NS', '500000,1000000,1500000').
     for homo in ((True,) if os.environ.get('BE_EXP_HOMO_ONLY') else (True, False)):
         w = torch.ones(1, device=dev) if homo else torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
         for seg_min in (1, 1000):
-            C.PLAN_MIN_SEGMENT = seg_min
+            C.PLAN_MIN_SEGMENT = C.PLAN_MIN_SEGMENT_HOMO = seg_min
             conn = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False).prepare()
             for i in range(5):
                 out = be.BinaryArray(spikes[i]) @ conn
