@@ -315,6 +315,87 @@ __global__ void __launch_bounds__(256) k_gather_seg(const uint2* __restrict__ se
   }
 }
 
+// activity bits of rows [16 g, 16 g + 16) (bit-packed words or 1-byte spikes)
+template <int FUSED>
+__device__ __forceinline__ uint32_t fused_half(const void* __restrict__ spikes, int64_t g, int64_t m) {
+  uint32_t w = 0;
+  if (FUSED == 1) {
+    w = (static_cast<const uint32_t*>(spikes)[g >> 1] >> ((uint32_t)(g & 1) * 16u)) & 0xffffu;
+  } else {
+    const uint8_t* sp = static_cast<const uint8_t*>(spikes) + g * 16;
+    if (g * 16 + 16 <= m) {
+      const uint4 a = reinterpret_cast<const uint4*>(sp)[0];
+      const uint32_t v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (((v[q] >> (8 * e)) & 0xffu) != 0u ? 1u : 0u) << (4 * q + e);
+    } else {
+      for (int e = 0; e < 16 && g * 16 + e < m; ++e) w |= (sp[e] != 0 ? 1u : 0u) << e;
+    }
+  }
+  const int64_t left = m - g * 16;
+  return left >= 16 ? w : (left > 0 ? (w & ((1u << (uint32_t)left) - 1u)) : 0u);
+}
+
+// Compaction and gather in one launch (bit-packed or 1-byte spikes): a workgroup scans 4096 rows, reserves its range of list
+// positions with one atomic — any order of the positions gives the same sums: the accumulators are integers — and gathers its
+// own rows' table entries straight from the ids it holds in LDS; the id list itself never reaches memory.
+template <int FUSED>
+__global__ void __launch_bounds__(256) k_compact_gather_seg(const void* __restrict__ spikes, int64_t m,
+                                                            const uint2* __restrict__ seg, int n_slices, int64_t a_stride,
+                                                            uint2* __restrict__ dense, uint32_t* __restrict__ count) {
+  __shared__ uint2 tile[64][65];
+  __shared__ uint32_t ids_s[4096];
+  __shared__ uint32_t wtot[4], s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_groups = (m + 15) >> 4;
+  const int64_t gw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t w = gw < n_groups ? fused_half<FUSED>(spikes, gw, m) : 0u;
+  const uint32_t v = __popc(w);
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < wave) wave_off += wtot[q];
+    total += wtot[q];
+  }
+  if (total == 0) return;                                   // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(count, total);
+  uint32_t pos = wave_off + incl - v;
+  while (w) {
+    const uint32_t b = __ffs(w) - 1u;
+    ids_s[pos++] = (uint32_t)(gw * 16) + b;
+    w &= w - 1u;
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+    const uint32_t n_here = total - c0 < 64u ? total - c0 : 64u;
+    const uint32_t i_mine = (uint32_t)wave * 16u + (uint32_t)(lane & 15);
+    const uint32_t rid = ids_s[c0 + (i_mine < n_here ? i_mine : 0u)];
+    for (int s0 = 0; s0 < n_slices; s0 += 64) {
+      const int sl = s0 + lane < n_slices ? s0 + lane : n_slices - 1;
+      uint2 x[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = seg[(uint64_t)__builtin_amdgcn_readlane((int)rid, j) * n_slices + sl];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tile[wave * 16 + j][lane] = x[j];
+      __syncthreads();
+      for (int s = wave; s < 64 && s0 + s < n_slices; s += 4)
+        if ((uint32_t)lane < n_here) dense[(int64_t)(s0 + s) * a_stride + base + c0 + lane] = tile[lane][s];
+      __syncthreads();
+    }
+  }
+}
+
 // =================================================================================================
 // planned scatter step
 // =================================================================================================
@@ -1735,7 +1816,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   const int64_t fused_stride = spike_dtype == BE_SPIKE_BITS ? ((m + 31) / 32) * 4 : m;       // bytes per batch row of spikes
   const int64_t glob_region = fused == 3 ? astride : fused_region_of(m, parts);
   ActiveList al{active, count};
-  if (fused == 0 || fused == 3) {
+  // fused == 3: bit-packed / aligned 1-byte spikes are compacted by the gather launch itself
+  const int pre_mode = fused != 3 ? 0 : (spike_dtype == BE_SPIKE_BITS ? 1 :
+                       (spike_dtype == BE_SPIKE_BOOL && (reinterpret_cast<uintptr_t>(spikes) & 15) == 0) ? 2 : 0);
+  if (fused == 0 || (fused == 3 && pre_mode == 0)) {
     int rc = be_resolve_active(spikes, spike_dtype, m, n_batch, active, astride, count, st, /*zero_first=*/false, &al);
     if (rc != BE_OK) return rc;
   }
@@ -1743,8 +1827,16 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   if (fused == 3) {       // dense[slice][list position] behind the partial sums
     uint2* dense = reinterpret_cast<uint2*>(static_cast<unsigned char*>(partial) +
                                             be_align_up((int64_t)n_slices * parts * S * (homo ? 4 : 8), 256));
-    hipLaunchKernelGGL(k_gather_seg, dim3(512), dim3(256), 0, st, static_cast<const uint2*>(seg), al.ids, al.count, n_slices,
-                       astride, dense);
+    const unsigned cg_grid = (unsigned)(((m + 15) / 16 + 255) / 256);
+    if (pre_mode == 1)
+      hipLaunchKernelGGL(k_compact_gather_seg<1>, dim3(cg_grid), dim3(256), 0, st, spikes, m, static_cast<const uint2*>(seg), n_slices,
+                         astride, dense, count);
+    else if (pre_mode == 2)
+      hipLaunchKernelGGL(k_compact_gather_seg<2>, dim3(cg_grid), dim3(256), 0, st, spikes, m, static_cast<const uint2*>(seg), n_slices,
+                         astride, dense, count);
+    else
+      hipLaunchKernelGGL(k_gather_seg, dim3(512), dim3(256), 0, st, static_cast<const uint2*>(seg), al.ids, al.count, n_slices,
+                         astride, dense);
     BE_LAUNCH_CHECK();
     seg_used = dense;
   }
