@@ -697,6 +697,9 @@ def run_scatter(args):
 
 def main():
     args = parse()
+    if os.environ.get('BENCH_FAULT_TIMEOUT'):        # rehearsals: where is every rank if the run has not finished by then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['BENCH_FAULT_TIMEOUT']), exit=False, file=sys.stderr)
     line = run_scatter(args)
     if line is not None and line.get('secondary') == 'pending':
         torch.cuda.synchronize()
