@@ -789,6 +789,12 @@ def test_d8_layout_randomized_against_oracle_and_u16(be, oracle, seed):
     assert plan.layout == ScatterPlan.LAYOUT_D8
     w16 = None if width is None else min(width, cap)
     plan16 = ScatterPlan.build(w, idx, torch.tensor(ptr), shape=(m, k), slice_shift=shift, slice_width=w16, layout='u16')
+    # the speed hint picks the decoder (lanes per block, serial tails for longer blocks, pre-gathered segment table with
+    # >= 40 slices): any value has to give the same bits
+    for p_ in (plan, plan16):
+        h = [None, 1, 10, 30, 60, 100000][int(rng.integers(0, 6))]
+        if h is not None:
+            p_.block_hint_override = h
     tol = 1e-5 if dtype == np.float32 else 2e-2
     for fire in (0.05, 0.5, 1.0):
         v = rng.random(m) < fire
