@@ -466,7 +466,10 @@ typedef short be_v8s __attribute__((ext_vector_type(8)));
 typedef short be_v4s __attribute__((__vector_size__(4 * sizeof(short))));
 typedef float be_v16f __attribute__((ext_vector_type(16)));
 
-constexpr int kMfmaCols = 256;                       // columns per workgroup
+#ifndef BE_MFMA_COLS
+#define BE_MFMA_COLS 256
+#endif
+constexpr int kMfmaCols = BE_MFMA_COLS;              // columns per workgroup (256 or 512): a tile row is 512 B / 1 KB of one weight row
 constexpr int kMfmaRowBytes = kMfmaCols * 2 + 64;    // LDS row stride (padded)
 constexpr int kMfmaTileBytes = 16 * kMfmaRowBytes;   // one K-step tile
 
@@ -492,7 +495,10 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
                                                       const uint32_t* __restrict__ mask, const uint32_t* __restrict__ ulist,
                                                       const uint32_t* __restrict__ ucount, float* __restrict__ partial) {
   __shared__ __align__(16) unsigned char tile[2][kMfmaTileBytes];
-  constexpr int D = 4;     // K-steps of weight rows in flight per thread (register ring); even
+#ifndef BE_MFMA_D
+#define BE_MFMA_D 4
+#endif
+  constexpr int D = BE_MFMA_D;     // K-steps of weight rows in flight per thread (register ring); even
   // D extra all-zero steps behind every chunk: the ring runs past the chunk end without any branch
   __shared__ uint32_t rows_s[(kMfmaChunk + D) * 16];
   __shared__ uint32_t masks_s[(kMfmaChunk + D) * 16];
@@ -506,17 +512,21 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 
   // staging role: thread loads 16-B chunk `ch` of tile rows `r0` and `r0 + 8`.  Loads are unconditional
   // (clamped address, result zeroed by a select) so that hipcc keeps counted vmcnt waits across the ring.
-  const int ch = tid & 31, r0 = tid >> 5;
+  constexpr int CPR = kMfmaCols / 8;                   // 16-byte chunks per tile row
+  constexpr int NLD = 16 * CPR / 256;                 // loads per thread and step (2 or 4): tile rows r0, r0 + RSTEP, ...
+  constexpr int RSTEP = 256 / CPR;
+  constexpr int NB = kMfmaCols / 128;                 // 32-column accumulator blocks per wave
+  const int ch = tid % CPR, r0 = tid / CPR;
   const bool col_ok = col0 + (int64_t)ch * 8 < n;     // n % 8 == 0: a chunk is all-in or all-out
   const W* wcol = weights + (col_ok ? col0 + (int64_t)ch * 8 : 0);
 
   // MFMA role
   const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pq = gi & 3;
   const int b_row = lane & 31, h = lane >> 5;
-  const int tr_off = ((grp >> 1) * 8 + q) * kMfmaRowBytes + (wave * 64 + (grp & 1) * 16 + 4 * pq) * 2;
+  const int tr_off = ((grp >> 1) * 8 + q) * kMfmaRowBytes + (wave * (kMfmaCols / 4) + (grp & 1) * 16 + 4 * pq) * 2;
 
-  be_v16f acc0 = {}, acc1 = {};
-  uint4 ra[D], rb[D];
+  be_v16f acc[NB] = {};
+  uint4 rr[D][NLD];
   uint32_t rk[D];
 
   for (uint32_t c0 = t_begin; c0 < t_end; c0 += kMfmaChunk) {
@@ -533,22 +543,26 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 
     // fetch only issues the loads (nothing may consume a loaded register here, or the wait lands right
     // behind the load); padded rows / columns are turned into exact zeros when the slot is stashed
-    auto fetch = [&](uint32_t t, uint4& a, uint4& b, uint32_t& ok) {     // steps past c_end are zero steps
+    auto fetch = [&](uint32_t t, uint4 (&r)[NLD], uint32_t& ok) {     // steps past c_end are zero steps
       const uint32_t s = (t - c0) < (uint32_t)(kMfmaChunk + D - 1) ? (t - c0) : (uint32_t)(kMfmaChunk + D - 1);
-      a = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[s * 16 + r0] * n);
-      b = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[s * 16 + r0 + 8] * n);
-      ok = (col_ok && masks_s[s * 16 + r0] != 0u ? 1u : 0u) | (col_ok && masks_s[s * 16 + r0 + 8] != 0u ? 2u : 0u);
+      ok = 0u;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        r[u] = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[s * 16 + r0 + u * RSTEP] * n);
+        ok |= (col_ok && masks_s[s * 16 + r0 + u * RSTEP] != 0u ? 1u : 0u) << u;
+      }
     };
-    auto stash = [&](int buf, const uint4& a, const uint4& b, uint32_t ok) {        // registers -> LDS
-      *reinterpret_cast<uint4*>(&tile[buf][r0 * kMfmaRowBytes + ch * 16]) = (ok & 1u) ? a : make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(&tile[buf][(r0 + 8) * kMfmaRowBytes + ch * 16]) = (ok & 2u) ? b : make_uint4(0, 0, 0, 0);
+    auto stash = [&](int buf, const uint4 (&r)[NLD], uint32_t ok) {        // registers -> LDS
+#pragma unroll
+      for (int u = 0; u < NLD; ++u)
+        *reinterpret_cast<uint4*>(&tile[buf][(r0 + u * RSTEP) * kMfmaRowBytes + ch * 16]) = ((ok >> u) & 1u) ? r[u] : make_uint4(0, 0, 0, 0);
     };
 
     // prologue: step c0 -> LDS[0]; steps c0+1 .. c0+D -> ring slots 1 .. D-1, 0
-    fetch(c0, ra[0], rb[0], rk[0]);
-    stash(0, ra[0], rb[0], rk[0]);
+    fetch(c0, rr[0], rk[0]);
+    stash(0, rr[0], rk[0]);
 #pragma unroll
-    for (int s = 1; s <= D; ++s) fetch(c0 + s, ra[s % D], rb[s % D], rk[s % D]);
+    for (int s = 1; s <= D; ++s) fetch(c0 + s, rr[s % D], rk[s % D]);
     lds_barrier();
     for (uint32_t t0 = c0; t0 < c_end; t0 += D) {
 #pragma unroll
@@ -564,17 +578,16 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
           // B operands through the hardware transpose read (all 64 lanes active here: EXEC is full)
           const unsigned char* tb = &tile[buf][0] + tr_off;
           typedef __attribute__((address_space(3))) be_v4s* lds_v4s;
-          const be_v4s b0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb));
-          const be_v4s b0hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 4 * kMfmaRowBytes));
-          const be_v4s b1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 64));
-          const be_v4s b1hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 64 + 4 * kMfmaRowBytes));
-          const be_v8s b0 = {b0lo[0], b0lo[1], b0lo[2], b0lo[3], b0hi[0], b0hi[1], b0hi[2], b0hi[3]};
-          const be_v8s b1 = {b1lo[0], b1lo[1], b1lo[2], b1lo[3], b1hi[0], b1hi[1], b1hi[2], b1hi[3]};
-          acc0 = mfma_32x32x16<W>(a, b0, acc0);
-          acc1 = mfma_32x32x16<W>(a, b1, acc1);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const be_v4s blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 64 * j));
+            const be_v4s bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 64 * j + 4 * kMfmaRowBytes));
+            const be_v8s b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+            acc[j] = mfma_32x32x16<W>(a, b, acc[j]);
+          }
           // next step's rows go to the other LDS buffer; their ring slot is refilled D steps ahead
-          stash(buf ^ 1, ra[(ii + 1) % D], rb[(ii + 1) % D], rk[(ii + 1) % D]);
-          fetch(t + 1 + D, ra[(ii + 1) % D], rb[(ii + 1) % D], rk[(ii + 1) % D]);
+          stash(buf ^ 1, rr[(ii + 1) % D], rk[(ii + 1) % D]);
+          fetch(t + 1 + D, rr[(ii + 1) % D], rk[(ii + 1) % D]);
           lds_barrier();
         }
       }
@@ -585,9 +598,10 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int64_t c0 = col0 + wave * 64 + (lane & 31);
-    if (c0 < n) pbase[(int64_t)row * n + c0] = acc0[r];
-    if (c0 + 32 < n) pbase[(int64_t)row * n + c0 + 32] = acc1[r];
+    const int64_t c0 = col0 + wave * (kMfmaCols / 4) + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (c0 + 32 * j < n) pbase[(int64_t)row * n + c0 + 32 * j] = acc[j][r];
   }
 }
 
