@@ -230,7 +230,9 @@ int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indi
  *               blocks finish in a serial tail), and with >= 40 slices of blocks <= 64 items the step first gathers the
  *               active rows' table entries into the workspace (two small launches more).
  *   parts : number of workgroups that share one slice (each takes 1/parts of the active rows)
- *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) bytes.
+ *   workspace : >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) bytes
+ *               (spike counters + active-row list + partial sums; for a single vector and >= 40 slices also room for the
+ *               pre-gathered segment table, 8 B x m x slices, up to 8 GiB).
  *               Its first 4 * n_batch bytes (the spike counters) must be ZERO on entry; they are zero again when the
  *               call has completed, so a workspace zero-filled once can be reused for every step.
  */
