@@ -21,6 +21,7 @@ from ._dense import (Dense, binary_densemv, binary_densemm, binary_densemv_p, bi
 from ._convert import (csr_to_coo_index, coo_to_csc_index, coo2csr, csr_to_csc_index, csc_to_csr_index,
                        fixed_conn_num_csr_indptr, fixed_conn_num_csc_structure, fixed_conn_num_to_csc)
 from ._graph import GraphedStep, capture_step
+from ._neuron import lif_coba_step
 from ._op import OpKernel
 XLACustomKernel = OpKernel      # the operator object under the reference's name (no XLA underneath)
 from ._data import DataRepresentation

@@ -1,0 +1,39 @@
+"""The neuron half of the COBA step loop: one fused, in-place state update of a population of
+conductance-based LIF neurons with exponential synapses (``be_lif_coba_step``), to sit between the two ``spikes @ CSR``
+scatters of a time step.  The reference example composes the same dynamics from brainstate modules
+(``examples/COBA_2005.py:35-87``); as separate elementwise launches they are ~20 launches per step — all a 4000-neuron
+network's step consists of."""
+import ctypes
+import math
+
+import torch
+
+from . import _array as A
+from ._lib import check, fn
+
+__all__ = ['lif_coba_step']
+
+
+def lif_coba_step(v: torch.Tensor, g_exc: torch.Tensor, g_inh: torch.Tensor, refractory: torch.Tensor,
+                  in_exc: torch.Tensor, in_inh: torch.Tensor, spikes: torch.Tensor, spike_count: torch.Tensor = None, *,
+                  dt: float = 0.1, tau_m: float = 20.0, v_rest: float = -60.0, v_th: float = -50.0, v_reset: float = -60.0,
+                  t_ref: float = 5.0, e_exc: float = 0.0, e_inh: float = -80.0, tau_exc: float = 5.0, tau_inh: float = 10.0,
+                  i_ext: float = 20.0, syn_scale: float = 1e-3) -> None:
+    """Advance ``v``, ``g_exc``, ``g_inh``, ``refractory`` (f32 device tensors of one length) by one step **in place**, write
+    this step's spikes (``bool`` / ``uint8``) to ``spikes`` and add them to ``spike_count`` if given.  ``in_exc`` / ``in_inh``
+    are this step's synaptic inputs (the outputs of ``BinaryArray(spikes) @ W_exc`` / ``@ W_inh``).  Defaults: the COBA
+    benchmark network (Vogels & Abbott 2005).  Every operation is rounded separately, in the order the header states, so the
+    result equals the same formulas written as elementwise tensor ops bit for bit."""
+    n = int(v.numel())
+    for t in (v, g_exc, g_inh, refractory, in_exc, in_inh):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+            raise ValueError('lif_coba_step: state and input tensors must be contiguous f32 device tensors of one length.')
+    if spikes.numel() != n or spikes.dtype not in (torch.bool, torch.uint8) or not spikes.is_cuda or not spikes.is_contiguous():
+        raise ValueError('lif_coba_step: spikes must be a contiguous bool / uint8 device tensor of the same length.')
+    if spike_count is not None and (spike_count.dtype != torch.float32 or spike_count.numel() != n or not spike_count.is_cuda):
+        raise ValueError('lif_coba_step: spike_count must be an f32 device tensor of the same length.')
+    c_d, c_vp = ctypes.c_double, ctypes.c_void_p
+    f = fn('be_lif_coba_step', ctypes.c_int, [c_vp] * 8 + [ctypes.c_int64] + [c_d] * 12 + [c_vp])
+    check(f(A.ptr(v), A.ptr(g_exc), A.ptr(g_inh), A.ptr(refractory), A.ptr(in_exc), A.ptr(in_inh), A.ptr(spikes),
+            A.ptr(spike_count) if spike_count is not None else None, n, dt, tau_m, v_rest, v_th, v_reset, t_ref, e_exc, e_inh,
+            math.exp(-dt / tau_exc), math.exp(-dt / tau_inh), i_ext, syn_scale, A.stream_ptr()), 'be_lif_coba_step')

@@ -1,0 +1,64 @@
+// be_neuron.hip — the neuron half of the COBA step loop: one fused state update of a population of
+// conductance-based leaky integrate-and-fire neurons with exponential synapses, around the two `spikes @ CSR` scatters of
+// a time step.  The reference example builds these dynamics from brainstate modules (examples/COBA_2005.py:35-87: LIF,
+// V_rest -60 mV, V_th -50 mV, V_reset -60 mV, tau 20 ms, refractory 5 ms; Expon synapses tau 5 / 10 ms, COBA outputs with
+// reversal 0 / -80 mV); as separate elementwise launches they cost ~20 launches per step, which is all a 4000-neuron
+// network's step consists of.  Every operation is rounded separately (no FMA contraction), in the order the plain
+// elementwise formulation applies them, so the fused step reproduces that formulation bit for bit.
+#include "be_common.h"
+#include <algorithm>
+
+namespace {
+
+struct LifCobaP {
+  float dt, dt_over_tau, v_rest, v_th, v_reset, t_ref, e_exc, e_inh, decay_exc, decay_inh, i_ext, syn_scale;
+};
+
+__global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, float* __restrict__ ge, float* __restrict__ gi,
+                                                       float* __restrict__ refr, const float* __restrict__ in_exc,
+                                                       const float* __restrict__ in_inh, uint8_t* __restrict__ spikes,
+                                                       float* __restrict__ spike_count, int64_t n, LifCobaP p) {
+#pragma clang fp contract(off)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = V[i];
+    const float g_e = ge[i] * p.decay_exc + in_exc[i];
+    const float g_i = gi[i] * p.decay_inh + in_inh[i];
+    const float i_syn = (g_e * (p.e_exc - v) + g_i * (p.e_inh - v)) * p.syn_scale;
+    const float dv = (-(v - p.v_rest) + i_syn + p.i_ext) * p.dt_over_tau;
+    const float r = refr[i];
+    const bool active = r <= 0.f;
+    const float vn = active ? v + dv : v;
+    const bool s = active && vn >= p.v_th;
+    V[i] = s ? p.v_reset : vn;
+    refr[i] = s ? p.t_ref : r - p.dt;
+    ge[i] = g_e;
+    gi[i] = g_i;
+    spikes[i] = s ? 1 : 0;
+    if (spike_count != nullptr && s) spike_count[i] += 1.f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int be_lif_coba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                     uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
+                     double v_reset, double t_ref, double e_exc, double e_inh, double decay_exc, double decay_inh, double i_ext,
+                     double syn_scale, be_stream_t stream) {
+  BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
+  if (n == 0) return BE_OK;
+  BE_REQUIRE(v && g_exc && g_inh && refractory && in_exc && in_inh && spikes_out, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(tau_m > 0. && dt > 0., BE_ERR_INVALID, "dt and tau_m must be positive");
+  // derived constants in double, rounded to f32 once (what a host formulation with Python / C doubles hands to f32 arrays)
+  const LifCobaP p{(float)dt, (float)(dt / tau_m), (float)v_rest, (float)v_th, (float)v_reset, (float)t_ref, (float)e_exc, (float)e_inh,
+                   (float)decay_exc, (float)decay_inh, (float)i_ext, (float)syn_scale};
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_lif_coba_step, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, g_exc,
+                     g_inh, refractory, in_exc, in_inh, spikes_out, spike_count, n, p);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+}  // extern "C"

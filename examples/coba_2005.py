@@ -5,7 +5,9 @@
 3200*scale excitatory + 800*scale inhibitory LIF neurons (V_rest -60 mV, V_th -50 mV, V_reset -60 mV, tau 20 ms,
 refractory 5 ms, V0 ~ N(-55, 2) mV, constant input 20), every neuron projects to 80 random targets
 (weights 0.6 / 6.7 mS), exponential conductance synapses (tau 5 / 10 ms, reversal 0 / -80 mV), dt = 0.1 ms.
-The two projections are `BinaryArray(spikes) @ CSR`; neuron and synapse state updates are plain torch ops.
+The two projections are `BinaryArray(spikes) @ CSR`; neuron and synapse state updates are plain torch ops (`run`,
+`run_graph`) or the library's fused neuron step `be.lif_coba_step` (`run_fused`: three launches per time step, replayed
+as a HIP graph; the same spikes bit for bit).
 
     python examples/coba_2005.py [scale] [steps]
 """
@@ -98,6 +100,31 @@ def run(scale=1.0, steps=10000, dt=0.1):
     return n, el, rate
 
 
+def run_fused(scale=1.0, steps=10000, dt=0.1, graph=True):
+    """Same simulation with the neuron / synapse update as ONE launch (``be.lif_coba_step``: the formulas of :func:`run`, every
+    operation rounded separately in the same order — identical spikes): a time step is two scatters and one neuron kernel."""
+    dev = torch.device('cuda', 0)
+    n_exc, n_inh, n, E, I, g = build(scale, dev)
+    V = torch.empty(n, device=dev).normal_(-55.0, 2.0, generator=g)
+    ge, gi, refr, count = (torch.zeros(n, device=dev) for _ in range(4))
+    spk = torch.zeros(n, dtype=torch.bool, device=dev)
+
+    def step():
+        in_e = be.BinaryArray(spk[:n_exc]) @ E
+        in_i = be.BinaryArray(spk[n_exc:]) @ I
+        be.lif_coba_step(V, ge, gi, refr, in_e, in_i, spk, count, dt=dt)
+
+    fn_ = be.capture_step(step) if graph else step
+    count.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn_()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return n, el, float(count.sum().item()) / n / (steps * dt * 1e-3), V, spk
+
+
 if __name__ == '__main__':
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
@@ -110,3 +137,10 @@ if __name__ == '__main__':
         print(f'  HIP-graph replay: time = {el:.3f} s ({el / steps * 1e6:.1f} us/step), firing rate = {rate:.2f} Hz', flush=True)
     except Exception as e:      # capture support depends on the torch build; the eager loop above is the reference
         print('  HIP-graph replay unavailable:', repr(e)[:200], flush=True)
+    for graph in (False, True):
+        try:
+            n, el, rate, _, _ = run_fused(scale, steps, graph=graph)
+            print(f'  fused neuron step{", HIP-graph replay" if graph else ""}: time = {el:.3f} s ({el / steps * 1e6:.1f} us/step), '
+                  f'firing rate = {rate:.2f} Hz', flush=True)
+        except Exception as e:
+            print('  fused neuron step unavailable:', repr(e)[:200], flush=True)

@@ -76,6 +76,24 @@ int be_profile_read(float* ms_host, int capacity);
 /* releases the little the library keeps between calls (profiling events); exchange handles have be_exchange_destroy */
 int be_shutdown(void);
 
+/* ----------------------------------------------------------------------------------------------
+ * Neuron half of the COBA step loop (the reference example composes the same dynamics from brainstate
+ * modules, examples/COBA_2005.py:35-87): ONE fused update of n conductance-based LIF neurons with exponential synapses,
+ * in place.  Per neuron, every operation rounded separately in this order (so it reproduces the plain elementwise
+ * formulation bit for bit):
+ *   g_exc = g_exc * decay_exc + in_exc;   g_inh = g_inh * decay_inh + in_inh          (in_*: this step's scatter outputs)
+ *   i_syn = (g_exc * (e_exc - v) + g_inh * (e_inh - v)) * syn_scale
+ *   dv    = (-(v - v_rest) + i_syn + i_ext) * (dt / tau_m)
+ *   active = refractory <= 0;  v' = active ? v + dv : v;  spike = active && v' >= v_th
+ *   v = spike ? v_reset : v';  refractory = spike ? t_ref : refractory - dt;  spikes_out = spike (1 byte);
+ *   spike_count += spike (optional, may be NULL)
+ * A time step of the network is then: scatter(spikes_exc) -> in_exc, scatter(spikes_inh) -> in_inh, be_lif_coba_step.
+ * ---------------------------------------------------------------------------------------------- */
+int be_lif_coba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                     uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
+                     double v_reset, double t_ref, double e_exc, double e_inh, double decay_exc, double decay_inh, double i_ext,
+                     double syn_scale, be_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * event vector helpers (replace: brainevent/_jit_scalar/binary_jitsmv.cu:107-125 `_pack_bool_kern`
  * and the active-row extraction of brainevent/_csr/binary_csrmv_hybrid.cu:275-327)
