@@ -5,6 +5,7 @@
  *   2. planned route:  be_scatter_plan_count -> _fill -> be_fixed_point_exponent -> be_binary_csrmv_t_plan
  *   3. weight refresh: be_scatter_plan_refresh_weights, then step 2's call again
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
+ *   5. neuron step:    be_lif_coba_step
  * Every result is compared with the serial loop of the reference's CPU kernel (brainevent/_csr/binary.py:446-451 /
  * :466-472), restated inline in double precision; tolerance rtol = atol = 1e-5 (the tolerance of the path).
  * Build:  gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/c/abi_smoke.c \
@@ -134,6 +135,35 @@ int main(void) {
   CHECK_BE(be_binary_csrmv_nt_hetero_f32_bool(d_w, d_idx, d_ptr, 0, d_spk_k, d_out, m, k, d_gws, gws_bytes, NULL));
   CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
   fails += compare("gather", got, ref, m);
+
+  /* 5. the neuron half of a time step (be_lif_coba_step) on the gathered currents: one neuron far above threshold, one
+   *    refractory, the rest at rest — checked against the formulas of the header evaluated here */
+  {
+    float hv[4] = {-50.5f, -55.f, -60.f, -40.f}, hge[4] = {0.f, 1.f, 0.f, 0.f}, hgi[4] = {0.f, 0.f, 2.f, 0.f}, hrf[4] = {0.f, 0.f, 0.f, 3.f};
+    float hin[4] = {50.f, 0.f, 0.f, 0.f}, hzero[4] = {0.f, 0.f, 0.f, 0.f};
+    void *dv = dev_copy(hv, 16), *dge = dev_copy(hge, 16), *dgi = dev_copy(hgi, 16), *drf = dev_copy(hrf, 16);
+    void *din = dev_copy(hin, 16), *dz = dev_copy(hzero, 16), *dsp = dev_copy(NULL, 4), *dcnt = dev_copy(hzero, 16);
+    const double dt = 0.1, de = exp(-dt / 5.0), di = exp(-dt / 10.0);
+    CHECK_BE(be_lif_coba_step(dv, dge, dgi, drf, din, dz, dsp, dcnt, 4, dt, 20.0, -60.0, -50.0, -60.0, 5.0, 0.0, -80.0, de, di, 20.0,
+                              1e-3, NULL));
+    float gv[4], grf[4]; unsigned char gsp[4];
+    CHECK_HIP(hipMemcpy(gv, dv, 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(grf, drf, 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(gsp, dsp, 4, hipMemcpyDeviceToHost));
+    double rv[4]; int rs[4];
+    for (int i = 0; i < 4; ++i) {
+      const double ge = hge[i] * de + hin[i], gi = hgi[i] * di;
+      const double dvv = (-(hv[i] + 60.0) + (ge * (0.0 - hv[i]) + gi * (-80.0 - hv[i])) * 1e-3 + 20.0) * (dt / 20.0);
+      const int act = hrf[i] <= 0.f;
+      const double vn = act ? hv[i] + dvv : hv[i];
+      rs[i] = act && vn >= -50.0;
+      rv[i] = rs[i] ? -60.0 : vn;
+    }
+    int bad = 0;
+    for (int i = 0; i < 4; ++i) bad += (gsp[i] != rs[i]) || fabs(gv[i] - rv[i]) > 1e-4 || fabs(grf[i] - (rs[i] ? 5.0 : hrf[i] - dt)) > 1e-5;
+    printf("%-28s spikes %d%d%d%d %s\n", "neuron step", gsp[0], gsp[1], gsp[2], gsp[3], bad ? "FAIL" : "ok");
+    fails += bad ? 1 : 0;
+  }
 
   /* error convention: status code + message, never an abort */
   if (be_binary_csrmv_t_plan(NULL, 0, BE_F32, d_blob, d_seg, d_spk, BE_SPIKE_BOOL, d_out, m, k, shift, width, layout, block_hint,
