@@ -407,6 +407,23 @@ def secondary_configs(base):
             out[name] = {'error': repr(e)}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    # C1 of BASELINE.json (the reference's own CPU-runnable case): the 4000-neuron COBA network of examples/coba_2005.py as a
+    # replayed HIP graph of three launches per 0.1-ms step (two `spikes @ CSR` scatters + the fused neuron step)
+    try:
+        import importlib.util
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'examples', 'coba_2005.py')
+        spec = importlib.util.spec_from_file_location('coba_2005_example', path)
+        coba = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(coba)
+        n, el, rate, _, _ = coba.run_fused(1.0, 10000, graph=True)
+        out['C1_coba'] = {'metric': 'time per 0.1-ms step of the 4000-neuron COBA network (two BinaryArray @ CSR scatters + be_lif_coba_step, '
+                                    'replayed HIP graph)', 'value': round(el / 10000 * 1e6, 2), 'unit': 'us/step', 'higher_is_better': False,
+                          'steps': 10000, 'neurons': n, 'firing_rate_hz': round(rate, 2), 'reference_firing_rate_hz': 50.6,
+                          'synaptic_events_per_s': round(rate * n * 80 / (el / (10000 * 1e-4)), 1)}
+    except Exception as e:
+        out['C1_coba'] = {'error': repr(e)}
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     return out
 
 
