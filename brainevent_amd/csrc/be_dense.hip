@@ -187,18 +187,19 @@ __global__ void __launch_bounds__(256) k_densemm_t(const W* __restrict__ weights
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[b][v] = ACC(0);
 
-  // rows of this part: a = part, part + parts, ...  (4 loads in flight)
+  // rows of this part: a = part, part + parts, ...  (UNR row loads in flight per lane)
+  constexpr int UNR = 8;       // (4 in flight: f32 32k^2 at 50 % firing 3.5 TB/s; 8: 4.5; with 32 row parts 5.5)
   uint32_t a = part;
-  for (; a + 3u * parts < cnt; a += 4u * parts) {
-    uint32_t e[4];
-    ACC w[4][VEC];
+  for (; a + (uint32_t)(UNR - 1) * parts < cnt; a += (uint32_t)UNR * parts) {
+    uint32_t e[UNR];
+    ACC w[UNR][VEC];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) e[q] = list[a + q * parts];
+    for (int q = 0; q < UNR; ++q) e[q] = list[a + q * parts];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < UNR; ++q)
       if (in) RowLoad<W, VEC>::load(weights + (int64_t)(e[q] & 0x0fffffffu) * n + col, w[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < UNR; ++q) {
       const uint32_t sm = e[q] >> 28;
 #pragma unroll
       for (int b = 0; b < kGroup; ++b)
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256) k_densemm_t(const W* __restrict__ weights
         }
     }
   }
-  for (; a < cnt; a += parts) {
+  for (; a < cnt; a += parts) {      // (a predicated last round instead of this tail was measured: no faster at 1 % firing, slower dense)
     const uint32_t e = list[a];
     ACC w[VEC];
     if (in) RowLoad<W, VEC>::load(weights + (int64_t)(e & 0x0fffffffu) * n + col, w);
@@ -316,9 +317,14 @@ constexpr int kMaxGroups = kMaxChunk / kGroup;   // 8
 inline int parts_for(int64_t n, int vec, int n_groups) {
   const int64_t tasks = ((n + 64 * vec - 1) / (64 * vec)) * n_groups;
   const int64_t wgs = (tasks + 3) / 4;
-  int64_t p = 1024 / (wgs > 0 ? wgs : 1);
+  // workgroups to aim for / row parts at most.  A single vector (one batch group) has few strips: 2048 workgroups of four
+  // waves, each lane with 8 row loads in flight, are what it takes to keep HBM busy (fp16 64k^2 at 50 % firing: 16 parts
+  // 2.9 TB/s, 32 parts 4.6; f32 32k^2: 3.5 -> 5.5); with several groups the partial sums of more parts cost more than they
+  // buy (f32, 8 batch rows: 16 parts 3.8 TB/s, 32 parts 3.4).  The partial buffer is sized for 16 parts x 32 batch rows.
+  const int64_t target = n_groups == 1 ? 2048 : 1024, cap = n_groups == 1 ? 32 : 16;
+  int64_t p = target / (wgs > 0 ? wgs : 1);
   if (p < 1) p = 1;
-  if (p > 16) p = 16;
+  if (p > cap) p = cap;
   return (int)p;
 }
 
@@ -332,7 +338,7 @@ inline int64_t dense_ws_bytes(int64_t rows_w, int64_t cols_w, int64_t nb, int tr
   if (transpose) {
     const int64_t acc = (wdtype == BE_F64) ? 8 : 4;
     const int64_t rows_p = nb < 32 ? 32 : nb;                            // the MFMA path keeps 32 batch rows per part
-    b += be_align_up((int64_t)16 * rows_p * cols_w * acc, 256);          // partial (<= 16 parts)
+    b += be_align_up((int64_t)16 * rows_p * cols_w * acc, 256);          // partial (<= 16 parts x >= 32 rows: also 32 parts x <= 4 rows)
   }
   return b;
 }
