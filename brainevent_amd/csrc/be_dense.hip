@@ -264,7 +264,20 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
 #pragma unroll
     for (int b = 0; b < NBT; ++b) acc[b] = ACC(0);
     if (gather) {
-      for (uint32_t a = lane; a < n_union; a += 64) {
+      uint32_t a = lane;
+      for (; a + 3u * 64u < n_union; a += 4u * 64u) {      // four scattered elements in flight per lane
+        uint32_t j[4], mk[4];
+        ACC w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = ulist[a + 64u * u] & 0x0fffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { mk[u] = mask[j[u]]; w[u] = (ACC)WTraits<W>::load(row, j[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int b = 0; b < NBT; ++b) acc[b] += ((mk[u] >> b) & 1u) ? w[u] : ACC(0);
+      }
+      for (; a < n_union; a += 64) {
         const uint32_t j = ulist[a] & 0x0fffffffu;
         const uint32_t mk = mask[j];
         const ACC w = (ACC)WTraits<W>::load(row, j);
@@ -272,7 +285,39 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
         for (int b = 0; b < NBT; ++b) acc[b] += ((mk >> b) & 1u) ? w : ACC(0);
       }
     } else {
-      for (int64_t j = (int64_t)lane * VEC; j < k; j += 64 * VEC) {
+      // U row pieces of 16 B and their masks (one vector load per piece) in flight per lane, then the tail piece by piece
+      constexpr int U = 4;
+      int64_t j = (int64_t)lane * VEC;
+      for (; j + (int64_t)(U - 1) * 64 * VEC < k; j += (int64_t)U * 64 * VEC) {
+        ACC w[U][VEC];
+        uint32_t mk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) RowLoad<W, VEC>::load(row + j + (int64_t)u * 64 * VEC, w[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t* mp = mask + j + (int64_t)u * 64 * VEC;
+          if constexpr (VEC % 4 == 0) {
+#pragma unroll
+            for (int v4 = 0; v4 < VEC / 4; ++v4) {
+              const uint4 t = reinterpret_cast<const uint4*>(mp)[v4];
+              mk[u][4 * v4] = t.x; mk[u][4 * v4 + 1] = t.y; mk[u][4 * v4 + 2] = t.z; mk[u][4 * v4 + 3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) mk[u][v] = mp[v];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            if (mk[u][v]) {
+#pragma unroll
+              for (int b = 0; b < NBT; ++b) acc[b] += ((mk[u][v] >> b) & 1u) ? w[u][v] : ACC(0);
+            }
+          }
+      }
+      for (; j < k; j += 64 * VEC) {
         ACC w[VEC];
         RowLoad<W, VEC>::load(row + j, w);
 #pragma unroll
