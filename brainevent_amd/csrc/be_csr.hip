@@ -227,60 +227,15 @@ __global__ void __launch_bounds__(256) k_convert_from_f32(const float* __restric
 }
 
 // =================================================================================================
-// gather (transpose=False): lanes-per-row groups, bit-packed spikes in LDS when they fit
+// gather (transpose=False): bit-packed spikes in LDS when they fit; a wave per long row, 2 ... 32 lanes per shorter row
 // =================================================================================================
-template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
-__global__ void __launch_bounds__(256) k_csrmv_nt(const W* __restrict__ weights, const int32_t* __restrict__ indices,
-                                                  RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
-                                                  W* __restrict__ out, int64_t m) {
-  bits_g += (int64_t)blockIdx.y * n_words;    // batch-major bitmaps and outputs
-  out += (int64_t)blockIdx.y * m;
-  extern __shared__ uint32_t bits_s[];
-  const uint32_t* bits = bits_g;
-  if (BITS_IN_LDS) {
-    for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) bits_s[i] = bits_g[i];
-    __syncthreads();
-    bits = bits_s;
-  }
-  using ACC = typename WTraits<W>::acc;
-  constexpr int GROUPS = 256 / LPR;
-  const int sub = threadIdx.x % LPR;
-  const int64_t group = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
-  const int64_t n_groups = (int64_t)gridDim.x * GROUPS;
-  ACC w0 = ACC(0);
-  if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
-  // rows are dealt to groups round-robin; all lanes of a wave run the same number of iterations
-  const int64_t m_round = (m + n_groups - 1) / n_groups * n_groups;
-  for (int64_t r = group; r < m_round; r += n_groups) {
-    ACC acc = ACC(0);
-    int cnt = 0;
-    if (r < m) {
-      const int64_t b = rp.at(r), e = rp.at(r + 1);
-      for (int64_t j = b + sub; j < e; j += LPR) {
-        const uint32_t c = (uint32_t)indices[j];
-        const bool on = (bits[c >> 5] >> (c & 31)) & 1u;
-        if (HOMO) cnt += on ? 1 : 0;
-        else if (on) acc += (ACC)WTraits<W>::load(weights, j);
-      }
-    }
-    if (HOMO) {
-#pragma unroll
-      for (int off = LPR / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, LPR);
-      acc = (ACC)cnt * w0;
-    } else {
-#pragma unroll
-      for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
-    }
-    if (sub == 0 && r < m) WTraits<W>::store(out, r, acc);
-  }
-}
-
 // long rows: one wave per row, 16 waves per workgroup (they share the LDS bitmap, which takes most of the LDS, so
 // these 16 waves are all the latency hiding a CU gets), 4 consecutive entries per lane per load through raw buffer
 // descriptors (range-checked: no tail branches), two iterations (2 KB of indices [+ 2 KB of f32 weights]) in flight.
 // f32 weights are streamed unconditionally with the same vector loads — a dependent load per active entry would
 // serialise the row at one HBM round trip per hit; other weight dtypes keep the conditional scalar load.
 typedef unsigned be_nt_v4u __attribute__((ext_vector_type(4)));
+constexpr int64_t kGatherVecMaxRow = 512;   // average row length up to which the lanes-per-row vector kernel is used
 
 template <typename W, bool HOMO, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ weights, const int32_t* __restrict__ indices,
@@ -398,6 +353,108 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
         }
         if (lane == 0) WTraits<W>::store(out, wave + n_waves * (t0 + i + q), acc);
       }
+    }
+  }
+}
+
+// short and medium rows (a few to a few hundred entries): LPR lanes per row, 64 / LPR rows per wave step, four consecutive
+// entries per lane and load (16 B of indices [+ 16 B of f32 weights]), two passes of a row in flight.  The wave-per-row
+// kernel above keeps four rows in flight per wave and 25 of 64 lanes busy on a 100-entry row; the scalar lanes-per-row
+// kernel this replaces loaded a weight only behind its spike test (a dependent round trip per hit).  2e8 entries, 1 % of
+// the inputs active, ms per product (tools/bench_gather_rows.py), weighted: 4 per row 3.77 -> 0.88, 12: 4.86 -> 0.57,
+// 48: 2.52 -> 0.46, 100: 0.50 -> 0.38 (4.2 TB/s), 250: 0.31 -> 0.30; counted: 12: 4.45 -> 0.46, 100: 0.41 -> 0.24.
+template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
+__global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                       RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
+                                                       W* __restrict__ out, int64_t m) {
+  bits_g += (int64_t)blockIdx.y * n_words;
+  out += (int64_t)blockIdx.y * m;
+  extern __shared__ uint32_t bits_s[];
+  const uint32_t* bits = bits_g;
+  if (BITS_IN_LDS) {
+    for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) bits_s[i] = bits_g[i];
+    __syncthreads();
+    bits = bits_s;
+  }
+  using ACC = typename WTraits<W>::acc;
+  constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
+  constexpr int RPW = 64 / LPR;                  // rows per wave step
+  constexpr int PASS = 4 * LPR;                  // entries of a row per pass
+  const int lane = lane_id(), sub = lane % LPR, slot = lane / LPR;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t nnz_end = rp.at(m);              // a 16-byte load may not run past the arrays
+  ACC w0 = ACC(0);
+  if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
+
+  for (int64_t t0 = 0;; t0 += 64) {              // bounds of this wave's next 64 rows: lane l -> row wave + n_waves * (t0 + l)
+    const int64_t my_r = wave + n_waves * (t0 + lane);
+    const bool valid = my_r < m;
+    const unsigned long long vmask = __ballot(valid);
+    if (vmask == 0ull) break;
+    const int64_t rc = valid ? my_r : 0;
+    int64_t rb = rp.at(rc), re = rp.at(rc + 1);
+    if (!valid) { rb = 0; re = 0; }
+    const int64_t rl = re - rb;
+    const int nvalid = __popcll(vmask);
+    for (int i = 0; i < nvalid; i += RPW) {
+      const int src = (i + slot) & 63;
+      const int64_t b = __shfl(rb, src, 64);
+      const int64_t len = (i + slot < nvalid) ? __shfl(rl, src, 64) : 0;
+      int64_t maxlen = len;                       // longest row of the step (uniform loop bound)
+#pragma unroll
+      for (int off = 32; off >= LPR; off >>= 1) {
+        const int64_t o = __shfl_xor(maxlen, off, 64);
+        maxlen = o > maxlen ? o : maxlen;
+      }
+      maxlen = __shfl(maxlen, 0, 64);
+      ACC acc = ACC(0);
+      int cnt = 0;
+      for (int64_t j0 = 0; j0 < maxlen; j0 += 2 * PASS) {
+        be_nt_v4u c[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, wv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t j = j0 + (int64_t)u * PASS + 4 * sub;
+          if (j + 4 <= len || (j < len && b + j + 4 <= nnz_end)) {       // whole piece (a row's last piece may read into the next row)
+            const uint4 t = *reinterpret_cast<const uint4*>(indices + b + j);
+            c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
+            if (VECW) {
+              const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + b + j);
+              wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
+            }
+          } else if (j < len) {                                          // the last entries of the arrays: one by one
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j + q < len) {
+                c[u][q] = (uint32_t)indices[b + j + q];
+                if (VECW) wv[u][q] = __float_as_uint(reinterpret_cast<const float*>(weights)[b + j + q]);
+              }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t j = j0 + (int64_t)u * PASS + 4 * sub;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (j + q < len) {
+              const uint32_t col = c[u][q];
+              const bool on = (bits[col >> 5] >> (col & 31)) & 1u;
+              if (HOMO) cnt += on ? 1 : 0;
+              else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
+              else if (on) acc += (ACC)WTraits<W>::load(weights, b + j + q);
+            }
+          }
+        }
+      }
+      if (HOMO) {
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, LPR);
+        acc = (ACC)cnt * w0;
+      } else {
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
+      }
+      if (sub == 0 && i + slot < nvalid) WTraits<W>::store(out, wave + n_waves * (t0 + i + slot), acc);
     }
   }
 }
@@ -616,27 +673,6 @@ int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const
   return BE_OK;
 }
 
-template <typename W, bool HOMO, int LPR>
-int csrmv_nt_launch(const void* weights, const int32_t* indices, RowPtr rp, const uint32_t* bits, int64_t n_words,
-                    void* out, int64_t m, int64_t nb, hipStream_t st) {
-  constexpr int GROUPS = 256 / LPR;
-  const size_t lds = (size_t)n_words * 4;
-  const int grid = grid_for(m, GROUPS, nb >= 8 ? 256 : 256 * 8);
-  const int prof = be_prof_begin(st);
-  if (lds <= 150 * 1024) {
-    auto kern = k_csrmv_nt<W, HOMO, LPR, true>;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(256), lds, st, static_cast<const W*>(weights), indices, rp,
-                       bits, n_words, static_cast<W*>(out), m);
-  } else {
-    hipLaunchKernelGGL((k_csrmv_nt<W, HOMO, LPR, false>), dim3(grid, (unsigned)nb), dim3(256), 0, st,
-                       static_cast<const W*>(weights), indices, rp, bits, n_words, static_cast<W*>(out), m);
-  }
-  be_prof_end(prof, st);
-  BE_LAUNCH_CHECK();
-  return BE_OK;
-}
-
 template <typename W, bool HOMO>
 int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
              void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
@@ -674,8 +710,33 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
   }
   if (m == 0 || nb == 0) return BE_OK;
   const int64_t avg = nnz_hint / (m > 0 ? m : 1);
-  if (avg <= 8) return csrmv_nt_launch<W, HOMO, 4>(weights, indices, rp, bits, n_words, out, m, nb, st);
-  if (avg <= 48) return csrmv_nt_launch<W, HOMO, 16>(weights, indices, rp, bits, n_words, out, m, nb, st);
+  if (avg <= kGatherVecMaxRow) {      // short and medium rows: 2 ... 32 lanes per row, four entries per lane and load
+    const size_t lds = (size_t)n_words * 4;
+    const bool in_lds = lds <= 150 * 1024;
+    const int prof = be_prof_begin(st);
+#define BE_NT_VEC(LPR_)                                                                                                     \
+    do {                                                                                                                    \
+      const int grid = grid_for(m, 16 * (64 / LPR_), nb >= 8 ? 256 : 512);                                                   \
+      if (in_lds) {                                                                                                          \
+        auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, true>;                                                                    \
+        BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                \
+        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp, \
+                           bits, n_words, static_cast<W*>(out), m);                                                         \
+      } else {                                                                                                               \
+        hipLaunchKernelGGL((k_csrmv_nt_vec<W, HOMO, LPR_, false>), dim3(grid, (unsigned)nb), dim3(1024), 0, st,              \
+                           static_cast<const W*>(weights), indices, rp, bits, n_words, static_cast<W*>(out), m);            \
+      }                                                                                                                      \
+    } while (0)
+    if (avg <= 6) BE_NT_VEC(2);
+    else if (avg <= 16) BE_NT_VEC(4);
+    else if (avg <= 40) BE_NT_VEC(8);
+    else if (avg <= 160) BE_NT_VEC(16);
+    else BE_NT_VEC(32);
+#undef BE_NT_VEC
+    be_prof_end(prof, st);
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
   {
     const size_t lds = (size_t)n_words * 4;
     const int grid = grid_for(m, 16, nb >= 8 ? 256 : 512);
