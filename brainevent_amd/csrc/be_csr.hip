@@ -226,6 +226,64 @@ __global__ void __launch_bounds__(256) k_convert_from_f32(const float* __restric
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) WTraits<W>::store(dst, i, src[i]);
 }
 
+// Spike test of the gather kernels.  The bit-packed input vector sits in LDS when it fits (k <= 1.2M columns: IN_LDS); a
+// longer one would cost a 64-byte L2 sector per stored entry (2M columns, 100 per row: 0.83 ms against 0.39 ms at 1M).
+// Then LDS holds a COARSE bitmap instead — one bit per group of 2^g_shift columns, set iff any of them fired — and only
+// entries whose group fired go on to the exact bitmap in global memory: at 1 % firing and groups of 2 ... 8 columns that
+// is 2 ... 8 % of them.
+constexpr int64_t kLdsBitmapBytes = 150 * 1024;
+// N entries at once (bit e of `valid`: entry e exists; returns bit e set iff its input fired): the exact-bitmap reads of the
+// coarse route are issued together and waited for once — one global round trip per group of entries, not one per hit
+template <bool IN_LDS, int N>
+__device__ __forceinline__ uint32_t spike_mask(const uint32_t* __restrict__ lds_bits, const uint32_t* __restrict__ fine_g,
+                                               const uint32_t (&col)[N], uint32_t valid, int g_shift) {
+  uint32_t m = 0;
+  if (IN_LDS) {
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+      if ((valid >> e) & 1u) m |= ((lds_bits[col[e] >> 5] >> (col[e] & 31)) & 1u) << e;
+    return m;
+  }
+  uint32_t ch = 0;
+#pragma unroll
+  for (int e = 0; e < N; ++e)
+    if ((valid >> e) & 1u) {
+      const uint32_t cc = col[e] >> g_shift;
+      ch |= ((lds_bits[cc >> 5] >> (cc & 31)) & 1u) << e;
+    }
+  if (ch == 0u) return 0u;
+  uint32_t fw[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) fw[e] = ((ch >> e) & 1u) ? fine_g[col[e] >> 5] : 0u;
+#pragma unroll
+  for (int e = 0; e < N; ++e) m |= ((fw[e] >> (col[e] & 31)) & 1u) << e;
+  return m;
+}
+
+// coarse[b][w] bit i = any fine bit of batch row b in columns [(32 w + i) << g_shift, (32 w + i + 1) << g_shift)
+__global__ void __launch_bounds__(256) k_coarsen_bits(const uint32_t* __restrict__ fine, int64_t n_words, uint32_t* __restrict__ coarse,
+                                                      int64_t n_cwords, int g_shift) {
+  fine += (int64_t)blockIdx.y * n_words;
+  coarse += (int64_t)blockIdx.y * n_cwords;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_cwords; w += stride) {
+    uint32_t cw = 0;
+    for (int i = 0; i < 32; ++i) {
+      const int64_t c0 = (w * 32 + i) << g_shift;          // first fine bit of the group (a multiple of the group size)
+      bool any = false;
+      if (g_shift < 5) {
+        const int64_t fw = c0 >> 5;
+        if (fw < n_words) any = ((fine[fw] >> (c0 & 31)) & ((1u << (1 << g_shift)) - 1u)) != 0u;
+      } else {
+        const int64_t fw0 = c0 >> 5, nfw = (int64_t)1 << (g_shift - 5);
+        for (int64_t t = 0; t < nfw && fw0 + t < n_words; ++t) any = any || fine[fw0 + t] != 0u;
+      }
+      cw |= (any ? 1u : 0u) << i;
+    }
+    coarse[w] = cw;
+  }
+}
+
 // =================================================================================================
 // gather (transpose=False): bit-packed spikes in LDS when they fit; a wave per long row, 2 ... 32 lanes per shorter row
 // =================================================================================================
@@ -240,15 +298,16 @@ constexpr int64_t kGatherVecMaxRow = 512;   // average row length up to which th
 template <typename W, bool HOMO, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                         RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
-                                                        W* __restrict__ out, int64_t m) {
+                                                        W* __restrict__ out, int64_t m, const uint32_t* __restrict__ coarse_g,
+                                                        int64_t n_cwords, int g_shift) {
   bits_g += (int64_t)blockIdx.y * n_words;
   out += (int64_t)blockIdx.y * m;
   extern __shared__ uint32_t bits_s[];
-  const uint32_t* bits = bits_g;
-  if (BITS_IN_LDS) {
-    for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) bits_s[i] = bits_g[i];
+  {   // the exact bitmap (BITS_IN_LDS) or the coarse one (spike_on)
+    const uint32_t* src = BITS_IN_LDS ? bits_g : coarse_g + (int64_t)blockIdx.y * n_cwords;
+    const int64_t nw = BITS_IN_LDS ? n_words : n_cwords;
+    for (int64_t i = threadIdx.x; i < nw; i += blockDim.x) bits_s[i] = src[i];
     __syncthreads();
-    bits = bits_s;
   }
   using ACC = typename WTraits<W>::acc;
   constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
@@ -273,18 +332,24 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
           c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0);
           if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
         }
+        uint32_t cols[8], valid = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            cols[4 * u + q] = c[u][q];
+            valid |= (j0 + 256 * u + 4 * lane + q < plen ? 1u : 0u) << (4 * u + q);
+          }
+        const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, valid, g_shift);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int64_t j = j0 + 256 * u + 4 * lane + q;
-            if (j < plen) {
-              const uint32_t col = c[u][q];
-              const bool on = (bits[col >> 5] >> (col & 31)) & 1u;
-              if (HOMO) cnt += on ? 1 : 0;
-              else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
-              else if (on) acc += (ACC)WTraits<W>::load(weights, b + p0 + j);
-            }
+            const bool on = (onm >> (4 * u + q)) & 1u;
+            if (HOMO) cnt += on ? 1 : 0;
+            else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
+            else if (on) acc += (ACC)WTraits<W>::load(weights, b + p0 + j);
           }
         }
       }
@@ -331,16 +396,20 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
         if (i + q >= nvalid) break;                           // uniform
         ACC acc = ACC(0);
         int cnt = 0;
+        uint32_t cols[4], valid = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cols[e] = c[q][e];
+          valid |= ((4 * lane + e < gl[q] && 4 * lane + e < 256) ? 1u : 0u) << e;
+        }
+        const uint32_t onm = spike_mask<BITS_IN_LDS, 4>(bits_s, bits_g, cols, valid, g_shift);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t j = 4 * lane + e;
-          if (j < gl[q] && j < 256) {
-            const uint32_t col = c[q][e];
-            const bool on = (bits[col >> 5] >> (col & 31)) & 1u;
-            if (HOMO) cnt += on ? 1 : 0;
-            else if (VECW) acc += on ? (ACC)__uint_as_float(wv[q][e]) : ACC(0);
-            else if (on) acc += (ACC)WTraits<W>::load(weights, gb[q] + j);
-          }
+          const bool on = (onm >> e) & 1u;
+          if (HOMO) cnt += on ? 1 : 0;
+          else if (VECW) acc += on ? (ACC)__uint_as_float(wv[q][e]) : ACC(0);
+          else if (on) acc += (ACC)WTraits<W>::load(weights, gb[q] + j);
         }
         if (gl[q] > 256) row_tail(gb[q], gl[q], 256, acc, cnt);   // uniform
         if (HOMO) {
@@ -366,15 +435,16 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
 template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                        RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
-                                                       W* __restrict__ out, int64_t m) {
+                                                       W* __restrict__ out, int64_t m, const uint32_t* __restrict__ coarse_g,
+                                                       int64_t n_cwords, int g_shift) {
   bits_g += (int64_t)blockIdx.y * n_words;
   out += (int64_t)blockIdx.y * m;
   extern __shared__ uint32_t bits_s[];
-  const uint32_t* bits = bits_g;
-  if (BITS_IN_LDS) {
-    for (int64_t i = threadIdx.x; i < n_words; i += blockDim.x) bits_s[i] = bits_g[i];
+  {   // the exact bitmap (BITS_IN_LDS) or the coarse one (spike_on)
+    const uint32_t* src = BITS_IN_LDS ? bits_g : coarse_g + (int64_t)blockIdx.y * n_cwords;
+    const int64_t nw = BITS_IN_LDS ? n_words : n_cwords;
+    for (int64_t i = threadIdx.x; i < nw; i += blockDim.x) bits_s[i] = src[i];
     __syncthreads();
-    bits = bits_s;
   }
   using ACC = typename WTraits<W>::acc;
   constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
@@ -431,18 +501,24 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
               }
           }
         }
+        uint32_t cols[8], valid = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            cols[4 * u + q] = c[u][q];
+            valid |= (j0 + (int64_t)u * PASS + 4 * sub + q < len ? 1u : 0u) << (4 * u + q);
+          }
+        const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, valid, g_shift);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int64_t j = j0 + (int64_t)u * PASS + 4 * sub;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            if (j + q < len) {
-              const uint32_t col = c[u][q];
-              const bool on = (bits[col >> 5] >> (col & 31)) & 1u;
-              if (HOMO) cnt += on ? 1 : 0;
-              else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
-              else if (on) acc += (ACC)WTraits<W>::load(weights, b + j + q);
-            }
+            const bool on = (onm >> (4 * u + q)) & 1u;
+            if (HOMO) cnt += on ? 1 : 0;
+            else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
+            else if (on) acc += (ACC)WTraits<W>::load(weights, b + j + q);
           }
         }
       }
@@ -673,6 +749,14 @@ int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const
   return BE_OK;
 }
 
+// coarse bitmap geometry of a gather over k input columns: group size 2^g_shift (0: the exact bitmap fits LDS)
+static inline int gather_g_shift(int64_t k) {
+  int g = 0;
+  while ((((k + ((int64_t)1 << g) - 1) >> g) + 31) / 32 * 4 > kLdsBitmapBytes) ++g;
+  return g;
+}
+static inline int64_t gather_cwords(int64_t k, int g_shift) { return g_shift ? (((k + ((int64_t)1 << g_shift) - 1) >> g_shift) + 31) / 32 : 0; }
+
 template <typename W, bool HOMO>
 int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
              void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
@@ -709,10 +793,21 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     bits = static_cast<const uint32_t*>(ws);
   }
   if (m == 0 || nb == 0) return BE_OK;
+  // more columns than the LDS holds bits for: a coarse bitmap (behind the exact one in the workspace) goes to LDS instead
+  const int g_shift = gather_g_shift(k);
+  const int64_t n_cwords = gather_cwords(k, g_shift);
+  const uint32_t* coarse = nullptr;
+  if (g_shift) {
+    uint32_t* cw = static_cast<uint32_t*>(ws) + n_words * nb + 2;
+    hipLaunchKernelGGL(k_coarsen_bits, dim3(grid_for(n_cwords, 256, 1024), (unsigned)nb), dim3(256), 0, st, bits, n_words, cw, n_cwords,
+                       g_shift);
+    BE_LAUNCH_CHECK();
+    coarse = cw;
+  }
+  const bool in_lds = g_shift == 0;
+  const size_t lds = (size_t)(in_lds ? n_words : n_cwords) * 4;
   const int64_t avg = nnz_hint / (m > 0 ? m : 1);
   if (avg <= kGatherVecMaxRow) {      // short and medium rows: 2 ... 32 lanes per row, four entries per lane and load
-    const size_t lds = (size_t)n_words * 4;
-    const bool in_lds = lds <= 150 * 1024;
     const int prof = be_prof_begin(st);
 #define BE_NT_VEC(LPR_)                                                                                                     \
     do {                                                                                                                    \
@@ -721,10 +816,12 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
         auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, true>;                                                                    \
         BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                \
         hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp, \
-                           bits, n_words, static_cast<W*>(out), m);                                                         \
+                           bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       } else {                                                                                                               \
-        hipLaunchKernelGGL((k_csrmv_nt_vec<W, HOMO, LPR_, false>), dim3(grid, (unsigned)nb), dim3(1024), 0, st,              \
-                           static_cast<const W*>(weights), indices, rp, bits, n_words, static_cast<W*>(out), m);            \
+        auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, false>;                                                                   \
+        BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                \
+        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp, \
+                           bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       }                                                                                                                      \
     } while (0)
     if (avg <= 6) BE_NT_VEC(2);
@@ -738,17 +835,18 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     return BE_OK;
   }
   {
-    const size_t lds = (size_t)n_words * 4;
     const int grid = grid_for(m, 16, nb >= 8 ? 256 : 512);
     const int prof = be_prof_begin(st);
-    if (lds <= 150 * 1024) {
+    if (in_lds) {
       auto kern = k_csrmv_nt_wave<W, HOMO, true>;
       BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
       hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
-                         bits, n_words, static_cast<W*>(out), m);
+                         bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);
     } else {
-      hipLaunchKernelGGL((k_csrmv_nt_wave<W, HOMO, false>), dim3(grid, (unsigned)nb), dim3(1024), 0, st,
-                         static_cast<const W*>(weights), indices, rp, bits, n_words, static_cast<W*>(out), m);
+      auto kern = k_csrmv_nt_wave<W, HOMO, false>;
+      BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
+      hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
+                         bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);
     }
     be_prof_end(prof, st);
     BE_LAUNCH_CHECK();
@@ -851,7 +949,7 @@ int be_binary_csrmv_t(const void* weights, int homo, int wdtype, const int32_t* 
 
 int64_t be_binary_csrmm_nt_workspace_bytes(int64_t m, int64_t k, int64_t n_batch) {
   (void)m;
-  const int64_t bits = (((k + 31) / 32) * n_batch + 2) * 4;            // per-column bitmaps
+  const int64_t bits = (((k + 31) / 32) * n_batch + 2 + gather_cwords(k, gather_g_shift(k)) * n_batch) * 4;   // per-column bitmaps (+ coarse ones)
   const int64_t masks = n_batch >= kFusedMinBatch ? (k + 2) * 4 : 0;   // per-neuron column masks of the fused kernel
   return be_align_up(std::max(bits, masks), 256);
 }

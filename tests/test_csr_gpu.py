@@ -1007,3 +1007,29 @@ def test_single_launch_planned_step(be, oracle, layout, m):
             sp, sd = A.spikes_to_device(v)
             _plan_call(plan, A.to_device(ww), sp, sd, got3.reshape(1, -1), parts=2)
             np.testing.assert_array_equal(got3.float().cpu().numpy(), np.asarray(got, np.float32))
+
+
+@pytest.mark.parametrize('k', [1_300_000, 5_000_000])
+def test_gather_with_more_columns_than_lds_holds_bits_for(be, oracle, k):
+    """Gather over more than 1.2M input columns: LDS holds a coarse bitmap (one bit per 2 / 8 columns) and only entries whose
+    group fired test the exact bitmap in global memory.  Short, medium and long rows (every kernel tier), sparse and dense
+    firing, a batch, bit-packed events."""
+    rng = np.random.default_rng(k)
+    for m, lens in ((3000, rng.integers(0, 30, 3000)), (800, rng.integers(0, 400, 800)), (60, rng.integers(500, 3000, 60))):
+        lens[::11] = 0
+        for homo in (False, True):
+            w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+            idx[: min(idx.size, 50)] = k - 1 - np.arange(min(idx.size, 50))          # the last columns: the tail of the bitmaps
+            for fire in (0.0, 0.01, 0.5):
+                v = rng.random(k) < fire
+                got = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=False)
+                np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, v, (m, k), False), rtol=1e-5, atol=1e-5)
+            csr = be.CSR((w, idx, ptr), shape=(m, k))
+            got = csr @ be.BitPackedBinary(v)
+            got = got.cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+            np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, v, (m, k), False), rtol=1e-5, atol=1e-5)
+            B = rng.random((k, 3)) < 0.02
+            gotm = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=False)
+            for c in range(3):
+                np.testing.assert_allclose(np.asarray(gotm)[:, c], oracle.binary_csrmv(w, idx, ptr, B[:, c], (m, k), False),
+                                           rtol=1e-5, atol=1e-5)
