@@ -320,14 +320,20 @@ __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename Scatt
 // gather : one thread per generator row; spike matrix as per-column masks (<= 32 batch columns per pass):
 //          out_bm[c, row] = sum over edges j of row with bit c of mask[j] set
 // scatter: the residue-class kernel above with lane stride 4 and gridDim.y = batch column (jit_scatter_batched)
-template <int MODE, typename A>
+// a += x with the sum forced back into a's own register: written as plain C++ inside the `mask != 0` branch, the compiler
+// gives the updated accumulators new registers and copies ALL of them at the branch's merge point on every generated edge
+// (16 v_mov_b64 per edge in the loop below — as much as the generator itself)
+__device__ __forceinline__ void acc_add_inplace(float& a, float x) { asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a) : "v"(x)); }
+__device__ __forceinline__ void acc_add_inplace(double& a, double x) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(x)); }
+
+template <int MODE, typename A, int NCOL>
 __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
                                                        A* __restrict__ out_bm) {
   const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < m; row += stride_t) {
-    A acc[32];
+    A acc[NCOL];                                   // NCOL = 8 / 16 / 32 >= nc: the columns the masks can hold
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = A(0);
+    for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
       const int64_t cs = (int64_t)chunk * p.chunk_size;
       const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
           if (mk) {
             const A w = (MODE == MODE_SCALAR) ? A(1) : edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)j);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) acc[c] += ((mk >> c) & 1u) ? w : A(0);
+            for (int c = 0; c < NCOL; ++c) acc_add_inplace(acc[c], ((mk >> c) & 1u) ? w : A(0));
           }
           state = lr_next_nz(state);
           q = q + 1u + lr_bounded(state, p.cl - 1u);
@@ -351,7 +357,75 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
       }
     }
 #pragma unroll
-    for (int c = 0; c < 32; ++c)
+    for (int c = 0; c < NCOL; ++c)
+      if (c < nc) out_bm[(int64_t)c * m + row] = (MODE == MODE_SCALAR) ? (A)(acc[c] * (A)p.w0) : acc[c];
+  }
+}
+
+// gather with the chunk's column masks staged in LDS (as the mv gather stages its bits): the 32-bit masks are narrowed to
+// the batch width (uint8 for <= 8 columns, uint16 for <= 16) so that a whole chunk — a quarter of the input population —
+// fits 128 KB: populations up to 512k / 256k / 128k, and four times that with windows (below).  A thread keeps its row's
+// accumulators over the four chunks; the workgroup reloads the masks between chunks / windows.  The global-mask kernel above pays a 64-byte sector per generated edge
+// (~5 ps per edge whatever the population: n = 250k ... 2M); this one runs at the generator's rate.
+template <int MODE, typename A, typename T>
+__global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
+                                                            A* __restrict__ out_bm, int64_t win_cols) {
+  // win_cols: columns of a chunk whose masks LDS holds at a time.  A chunk wider than that is swept in windows; the walks
+  // are sequential generators, so every window re-walks the chunk from its start up to the window's end (W windows cost
+  // (W + 1) / 2 walks of the chunk — still cheaper than a 64-byte sector per edge up to W = 4).
+  extern __shared__ __align__(16) unsigned char jit_mm_lds[];
+  T* ms = reinterpret_cast<T*>(jit_mm_lds);
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NCOL = 8 * (int)sizeof(T);                 // batch columns a mask of type T holds
+  A acc[NCOL];
+#pragma unroll
+  for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
+  for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+    const int64_t cs = (int64_t)chunk * p.chunk_size;
+    const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+    const int64_t width = ce - cs;
+    for (int64_t w_lo = 0; w_lo < width; w_lo += win_cols) {
+      const int64_t w_hi = w_lo + win_cols < width ? w_lo + win_cols : width;
+      const int64_t w_n = w_hi - w_lo;
+      __syncthreads();                                       // the previous window's masks are no longer read
+      for (int64_t i0 = threadIdx.x; i0 < w_n; i0 += 8 * (int64_t)blockDim.x) {      // eight loads in flight per thread
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * blockDim.x;
+          v[u] = mask[cs + w_lo + (i < w_n ? i : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * blockDim.x;
+          if (i < w_n) ms[i] = (T)v[u];
+        }
+      }
+      __syncthreads();
+      if (row < m) {
+        for (uint32_t l = 0; l < (uint32_t)p.stride; ++l) {
+          uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+          uint32_t q = lr_initial_q(state, p.cl);
+          uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
+          while ((int64_t)lj < w_hi) {
+            uint32_t mk = (int64_t)lj >= w_lo ? (uint32_t)ms[(int64_t)lj - w_lo] : 0u;
+            if (mk) {
+              asm volatile("" : "+v"(mk));                   // keeps the per-column adds behind the branch
+              const A w = (MODE == MODE_SCALAR) ? A(1) : edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)(cs + (int64_t)lj));
+#pragma unroll
+              for (int c = 0; c < NCOL; ++c) acc_add_inplace(acc[c], ((mk >> c) & 1u) ? w : A(0));
+            }
+            state = lr_next_nz(state);
+            q = q + 1u + lr_bounded(state, p.cl - 1u);
+            lj = (uint64_t)l + (uint64_t)p.stride * q;
+          }
+        }
+      }
+    }
+  }
+  if (row < m) {
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c)
       if (c < nc) out_bm[(int64_t)c * m + row] = (MODE == MODE_SCALAR) ? (A)(acc[c] * (A)p.w0) : acc[c];
   }
 }
@@ -620,7 +694,33 @@ int jit_mv_dispatch(const JitP& p, int wdtype, const void* spikes, int sd, void*
 template <int MODE, typename A>
 int jit_mm_run(const JitP& p, const uint32_t* mask, int64_t rows, int nc, int gather, A* out_bm, hipStream_t st) {
   (void)gather;   // only the gather ("notrans") direction comes here; the scatter runs jit_scatter_batched
-  hipLaunchKernelGGL((k_jit_mm_gather<MODE, A>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
+  // a chunk's masks in LDS when they fit 128 KB at the batch's width
+  const int64_t mask_sz = nc <= 8 ? 1 : (nc <= 16 ? 2 : 4);
+  const int64_t chunk_cols = std::min<int64_t>(p.chunk_size, p.walk_len);
+  const int64_t win_cap = 128 * 1024 / mask_sz;                      // columns whose masks fit LDS
+  const int64_t n_win = (chunk_cols + win_cap - 1) / win_cap;
+  // windows only pay for <= 8 batch columns (n = 1M: 3.75 -> 2.87 ms, 2M: 19 -> 15 ms); with 32 columns the re-walks cost
+  // more than the sectors they save (n = 500k: 1.4 -> 3.0 ms), so wider batches use LDS only when a whole chunk fits
+  if ((n_win == 1 || (mask_sz == 1 && n_win <= 4)) && rows > 0) {
+    const int64_t win_cols = (chunk_cols + n_win - 1) / n_win;
+    const size_t lds = (size_t)be_align_up(win_cols * mask_sz, 16);
+    const unsigned grid = (unsigned)((rows + 1023) / 1024);
+#define BE_JIT_MM_LDS(T_)                                                                                     \
+    do {                                                                                                      \
+      auto kern = k_jit_mm_gather_lds<MODE, A, T_>;                                                          \
+      BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                   \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, p, mask, rows, nc, out_bm, win_cols);        \
+    } while (0)
+    if (mask_sz == 1) BE_JIT_MM_LDS(uint8_t);
+    else if (mask_sz == 2) BE_JIT_MM_LDS(uint16_t);
+    else BE_JIT_MM_LDS(uint32_t);
+#undef BE_JIT_MM_LDS
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  }
+  if (nc <= 8) hipLaunchKernelGGL((k_jit_mm_gather<MODE, A, 8>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
+  else if (nc <= 16) hipLaunchKernelGGL((k_jit_mm_gather<MODE, A, 16>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
+  else hipLaunchKernelGGL((k_jit_mm_gather<MODE, A, 32>), dim3(gcap(rows, 256, 4096)), dim3(256), 0, st, p, mask, rows, nc, out_bm);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
