@@ -275,14 +275,14 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int b = 0; b < NBT; ++b) acc[b] += ((mk[u] >> b) & 1u) ? w[u] : ACC(0);
+          for (int b = 0; b < NBT; ++b) acc_add_inplace(acc[b], ((mk[u] >> b) & 1u) ? w[u] : ACC(0));
       }
       for (; a < n_union; a += 64) {
         const uint32_t j = ulist[a] & 0x0fffffffu;
         const uint32_t mk = mask[j];
         const ACC w = (ACC)WTraits<W>::load(row, j);
 #pragma unroll
-        for (int b = 0; b < NBT; ++b) acc[b] += ((mk >> b) & 1u) ? w : ACC(0);
+        for (int b = 0; b < NBT; ++b) acc_add_inplace(acc[b], ((mk >> b) & 1u) ? w : ACC(0));
       }
     } else {
       // U row pieces of 16 B and their masks (one vector load per piece) in flight per lane, then the tail piece by piece
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
           for (int v = 0; v < VEC; ++v) {
             if (mk[u][v]) {
 #pragma unroll
-              for (int b = 0; b < NBT; ++b) acc[b] += ((mk[u][v] >> b) & 1u) ? w[u][v] : ACC(0);
+              for (int b = 0; b < NBT; ++b) acc_add_inplace(acc[b], ((mk[u][v] >> b) & 1u) ? w[u][v] : ACC(0));
             }
           }
       }
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
           const uint32_t mk = mask[j + v];
           if (mk) {
 #pragma unroll
-            for (int b = 0; b < NBT; ++b) acc[b] += ((mk >> b) & 1u) ? w[v] : ACC(0);
+            for (int b = 0; b < NBT; ++b) acc_add_inplace(acc[b], ((mk >> b) & 1u) ? w[v] : ACC(0));
           }
         }
       }
@@ -725,6 +725,143 @@ __global__ void __launch_bounds__(256) k_densemm_nt_mfma(const W* __restrict__ w
   }
 }
 
+// The same kernel for f32 weights: v_mfma_f32_32x32x2_f32 (M = 32 weight rows, N = 32 batch rows, K = 2 per instruction).
+// A lane (row r, half h) loads 16 B = 4 consecutive k of its row at 4h; instruction j of a step multiplies element j of every
+// lane, i.e. k = k0 + j (h = 0) and k0 + 4 + j (h = 1) — the two K slots of an instruction need not be neighbours, only the
+// same for A and B — so a step covers 8 k with one load per lane and four MFMAs.  The products are w * 1 or w * 0 in f32:
+// exact, and the sums differ from the vector kernel's only in their order.  With 32 batch rows the vector kernel spends 64
+// select / add operations per weight and is VALU-bound at 2.4 ms for 32768^2 (1.0 ms with 8 batch rows).
+template <int DUMMY = 0>
+__global__ void __launch_bounds__(256) k_densemm_nt_mfma_f32(const float* __restrict__ weights, int64_t m, int64_t k,
+                                                             const uint32_t* __restrict__ mask, float* __restrict__ out_bm,
+                                                             int nc, int b0) {
+  __shared__ uint32_t masks_s[kNtChunk + 16 * kNtRing];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int r_lane = lane & 31, h = lane >> 5;
+  const int64_t row = m0 + r_lane < m ? m0 + r_lane : m - 1;            // clamped: results of rows >= m are dropped
+  const float* wrow = weights + row * k + 4 * h;
+  be_v16f acc = {};
+  uint4 ring[kNtRing];
+  for (int64_t c0 = 0; c0 < k; c0 += kNtChunk) {
+    const int64_t clen = k - c0 < kNtChunk ? k - c0 : kNtChunk;          // multiple of 4 (k % 4 == 0)
+    const int steps = (int)((clen + 7) >> 3);
+    __syncthreads();
+    for (int j = tid; j < kNtChunk + 16 * kNtRing; j += 256) masks_s[j] = (j < clen) ? mask[c0 + j] : 0u;
+    __syncthreads();
+    auto fetch = [&](int t, uint4& a) {      // only issues the load (address clamped into the row; zeroed at use)
+      int64_t kpos = c0 + 8 * (int64_t)t;
+      kpos = kpos + 4 * h + 4 <= k ? kpos : (k - 4 - 4 * h > 0 ? k - 4 - 4 * h : 0);
+      a = *reinterpret_cast<const uint4*>(wrow + kpos);
+    };
+#pragma unroll
+    for (int s = 0; s < kNtRing; ++s) {
+      fetch(s, ring[s]);
+      __builtin_amdgcn_sched_barrier(0);      // keep the issue order = the consume order (counted vmcnt needs it)
+    }
+    for (int t0 = 0; t0 < steps; t0 += kNtRing) {
+#pragma unroll
+      for (int ii = 0; ii < kNtRing; ++ii) {
+        const int t = t0 + ii;            // steps beyond `steps` multiply zero masks (padding of masks_s)
+        const uint32_t* mk = &masks_s[8 * t + 4 * h];
+        const bool in_k = c0 + 8 * (int64_t)t + 4 * h + 4 <= k;
+        const uint4 av = in_k ? ring[ii] : make_uint4(0, 0, 0, 0);
+        const float a4[4] = {__uint_as_float(av.x), __uint_as_float(av.y), __uint_as_float(av.z), __uint_as_float(av.w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float bj = ((mk[j] >> r_lane) & 1u) ? 1.0f : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bj, acc, 0, 0, 0);
+        }
+        fetch(t + kNtRing, ring[ii]);
+        __builtin_amdgcn_sched_barrier(0);    // pin the refill here (see k_densemm_nt_mfma)
+      }
+    }
+  }
+  // C layout: col (batch) = lane & 31, row (weight row) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int b = lane & 31;
+  if (b < nc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (i < m) out_bm[(int64_t)(b0 + b) * m + i] = acc[r];
+    }
+  }
+}
+
+// transpose=True for f32 weights on v_mfma_f32_32x32x2_f32: M = 32 batch rows (A = the 0/1 spike tile), N = 32 weight columns,
+// K = 2 union rows per instruction (lanes 0-31 the first, 32-63 the second).  A lane loads 16 B = 4 consecutive columns of
+// its row at 4 (lane & 31): instruction j of a step takes element j, so a wave owns 128 columns as four 32 x 32 accumulators
+// over the column sets {4 i + j}.  No LDS staging of the weights: the B operand wants one column per lane, which is what a
+// row-major load gives.  The vector kernel re-reads the matrix once per group of 4 batch rows (32 rows at 50 % firing:
+// 3.6 ms for 32768^2, 8 passes); this one reads the union rows once.
+constexpr int kTfChunk = 128;     // steps (pairs of union rows) staged in LDS at a time
+constexpr int kTfRing = 8;
+template <int DUMMY = 0>
+__global__ void __launch_bounds__(256) k_densemm_t_mfma_f32(const float* __restrict__ weights, int64_t n,
+                                                            const uint32_t* __restrict__ mask, const uint32_t* __restrict__ ulist,
+                                                            const uint32_t* __restrict__ ucount, float* __restrict__ partial) {
+  __shared__ uint32_t rows_s[2 * (kTfChunk + kTfRing)];
+  __shared__ uint32_t masks_s[2 * (kTfChunk + kTfRing)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c_lane = lane & 31, h = lane >> 5;
+  const int64_t col = ((int64_t)blockIdx.x * 4 + wave) * 128 + 4 * c_lane;
+  const bool col_ok = col < n;                            // n % 4 == 0: a lane's four columns are all in or all out
+  const float* wcol = weights + (col_ok ? col : 0);
+  const uint32_t n_union = ucount[0];
+  const uint32_t steps_total = (n_union + 1u) >> 1;
+  const uint32_t per_part = (steps_total + gridDim.y - 1) / gridDim.y;
+  const uint32_t t_begin = blockIdx.y * per_part;
+  const uint32_t t_end = t_begin + per_part < steps_total ? t_begin + per_part : steps_total;
+  be_v16f acc[4] = {};
+  uint4 ring[kTfRing];
+  for (uint32_t c0 = t_begin; c0 < t_end; c0 += kTfChunk) {
+    const uint32_t c_end = c0 + kTfChunk < t_end ? c0 + kTfChunk : t_end;
+    __syncthreads();
+    for (int j = tid; j < 2 * (kTfChunk + kTfRing); j += 256) {
+      const uint32_t i = 2u * c0 + (uint32_t)j;
+      const bool v = i < n_union && (c0 + ((uint32_t)j >> 1)) < c_end;
+      const uint32_t rid = v ? (ulist[i] & 0x0fffffffu) : 0u;
+      rows_s[j] = rid;
+      masks_s[j] = v ? mask[rid] : 0u;                     // mask 0: the row contributes nothing (its weights are zeroed at use)
+    }
+    __syncthreads();
+    auto fetch = [&](uint32_t t, uint4& b) {              // only issues the load; steps past c_end read row 0 with mask 0
+      const uint32_t s = (t - c0) < (uint32_t)(kTfChunk + kTfRing - 1) ? (t - c0) : (uint32_t)(kTfChunk + kTfRing - 1);
+      b = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[2 * s + h] * n);
+    };
+#pragma unroll
+    for (int s = 0; s < kTfRing; ++s) {
+      fetch(c0 + s, ring[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (uint32_t t0 = c0; t0 < c_end; t0 += kTfRing) {
+#pragma unroll
+      for (int ii = 0; ii < kTfRing; ++ii) {
+        const uint32_t t = t0 + ii;                       // steps in [c_end, c_end + ring) multiply zeros
+        const uint32_t mk = masks_s[2 * (t - c0) + h];
+        const float a = ((mk >> c_lane) & 1u) ? 1.0f : 0.0f;
+        const bool use = col_ok && mk != 0u;               // (0 * inf = NaN inside an MFMA: rows without a spike must be exact zeros)
+        const uint4 bv = use ? ring[ii] : make_uint4(0, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(bv.x), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(bv.y), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(bv.z), acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(bv.w), acc[3], 0, 0, 0);
+        fetch(t + kTfRing, ring[ii]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // C layout: N (column set index) = lane & 31, M (batch row) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (col_ok) {
+    float* pbase = partial + (int64_t)blockIdx.y * 32 * n + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      *reinterpret_cast<float4*>(pbase + (int64_t)row * n) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+  }
+}
+
 template <typename W>
 __global__ void __launch_bounds__(256) k_mfma_reduce(const float* __restrict__ partial, int parts, int64_t part_stride,
                                                      int64_t total, W* __restrict__ out) {
@@ -752,7 +889,7 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
   uint32_t* flag = d.lists;
   uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;
   uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
-  const int parts = mfma_parts(n);
+  const int parts = std::is_same<W, float>::value ? mfma_parts(n / 2) : mfma_parts(n);      // f32: workgroups of 512 columns
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
@@ -772,8 +909,12 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
     BE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile, ulist, k);
     BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_densemm_mfma<W>, dim3((unsigned)((n + kMfmaCols - 1) / kMfmaCols), parts), dim3(256), 0, st, weights,
-                       n, d.mask, ulist, d.count + kMaxGroups, partial);
+    if constexpr (std::is_same<W, float>::value)
+      hipLaunchKernelGGL(k_densemm_t_mfma_f32<0>, dim3((unsigned)((n + 511) / 512), parts), dim3(256), 0, st, weights, n, d.mask,
+                         ulist, d.count + kMaxGroups, partial);
+    else
+      hipLaunchKernelGGL(k_densemm_mfma<W>, dim3((unsigned)((n + kMfmaCols - 1) / kMfmaCols), parts), dim3(256), 0, st, weights,
+                         n, d.mask, ulist, d.count + kMaxGroups, partial);
     BE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mfma_reduce<W>, dim3(grid_cap((int64_t)nc * n, 256, 2048)), dim3(256), 0, st, partial, parts,
                        (int64_t)32 * n, (int64_t)nc * n, out_bm + b0 * n);
@@ -799,8 +940,12 @@ int densemm_nt_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, 
       hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
                          static_cast<const uint8_t*>(chunk), k, nc, d.mask);
     BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_densemm_nt_mfma<W>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
-                       out_bm, nc, (int)b0);
+    if constexpr (std::is_same<W, float>::value)
+      hipLaunchKernelGGL(k_densemm_nt_mfma_f32<0>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
+                         out_bm, nc, (int)b0);
+    else
+      hipLaunchKernelGGL(k_densemm_nt_mfma<W>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
+                         out_bm, nc, (int)b0);
     BE_LAUNCH_CHECK();
   }
   be_prof_end(prof, st);
@@ -815,7 +960,7 @@ int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm
   constexpr int V = Vec16<W>::n;
   const bool vec_ok = (cols_w % V == 0) && ((reinterpret_cast<uintptr_t>(weights) & 15) == 0);
   if (transpose) {
-    if constexpr (std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value) {
+    if constexpr (std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value || std::is_same<W, float>::value) {
       if (vec_ok && nb >= 8) return densemm_t_mfma<W>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
     }
     if (vec_ok) return densemm_t_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
@@ -824,6 +969,11 @@ int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm
   if constexpr (std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value) {
     // enough rows to fill the chip with 32-row waves; k >= 16 so that the clamped tail load stays inside the row
     if (vec_ok && nb >= 8 && rows_w >= 4096 && cols_w >= 16)
+      return densemm_nt_mfma<W>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
+  }
+  if constexpr (std::is_same<W, float>::value) {
+    // f32, more than 8 batch rows: the vector kernel is VALU-bound there (see k_densemm_nt_mfma_f32)
+    if (vec_ok && nb >= 8 && rows_w >= 4096 && cols_w >= 8)
       return densemm_nt_mfma<W>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
   }
   if (vec_ok) return densemm_nt_vec<W, V>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);

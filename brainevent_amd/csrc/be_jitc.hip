@@ -320,12 +320,6 @@ __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename Scatt
 // gather : one thread per generator row; spike matrix as per-column masks (<= 32 batch columns per pass):
 //          out_bm[c, row] = sum over edges j of row with bit c of mask[j] set
 // scatter: the residue-class kernel above with lane stride 4 and gridDim.y = batch column (jit_scatter_batched)
-// a += x with the sum forced back into a's own register: written as plain C++ inside the `mask != 0` branch, the compiler
-// gives the updated accumulators new registers and copies ALL of them at the branch's merge point on every generated edge
-// (16 v_mov_b64 per edge in the loop below — as much as the generator itself)
-__device__ __forceinline__ void acc_add_inplace(float& a, float x) { asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a) : "v"(x)); }
-__device__ __forceinline__ void acc_add_inplace(double& a, double x) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(x)); }
-
 template <int MODE, typename A, int NCOL>
 __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
                                                        A* __restrict__ out_bm) {

@@ -163,3 +163,37 @@ def test_dense_container(be, oracle):
     assert isinstance(out, torch.Tensor)
     with pytest.raises(NotImplementedError):
         D @ np.ones(21, np.float32)
+
+
+@pytest.mark.parametrize('shape,nb', [((4096, 520), 9), ((5003, 1028), 32), ((4133, 8), 17), ((8192, 4100), 40)])
+def test_densemm_f32_mfma_both_directions(be, oracle, shape, nb):
+    """f32 weights, >= 8 batch rows (no-transpose: also >= 4096 weight rows): both products run on v_mfma_f32_32x32x2_f32
+    (exact products w * {0, 1}; sums in another order than the vector kernel's).  Row counts that are not tile multiples, k
+    that is 4- but not 8-aligned, more than 32 batch rows (two passes), float spikes."""
+    rng = np.random.default_rng(shape[0] + nb)
+    W = torch.tensor(rng.normal(0, 1, shape), dtype=torch.float32, device='cuda')
+    Wd = W.double().cpu().numpy()
+    for fire in (0.02, 0.6):
+        S = rng.random((shape[1], nb)) < fire
+        ref = oracle.binary_densemm(Wd, S, False)
+        got = be.binary_densemm(W, torch.tensor(S, device='cuda'), transpose=False)
+        assert tuple(got.shape) == (shape[0], nb) and got.dtype == torch.float32
+        np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+        gotf = be.binary_densemm(W, torch.tensor(np.where(S, 0.7, -1.0).astype(np.float32), device='cuda'), transpose=False)
+        np.testing.assert_array_equal(gotf.cpu().numpy(), got.cpu().numpy())
+        # the vector kernel (< 8 batch rows) on the first columns
+        vec = be.binary_densemm(W, torch.tensor(S[:, :7].copy(), device='cuda'), transpose=False)
+        np.testing.assert_allclose(vec.cpu().numpy(), got[:, :7].cpu().numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+        # transpose=True (out[n, b] = sum over active k of W[k, n]): the union-row MFMA kernel, against oracle and vector kernel
+        St = rng.random((shape[0], nb)) < fire
+        reft = oracle.binary_densemm(Wd, St, True)
+        gott = be.binary_densemm(W, torch.tensor(St, device='cuda'), transpose=True)
+        assert tuple(gott.shape) == (shape[1], nb)
+        np.testing.assert_allclose(gott.double().cpu().numpy(), reft, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(reft).max())))
+        vect = be.binary_densemm(W, torch.tensor(St[:, :7].copy(), device='cuda'), transpose=True)
+        np.testing.assert_allclose(vect.cpu().numpy(), gott[:, :7].cpu().numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(reft).max())))
+    # a non-finite weight in a row WITHOUT a spike must not leak (0 * inf inside an MFMA): rows without spikes are zeroed
+    W2 = W.clone(); W2[3, :] = float('inf')
+    St = rng.random((shape[0], nb)) < 0.3; St[3, :] = False
+    gott = be.binary_densemm(W2, torch.tensor(St, device='cuda'), transpose=True)
+    assert torch.isfinite(gott).all()
