@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) k_coarsen_bits(const uint32_t* __restrict
 // f32 weights are streamed unconditionally with the same vector loads — a dependent load per active entry would
 // serialise the row at one HBM round trip per hit; other weight dtypes keep the conditional scalar load.
 typedef unsigned be_nt_v4u __attribute__((ext_vector_type(4)));
-constexpr int64_t kGatherVecMaxRow = 512;   // average row length up to which the lanes-per-row vector kernel is used
+constexpr int64_t kGatherVecMaxRow = 200;   // average row length up to which the lanes-per-row vector kernel is used (32 lanes: 256 entries in two passes)
 
 template <typename W, bool HOMO, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ weights, const int32_t* __restrict__ indices,
@@ -426,12 +426,14 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
   }
 }
 
-// short and medium rows (a few to a few hundred entries): LPR lanes per row, 64 / LPR rows per wave step, four consecutive
-// entries per lane and load (16 B of indices [+ 16 B of f32 weights]), two passes of a row in flight.  The wave-per-row
-// kernel above keeps four rows in flight per wave and 25 of 64 lanes busy on a 100-entry row; the scalar lanes-per-row
-// kernel this replaces loaded a weight only behind its spike test (a dependent round trip per hit).  2e8 entries, 1 % of
-// the inputs active, ms per product (tools/bench_gather_rows.py), weighted: 4 per row 3.77 -> 0.88, 12: 4.86 -> 0.57,
-// 48: 2.52 -> 0.46, 100: 0.50 -> 0.38 (4.2 TB/s), 250: 0.31 -> 0.30; counted: 12: 4.45 -> 0.46, 100: 0.41 -> 0.24.
+// short and medium rows (a few to ~200 entries on average): LPR lanes per row, 64 / LPR rows per group (one load
+// instruction), four consecutive entries per lane and load (16 B of indices [+ 16 B of f32 weights]), two passes of a row
+// per group.  A wave takes 64 CONSECUTIVE rows at a time (coalesced row pointers; results leave as one 256-byte store
+// through a per-wave LDS row) and walks their groups in straight-line code two groups ahead — the first version looped
+// over the groups and paid one full memory latency per group.  Rows longer than two passes finish in a serial tail.
+// The scalar lanes-per-row kernel of round 1 loaded a weight only behind its spike test (a dependent round trip per hit).
+// 2e8 entries, 1 % of the inputs active, ms per product (tools/bench_gather_rows.py), weighted: 4 per row 3.77 -> 0.57,
+// 12: 4.86 -> 0.35, 48: 2.52 -> 0.33, 100: 0.50 -> 0.31 (5.2 TB/s); counted: 12: 4.45 -> 0.28, 100: 0.41 -> 0.19.
 template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                        RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
   bits_g += (int64_t)blockIdx.y * n_words;
   out += (int64_t)blockIdx.y * m;
   extern __shared__ uint32_t bits_s[];
-  {   // the exact bitmap (BITS_IN_LDS) or the coarse one (spike_on)
+  {   // the exact bitmap (BITS_IN_LDS) or the coarse one (spike_mask)
     const uint32_t* src = BITS_IN_LDS ? bits_g : coarse_g + (int64_t)blockIdx.y * n_cwords;
     const int64_t nw = BITS_IN_LDS ? n_words : n_cwords;
     for (int64_t i = threadIdx.x; i < nw; i += blockDim.x) bits_s[i] = src[i];
@@ -448,89 +450,163 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
   }
   using ACC = typename WTraits<W>::acc;
   constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
-  constexpr int RPW = 64 / LPR;                  // rows per wave step
-  constexpr int PASS = 4 * LPR;                  // entries of a row per pass
-  const int lane = lane_id(), sub = lane % LPR, slot = lane / LPR;
+  constexpr int RPW = 64 / LPR;                  // rows per group (one load instruction)
+  constexpr int NGRP = 64 / RPW;                 // groups of a 64-row batch
+  constexpr int PASS = 4 * LPR;                  // entries of a row per pass; a group holds two passes of its rows
+  constexpr int DEPTH = NGRP < 2 ? NGRP : 2;     // groups in flight ahead of the one being consumed (registers: 19 per group)
+  __shared__ ACC res_s[16][64];                  // per wave: the 64 results of a batch (long rows add their tails here)
+  const int lane = lane_id(), sub = lane % LPR, slot = lane / LPR, wv_id = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t nnz_end = rp.at(m);              // a 16-byte load may not run past the arrays
   ACC w0 = ACC(0);
   if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
 
-  for (int64_t t0 = 0;; t0 += 64) {              // bounds of this wave's next 64 rows: lane l -> row wave + n_waves * (t0 + l)
-    const int64_t my_r = wave + n_waves * (t0 + lane);
+  struct Grp {
+    be_nt_v4u c[2], wv[2];
+    int64_t b;
+    int32_t len;               // clamped to two passes: all a group looks at
+  };
+  // a batch = 64 CONSECUTIVE rows (coalesced row pointers and results); batches are dealt to the waves round-robin
+  for (int64_t r0 = wave * 64; r0 < m; r0 += n_waves * 64) {
+    const int64_t my_r = r0 + lane;
     const bool valid = my_r < m;
-    const unsigned long long vmask = __ballot(valid);
-    if (vmask == 0ull) break;
-    const int64_t rc = valid ? my_r : 0;
-    int64_t rb = rp.at(rc), re = rp.at(rc + 1);
-    if (!valid) { rb = 0; re = 0; }
-    const int64_t rl = re - rb;
-    const int nvalid = __popcll(vmask);
-    for (int i = 0; i < nvalid; i += RPW) {
-      const int src = (i + slot) & 63;
-      const int64_t b = __shfl(rb, src, 64);
-      const int64_t len = (i + slot < nvalid) ? __shfl(rl, src, 64) : 0;
-      int64_t maxlen = len;                       // longest row of the step (uniform loop bound)
-#pragma unroll
-      for (int off = 32; off >= LPR; off >>= 1) {
-        const int64_t o = __shfl_xor(maxlen, off, 64);
-        maxlen = o > maxlen ? o : maxlen;
+    const int64_t rc = valid ? my_r : m - 1;
+    const int64_t rb = rp.at(rc);
+    const int64_t rl = valid ? rp.at(rc + 1) - rb : 0;
+    // The groups of the batch are walked in straight-line code, DEPTH groups ahead: no load crosses a back edge, so the
+    // wait counts stay exact (a loop around issue / consume makes hipcc wait for every load in flight: be_csr_plan.hip).
+    auto issue = [&](Grp& g, int q) {
+      const int src = q * RPW + slot;
+      g.b = __shfl(rb, src, 64);
+      {
+        const int64_t l64 = __shfl(rl, src, 64);
+        g.len = (int32_t)(l64 < 2 * PASS ? l64 : 2 * PASS);
       }
-      maxlen = __shfl(maxlen, 0, 64);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        g.c[u] = be_nt_v4u{0u, 0u, 0u, 0u};
+        g.wv[u] = be_nt_v4u{0u, 0u, 0u, 0u};
+        const int32_t j = u * PASS + 4 * sub;
+        if (j + 4 <= g.len || (j < g.len && g.b + j + 4 <= nnz_end)) {   // whole piece (a row's last piece may read into the next row)
+          const uint4 t = *reinterpret_cast<const uint4*>(indices + g.b + j);
+          g.c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
+          if (VECW) {
+            const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + g.b + j);
+            g.wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
+          }
+        } else if (j < g.len) {                                          // the last entries of the arrays: one by one
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < g.len) {
+              g.c[u][e] = (uint32_t)indices[g.b + j + e];
+              if (VECW) g.wv[u][e] = __float_as_uint(reinterpret_cast<const float*>(weights)[g.b + j + e]);
+            }
+        }
+      }
+    };
+    auto consume = [&](const Grp& g, int q) {
+      uint32_t cols[8], vmask = 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cols[4 * u + e] = g.c[u][e];
+          vmask |= (u * PASS + 4 * sub + e < g.len ? 1u : 0u) << (4 * u + e);
+        }
+      const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, vmask, g_shift);
       ACC acc = ACC(0);
       int cnt = 0;
-      for (int64_t j0 = 0; j0 < maxlen; j0 += 2 * PASS) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool on = (onm >> (4 * u + e)) & 1u;
+          if (HOMO) cnt += on ? 1 : 0;
+          else if (VECW) acc += on ? (ACC)__uint_as_float(g.wv[u][e]) : ACC(0);
+          else if (on) acc += (ACC)WTraits<W>::load(weights, g.b + (int64_t)u * PASS + 4 * sub + e);
+        }
+      if (HOMO) {
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, LPR);
+        acc = (ACC)cnt;
+      } else {
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
+      }
+      if (sub == 0) res_s[wv_id][q * RPW + slot] = acc;
+    };
+    Grp g[NGRP];
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) issue(g[q], q);
+#pragma unroll
+    for (int q = 0; q < NGRP; ++q) {
+      if (q + DEPTH < NGRP) issue(g[q + DEPTH], q + DEPTH);
+      consume(g[q], q);
+    }
+    // rows longer than two passes: the rest of the row, a wave per row (the host picks LPR so that these are the exception)
+    unsigned long long longm = __ballot(rl > 2 * PASS);
+    while (longm) {
+      const int src = __ffsll((long long)longm) - 1;
+      longm &= longm - 1;
+      const int64_t b = __shfl(rb, src, 64), len = __shfl(rl, src, 64);
+      ACC acc = ACC(0);
+      int cnt = 0;
+      for (int64_t j0 = 2 * PASS; j0 < len; j0 += 2 * 256) {
         be_nt_v4u c[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, wv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int64_t j = j0 + (int64_t)u * PASS + 4 * sub;
-          if (j + 4 <= len || (j < len && b + j + 4 <= nnz_end)) {       // whole piece (a row's last piece may read into the next row)
+          const int64_t j = j0 + (int64_t)u * 256 + 4 * lane;
+          if (j + 4 <= len || (j < len && b + j + 4 <= nnz_end)) {
             const uint4 t = *reinterpret_cast<const uint4*>(indices + b + j);
             c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
             if (VECW) {
               const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + b + j);
               wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
             }
-          } else if (j < len) {                                          // the last entries of the arrays: one by one
+          } else if (j < len) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (j + q < len) {
-                c[u][q] = (uint32_t)indices[b + j + q];
-                if (VECW) wv[u][q] = __float_as_uint(reinterpret_cast<const float*>(weights)[b + j + q]);
+            for (int e = 0; e < 4; ++e)
+              if (j + e < len) {
+                c[u][e] = (uint32_t)indices[b + j + e];
+                if (VECW) wv[u][e] = __float_as_uint(reinterpret_cast<const float*>(weights)[b + j + e]);
               }
           }
         }
-        uint32_t cols[8], valid = 0;
+        uint32_t cols[8], vmask = 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            cols[4 * u + q] = c[u][q];
-            valid |= (j0 + (int64_t)u * PASS + 4 * sub + q < len ? 1u : 0u) << (4 * u + q);
+          for (int e = 0; e < 4; ++e) {
+            cols[4 * u + e] = c[u][e];
+            vmask |= (j0 + (int64_t)u * 256 + 4 * lane + e < len ? 1u : 0u) << (4 * u + e);
           }
-        const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, valid, g_shift);
+        const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, vmask, g_shift);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int64_t j = j0 + (int64_t)u * PASS + 4 * sub;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool on = (onm >> (4 * u + q)) & 1u;
+          for (int e = 0; e < 4; ++e) {
+            const bool on = (onm >> (4 * u + e)) & 1u;
             if (HOMO) cnt += on ? 1 : 0;
-            else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][q]) : ACC(0);
-            else if (on) acc += (ACC)WTraits<W>::load(weights, b + j + q);
+            else if (VECW) acc += on ? (ACC)__uint_as_float(wv[u][e]) : ACC(0);
+            else if (on) acc += (ACC)WTraits<W>::load(weights, b + j0 + (int64_t)u * 256 + 4 * lane + e);
           }
-        }
       }
       if (HOMO) {
 #pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, LPR);
-        acc = (ACC)cnt * w0;
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+        acc = (ACC)cnt;
       } else {
 #pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
       }
-      if (sub == 0 && i + slot < nvalid) WTraits<W>::store(out, wave + n_waves * (t0 + i + slot), acc);
+      if (lane == 0) res_s[wv_id][src] += acc;        // (same wave wrote the slot: program order)
+    }
+    // one coalesced store of the batch's 64 results (LDS traffic of one wave needs no barrier, only the wait below)
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+    if (valid) {
+      const ACC r = res_s[wv_id][lane];
+      WTraits<W>::store(out, my_r, HOMO ? r * w0 : r);
     }
   }
 }
@@ -811,7 +887,7 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     const int prof = be_prof_begin(st);
 #define BE_NT_VEC(LPR_)                                                                                                     \
     do {                                                                                                                    \
-      const int grid = grid_for(m, 16 * (64 / LPR_), nb >= 8 ? 256 : 512);                                                   \
+      const int grid = grid_for(m, 16 * 64, nb >= 8 ? 256 : 512);                                                   \
       if (in_lds) {                                                                                                          \
         auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, true>;                                                                    \
         BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                \
@@ -824,10 +900,11 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
                            bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       }                                                                                                                      \
     } while (0)
-    if (avg <= 6) BE_NT_VEC(2);
-    else if (avg <= 16) BE_NT_VEC(4);
-    else if (avg <= 40) BE_NT_VEC(8);
-    else if (avg <= 160) BE_NT_VEC(16);
+    // two passes of a row (8 x LPR entries) should hold nearly every row: LPR by the average length
+    if (avg <= 8) BE_NT_VEC(2);
+    else if (avg <= 20) BE_NT_VEC(4);
+    else if (avg <= 45) BE_NT_VEC(8);
+    else if (avg <= 100) BE_NT_VEC(16);
     else BE_NT_VEC(32);
 #undef BE_NT_VEC
     be_prof_end(prof, st);
