@@ -837,7 +837,10 @@ template <typename W, bool HOMO>
 int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz_hint, const void* spikes, int sd,
              void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
   const int64_t n_words = (k + 31) / 32;
-  if (nb >= kFusedMinBatch && m > 0 && nnz_hint / m >= kFusedMinRow && !std::is_same<W, double>::value &&
+  // one pass over the matrix for all columns against one pass of the vector kernel per column (2e8 entries, 8 / 32
+  // columns, ms: rows of 24: 4.8 / 7.0 fused, 2.7 / 9.7 per column; 100: 1.9 / 3.2 against 2.4 / 9.3; 250: 1.5 / 2.1
+  // against 2.3 / 9.4; tools/bench_gather_batched.py): fused from (average row length x columns) >= kFusedMinWork
+  if (nb >= kFusedMinBatch && m > 0 && (nnz_hint / m) * nb >= kFusedMinWork && nnz_hint / m >= 16 && !std::is_same<W, double>::value &&
       (sd == BE_SPIKE_BOOL || sd == BE_SPIKE_FLOAT)) {
     // long rows, several columns: one pass over the matrix per 32 columns (k_csrmm_nt_fused)
     uint32_t* mask = static_cast<uint32_t*>(ws);

@@ -16,7 +16,7 @@ static inline int grid_for(int64_t n, int block, int cap) {
 
 constexpr int kMaxBatch = 65535;
 constexpr int kFusedMinBatch = 4;      // batched gather: fuse over the batch from this many columns ...
-constexpr int64_t kFusedMinRow = 256;  // ... when rows average at least this many entries
+constexpr int64_t kFusedMinWork = 768; // ... when (average row length x columns) reaches this (and rows average >= 16 entries)
 
 static inline int64_t counts_bytes(int64_t nb) { return be_align_up(nb * 4, 256); }
 static inline int64_t active_stride_of(int64_t m) { return be_align_up(m * 4, 256) / 4; }   // in uint32 elements
