@@ -715,6 +715,168 @@ __global__ void __launch_bounds__(1024) k_csrmm_nt_fused(const W* __restrict__ w
   }
 }
 
+// The same product for rows of up to ~200 entries: LPR lanes per row and 64 / LPR rows per group, as in k_csrmv_nt_vec
+// (64 consecutive rows per wave batch, two passes of a row per group, the next group's index / weight loads issued before
+// the current group's mask gathers are waited for).  The wave-per-row kernel above pays both dependent round trips (entries,
+// then masks) and a 64-lane fold + clear of the private slots for every row: 16 ps per entry on rows of 100 against 7 ps
+// on rows of 1000.  Rows longer than two passes are finished by the whole wave before the group's fold.
+template <typename W, bool HOMO, int LPR>
+__global__ void __launch_bounds__(1024) k_csrmm_nt_fused_vec(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                             RowPtr rp, const uint32_t* __restrict__ mask, int nc,
+                                                             W* __restrict__ out_bm, int64_t m) {
+  extern __shared__ float fused_s[];                 // [1024][kFusedSlots]; uint32 counts when HOMO
+  constexpr bool VECW = std::is_same<W, float>::value && !HOMO;
+  constexpr int RPW = 64 / LPR, NGRP = 64 / RPW, PASS = 4 * LPR;
+  float* my = fused_s + threadIdx.x * kFusedSlots;
+  uint32_t* my_u = reinterpret_cast<uint32_t*>(my);
+#pragma unroll
+  for (int b = 0; b < 32; ++b) my[b] = 0.0f;
+  const int lane = lane_id(), sub = lane % LPR, slot = lane / LPR;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float* wave_slots = fused_s + (threadIdx.x & ~63) * kFusedSlots;
+  const int64_t nnz_end = rp.at(m);
+  float w0 = 0.0f;
+  if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
+
+  struct Grp {
+    be_nt_v4u c[2], wv[2];
+    int64_t b;
+    int32_t len;               // clamped to two passes
+  };
+  auto add_entry = [&](uint32_t bits, uint32_t wbits, int64_t pos) {          // visit the set bits of one entry's mask
+    if (bits) {
+      float w = 0.0f;
+      if (!HOMO) w = VECW ? __uint_as_float(wbits) : (float)WTraits<W>::load(weights, pos);
+      do {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (HOMO) my_u[b] += 1u;
+        else my[b] += w;
+      } while (bits);
+    }
+  };
+  for (int64_t r0 = wave * 64; r0 < m; r0 += n_waves * 64) {
+    const int64_t my_r = r0 + lane;
+    const bool valid = my_r < m;
+    const int64_t rc = valid ? my_r : m - 1;
+    const int64_t rb = rp.at(rc);
+    const int64_t rl = valid ? rp.at(rc + 1) - rb : 0;
+    auto issue = [&](Grp& g, int q) {
+      const int src = q * RPW + slot;
+      g.b = __shfl(rb, src, 64);
+      {
+        const int64_t l64 = __shfl(rl, src, 64);
+        g.len = (int32_t)(l64 < 2 * PASS ? l64 : 2 * PASS);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        g.c[u] = be_nt_v4u{0u, 0u, 0u, 0u};
+        g.wv[u] = be_nt_v4u{0u, 0u, 0u, 0u};
+        const int32_t j = u * PASS + 4 * sub;
+        if (j + 4 <= g.len || (j < g.len && g.b + j + 4 <= nnz_end)) {
+          const uint4 t = *reinterpret_cast<const uint4*>(indices + g.b + j);
+          g.c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
+          if (VECW) {
+            const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + g.b + j);
+            g.wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
+          }
+        } else if (j < g.len) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < g.len) {
+              g.c[u][e] = (uint32_t)indices[g.b + j + e];
+              if (VECW) g.wv[u][e] = __float_as_uint(reinterpret_cast<const float*>(weights)[g.b + j + e]);
+            }
+        }
+      }
+    };
+    // One group at a time, in a real loop (the body — tails, fold — is too long to unroll 8 ... 32 times): the mask gathers
+    // of group q and the index / weight loads of group q + 1 are issued together and waited for once.
+    Grp g;
+    issue(g, 0);
+#pragma unroll 1
+    for (int q = 0; q < NGRP; ++q) {
+      uint32_t mk[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mk[4 * u + e] = mask[g.c[u][e]];          // unconditional gathers (column 0 past a row's end)
+      Grp gn = g;
+      if (q + 1 < NGRP) issue(gn, q + 1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int32_t j = u * PASS + 4 * sub + e;
+          add_entry(j < g.len ? mk[4 * u + e] : 0u, g.wv[u][e], g.b + j);
+        }
+      // rows of this group longer than two passes: the whole wave takes the rest of each (the slots of ALL its lanes are
+      // folded into that row below, so the tail entries go to the slots of the row's own lanes: lane l -> slot lane l % LPR)
+      const int64_t my_row_len = __shfl(rl, q * RPW + slot, 64);             // (every lane takes part in the shuffle)
+      unsigned long long longm = __ballot(sub == 0 && my_row_len > 2 * PASS);
+      while (longm) {
+        const int src_lane = __ffsll((long long)longm) - 1;                       // first lane of the long row's lane group
+        longm &= longm - 1;
+        const int src = q * RPW + src_lane / LPR;
+        const int64_t b = __shfl(rb, src, 64), len = __shfl(rl, src, 64);
+        float* tgt = wave_slots + (src_lane + sub) * kFusedSlots;                // a slot row of that group, by this lane's sub index
+        uint32_t* tgt_u = reinterpret_cast<uint32_t*>(tgt);
+        for (int64_t j0 = 2 * PASS; j0 < len; j0 += 64) {
+          const int64_t j = j0 + lane;
+          uint32_t bits = 0;
+          float w = 0.0f;
+          if (j < len) {
+            bits = mask[indices[b + j]];
+            if (!HOMO && bits) w = (float)WTraits<W>::load(weights, b + j);
+          }
+          // lanes with the same sub index share a slot row here: serialise them by their slot number (RPW rounds)
+#pragma unroll
+          for (int turn = 0; turn < RPW; ++turn) {
+            if (slot == turn) {
+              uint32_t bb = bits;
+              while (bb) {
+                const int bi = __ffs(bb) - 1;
+                bb &= bb - 1;
+                if (HOMO) tgt_u[bi] += 1u;
+                else tgt[bi] += w;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+        }
+      }
+      // fold the group's rows: lane (slot, sub) sums columns sub, sub + LPR, ... over the LPR lanes of its row
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      {
+        const int64_t row = r0 + q * RPW + slot;
+        const float* src = wave_slots + (slot * LPR) * kFusedSlots;
+        for (int col = sub; col < 32; col += LPR) {
+          float sum = 0.0f;
+          uint32_t cnt = 0;
+#pragma unroll 8
+          for (int t = 0; t < LPR; ++t) {
+            if (HOMO) cnt += reinterpret_cast<const uint32_t*>(src)[t * kFusedSlots + col];
+            else sum += src[t * kFusedSlots + col];
+          }
+          if (HOMO) sum = (float)cnt * w0;
+          if (col < nc && row < m) WTraits<W>::store(out_bm, (int64_t)col * m + row, sum);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int b = 0; b < 32; ++b) my[b] = 0.0f;
+      g = gn;
+    }
+  }
+}
+
 // =================================================================================================
 // host-side launch helpers.  Every op takes a batch: spikes are batch-major [n_batch, len], outputs
 // batch-major [n_batch, out_len]; the *mv entry points are the n_batch = 1 case, the *mm entry points
@@ -846,6 +1008,11 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     uint32_t* mask = static_cast<uint32_t*>(ws);
     const size_t lds = (size_t)1024 * kFusedSlots * 4;
     auto kern = k_csrmm_nt_fused<W, HOMO>;
+    const int64_t avg_row = nnz_hint / m;
+    const int grid_rows = avg_row <= kGatherVecMaxRow ? 16 * 64 : 16;      // rows a workgroup takes per round
+    if (avg_row <= 45) kern = k_csrmm_nt_fused_vec<W, HOMO, 8>;
+    else if (avg_row <= 100) kern = k_csrmm_nt_fused_vec<W, HOMO, 16>;
+    else if (avg_row <= kGatherVecMaxRow) kern = k_csrmm_nt_fused_vec<W, HOMO, 32>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
     const size_t ssz = sd == BE_SPIKE_FLOAT ? 4 : 1;
     for (int64_t c0 = 0; c0 < nb; c0 += 32) {
@@ -858,7 +1025,7 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
         hipLaunchKernelGGL(k_batch_masks<SpikeBool>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st, sp, k, nc, mask);
       BE_LAUNCH_CHECK();
       const int prof = be_prof_begin(st);
-      hipLaunchKernelGGL(kern, dim3(grid_for(m, 16, 256)), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
+      hipLaunchKernelGGL(kern, dim3(grid_for(m, grid_rows, 256)), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp,
                          mask, nc, static_cast<W*>(out) + c0 * m, m);
       be_prof_end(prof, st);
       BE_LAUNCH_CHECK();

@@ -1033,3 +1033,27 @@ def test_gather_with_more_columns_than_lds_holds_bits_for(be, oracle, k):
             for c in range(3):
                 np.testing.assert_allclose(np.asarray(gotm)[:, c], oracle.binary_csrmv(w, idx, ptr, B[:, c], (m, k), False),
                                            rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('avg', [30, 80, 150])
+def test_batched_gather_fused_over_the_batch_with_lanes_per_row(be, oracle, avg):
+    """binary_csrmm, transpose=False, rows of tens to ~200 entries and enough columns: one pass over the matrix fused over the
+    batch with 8 / 16 / 32 lanes per row (k_csrmm_nt_fused_vec).  Rows from empty to several passes long (the wave finishes
+    those before the group's fold), more than 32 columns (two passes), counted and weighted entries, float spikes."""
+    rng = np.random.default_rng(avg)
+    m, k = 2500, 40000
+    lens = rng.integers(0, 2 * avg, m)
+    lens[rng.random(m) < 0.03] = rng.integers(4 * avg, 3000, int((rng.random(m) < 0.03).sum()) or 1)[0]
+    lens[::13] = 0
+    for homo in (False, True):
+        w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+        for nb in (8, 32, 40):
+            if (lens.mean() * nb) < 768:
+                continue
+            B = rng.random((k, nb)) < 0.03
+            got = np.asarray(be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=False))
+            assert got.shape == (m, nb)
+            for c in range(nb):
+                np.testing.assert_allclose(got[:, c], oracle.binary_csrmv(w, idx, ptr, B[:, c], (m, k), False), rtol=1e-5, atol=1e-5)
+            gotf = np.asarray(be.binary_csrmm(w, idx, ptr, np.where(B, 1.5, -2.0).astype(np.float32), shape=(m, k), transpose=False))
+            np.testing.assert_array_equal(gotf, got)
