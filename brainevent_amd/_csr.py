@@ -431,6 +431,27 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
     return 'direct'
 
 
+def make_scatter_workspace(route: str, weights, indices, indptr, m: int, k: int, nse: int, row_len: int = -1):
+    """The scatter workspace of a matrix for the chosen ``route`` (``None`` = direct route).  A plan that does not fit the
+    free device memory (128 bytes per (row, slice) block: up to ~3x the raw matrix for short blocks) falls back to the binned
+    route, which needs no per-matrix layout; non-finite weights or an extreme dynamic range fall back to the direct route."""
+    oom = getattr(torch, 'OutOfMemoryError', getattr(torch.cuda, 'OutOfMemoryError', RuntimeError))
+    try:
+        if route == 'plan':
+            try:
+                return ScatterPlan.build(weights, indices, indptr, shape=(m, k), row_len=row_len)
+            except oom:
+                torch.cuda.empty_cache()
+                route = 'binned' if BinnedScatter.applicable(weights, k) else 'direct'
+        if route == 'binned':
+            return BinnedScatter(weights, m, k, nse, indices=indices)
+    except MathError:
+        return None           # inf / nan / extreme dynamic range: float atomics (direct route) handle those
+    except oom:
+        torch.cuda.empty_cache()
+    return None
+
+
 class BinnedScatter:
     """Workspace of the *binned* scatter route: no per-matrix layout, only per-slice bins that are refilled every call
     (``be_binary_csrmv_t_binned``).  Used when a matrix is large but a :class:`ScatterPlan` does not pay — fewer than
@@ -869,14 +890,8 @@ class CompressedSparseData(DataRepresentation):
         m, k = self._plan_shape()
         plan = None
         if self.nse >= PLAN_MIN_NNZ and m > 0 and k > 0:
-            route = choose_scatter_route(self.nse, m, k, self.data)
-            try:
-                if route == 'plan':
-                    plan = ScatterPlan.build(self.data, self.indices, self.indptr, shape=(m, k))
-                elif route == 'binned':
-                    plan = BinnedScatter(self.data, m, k, self.nse, indices=self.indices)
-            except MathError:
-                plan = None           # inf / nan / extreme dynamic range: float atomics (direct route) handle those
+            plan = make_scatter_workspace(choose_scatter_route(self.nse, m, k, self.data), self.data, self.indices, self.indptr,
+                                          m, k, self.nse)
         self.buffers['scatter_plan'] = plan
         return plan
 

@@ -219,14 +219,8 @@ class FixedNumConn(DataRepresentation):
             return plan
         n_rows, n_cols = self._a_shape
         plan = None
-        route = _csr_mod.choose_scatter_route(self.nse, n_rows, n_cols, self.data)
-        try:
-            if route == 'plan':
-                plan = ScatterPlan.build(self.data, self.indices, None, shape=(n_rows, n_cols), row_len=self.num_conn)
-            elif route == 'binned':
-                plan = BinnedScatter(self.data, n_rows, n_cols, self.nse, indices=self.indices)
-        except _csr_mod.MathError:
-            plan = None
+        plan = _csr_mod.make_scatter_workspace(_csr_mod.choose_scatter_route(self.nse, n_rows, n_cols, self.data), self.data,
+                                               self.indices, None, n_rows, n_cols, self.nse, row_len=self.num_conn)
         self.buffers['scatter_plan'] = plan
         return plan
 

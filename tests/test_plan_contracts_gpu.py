@@ -316,3 +316,26 @@ def test_fused_step_lists_its_rows_in_the_kernel_and_spills_to_the_workspace(be,
         np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL * max(1.0, float(np.abs(ref).max())))
         outs.append(out.clone())
     assert len(outs) == 3
+
+
+def test_plan_that_does_not_fit_memory_falls_back_to_the_binned_route(be, oracle, monkeypatch):
+    """A scatter plan costs 128 bytes per (row, slice) block; when it does not fit the free device memory the container
+    takes the binned route (no per-matrix layout) instead of failing — simulated by an out-of-memory error in the build."""
+    from brainevent_amd import _csr as C
+    rng = np.random.default_rng(8)
+    m, k, row = 3000, 40000, 60
+    idx = rng.integers(0, k, (m, row)).astype(np.int32)
+    w = rng.random((m, row)).astype(np.float32)
+    oom = getattr(torch, 'OutOfMemoryError', RuntimeError)
+
+    def no_room(*a, **kw):
+        raise oom('HIP out of memory (simulated)')
+    monkeypatch.setattr(C.ScatterPlan, 'build', classmethod(lambda cls, *a, **kw: no_room()))
+    monkeypatch.setattr(C, 'choose_scatter_route', lambda *a, **kw: 'plan')
+    conn = be.FixedNumPerPre((w, idx), shape=(m, k)).prepare()
+    assert isinstance(conn.buffers['scatter_plan'], C.BinnedScatter)
+    spk = rng.random(m) < 0.1
+    ptr = (np.arange(m + 1) * row).astype(np.int32)
+    got = be.BinaryArray(spk) @ conn
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    np.testing.assert_allclose(got, oracle.binary_csrmv(w.reshape(-1), idx.reshape(-1), ptr, spk, (m, k), True), rtol=1e-5, atol=1e-5)
