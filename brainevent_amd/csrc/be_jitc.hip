@@ -240,8 +240,9 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
       uint32_t q = lr_initial_q(state, p.cl);
       while (q < qe) {
         if (ONE_PIECE || q >= qb) {        // one piece per class: qb == 0, no test in the loop
-          if (MODE == MODE_SCALAR) atomicAdd(&acc[q - qb], (AccT)1);
-          else atomicAdd(&acc[q - qb], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + S * q), fx_scale));
+          const uint32_t slot = ONE_PIECE ? q : q - qb;       // one piece: qb == 0, one vector operation less per edge
+          if (MODE == MODE_SCALAR) atomicAdd(&acc[slot], (AccT)1);
+          else atomicAdd(&acc[slot], (AccT)jit_fixed_from_f32(edge_weight<MODE, float>(p, row, j0 + S * q), fx_scale));
         }
         state = lr_next_nz(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
