@@ -293,6 +293,17 @@ __global__ void __launch_bounds__(256) k_coarsen_bits(const uint32_t* __restrict
 // f32 weights are streamed unconditionally with the same vector loads — a dependent load per active entry would
 // serialise the row at one HBM round trip per hit; other weight dtypes keep the conditional scalar load.
 typedef unsigned be_nt_v4u __attribute__((ext_vector_type(4)));
+#ifndef BE_GATHER_AUX
+#define BE_GATHER_AUX 2      // cache policy of the wave-per-row matrix streams: nt (read once; +3 ... 8 % at 2e8 entries)
+#endif
+#ifndef BE_GATHER_VEC_NT
+#define BE_GATHER_VEC_NT 1   // nt on the lanes-per-row matrix streams too (+2 ... 8 %; the 16-lane tier at 100 entries
+                             // per row loses 6 % because a row's last piece reads into the next row)
+#endif
+__device__ __forceinline__ uint4 gather_ld16(const void* p) {
+  if (BE_GATHER_VEC_NT) { const be_nt_v4u t = __builtin_nontemporal_load(reinterpret_cast<const be_nt_v4u*>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
+  return *reinterpret_cast<const uint4*>(p);
+}
 constexpr int64_t kGatherVecMaxRow = 200;   // average row length up to which the lanes-per-row vector kernel is used (32 lanes: 256 entries in two passes)
 
 template <typename W, bool HOMO, bool BITS_IN_LDS>
@@ -329,8 +340,8 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int off = (int)(j0 + 256 * u + 4 * lane) * 4;
-          c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0);
-          if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+          c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, BE_GATHER_AUX);
+          if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, BE_GATHER_AUX);
         }
         uint32_t cols[8], valid = 0;
 #pragma unroll
@@ -385,10 +396,10 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
       for (int q = 0; q < 4; ++q) {
         const int64_t hl = gl[q] < 256 ? gl[q] : 256;       // head: first 256 entries
         auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(indices + gb[q]), 0, (int)(hl * 4), 0x00020000);
-        c[q] = __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, 0, 0);
+        c[q] = __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, 0, BE_GATHER_AUX);
         if (VECW) {
           auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(weights + gb[q]), 0, (int)(hl * 4), 0x00020000);
-          wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, 0);
+          wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, BE_GATHER_AUX);
         }
       }
 #pragma unroll
@@ -489,10 +500,10 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
         g.wv[u] = be_nt_v4u{0u, 0u, 0u, 0u};
         const int32_t j = u * PASS + 4 * sub;
         if (j + 4 <= g.len || (j < g.len && g.b + j + 4 <= nnz_end)) {   // whole piece (a row's last piece may read into the next row)
-          const uint4 t = *reinterpret_cast<const uint4*>(indices + g.b + j);
+          const uint4 t = gather_ld16(indices + g.b + j);
           g.c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
           if (VECW) {
-            const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + g.b + j);
+            const uint4 tw = gather_ld16(reinterpret_cast<const float*>(weights) + g.b + j);
             g.wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
           }
         } else if (j < g.len) {                                          // the last entries of the arrays: one by one
@@ -558,10 +569,10 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
         for (int u = 0; u < 2; ++u) {
           const int64_t j = j0 + (int64_t)u * 256 + 4 * lane;
           if (j + 4 <= len || (j < len && b + j + 4 <= nnz_end)) {
-            const uint4 t = *reinterpret_cast<const uint4*>(indices + b + j);
+            const uint4 t = gather_ld16(indices + b + j);
             c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
             if (VECW) {
-              const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + b + j);
+              const uint4 tw = gather_ld16(reinterpret_cast<const float*>(weights) + b + j);
               wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
             }
           } else if (j < len) {
@@ -659,8 +670,8 @@ __global__ void __launch_bounds__(1024) k_csrmm_nt_fused(const W* __restrict__ w
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int off = (int)(j0 + 256 * u + 4 * lane) * 4;
-          c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0);       // out-of-range lanes read 0
-          if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+          c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, BE_GATHER_AUX);       // out-of-range lanes read 0
+          if (VECW) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, BE_GATHER_AUX);
         }
         uint32_t mk[8];
 #pragma unroll
@@ -775,10 +786,10 @@ __global__ void __launch_bounds__(1024) k_csrmm_nt_fused_vec(const W* __restrict
         g.wv[u] = be_nt_v4u{0u, 0u, 0u, 0u};
         const int32_t j = u * PASS + 4 * sub;
         if (j + 4 <= g.len || (j < g.len && g.b + j + 4 <= nnz_end)) {
-          const uint4 t = *reinterpret_cast<const uint4*>(indices + g.b + j);
+          const uint4 t = gather_ld16(indices + g.b + j);
           g.c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
           if (VECW) {
-            const uint4 tw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(weights) + g.b + j);
+            const uint4 tw = gather_ld16(reinterpret_cast<const float*>(weights) + g.b + j);
             g.wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
           }
         } else if (j < g.len) {

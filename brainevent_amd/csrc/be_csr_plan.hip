@@ -3,6 +3,11 @@
 // single-launch kernel for small matrices.  Semantics as in be_csr.hip (reference brainevent/_csr/binary.py:387-489,
 // transpose=True); the role of the reference's per-matrix task workspace (brainevent/_csr/main.py:58-88).
 #include "be_csr_shared.h"
+#ifndef BE_BLOCK_AUX
+#define BE_BLOCK_AUX 2      // cache policy of the wave-per-block d8 loads: nt — blocks are streamed once per step (C2: kernel 119.6 -> 108-112 us,
+                            // 716 -> 750-780 Geff/s; sc0 / sc1 on top change nothing).  NOT on the other decoders: uint16 blocks by part of a wave
+                            // 26 -> 32 us at N = 350k, 162 -> 186 at 2.5M; h8 at C2 1522 -> 1489 Geff/s.
+#endif
 
 namespace {
 
@@ -497,12 +502,8 @@ __device__ __forceinline__ void sub_issue(SubGroup& g, int i, int nvalid, uint32
   g.blk = g.n ? blob + ((uint64_t)st << 7) : blob;          // nothing to do: the head of the blob (in bounds, cached)
   const uint32_t l = (uint32_t)(lane % LPB);
   const uint32_t o = l < g.n ? l : 0u;                       // clamped: the loads stay unconditional (counted vmcnt waits)
-  const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
-  g.c = be_v4u{x.x, x.y, x.z, x.w};
-  if constexpr (!HOMO) {
-    const uint2 y = reinterpret_cast<const uint2*>(g.blk + (uint64_t)g.n * 16u)[o];
-    g.iv = be_v2u{y.x, y.y};
-  }
+  g.c = *(reinterpret_cast<const be_v4u*>(g.blk) + o);
+  if constexpr (!HOMO) g.iv = *(reinterpret_cast<const be_v2u*>(g.blk + (uint64_t)g.n * 16u) + o);
 }
 template <bool HOMO, int LPB>
 __device__ __forceinline__ void sub_consume(SubGroup& g, typename PlanAcc<HOMO>::type* acc, int lane, float scale) {
@@ -938,9 +939,9 @@ __device__ __forceinline__ void d8_issue(SegGroupD8& g, int i, int nvalid, uint3
   for (int q = 0; q < 4; ++q) {
     unsigned char* blk = const_cast<unsigned char*>(blob) + ((uint64_t)g.start[q] << 7);
     auto rw = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(g.ng[q] * 16u), kBufFlags);
-    g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, 0);
+    g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, BE_BLOCK_AUX);
     auto rd = __builtin_amdgcn_make_buffer_rsrc(blk + (uint64_t)g.ng[q] * 16u, 0, (int)(g.ng[q] * 4u), kBufFlags);
-    g.dv[q] = __builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 0, 0);     // lanes past the block read 0
+    g.dv[q] = __builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 0, BE_BLOCK_AUX);     // lanes past the block read 0
   }
 }
 
@@ -1017,9 +1018,8 @@ __device__ __forceinline__ void d8q_issue(QGroupD8& g, int i, int nvalid, uint32
   g.blk = g.ng ? blob + ((uint64_t)st << 7) : blob;          // nothing to do: read the head of the blob (in bounds, cached)
   const uint32_t l = (uint32_t)(lane % LPB);
   const uint32_t o = l < g.ng ? l : 0u;                       // clamped: loads stay unconditional (counted vmcnt waits)
-  const uint4 x = reinterpret_cast<const uint4*>(g.blk)[o];
-  g.w = be_v4u{x.x, x.y, x.z, x.w};
-  g.d = reinterpret_cast<const uint32_t*>(g.blk + (uint64_t)g.ng * 16u)[o];
+  g.w = *(reinterpret_cast<const be_v4u*>(g.blk) + o);
+  g.d = *(reinterpret_cast<const uint32_t*>(g.blk + (uint64_t)g.ng * 16u) + o);
 }
 
 template <int LPB>

@@ -20,6 +20,17 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef BE_DENSE_NT
+#define BE_DENSE_NT 1     // nt policy on the row gathers of the S @ W MFMA kernels: each row piece is
+                          // used once, and keeping it out of L2's way measured +8 % (C5 0.467 -> 0.427 ms).
+                          // NOT on the W @ S.T kernels, whose strided 16-B pieces share sectors (1.8 -> 2.7 ms).
+#endif
+typedef unsigned be_dv4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 dense_row_load(const void* p) {
+  if (BE_DENSE_NT) { const be_dv4u t = __builtin_nontemporal_load(reinterpret_cast<const be_dv4u*>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
+  return *reinterpret_cast<const uint4*>(p);
+}
+
 namespace {
 
 constexpr int kGroup = 4;        // batches per wave in the transpose=True kernel
@@ -122,26 +133,36 @@ __global__ void __launch_bounds__(256) k_gl_write(const uint32_t* __restrict__ m
 // ------------------------------------------------------------------------------------------------
 // transpose=True accumulate: wave task = (strip, group); blockIdx.y = row part
 // ------------------------------------------------------------------------------------------------
+#ifndef BE_DENSE_T_NT
+#define BE_DENSE_T_NT 1   // nt on the row-piece gathers of the vector S @ W kernel (f32 n=32768 p=0.5: 0.39 -> 0.35 ms)
+#endif
+#ifndef BE_DENSE_S_NT
+#define BE_DENSE_S_NT 1   // nt on the streamed rows of the vector W @ S.T kernel (f32 n=32768 p=0.5: 0.81 -> 0.72 ms)
+#endif
+template <int POL> __device__ __forceinline__ uint4 load16(const void* p) {
+  if (POL) { const be_dv4u t = __builtin_nontemporal_load(reinterpret_cast<const be_dv4u*>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
+  return *reinterpret_cast<const uint4*>(p);
+}
 template <typename W, int VEC> struct RowLoad;
 template <typename W> struct RowLoad<W, 1> {
   using ACC = typename WTraits<W>::acc;
-  __device__ static __forceinline__ void load(const W* p, ACC (&v)[1]) { v[0] = (ACC)WTraits<W>::load(p, 0); }
+  template <int POL = 0> __device__ static __forceinline__ void load(const W* p, ACC (&v)[1]) { v[0] = (ACC)WTraits<W>::load(p, 0); }
 };
 template <> struct RowLoad<float, 4> {
-  __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  template <int POL = 0> __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+    const uint4 t = load16<POL>(p);
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
   }
 };
 template <> struct RowLoad<double, 2> {
-  __device__ static __forceinline__ void load(const double* p, double (&v)[2]) {
-    const double2 t = *reinterpret_cast<const double2*>(p);
-    v[0] = t.x; v[1] = t.y;
+  template <int POL = 0> __device__ static __forceinline__ void load(const double* p, double (&v)[2]) {
+    const uint4 t = load16<POL>(p);
+    v[0] = __hiloint2double((int)t.y, (int)t.x); v[1] = __hiloint2double((int)t.w, (int)t.z);
   }
 };
 template <> struct RowLoad<__half, 8> {
-  __device__ static __forceinline__ void load(const __half* p, float (&v)[8]) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
+  template <int POL = 0> __device__ static __forceinline__ void load(const __half* p, float (&v)[8]) {
+    const uint4 t = load16<POL>(p);
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -152,8 +173,8 @@ template <> struct RowLoad<__half, 8> {
   }
 };
 template <> struct RowLoad<__hip_bfloat16, 8> {
-  __device__ static __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
+  template <int POL = 0> __device__ static __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+    const uint4 t = load16<POL>(p);
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -197,7 +218,7 @@ __global__ void __launch_bounds__(256) k_densemm_t(const W* __restrict__ weights
     for (int q = 0; q < UNR; ++q) e[q] = list[a + q * parts];
 #pragma unroll
     for (int q = 0; q < UNR; ++q)
-      if (in) RowLoad<W, VEC>::load(weights + (int64_t)(e[q] & 0x0fffffffu) * n + col, w[q]);
+      if (in) RowLoad<W, VEC>::template load<BE_DENSE_T_NT>(weights + (int64_t)(e[q] & 0x0fffffffu) * n + col, w[q]);
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
       const uint32_t sm = e[q] >> 28;
@@ -212,7 +233,7 @@ __global__ void __launch_bounds__(256) k_densemm_t(const W* __restrict__ weights
   for (; a < cnt; a += parts) {      // (a predicated last round instead of this tail was measured: no faster at 1 % firing, slower dense)
     const uint32_t e = list[a];
     ACC w[VEC];
-    if (in) RowLoad<W, VEC>::load(weights + (int64_t)(e & 0x0fffffffu) * n + col, w);
+    if (in) RowLoad<W, VEC>::template load<BE_DENSE_T_NT>(weights + (int64_t)(e & 0x0fffffffu) * n + col, w);
     const uint32_t sm = e >> 28;
 #pragma unroll
     for (int b = 0; b < kGroup; ++b)
@@ -292,7 +313,7 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
         ACC w[U][VEC];
         uint32_t mk[U][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) RowLoad<W, VEC>::load(row + j + (int64_t)u * 64 * VEC, w[u]);
+        for (int u = 0; u < U; ++u) RowLoad<W, VEC>::template load<BE_DENSE_S_NT>(row + j + (int64_t)u * 64 * VEC, w[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t* mp = mask + j + (int64_t)u * 64 * VEC;
@@ -319,7 +340,7 @@ __global__ void __launch_bounds__(256) k_densemm_nt(const W* __restrict__ weight
       }
       for (; j < k; j += 64 * VEC) {
         ACC w[VEC];
-        RowLoad<W, VEC>::load(row + j, w);
+        RowLoad<W, VEC>::template load<BE_DENSE_S_NT>(row + j, w);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const uint32_t mk = mask[j + v];
@@ -599,7 +620,7 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
       ok = 0u;
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
-        r[u] = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[s * 16 + r0 + u * RSTEP] * n);
+        r[u] = dense_row_load(wcol + (int64_t)rows_s[s * 16 + r0 + u * RSTEP] * n);
         ok |= (col_ok && masks_s[s * 16 + r0 + u * RSTEP] != 0u ? 1u : 0u) << u;
       }
     };
@@ -827,7 +848,7 @@ __global__ void __launch_bounds__(256) k_densemm_t_mfma_f32(const float* __restr
     __syncthreads();
     auto fetch = [&](uint32_t t, uint4& b) {              // only issues the load; steps past c_end read row 0 with mask 0
       const uint32_t s = (t - c0) < (uint32_t)(kTfChunk + kTfRing - 1) ? (t - c0) : (uint32_t)(kTfChunk + kTfRing - 1);
-      b = *reinterpret_cast<const uint4*>(wcol + (int64_t)rows_s[2 * s + h] * n);
+      b = dense_row_load(wcol + (int64_t)rows_s[2 * s + h] * n);
     };
 #pragma unroll
     for (int s = 0; s < kTfRing; ++s) {

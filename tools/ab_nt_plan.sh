@@ -1,0 +1,4 @@
+set -e
+run() { (BE_EXP_NS=100000,350000,1000000,2500000 python tools/exp_layouts.py | grep -o "N=.*auto=.*"; BE_EXP_K=10000 BE_EXP_NS=100000,1000000 BE_EXP_LAYOUTS=None python tools/exp_layouts.py; python bench.py --homo --steps 100 --warmup 20 --no-cpu --no-secondary | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); print('C2 homo', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])") 2>&1 | grep -v amdgpu.ids; }
+export -f run
+bash tools/ab_build.sh "-DBE_BLOCK_AUX=0" "-DBE_BLOCK_AUX=2" -- bash -c run
