@@ -234,29 +234,37 @@ __global__ void __launch_bounds__(256) k_convert_from_f32(const float* __restric
 constexpr int64_t kLdsBitmapBytes = 150 * 1024;
 // N entries at once (bit e of `valid`: entry e exists; returns bit e set iff its input fired): the exact-bitmap reads of the
 // coarse route are issued together and waited for once — one global round trip per group of entries, not one per hit
-template <bool IN_LDS, int N>
+// AT0: the caller's bitmap starts at LDS address 0 (checked there), so a word's address is its byte offset — through the
+// generic pointer every read paid an add of the allocation's (link-time) base, which is 0.
+typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+template <bool AT0>
+__device__ __forceinline__ uint32_t lds_bit_word(const uint32_t* __restrict__ lds_bits, uint32_t word) {
+  if (AT0) return *(LdsWord*)(word << 2);
+  return lds_bits[word];
+}
+template <bool IN_LDS, int N, bool AT0 = false>
 __device__ __forceinline__ uint32_t spike_mask(const uint32_t* __restrict__ lds_bits, const uint32_t* __restrict__ fine_g,
                                                const uint32_t (&col)[N], uint32_t valid, int g_shift) {
   uint32_t m = 0;
   if (IN_LDS) {
 #pragma unroll
-    for (int e = 0; e < N; ++e)
-      if ((valid >> e) & 1u) m |= ((lds_bits[col[e] >> 5] >> (col[e] & 31)) & 1u) << e;
-    return m;
+    for (int e = 0; e < N; ++e) m |= __builtin_amdgcn_ubfe(lds_bit_word<AT0>(lds_bits, col[e] >> 5), col[e], 1u) << e;   // (v_bfe takes the offset mod 32)
+    return m & valid;      // entries that are not the row's hold other rows' ids or zeros: read them, then drop them —
+                           // a test per entry put every LDS read behind its own branch and wait
   }
   uint32_t ch = 0;
 #pragma unroll
-  for (int e = 0; e < N; ++e)
-    if ((valid >> e) & 1u) {
-      const uint32_t cc = col[e] >> g_shift;
-      ch |= ((lds_bits[cc >> 5] >> (cc & 31)) & 1u) << e;
-    }
+  for (int e = 0; e < N; ++e) {
+    const uint32_t cc = col[e] >> g_shift;
+    ch |= __builtin_amdgcn_ubfe(lds_bit_word<AT0>(lds_bits, cc >> 5), cc, 1u) << e;
+  }
+  ch &= valid;
   if (ch == 0u) return 0u;
   uint32_t fw[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) fw[e] = ((ch >> e) & 1u) ? fine_g[col[e] >> 5] : 0u;
 #pragma unroll
-  for (int e = 0; e < N; ++e) m |= ((fw[e] >> (col[e] & 31)) & 1u) << e;
+  for (int e = 0; e < N; ++e) m |= __builtin_amdgcn_ubfe(fw[e], col[e], 1u) << e;
   return m;
 }
 
@@ -295,6 +303,9 @@ __global__ void __launch_bounds__(256) k_coarsen_bits(const uint32_t* __restrict
 typedef unsigned be_nt_v4u __attribute__((ext_vector_type(4)));
 #ifndef BE_GATHER_AUX
 #define BE_GATHER_AUX 2      // cache policy of the wave-per-row matrix streams: nt (read once; +3 ... 8 % at 2e8 entries)
+#endif
+#ifndef BE_GATHER_DEPTH_HOMO
+#define BE_GATHER_DEPTH_HOMO 4   // groups ahead without per-entry weights (11 registers per group): 2 -> 4 measured 0 ... 6 %, 8 nothing more
 #endif
 #ifndef BE_GATHER_VEC_NT
 #define BE_GATHER_VEC_NT 1   // nt on the lanes-per-row matrix streams too (+2 ... 8 %; the 16-lane tier at 100 entries
@@ -464,8 +475,11 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
   constexpr int RPW = 64 / LPR;                  // rows per group (one load instruction)
   constexpr int NGRP = 64 / RPW;                 // groups of a 64-row batch
   constexpr int PASS = 4 * LPR;                  // entries of a row per pass; a group holds two passes of its rows
-  constexpr int DEPTH = NGRP < 2 ? NGRP : 2;     // groups in flight ahead of the one being consumed (registers: 19 per group)
-  __shared__ ACC res_s[16][64];                  // per wave: the 64 results of a batch (long rows add their tails here)
+  constexpr int DEPTH_WANT = (HOMO || !VECW) ? BE_GATHER_DEPTH_HOMO : 2;
+  constexpr int DEPTH = NGRP < DEPTH_WANT ? NGRP : DEPTH_WANT;   // groups in flight ahead of the one being consumed (registers: 19 per group, 11 without weights)
+  // per wave: the 64 results of a batch (long rows add their tails here).  Behind the bitmap in the dynamic allocation, so
+  // that the bitmap starts at LDS address 0 and a spike test needs no base add.
+  ACC (*res_s)[64] = reinterpret_cast<ACC (*)[64]>(bits_s + (((BITS_IN_LDS ? n_words : n_cwords) + 3) & ~(int64_t)3));
   const int lane = lane_id(), sub = lane % LPR, slot = lane / LPR, wv_id = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -473,9 +487,20 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
   ACC w0 = ACC(0);
   if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
 
+  if (nnz_end < 4) {           // fewer stored entries than one 16-byte piece: a thread per row, entry by entry
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
+      ACC acc = ACC(0);
+      for (int64_t j = rp.at(r); j < rp.at(r + 1); ++j) {
+        const uint32_t col[1] = {(uint32_t)indices[j]};
+        if (spike_mask<BITS_IN_LDS, 1, true>(bits_s, bits_g, col, 1u, g_shift)) acc += HOMO ? ACC(1) : (ACC)WTraits<W>::load(weights, j);
+      }
+      WTraits<W>::store(out, r, HOMO ? (ACC)(acc * w0) : acc);
+    }
+    return;
+  }
   struct Grp {
     be_nt_v4u c[2], wv[2];
-    int64_t b;
+    int32_t rel;               // row start, entries from the batch's first row
     int32_t len;               // clamped to two passes: all a group looks at
   };
   // a batch = 64 CONSECUTIVE rows (coalesced row pointers and results); batches are dealt to the waves round-robin
@@ -485,58 +510,58 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
     const int64_t rc = valid ? my_r : m - 1;
     const int64_t rb = rp.at(rc);
     const int64_t rl = valid ? rp.at(rc + 1) - rb : 0;
+    // The batch's entries are read through ONE descriptor over [first row's start, +2^29 entries) with 32-bit offsets
+    // relative to it: loads past the arrays' end return zeros (no end-of-array special case), a piece a row does not reach
+    // gets an out-of-range offset instead of a branch, and the address arithmetic is one add-shift per piece.  A batch that
+    // spans more than 2^29 entries (`far`) leaves all its rows to the tail loop below.
+    const int64_t b_first = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)rb));
+    const int32_t cap = (int32_t)(rl < 2 * PASS ? rl : 2 * PASS);
+    const bool far = __ballot(rb - b_first + cap > (1ll << 29)) != 0ull;
+    const int64_t span = nnz_end - b_first < (1ll << 29) ? nnz_end - b_first : (1ll << 29);
+    auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(indices + b_first), 0, (int)(span * 4), 0x00020000);
+    auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(VECW ? weights + b_first : weights), 0,
+                                                VECW ? (int)(span * 4) : 0, 0x00020000);
+    const int32_t my_rel = far ? 0 : (int32_t)(rb - b_first), my_cap = far ? 0 : cap;
     // The groups of the batch are walked in straight-line code, DEPTH groups ahead: no load crosses a back edge, so the
     // wait counts stay exact (a loop around issue / consume makes hipcc wait for every load in flight: be_csr_plan.hip).
     auto issue = [&](Grp& g, int q) {
       const int src = q * RPW + slot;
-      g.b = __shfl(rb, src, 64);
-      {
-        const int64_t l64 = __shfl(rl, src, 64);
-        g.len = (int32_t)(l64 < 2 * PASS ? l64 : 2 * PASS);
-      }
+      g.rel = __shfl(my_rel, src, 64);
+      g.len = __shfl(my_cap, src, 64);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        g.c[u] = be_nt_v4u{0u, 0u, 0u, 0u};
-        g.wv[u] = be_nt_v4u{0u, 0u, 0u, 0u};
         const int32_t j = u * PASS + 4 * sub;
-        if (j + 4 <= g.len || (j < g.len && g.b + j + 4 <= nnz_end)) {   // whole piece (a row's last piece may read into the next row)
-          const uint4 t = gather_ld16(indices + g.b + j);
-          g.c[u] = be_nt_v4u{t.x, t.y, t.z, t.w};
-          if (VECW) {
-            const uint4 tw = gather_ld16(reinterpret_cast<const float*>(weights) + g.b + j);
-            g.wv[u] = be_nt_v4u{tw.x, tw.y, tw.z, tw.w};
-          }
-        } else if (j < g.len) {                                          // the last entries of the arrays: one by one
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j + e < g.len) {
-              g.c[u][e] = (uint32_t)indices[g.b + j + e];
-              if (VECW) g.wv[u][e] = __float_as_uint(reinterpret_cast<const float*>(weights)[g.b + j + e]);
-            }
-        }
+        const int off = j < g.len ? (g.rel + j) * 4 : (int)0x80000000;     // (a row's last piece reads into the next row)
+        g.c[u] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, BE_GATHER_AUX);
+        if (VECW) g.wv[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, BE_GATHER_AUX);
+        else g.wv[u] = be_nt_v4u{0u, 0u, 0u, 0u};
       }
     };
     auto consume = [&](const Grp& g, int q) {
-      uint32_t cols[8], vmask = 0;
+      uint32_t cols[8];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cols[4 * u + e] = g.c[u][e];
-          vmask |= (u * PASS + 4 * sub + e < g.len ? 1u : 0u) << (4 * u + e);
-        }
-      const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, vmask, g_shift);
+        for (int e = 0; e < 4; ++e) cols[4 * u + e] = g.c[u][e];
+      // entries of the row in this lane's two pieces: 0 ... 4 each (a clamp, not a compare per entry)
+      const int32_t left = g.len - 4 * sub;
+      const int32_t n0 = left < 0 ? 0 : (left > 4 ? 4 : left);
+      const int32_t n1 = left - PASS < 0 ? 0 : (left - PASS > 4 ? 4 : left - PASS);
+      const uint32_t vmask = ((1u << n0) - 1u) | (((1u << n1) - 1u) << 4);
+      const uint32_t onm = spike_mask<BITS_IN_LDS, 8, true>(bits_s, bits_g, cols, vmask, g_shift);
       ACC acc = ACC(0);
-      int cnt = 0;
+      int cnt = HOMO ? __popc(onm) : 0;
+      if (!HOMO) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool on = (onm >> (4 * u + e)) & 1u;
-          if (HOMO) cnt += on ? 1 : 0;
-          else if (VECW) acc += on ? (ACC)__uint_as_float(g.wv[u][e]) : ACC(0);
-          else if (on) acc += (ACC)WTraits<W>::load(weights, g.b + (int64_t)u * PASS + 4 * sub + e);
-        }
+          for (int e = 0; e < 4; ++e) {
+            const bool on = (onm >> (4 * u + e)) & 1u;
+            if (VECW) acc += on ? (ACC)__uint_as_float(g.wv[u][e]) : ACC(0);
+            else if (on) acc += (ACC)WTraits<W>::load(weights, b_first + g.rel + (int64_t)u * PASS + 4 * sub + e);
+          }
+      }
       if (HOMO) {
 #pragma unroll
         for (int off = LPR / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, LPR);
@@ -556,14 +581,15 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
       consume(g[q], q);
     }
     // rows longer than two passes: the rest of the row, a wave per row (the host picks LPR so that these are the exception)
-    unsigned long long longm = __ballot(rl > 2 * PASS);
+    const int64_t tail_from = far ? 0 : 2 * PASS;     // (a `far` batch took nothing above)
+    unsigned long long longm = __ballot(rl > tail_from);
     while (longm) {
       const int src = __ffsll((long long)longm) - 1;
       longm &= longm - 1;
       const int64_t b = __shfl(rb, src, 64), len = __shfl(rl, src, 64);
       ACC acc = ACC(0);
       int cnt = 0;
-      for (int64_t j0 = 2 * PASS; j0 < len; j0 += 2 * 256) {
+      for (int64_t j0 = tail_from; j0 < len; j0 += 2 * 256) {
         be_nt_v4u c[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, wv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -592,7 +618,7 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
             cols[4 * u + e] = c[u][e];
             vmask |= (j0 + (int64_t)u * 256 + 4 * lane + e < len ? 1u : 0u) << (4 * u + e);
           }
-        const uint32_t onm = spike_mask<BITS_IN_LDS, 8>(bits_s, bits_g, cols, vmask, g_shift);
+        const uint32_t onm = spike_mask<BITS_IN_LDS, 8, true>(bits_s, bits_g, cols, vmask, g_shift);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1066,22 +1092,36 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
   const int64_t avg = nnz_hint / (m > 0 ? m : 1);
   if (avg <= kGatherVecMaxRow) {      // short and medium rows: 2 ... 32 lanes per row, four entries per lane and load
     const int prof = be_prof_begin(st);
+    // bitmap (rounded to 16 bytes) + the 16 waves' result rows
+    const size_t vlds = (size_t)((((in_lds ? n_words : n_cwords) + 3) & ~(int64_t)3) * 4) + 16 * 64 * sizeof(typename WTraits<W>::acc);
 #define BE_NT_VEC(LPR_)                                                                                                     \
     do {                                                                                                                    \
       const int grid = grid_for(m, 16 * 64, nb >= 8 ? 256 : 512);                                                   \
       if (in_lds) {                                                                                                          \
         auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, true>;                                                                    \
-        BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                \
-        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp, \
+        BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)vlds));                                               \
+        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), vlds, st, static_cast<const W*>(weights), indices, rp, \
                            bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       } else {                                                                                                               \
         auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, false>;                                                                   \
-        BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                \
-        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), lds, st, static_cast<const W*>(weights), indices, rp, \
+        BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)vlds));                                               \
+        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), vlds, st, static_cast<const W*>(weights), indices, rp, \
                            bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       }                                                                                                                      \
     } while (0)
     // two passes of a row (8 x LPR entries) should hold nearly every row: LPR by the average length
+    {   // the kernels address the bitmap from LDS address 0 (spike_mask AT0): true while they declare no static LDS
+      static bool checked = false;
+      if (!checked) {
+        hipFuncAttributes fa;
+        BE_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_csrmv_nt_vec<W, HOMO, 2, true>)));
+        if (fa.sharedSizeBytes != 0) {
+          be_set_error("k_csrmv_nt_vec: static LDS in front of the bitmap");
+          return BE_ERR_UNSUPPORTED;
+        }
+        checked = true;
+      }
+    }
     if (avg <= 8) BE_NT_VEC(2);
     else if (avg <= 20) BE_NT_VEC(4);
     else if (avg <= 45) BE_NT_VEC(8);

@@ -89,6 +89,35 @@ def test_csrmv_gather_tiers(be, oracle, nnz_per_row):
     np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, v, (m, k), False), rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize('homo', [True, False])
+def test_csrmv_gather_array_end_and_tiny_matrices(be, oracle, homo):
+    # the lanes-per-row gather reads 16-byte pieces: the last rows end at every alignment against the arrays' end, matrices
+    # hold fewer entries than one piece, and what lies behind the arrays in memory is poison (an active column with a huge
+    # weight) that must never reach a result
+    rng = np.random.default_rng(77)
+    k = 300
+    dev = torch.device('cuda', 0)
+    v = spikes_of(rng, k, 0.5, 'bool')
+    v[k - 1] = True
+    cases = [[n] for n in range(0, 10)] + [[0, 1, 0], [1, 1, 1], [2, 0, 1], [3], [5, 0, 0, 2]]
+    cases += [list(rng.integers(0, 40, 70)) + [t] for t in range(1, 9)]
+    for lens in cases:
+        m = len(lens)
+        w, idx, ptr = rand_csr(rng, m, k, lens, homo=homo)
+        nnz = int(ptr[-1])
+        idx_buf = torch.full((nnz + 64,), k - 1, dtype=torch.int32, device=dev)
+        idx_buf[:nnz] = torch.from_numpy(idx).to(dev)
+        if homo:
+            w_t = torch.from_numpy(w).to(dev)
+        else:
+            w_buf = torch.full((nnz + 64,), 1e30, dtype=torch.float32, device=dev)
+            w_buf[:nnz] = torch.from_numpy(w).to(dev)
+            w_t = w_buf[:nnz]
+        got = be.binary_csrmv(w_t, idx_buf[:nnz], torch.from_numpy(ptr).to(dev), torch.from_numpy(v).to(dev), shape=(m, k),
+                              transpose=False).cpu().numpy()
+        np.testing.assert_allclose(got, oracle.binary_csrmv(w, idx, ptr, v, (m, k), False), rtol=RTOL, atol=ATOL, err_msg=str(lens))
+
+
 def test_csrmv_int64_indptr(be, oracle):
     rng = np.random.default_rng(5)
     m, k = 64, 100

@@ -183,3 +183,31 @@ def test_c5_dense_fp16_64k_batch32(be):
         del S, out, vec, mf, ref
     del W
     _free()
+
+
+def test_gather_batch_spanning_more_than_2_pow_29_entries(be):
+    """The lanes-per-row gather (csrc/be_csr.hip k_csrmv_nt_vec) reads a 64-row batch through one buffer descriptor of 2^29
+    entries; a batch that one huge row stretches beyond that falls back to the per-row tail loop.  3M rows, one of them
+    with 5.4e8 entries (average row length still below the vector kernel's limit), counted weights; the expectation is a
+    prefix sum of the gathered spikes, computed by torch on the device."""
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    m, k, big_row, big_len = 3_000_000, 1_000_000, 100, (1 << 29) + 3_000_001
+    lens = torch.randint(0, 6, (m,), device=dev, generator=g, dtype=torch.int64)
+    lens[big_row] = big_len
+    ptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(lens, 0)
+    nnz = int(ptr[-1])
+    assert nnz // m <= 200 and nnz < 2 ** 31
+    idx = torch.randint(0, k, (nnz,), device=dev, generator=g, dtype=torch.int32)
+    spk = torch.rand(k, device=dev, generator=g) < 0.01
+    w = torch.full((1,), 0.5, device=dev)
+    got = be.binary_csrmv(w, idx, ptr, spk, shape=(m, k), transpose=False)
+    hits = spk[idx.long()]
+    cs = torch.zeros(nnz + 1, dtype=torch.int64, device=dev)
+    cs[1:] = torch.cumsum(hits, 0)
+    del hits
+    want = (cs[ptr[1:]] - cs[ptr[:-1]]).to(torch.float32) * 0.5
+    assert torch.equal(got, want)
+    assert float(got[big_row]) > 1e6       # the huge row really was summed
