@@ -544,6 +544,22 @@ __device__ __forceinline__ void sub_tails(uint32_t st_v, uint32_t n4_v, int nval
   }
 }
 
+#ifndef BE_PARTIAL_NT
+#define BE_PARTIAL_NT 1     // bit 0: the d8 kernel's partial sums leave with non-temporal stores, bit 1: the u16 kernels',
+                            // bit 2: the h8 kernel's (nobody reads them before the reduce launch; C2: 754-761 -> 777-781 Geff/s)
+#endif
+// a task's accumulators, LDS -> its partial sums (n16 pieces of 16 bytes)
+template <int BIT>
+__device__ __forceinline__ void store_partials(const unsigned char* smem_raw, void* partial, int n16) {
+  const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
+  uint4* dst = reinterpret_cast<uint4*>(partial);
+  typedef unsigned pv4 __attribute__((ext_vector_type(4)));
+  for (int i = threadIdx.x; i < n16; i += blockDim.x) {
+    const uint4 v = src[i];
+    if (BE_PARTIAL_NT & BIT) __builtin_nontemporal_store(pv4{v.x, v.y, v.z, v.w}, reinterpret_cast<pv4*>(dst) + i);
+    else dst[i] = v;
+  }
+}
 template <bool HOMO, int LPB = 0, int FUSED = 0>
 __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                           const uint32_t* active,
@@ -659,10 +675,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate(const unsigned char* _
   __syncthreads();
   {
     // stride * sizeof(acc_t) is a multiple of 16
-    const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
-    uint4* dst = reinterpret_cast<uint4*>(partial);
-    const int n16 = (int)((size_t)stride * sizeof(acc_t) / 16);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    store_partials<2>(smem_raw, partial, (int)((size_t)stride * sizeof(acc_t) / 16));
   }
 }
 
@@ -1188,10 +1201,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
   __syncthreads();
   PLAN_STAMP(4);     // every wave through
   {
-    const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
-    uint4* dst = reinterpret_cast<uint4*>(partial);
-    const int n16 = (int)((size_t)S * sizeof(acc_t) / 16);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    store_partials<1>(smem_raw, partial, (int)((size_t)S * sizeof(acc_t) / 16));
   }
 #ifdef BE_PLAN_PROF
   __builtin_amdgcn_s_waitcnt(0);
@@ -1403,10 +1413,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_h8(const unsigned char
   }
   __syncthreads();
   {
-    const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
-    uint4* dst = reinterpret_cast<uint4*>(partial);
-    const int n16 = (int)((size_t)S * 4 / 16);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    store_partials<4>(smem_raw, partial, (int)((size_t)S * 4 / 16));
   }
 }
 
