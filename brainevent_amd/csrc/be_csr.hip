@@ -456,6 +456,8 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
 // The scalar lanes-per-row kernel of round 1 loaded a weight only behind its spike test (a dependent round trip per hit).
 // 2e8 entries, 1 % of the inputs active, ms per product (tools/bench_gather_rows.py), weighted: 4 per row 3.77 -> 0.57,
 // 12: 4.86 -> 0.35, 48: 2.52 -> 0.33, 100: 0.50 -> 0.31 (5.2 TB/s); counted: 12: 4.45 -> 0.28, 100: 0.41 -> 0.19.
+// Then: no branch per entry or per piece (unconditional LDS reads masked afterwards, one buffer descriptor per batch with
+// out-of-range offsets for the pieces a row does not reach), bitmap at LDS address 0 — counted 12: 0.21, 48: 0.19, 100: 0.17.
 template <typename W, bool HOMO, int LPR, bool BITS_IN_LDS>
 __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                        RowPtr rp, const uint32_t* __restrict__ bits_g, int64_t n_words,
@@ -483,21 +485,10 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_vec(const W* __restrict__ wei
   const int lane = lane_id(), sub = lane % LPR, slot = lane / LPR, wv_id = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t nnz_end = rp.at(m);              // a 16-byte load may not run past the arrays
+  const int64_t nnz_end = rp.at(m);              // a 16-byte load may not run past the arrays (the descriptors end there)
   ACC w0 = ACC(0);
   if (HOMO) w0 = (ACC)WTraits<W>::load(weights, 0);
 
-  if (nnz_end < 4) {           // fewer stored entries than one 16-byte piece: a thread per row, entry by entry
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
-      ACC acc = ACC(0);
-      for (int64_t j = rp.at(r); j < rp.at(r + 1); ++j) {
-        const uint32_t col[1] = {(uint32_t)indices[j]};
-        if (spike_mask<BITS_IN_LDS, 1, true>(bits_s, bits_g, col, 1u, g_shift)) acc += HOMO ? ACC(1) : (ACC)WTraits<W>::load(weights, j);
-      }
-      WTraits<W>::store(out, r, HOMO ? (ACC)(acc * w0) : acc);
-    }
-    return;
-  }
   struct Grp {
     be_nt_v4u c[2], wv[2];
     int32_t rel;               // row start, entries from the batch's first row
