@@ -13,12 +13,18 @@ for homo in (False, True):
         k = 1_000_000
         w, idx, ptr = gen_csr_on_device(m, k, nc, homo, 3, dev)
         spk = torch.rand(k, device=dev) < 0.01
+        if os.environ.get('BE_EXP_FIXED') == '1':      # rows of one known length (FixedNumPerPost @ spk: no indptr)
+            conn = be.FixedNumPerPost((w if homo else w.view(m, nc), idx.view(m, nc)), shape=(k, m), check_indices=False)
+            ev = be.BinaryArray(spk)
+            call = lambda: ev @ conn
+        else:
+            call = lambda: be.binary_csrmv(w, idx, ptr, spk, shape=(m, k), transpose=False)
         for _ in range(3):
-            out = be.binary_csrmv(w, idx, ptr, spk, shape=(m, k), transpose=False)
+            out = call()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            out = be.binary_csrmv(w, idx, ptr, spk, shape=(m, k), transpose=False)
+            out = call()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         byts = m * nc * (4 if homo else 8)
