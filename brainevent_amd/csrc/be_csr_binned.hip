@@ -21,6 +21,9 @@ namespace {
 //   region per bin the short runs of different XCDs met in the same lines and each L2 wrote its own masked copy.
 // HBM traffic per update (hetero): 8 B read (pass B) + 6 B write + 6 B read = 20 B  vs  8 B algorithmic.
 // =================================================================================================
+#ifndef BE_BIN_U
+#define BE_BIN_U 4       // groups of 8 binned entries in flight per thread of pass C (counted C4: 0.305 -> 0.282 ms; weighted: no change)
+#endif
 constexpr int kMaxBins = 2048;       // 3 x 4 B x 2048 = 24 KiB of LDS bookkeeping (16-wave kernel; the 8-wave one takes 1024)
 constexpr int kBinRegions = 8;       // regions per bin: one per XCD
 constexpr uint16_t kBinPad = 0xffffu; // column marker of a pad entry in a bin of counted entries (local columns are < 2^15)
@@ -381,29 +384,52 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restr
   const uint32_t g_begin = part * per, g_end = g_begin + per < n8 ? g_begin + per : n8;
   const uint16_t* bin_i = bin_idx + (int64_t)bin * kBinRegions * cap;
   const float* bin_f = bin_w + (int64_t)bin * kBinRegions * cap;
-  for (uint32_t g = g_begin + threadIdx.x; g < g_end; g += blockDim.x) {
-    int x = 0;
+  // BE_BIN_U groups of 8 entries per thread and round, every load of the round issued before the first add: one group per
+  // round left the workgroup waiting a full memory latency per 48 bytes and thread (80 rounds of ~2 us at C4: the kernel
+  // ran at 3.7 TB/s of its 600 MB).  A group that is not a whole one (a region's last, or past the end) loads the bin's
+  // first entries instead — no branch around the loads — and goes through the entry-by-entry tail.
+  constexpr int U = BE_BIN_U;
+  for (uint32_t g0 = g_begin + threadIdx.x; g0 < g_end; g0 += U * blockDim.x) {
+    uint4 iv[U];
+    float4 wa[U], wb[U];
+    uint32_t e0s[U], cnts_u[U];
+    int xs[U];
+    bool whole[U];
 #pragma unroll
-    for (int q = 1; q < kBinRegions; ++q) x += g >= gstart[q] ? 1 : 0;
-    uint32_t gs = gstart[0], cnt = cnts[0];
+    for (int u = 0; u < U; ++u) {
+      const uint32_t g = g0 + (uint32_t)u * blockDim.x;
+      int x = 0;
 #pragma unroll
-    for (int q = 1; q < kBinRegions; ++q) if (x == q) { gs = gstart[q]; cnt = cnts[q]; }
-    const uint32_t e0 = (g - gs) * 8u;
-    const uint16_t* bi = bin_i + (int64_t)x * cap;
-    const float* bw = bin_f + (int64_t)x * cap;
-    if (e0 + 8u <= cnt) {        // cap is a multiple of 64: the regions are 128-byte aligned
-      const uint4 iv = *reinterpret_cast<const uint4*>(bi + e0);
-      if (HOMO) {
-        bin_count8(reinterpret_cast<uint32_t*>(acc), iv.x, iv.y, iv.z, iv.w);
-      } else {
-        const float4 wa = *reinterpret_cast<const float4*>(bw + e0), wb = *reinterpret_cast<const float4*>(bw + e0 + 4);
-        plan_add4<HOMO>(acc, make_uint2(iv.x, iv.y), wa, scale);
-        plan_add4<HOMO>(acc, make_uint2(iv.z, iv.w), wb, scale);
+      for (int q = 1; q < kBinRegions; ++q) x += g >= gstart[q] ? 1 : 0;
+      uint32_t gs = gstart[0], cnt = cnts[0];
+#pragma unroll
+      for (int q = 1; q < kBinRegions; ++q) if (x == q) { gs = gstart[q]; cnt = cnts[q]; }
+      const uint32_t e0 = (g - gs) * 8u;
+      whole[u] = g < g_end && e0 + 8u <= cnt;        // cap is a multiple of 64: the regions are 128-byte aligned
+      xs[u] = x; e0s[u] = e0; cnts_u[u] = g < g_end ? cnt : 0u;
+      const int64_t at = whole[u] ? (int64_t)x * cap + e0 : 0;
+      iv[u] = *reinterpret_cast<const uint4*>(bin_i + at);
+      if (!HOMO) {
+        wa[u] = *reinterpret_cast<const float4*>(bin_f + at);
+        wb[u] = *reinterpret_cast<const float4*>(bin_f + at + 4);
       }
-    } else {
-      for (uint32_t e = e0; e < cnt; ++e) {
-        if (HOMO) { if (bi[e] != kBinPad) atomicAdd(reinterpret_cast<uint32_t*>(acc) + bi[e], 1u); }
-        else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + bi[e], fixed_from_f32(bw[e], scale));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (whole[u]) {
+        if (HOMO) {
+          bin_count8(reinterpret_cast<uint32_t*>(acc), iv[u].x, iv[u].y, iv[u].z, iv[u].w);
+        } else {
+          plan_add4<HOMO>(acc, make_uint2(iv[u].x, iv[u].y), wa[u], scale);
+          plan_add4<HOMO>(acc, make_uint2(iv[u].z, iv[u].w), wb[u], scale);
+        }
+      } else {
+        const uint16_t* bi = bin_i + (int64_t)xs[u] * cap;
+        const float* bw = bin_f + (int64_t)xs[u] * cap;
+        for (uint32_t e = e0s[u]; e < cnts_u[u]; ++e) {
+          if (HOMO) { if (bi[e] != kBinPad) atomicAdd(reinterpret_cast<uint32_t*>(acc) + bi[e], 1u); }
+          else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + bi[e], fixed_from_f32(bw[e], scale));
+        }
       }
     }
   }
@@ -539,20 +565,23 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   }
   BE_LAUNCH_CHECK();
   // n_bins * parts ~ 256: every workgroup fills a CU (128 KB of LDS) and its slice is merged into the output with float
-  // atomics, one per non-zero accumulator, so more parts than CUs only add merge traffic (39 bins: 13 parts took 55 us, 6 take 30)
+  // atomics, one per non-zero accumulator, so more parts than CUs only add merge traffic (39 bins: 13 parts took 55 us, 6 take 30).
+  // (Beyond 256 bins the last round of workgroups is partly empty — C4: 611 bins = 2 rounds + 99 — but splitting only its
+  //  bins into parts that fill the round measured nothing, 165 -> 156 us at best: the pass is bound by its byte stream.)
   int parts = 256 / (n_bins > 0 ? n_bins : 1);
   parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+  const unsigned acc_grid = (unsigned)(n_bins * parts);
   const float scale = ldexpf(1.0f, scale_exp - 32);
   const double inv_scale = ldexp(1.0, -scale_exp);
   if (homo) {
     auto kern = k_bin_accumulate<true>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
+    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
                        slice_shift, parts, k, scale, inv_scale, weights, wdtype, static_cast<float*>(out));
   } else {
     auto kern = k_bin_accumulate<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_bins * parts)), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
+    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
                        slice_shift, parts, k, scale, inv_scale, static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out));
   }
   be_prof_end(prof, st);

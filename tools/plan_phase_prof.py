@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase-by-phase time of k_plan_accumulate_d8 as workgroup 0..255's first thread sees it (diagnostic build).  On the GPU box:
-    BE_HIPCC_FLAGS=-DBE_PLAN_PROF python tools/plan_phase_prof.py [N] [K]
+    BE_HIPCC_FLAGS=-DBE_PLAN_PROF python tools/plan_phase_prof.py [N] [K] [N_POST]
 Rebuild without the flag afterwards (the shipped library carries no stamps)."""
 import ctypes, os, sys
 import numpy as np, torch
@@ -11,15 +11,16 @@ import brainevent_amd as be
 from brainevent_amd import _csr as C, _array as A
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+n_post = int(sys.argv[3]) if len(sys.argv) > 3 else n      # e.g. 1000000 1250 125000: one post slice of an 8-way cut of C2
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev); g.manual_seed(0)
-idx = torch.randint(0, n, (n, K), dtype=torch.int32, device=dev, generator=g)
+idx = torch.randint(0, n_post, (n, K), dtype=torch.int32, device=dev, generator=g)
 w = torch.empty((n, K), device=dev).uniform_(0, 1, generator=g)
-plan = C.ScatterPlan.build(w, idx.reshape(-1), None, shape=(n, n), row_len=K)
+plan = C.ScatterPlan.build(w, idx.reshape(-1), None, shape=(n, n_post), row_len=K)
 if os.environ.get('BE_PLAN_SEGT') == '1':      # experiment: slice-major segment table
     plan.seg = plan.seg.view(n, plan.n_slices, 2).permute(1, 0, 2).contiguous().view(-1)
 spikes = [(torch.rand(n, device=dev, generator=g) < 0.01).to(torch.uint8) for _ in range(4)]
-out = torch.empty(n, dtype=torch.float32, device=dev)
+out = torch.empty(n_post, dtype=torch.float32, device=dev)
 for i in range(5):
     C._plan_call(plan, w, spikes[i % 4], A.BE_SPIKE_BOOL, out)
 torch.cuda.synchronize()
