@@ -235,3 +235,74 @@ def test_tocsc_tocsr_keep_the_matrix():
     np.testing.assert_array_equal(back.indices.cpu().numpy(), csr.indices.cpu().numpy())
     s = rng.random(23) < 0.5
     np.testing.assert_allclose(be.BinaryArray(s) @ csc, s.astype(np.float32) @ dense, rtol=1e-5, atol=1e-5)
+
+
+def test_odd_operand_layouts(be, oracle):
+    """Strided spike vectors, views with storage offsets (4-byte aligned only), int64 indices, non-contiguous (data, indices)
+    of a FixedNumPerPre, transposed views of a dense matrix: converted or consumed as they are, never misread."""
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(0)
+    m, k, K = 300, 500, 12
+    idx = rng.integers(0, k, (m, K)).astype(np.int32)
+    w = rng.uniform(0.1, 1, (m, K)).astype(np.float32)
+    ptr = (np.arange(m + 1) * K).astype(np.int32)
+    v, vk = rng.random(m) < 0.3, rng.random(k) < 0.3
+    ref_t = oracle.binary_csrmv(w.reshape(-1), idx.reshape(-1), ptr, v, (m, k), True)
+    ref_n = oracle.binary_csrmv(w.reshape(-1), idx.reshape(-1), ptr, vk, (m, k), False)
+    wt, it, pt = torch.tensor(w.reshape(-1), device=dev), torch.tensor(idx.reshape(-1), device=dev), torch.tensor(ptr, device=dev)
+    vt, vkt = torch.tensor(v, device=dev), torch.tensor(vk, device=dev)
+
+    def same(got, ref):
+        got = got.cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+    big = torch.zeros(2 * m, dtype=torch.bool, device=dev); big[::2] = vt
+    same(be.binary_csrmv(wt, it, pt, big[::2], shape=(m, k), transpose=True), ref_t)
+    bigk = torch.zeros(2 * k, dtype=torch.float32, device=dev); bigk[1::2] = vkt.float()
+    same(be.binary_csrmv(wt, it, pt, bigk[1::2], shape=(m, k), transpose=False), ref_n)
+    pad_w = torch.cat([torch.full((7,), 9e9, device=dev), wt])
+    pad_i = torch.cat([torch.full((5,), k - 1, dtype=torch.int32, device=dev), it])
+    same(be.binary_csrmv(pad_w[7:], pad_i[5:], pt, vt, shape=(m, k), transpose=True), ref_t)
+    same(be.binary_csrmv(pad_w[7:], pad_i[5:], pt, vkt, shape=(m, k), transpose=False), ref_n)
+    csr = be.CSR((w.reshape(-1), idx.reshape(-1), ptr), shape=(m, k))
+    same(be.BinaryArray(big[::2]) @ csr, ref_t)
+    same(csr @ be.BinaryArray(vkt), ref_n)
+    idx_t = torch.tensor(np.ascontiguousarray(idx.T), device=dev).T          # shape (m, K), strides (1, m)
+    w_t = torch.tensor(np.ascontiguousarray(w.T), device=dev).T
+    same(be.BinaryArray(v) @ be.FixedNumPerPre((w_t, idx_t), shape=(m, k)), ref_t)
+    W = rng.normal(0, 1, (k, m)).astype(np.float32)
+    Wv = torch.tensor(W, device=dev).T                                       # (m, k) view of a (k, m) array
+    same(be.BinaryArray(v) @ Wv, oracle.binary_densemv(W.T.astype(np.float64), v, True))
+    same(Wv @ be.BinaryArray(vk), oracle.binary_densemv(W.T.astype(np.float64), vk, False))
+    out = be.binary_csrmm(wt, it, pt, torch.zeros((m, 0), dtype=torch.bool, device=dev), shape=(m, k), transpose=True)
+    assert tuple(out.shape) == (k, 0)
+
+
+@pytest.mark.parametrize('route', ['plan', 'binned', 'gather'])
+def test_offset_views_through_the_fast_routes(be, oracle, route):
+    """Matrix arrays that start 4 bytes (not 16) into their storage, behind poison: the plan build, the binned passes and the
+    lanes-per-row gather read them with vector loads where alignment allows and never touch what lies in front."""
+    from brainevent_amd._csr import ScatterPlan, BinnedScatter
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(5)
+    m, k = 3000, 200_000
+    lens = rng.integers(20, 60, m)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(ptr[-1])
+    idx = rng.integers(0, k, nnz).astype(np.int32)
+    w = rng.uniform(0.1, 1, nnz).astype(np.float32)
+    pad_w = torch.cat([torch.full((1,), 9e9, device=dev), torch.tensor(w, device=dev), torch.full((64,), 9e9, device=dev)])
+    pad_i = torch.cat([torch.full((3,), k - 1, dtype=torch.int32, device=dev), torch.tensor(idx, device=dev),
+                       torch.full((64,), k - 1, dtype=torch.int32, device=dev)])
+    wv, iv, pt = pad_w[1:1 + nnz], pad_i[3:3 + nnz], torch.tensor(ptr, device=dev)
+    if route == 'gather':
+        v = rng.random(k) < 0.2
+        v[k - 1] = True
+        got = be.binary_csrmv(wv, iv, pt, torch.tensor(v, device=dev), shape=(m, k), transpose=False)
+        ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), False)
+    else:
+        v = rng.random(m) < 0.3
+        ws = ScatterPlan.build(wv, iv, pt, shape=(m, k)) if route == 'plan' else BinnedScatter(wv, m, k, nnz, max_active_fraction=0.5, indices=iv)
+        got = be.binary_csrmv(wv, iv, pt, torch.tensor(v, device=dev), shape=(m, k), transpose=True, workspace=ws)
+        ref = oracle.binary_csrmv(w, idx, ptr, v, (m, k), True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
