@@ -197,3 +197,25 @@ def test_densemm_f32_mfma_both_directions(be, oracle, shape, nb):
     St = rng.random((shape[0], nb)) < 0.3; St[3, :] = False
     gott = be.binary_densemm(W2, torch.tensor(St, device='cuda'), transpose=True)
     assert torch.isfinite(gott).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('nb', [1, 8, 32])
+def test_dense_weights_at_odd_storage_offsets(be, dtype, nb):
+    """A weight matrix that starts 1 or 3 elements into its storage (rows 2- or 4-byte aligned only, NaN in front and behind)
+    through the vector and the MFMA kernels of both directions."""
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    n = 1032
+    for off in (1, 3):
+        flat = torch.full((n * n + 16,), float('nan'), dtype=dtype, device=dev)
+        W = flat[off:off + n * n].view(n, n)
+        W.copy_(torch.randn((n, n), device=dev, generator=g).to(dtype))
+        S = torch.rand((nb, n), device=dev, generator=g) < 0.05
+        if nb == 1:
+            pairs = ((be.BinaryArray(S[0]) @ W, S[0].float() @ W.float()), (W @ be.BinaryArray(S[0]), W.float() @ S[0].float()))
+        else:
+            pairs = ((be.BinaryArray(S) @ W, S.float() @ W.float()), (W @ be.BinaryArray(S.T.contiguous()), W.float() @ S.T.float()))
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        for got, ref in pairs:
+            assert float((got.float() - ref).abs().max() / ref.abs().max()) < tol
