@@ -685,6 +685,9 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 //   One wave = 32 weight rows over the whole K range, 8 K-steps of weight rows in flight (register ring).
 //   The whole matrix is streamed (this direction cannot skip rows), so the bound is k * m * sizeof(W) / HBM.
 // ------------------------------------------------------------------------------------------------
+#ifndef BE_NT_MFMA16
+#define BE_NT_MFMA16 1
+#endif
 constexpr int kNtChunk = 4096;   // k per mask chunk staged in LDS (256 steps)
 constexpr int kNtRing = 8;
 
@@ -744,6 +747,94 @@ __global__ void __launch_bounds__(256) k_densemm_nt_mfma(const W* __restrict__ w
       if (i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[r]);
     }
   }
+}
+
+// The same product on v_mfma_f32_16x16x32_{f16,bf16}: an A fragment is 16 weight rows x 32 k, lane (row i = lane % 16,
+// k block kb = lane / 16) loads 16 B at W[row][k0 + 8 kb] — the four lanes of a row read one whole 64-byte sector per
+// instruction.  The 32x32x16 shape above reads 32 rows x 32 B per instruction: every sector is requested by two
+// instructions, 268 M sector requests for the 8.6 GB of a 65536^2 fp16 matrix in 1.9 ms = 143 G/s, close to what the L2 -> L1
+// path delivers (~190 G sectors/s), and the kernel sat at 4.5 TB/s whatever the ring depth.  A wave still owns 32 rows x 32
+// batch columns: two A fragments (rows 0-15, 16-31) x two B fragments (columns 0-15, 16-31), four MFMAs per 32 k.
+// fp16 65536^2, 32 columns: 1.90-1.97 -> 1.545 ms (5.55 TB/s).  The f32 twin on v_mfma_f32_16x16x4_f32 measured no gain
+// (0.89 -> 0.91 ms at 32768^2) and is not kept.
+typedef float be_v4f __attribute__((ext_vector_type(4)));
+template <typename W>
+__device__ __forceinline__ be_v4f mfma_16x16x32(be_v8s a, be_v8s b, be_v4f c) {
+  if (std::is_same<W, __half>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(be_v8h, a), __builtin_bit_cast(be_v8h, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(be_v8bf, a), __builtin_bit_cast(be_v8bf, b), c, 0, 0, 0);
+}
+template <typename W>
+__global__ void __launch_bounds__(256) k_densemm_nt_mfma16(const W* __restrict__ weights, int64_t m, int64_t k,
+                                                           const uint32_t* __restrict__ mask, W* __restrict__ out_bm, int nc,
+                                                           int b0) {
+  __shared__ uint32_t masks_s[kNtChunk + 32 * kNtRing];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int i_lane = lane & 15, kb = lane >> 4;
+  const int64_t row0 = m0 + i_lane < m ? m0 + i_lane : m - 1;           // clamped: results of rows >= m are dropped
+  const int64_t row1 = m0 + 16 + i_lane < m ? m0 + 16 + i_lane : m - 1;
+  const W* w0 = weights + row0 * k + 8 * kb;
+  const W* w1 = weights + row1 * k + 8 * kb;
+  be_v4f acc[2][2] = {};
+  uint4 ring[kNtRing][2];
+  for (int64_t c0 = 0; c0 < k; c0 += kNtChunk) {
+    const int64_t clen = k - c0 < kNtChunk ? k - c0 : kNtChunk;          // multiple of 8 (k % 8 == 0)
+    const int steps = (int)((clen + 31) >> 5);
+    __syncthreads();
+    for (int j = tid; j < kNtChunk + 32 * kNtRing; j += 256) masks_s[j] = (j < clen) ? mask[c0 + j] : 0u;
+    __syncthreads();
+    // fetch only issues the loads (address clamped into the row); a piece past the end of k is zeroed at use
+    auto fetch = [&](int t, uint4 (&a)[2]) {
+      int64_t kpos = c0 + 32 * (int64_t)t;
+      kpos = kpos + 8 * kb + 8 <= k ? kpos : (k - 8 - 8 * kb > 0 ? k - 8 - 8 * kb : 0);
+      a[0] = *reinterpret_cast<const uint4*>(w0 + kpos);      // (non-temporal: 1.53 -> 1.75 ms — the two sectors of a 128-byte
+      a[1] = *reinterpret_cast<const uint4*>(w1 + kpos);      //  line are read by consecutive steps)
+    };
+#pragma unroll
+    for (int s = 0; s < kNtRing; ++s) {
+      fetch(s, ring[s]);
+      __builtin_amdgcn_sched_barrier(0);      // keep the issue order = the consume order (counted vmcnt needs it)
+    }
+    for (int t0 = 0; t0 < steps; t0 += kNtRing) {
+#pragma unroll
+      for (int ii = 0; ii < kNtRing; ++ii) {
+        const int t = t0 + ii;            // steps beyond `steps` multiply zero masks (padding of masks_s)
+        const uint32_t* mk = &masks_s[32 * t + 8 * kb];
+        be_v8s bf0, bf1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t w = mk[j] >> i_lane;
+          bf0[j] = (short)((w & 1u) * MfmaOne<W>::one);
+          bf1[j] = (short)(((w >> 16) & 1u) * MfmaOne<W>::one);
+        }
+        const bool in_k = c0 + 32 * (int64_t)t + 8 * kb + 8 <= k;
+        const be_v8s a0 = __builtin_bit_cast(be_v8s, in_k ? ring[ii][0] : make_uint4(0, 0, 0, 0));
+        const be_v8s a1 = __builtin_bit_cast(be_v8s, in_k ? ring[ii][1] : make_uint4(0, 0, 0, 0));
+        acc[0][0] = mfma_16x16x32<W>(a0, bf0, acc[0][0]);
+        acc[0][1] = mfma_16x16x32<W>(a0, bf1, acc[0][1]);
+        acc[1][0] = mfma_16x16x32<W>(a1, bf0, acc[1][0]);
+        acc[1][1] = mfma_16x16x32<W>(a1, bf1, acc[1][1]);
+        fetch(t + kNtRing, ring[ii]);
+        // pin the refill here: hipcc otherwise sinks the loads next to their uses and the ring collapses to depth 2
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // D layout of a 16x16 tile: column (batch) = lane % 16, rows 4 * (lane / 16) + reg
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) {
+      const int b = i_lane + 16 * cg;
+      if (b < nc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t i = m0 + 16 * rg + 4 * kb + r;
+          if (i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[rg][cg][r]);
+        }
+      }
+    }
 }
 
 // The same kernel for f32 weights: v_mfma_f32_32x32x2_f32 (M = 32 weight rows, N = 32 batch rows, K = 2 per instruction).
@@ -965,8 +1056,8 @@ int densemm_nt_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, 
       hipLaunchKernelGGL(k_densemm_nt_mfma_f32<0>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
                          out_bm, nc, (int)b0);
     else
-      hipLaunchKernelGGL(k_densemm_nt_mfma<W>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
-                         out_bm, nc, (int)b0);
+      hipLaunchKernelGGL(BE_NT_MFMA16 ? k_densemm_nt_mfma16<W> : k_densemm_nt_mfma<W>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st,
+                         weights, m, k, d.mask, out_bm, nc, (int)b0);
     BE_LAUNCH_CHECK();
   }
   be_prof_end(prof, st);
