@@ -685,6 +685,9 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 //   One wave = 32 weight rows over the whole K range, 8 K-steps of weight rows in flight (register ring).
 //   The whole matrix is streamed (this direction cannot skip rows), so the bound is k * m * sizeof(W) / HBM.
 // ------------------------------------------------------------------------------------------------
+#ifndef BE_NT_MFMA_MIN_NB
+#define BE_NT_MFMA_MIN_NB 8
+#endif
 #ifndef BE_NT_MFMA16
 #define BE_NT_MFMA16 1
 #endif
@@ -1079,8 +1082,8 @@ int densemm_any(const void* weights, const void* spikes_bm, int sd, void* out_bm
     return densemm_t_vec<W, 1>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
   }
   if constexpr (std::is_same<W, __half>::value || std::is_same<W, __hip_bfloat16>::value) {
-    // enough rows to fill the chip with 32-row waves; k >= 16 so that the clamped tail load stays inside the row
-    if (vec_ok && nb >= 8 && rows_w >= 4096 && cols_w >= 16)
+    // enough rows to fill the chip with 32-row waves; k >= 32 so that the clamped tail load stays inside the row
+    if (vec_ok && nb >= BE_NT_MFMA_MIN_NB && rows_w >= 4096 && cols_w >= 32)
       return densemm_nt_mfma<W>(w, spikes_bm, sd, o, rows_w, cols_w, nb, ws, st);
   }
   if constexpr (std::is_same<W, float>::value) {

@@ -219,3 +219,23 @@ def test_dense_weights_at_odd_storage_offsets(be, dtype, nb):
         tol = 1e-5 if dtype == torch.float32 else 2e-2
         for got, ref in pairs:
             assert float((got.float() - ref).abs().max() / ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize('k', [16, 24, 32, 40, 72])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16, torch.float32])
+def test_batched_no_transpose_with_a_short_contraction(be, k, dtype):
+    """W [4200, k] @ S.T with 8 and 32 batch columns: the MFMA kernels read 32 k per step and clamp their last loads into the
+    row, which needs k >= 32 (f32: 8); shorter rows take the vector kernel.  NaN behind the matrix must stay out."""
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    m = 4200
+    flat = torch.full((m * k + 64,), float('nan'), dtype=dtype, device=dev)
+    W = flat[:m * k].view(m, k)
+    W.copy_(torch.randn((m, k), device=dev, generator=g).to(dtype))
+    for nb in (8, 32):
+        S = torch.rand((k, nb), device=dev, generator=g) < 0.4
+        got = (W @ be.BinaryArray(S)).float()
+        ref = W.float() @ S.float()
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert torch.isfinite(got).all()
+        assert float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)) < tol
