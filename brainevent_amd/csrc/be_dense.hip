@@ -266,7 +266,13 @@ __global__ void __launch_bounds__(256) k_dense_reduce(const typename WTraits<W>:
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     ACC s = ACC(0);
-    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * total + i];
+    for (int p0 = 0; p0 < parts; p0 += 8) {      // eight parts' loads in flight; the sum keeps the order of the parts
+      ACC v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(p0 + u < parts ? p0 + u : parts - 1) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += p0 + u < parts ? v[u] : ACC(0);
+    }
     WTraits<W>::store(out, i, s);
   }
 }
@@ -989,7 +995,13 @@ __global__ void __launch_bounds__(256) k_mfma_reduce(const float* __restrict__ p
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * part_stride + i];
+    for (int p0 = 0; p0 < parts; p0 += 8) {      // eight parts' loads in flight; the sum keeps the order of the parts
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(p0 + u < parts ? p0 + u : parts - 1) * part_stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += p0 + u < parts ? v[u] : 0.f;
+    }
     WTraits<W>::store(out, i, s);
   }
 }

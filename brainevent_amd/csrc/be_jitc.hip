@@ -431,7 +431,13 @@ __global__ void __launch_bounds__(256) k_jit_masks(const typename SP::type* __re
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
     uint32_t mk = 0;
-    for (int b = 0; b < nc; ++b) mk |= (SP::active(spikes_bm[(int64_t)b * len + i]) ? 1u : 0u) << b;
+    for (int b0 = 0; b0 < nc; b0 += 8) {       // eight batch rows' loads in flight
+      typename SP::type v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = spikes_bm[(int64_t)(b0 + u < nc ? b0 + u : nc - 1) * len + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) mk |= ((b0 + u < nc && SP::active(v[u])) ? 1u : 0u) << (b0 + u);
+    }
     mask[i] = mk;
   }
 }
