@@ -6,8 +6,11 @@
 #ifndef BE_BLOCK_AUX
 #define BE_BLOCK_AUX 2      // cache policy of the wave-per-block d8 loads: nt — blocks are streamed once per step (C2: kernel 119.6 -> 108-112 us,
                             // 716 -> 750-780 Geff/s; sc0 / sc1 on top change nothing).  NOT on the other decoders: uint16 blocks by part of a wave
-                            // 26 -> 32 us at N = 350k, 162 -> 186 at 2.5M; h8 at C2 1522 -> 1489 Geff/s.
+                            // 26 -> 32 us at N = 350k, 162 -> 186 at 2.5M; h8 at C2 1522 -> 1489 Geff/s.  And only for long blocks
+                            // (kD8NtMinBlock items on average): on one post slice of an 8-way cut of C2 (blocks of ~114 items, 5 lines
+                            // each) the kernel takes 32.5 us with nt and 30.3 without.
 #endif
+constexpr int kD8NtMinBlock = 160;
 
 namespace {
 
@@ -945,6 +948,7 @@ struct SegGroupD8 {
   be_v4u wv[4];
 };
 
+template <int AUX>
 __device__ __forceinline__ void d8_issue(SegGroupD8& g, int i, int nvalid, uint32_t st_v, uint32_t n4_v, int lane,
                                          const unsigned char* __restrict__ blob) {
 #pragma unroll
@@ -959,9 +963,9 @@ __device__ __forceinline__ void d8_issue(SegGroupD8& g, int i, int nvalid, uint3
   for (int q = 0; q < 4; ++q) {
     unsigned char* blk = const_cast<unsigned char*>(blob) + ((uint64_t)g.start[q] << 7);
     auto rw = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)(g.ng[q] * 16u), kBufFlags);
-    g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, BE_BLOCK_AUX);
+    g.wv[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, 0, AUX);
     auto rd = __builtin_amdgcn_make_buffer_rsrc(blk + (uint64_t)g.ng[q] * 16u, 0, (int)(g.ng[q] * 4u), kBufFlags);
-    g.dv[q] = __builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 0, BE_BLOCK_AUX);     // lanes past the block read 0
+    g.dv[q] = __builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 0, AUX);     // lanes past the block read 0
   }
 }
 
@@ -1095,7 +1099,7 @@ __device__ unsigned long long g_plan_prof[256 * 8];
 #define PLAN_STAMP(i) do { } while (0)
 #endif
 
-template <int LPB /* 0: a wave per block; 8 / 16: lanes per block */, int FUSED = 0>
+template <int LPB /* 0: a wave per block; 8 / 16: lanes per block */, int FUSED = 0, int AUX = 0 /* cache policy of the wave-per-block loads */>
 __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
                                                              const uint32_t* active,
                                                              const uint32_t* __restrict__ n_active_p, int n_slices,
@@ -1189,11 +1193,11 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
         d8q_tails<LPB>(st_v, n4_v, nvalid, acc, lane, scale, blob);
       } else {
         SegGroupD8 gA, gB;
-        d8_issue(gA, 0, nvalid, st_v, n4_v, lane, blob);
+        d8_issue<AUX>(gA, 0, nvalid, st_v, n4_v, lane, blob);
         for (int i = 0; i < nvalid; i += 8) {
-          d8_issue(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
+          d8_issue<AUX>(gB, i + 4, nvalid, st_v, n4_v, lane, blob);
           d8_consume(gA, acc, lane, scale, blob);
-          d8_issue(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
+          d8_issue<AUX>(gA, i + 8, nvalid, st_v, n4_v, lane, blob);
           d8_consume(gB, acc, lane, scale, blob);
         }
       }
@@ -1889,7 +1893,8 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
     unsigned long long* pp = static_cast<unsigned long long*>(partial);
     if (block_hint > 0 && block_hint <= kD8EighthMaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate_d8<8 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
     else if (block_hint > 0 && block_hint <= kD8QuarterMaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate_d8<16 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
-    else BE_PLAN_BY_FUSED(k_plan_accumulate_d8<0 COMMA, >, n_slices, (int)S, parts, scale, pp, astride);
+    else if (block_hint >= kD8NtMinBlock) BE_PLAN_BY_FUSED(k_plan_accumulate_d8<0 COMMA, COMMA BE_BLOCK_AUX>, n_slices, (int)S, parts, scale, pp, astride);
+    else BE_PLAN_BY_FUSED(k_plan_accumulate_d8<0 COMMA, COMMA 0>, n_slices, (int)S, parts, scale, pp, astride);
   } else {
     unsigned long long* pw = static_cast<unsigned long long*>(partial);
     if (block_hint > 0 && block_hint <= kSubW4MaxBlock) BE_PLAN_BY_FUSED(k_plan_accumulate<false COMMA 4 COMMA, >, n_slices, slice_shift, parts, scale, pw, astride, (int)S);
