@@ -64,6 +64,8 @@ constexpr int kTile = 2048;   // rows per workgroup (256 threads x 8)
 
 __device__ __forceinline__ uint32_t submask_of(uint32_t mk, int g) { return (mk >> (kGroup * g)) & ((1u << kGroup) - 1u); }
 
+// WHOLE: one list of the rows with any bit set (the union of the batch rows) instead of one list per batch group
+template <bool WHOLE = false>
 __global__ void __launch_bounds__(256) k_gl_count(const uint32_t* __restrict__ mask, int64_t k, uint32_t* __restrict__ tile_cnt) {
   __shared__ uint32_t red[4];
   const int g = blockIdx.y;
@@ -71,11 +73,39 @@ __global__ void __launch_bounds__(256) k_gl_count(const uint32_t* __restrict__ m
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
-    if (base + i < k && submask_of(mask[base + i], g)) ++c;
+    if (base + i < k && (WHOLE ? mask[base + i] : submask_of(mask[base + i], g))) ++c;
   c = wave_sum(c);
   if (lane_id() == 0) red[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) tile_cnt[(int64_t)g * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// k_dense_masks and k_gl_count<true> in one launch: workgroup = one tile of kTile rows (8 per thread)
+template <typename SP>
+__global__ void __launch_bounds__(256) k_dense_masks_count(const typename SP::type* __restrict__ spikes, int64_t k, int nc,
+                                                           uint32_t* __restrict__ mask, uint32_t* __restrict__ tile_cnt) {
+  __shared__ uint32_t red[4];
+  uint32_t c = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = (int64_t)blockIdx.x * kTile + r * 256 + threadIdx.x;       // coalesced over the workgroup
+    if (i < k) {
+      uint32_t mk = 0;
+      for (int b0 = 0; b0 < nc; b0 += 8) {
+        typename SP::type v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = spikes[(int64_t)(b0 + u < nc ? b0 + u : nc - 1) * k + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mk |= ((b0 + u < nc && SP::active(v[u])) ? 1u : 0u) << (b0 + u);
+      }
+      mask[i] = mk;
+      c += mk ? 1u : 0u;
+    }
+  }
+  c = wave_sum(c);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // one workgroup per group: exclusive scan of that group's tile counts; count[g] = total
@@ -105,6 +135,7 @@ __global__ void __launch_bounds__(1024) k_gl_scan(uint32_t* __restrict__ tile_cn
   if (threadIdx.x == 0) count[blockIdx.x] = carry;
 }
 
+template <bool WHOLE = false>
 __global__ void __launch_bounds__(256) k_gl_write(const uint32_t* __restrict__ mask, int64_t k,
                                                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ lists,
                                                   int64_t list_stride) {
@@ -115,7 +146,7 @@ __global__ void __launch_bounds__(256) k_gl_write(const uint32_t* __restrict__ m
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    sm[i] = (base + i < k) ? submask_of(mask[base + i], g) : 0u;
+    sm[i] = (base + i < k) ? (WHOLE ? (mask[base + i] ? 1u : 0u) : submask_of(mask[base + i], g)) : 0u;
     c += sm[i] ? 1u : 0u;
   }
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -438,11 +469,11 @@ int build_lists(const void* spikes_chunk, int64_t k, int nc, int n_groups, const
                      static_cast<const typename SP::type*>(spikes_chunk), k, nc, d.mask);
   BE_LAUNCH_CHECK();
   const int64_t nt = n_tiles_of(k);
-  hipLaunchKernelGGL(k_gl_count, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt);
+  hipLaunchKernelGGL(k_gl_count<false>, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt);
   BE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gl_scan, dim3(n_groups), dim3(1024), 0, st, d.tile_cnt, nt, d.count);
   BE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt, d.lists, k);
+  hipLaunchKernelGGL(k_gl_write<false>, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt, d.lists, k);
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
@@ -485,40 +516,30 @@ int densemm_nt_launch(const W* weights, int64_t m, int64_t k, const DenseWs& d, 
   return BE_OK;
 }
 
-// union list = "group" of all 32 bits: reuse the list kernels with one pseudo group by OR-ing sub-masks
-__global__ void __launch_bounds__(256) k_union_flags(const uint32_t* __restrict__ mask, int64_t k, uint32_t* __restrict__ flag) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) flag[i] = mask[i] ? 1u : 0u;
-}
-
 template <typename W, int VEC>
 int densemm_nt_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t m, int64_t k, int64_t nb, void* ws,
                    hipStream_t st) {
   DenseWs d = carve(ws, k);
   const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
   const int64_t nt = n_tiles_of(k);
-  uint32_t* flag = d.lists;                                     // scratch: first list slot holds 0/1 flags
   uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;          // union list in the last slot
   uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
     const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    // masks + per-tile counts of the active columns in one launch, scan, ordered union list: three launches (five before:
+    // masks, 0/1 flags, count, scan, write — 16 us more per call at C5)
     if (sd == BE_SPIKE_FLOAT)
-      hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                         static_cast<const float*>(chunk), k, nc, d.mask);
+      hipLaunchKernelGGL(k_dense_masks_count<SpikeFloat>, dim3((unsigned)nt), dim3(256), 0, st,
+                         static_cast<const float*>(chunk), k, nc, d.mask, utile);
     else
-      hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                         static_cast<const uint8_t*>(chunk), k, nc, d.mask);
-    BE_LAUNCH_CHECK();
-    // ordered union list of active columns (submask_of(flag, 0) = flag & 0xF = 0/1)
-    hipLaunchKernelGGL(k_union_flags, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st, d.mask, k, flag);
-    BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_count, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile);
+      hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st,
+                         static_cast<const uint8_t*>(chunk), k, nc, d.mask, utile);
     BE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
     BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile, ulist, k);
+    hipLaunchKernelGGL(k_gl_write<true>, dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k);
     BE_LAUNCH_CHECK();
     int rc;
     if (nc == 1) rc = densemm_nt_launch<W, VEC, 1>(weights, m, k, d, nc, out_bm, (int)b0, st);
@@ -1019,7 +1040,6 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
   float* partial = static_cast<float*>(d.partial);     // sized for 16 * nb * n floats >= parts * 32 * n when nb >= 8 ... see ws
   const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
   const int64_t nt = n_tiles_of(k);
-  uint32_t* flag = d.lists;
   uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;
   uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
   const int parts = std::is_same<W, float>::value ? mfma_parts(n / 2) : mfma_parts(n);      // f32: workgroups of 512 columns
@@ -1027,20 +1047,18 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
     const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    // masks + per-tile counts of the active columns in one launch, scan, ordered union list: three launches (five before:
+    // masks, 0/1 flags, count, scan, write — 16 us more per call at C5)
     if (sd == BE_SPIKE_FLOAT)
-      hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                         static_cast<const float*>(chunk), k, nc, d.mask);
+      hipLaunchKernelGGL(k_dense_masks_count<SpikeFloat>, dim3((unsigned)nt), dim3(256), 0, st,
+                         static_cast<const float*>(chunk), k, nc, d.mask, utile);
     else
-      hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                         static_cast<const uint8_t*>(chunk), k, nc, d.mask);
-    BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_union_flags, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st, d.mask, k, flag);
-    BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_count, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile);
+      hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st,
+                         static_cast<const uint8_t*>(chunk), k, nc, d.mask, utile);
     BE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
     BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_write, dim3((unsigned)nt, 1), dim3(256), 0, st, flag, k, utile, ulist, k);
+    hipLaunchKernelGGL(k_gl_write<true>, dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k);
     BE_LAUNCH_CHECK();
     if constexpr (std::is_same<W, float>::value)
       hipLaunchKernelGGL(k_densemm_t_mfma_f32<0>, dim3((unsigned)((n + 511) / 512), parts), dim3(256), 0, st, weights, n, d.mask,
