@@ -135,11 +135,27 @@ __global__ void __launch_bounds__(1024) k_gl_scan(uint32_t* __restrict__ tile_cn
   if (threadIdx.x == 0) count[blockIdx.x] = carry;
 }
 
-template <bool WHOLE = false>
+// SELF_SCAN: tile_off holds the raw per-tile counts (at most 1024 tiles) and every workgroup sums the tiles in front of
+// it itself; the last one also writes the total to *count — no scan launch.
+template <bool WHOLE = false, bool SELF_SCAN = false>
 __global__ void __launch_bounds__(256) k_gl_write(const uint32_t* __restrict__ mask, int64_t k,
                                                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ lists,
-                                                  int64_t list_stride) {
+                                                  int64_t list_stride, uint32_t* __restrict__ count = nullptr) {
   __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t front_s[4];
+  uint32_t front = 0;
+  if (SELF_SCAN) {
+    uint32_t f = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = q * 256 + (int)threadIdx.x;
+      f += t < (int)blockIdx.x ? tile_off[t] : 0u;
+    }
+    f = wave_sum(f);
+    if (lane_id() == 0) front_s[threadIdx.x >> 6] = f;
+    __syncthreads();
+    front = front_s[0] + front_s[1] + front_s[2] + front_s[3];
+  }
   const int g = blockIdx.y;
   const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * 8;
   uint32_t sm[8];
@@ -160,7 +176,8 @@ __global__ void __launch_bounds__(256) k_gl_write(const uint32_t* __restrict__ m
   __syncthreads();
   uint32_t wave_off = 0;
   for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-  uint32_t pos = tile_off[(int64_t)g * gridDim.x + blockIdx.x] + wave_off + incl - c;
+  uint32_t pos = (SELF_SCAN ? front : tile_off[(int64_t)g * gridDim.x + blockIdx.x]) + wave_off + incl - c;
+  if (SELF_SCAN && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) count[0] = front + wave_off + incl;   // the total
   uint32_t* out = lists + (int64_t)g * list_stride;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -473,7 +490,8 @@ int build_lists(const void* spikes_chunk, int64_t k, int nc, int n_groups, const
   BE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gl_scan, dim3(n_groups), dim3(1024), 0, st, d.tile_cnt, nt, d.count);
   BE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gl_write<false>, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt, d.lists, k);
+  hipLaunchKernelGGL((k_gl_write<false, false>), dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt, d.lists, k,
+                     static_cast<uint32_t*>(nullptr));
   BE_LAUNCH_CHECK();
   return BE_OK;
 }
@@ -537,9 +555,15 @@ int densemm_nt_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
       hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st,
                          static_cast<const uint8_t*>(chunk), k, nc, d.mask, utile);
     BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
-    BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_write<true>, dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k);
+    if (nt <= 1024) {      // every workgroup of the write sums the tiles in front of it: no scan launch
+      hipLaunchKernelGGL((k_gl_write<true, true>), dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k,
+                         d.count + kMaxGroups);
+    } else {
+      hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
+      BE_LAUNCH_CHECK();
+      hipLaunchKernelGGL((k_gl_write<true, false>), dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k,
+                         static_cast<uint32_t*>(nullptr));
+    }
     BE_LAUNCH_CHECK();
     int rc;
     if (nc == 1) rc = densemm_nt_launch<W, VEC, 1>(weights, m, k, d, nc, out_bm, (int)b0, st);
@@ -1056,9 +1080,15 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
       hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st,
                          static_cast<const uint8_t*>(chunk), k, nc, d.mask, utile);
     BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
-    BE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gl_write<true>, dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k);
+    if (nt <= 1024) {      // every workgroup of the write sums the tiles in front of it: no scan launch
+      hipLaunchKernelGGL((k_gl_write<true, true>), dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k,
+                         d.count + kMaxGroups);
+    } else {
+      hipLaunchKernelGGL(k_gl_scan, dim3(1), dim3(1024), 0, st, utile, nt, d.count + kMaxGroups);
+      BE_LAUNCH_CHECK();
+      hipLaunchKernelGGL((k_gl_write<true, false>), dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k,
+                         static_cast<uint32_t*>(nullptr));
+    }
     BE_LAUNCH_CHECK();
     if constexpr (std::is_same<W, float>::value)
       hipLaunchKernelGGL(k_densemm_t_mfma_f32<0>, dim3((unsigned)((n + 511) / 512), parts), dim3(256), 0, st, weights, n, d.mask,
