@@ -771,6 +771,11 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 //   One wave = 32 weight rows over the whole K range, 8 K-steps of weight rows in flight (register ring).
 //   The whole matrix is streamed (this direction cannot skip rows), so the bound is k * m * sizeof(W) / HBM.
 // ------------------------------------------------------------------------------------------------
+#ifndef BE_MFMA_WG_TARGET
+#define BE_MFMA_WG_TARGET 768    // workgroups of the S @ W MFMA kernels (column tiles x row parts): 3 per CU.  C5, ms per step:
+                                 // 2048: 0.478, 1536 (round 1): 0.466, 1024: 0.449, 768: 0.438, 512: 0.441 (1.48 at 50 % firing), 256: 0.571
+                                 // — fewer parts = fewer partial sums to write and reduce, until the chip runs out of waves
+#endif
 #ifndef BE_NT_MFMA_MIN_NB
 #define BE_NT_MFMA_MIN_NB 8
 #endif
@@ -1082,7 +1087,7 @@ __global__ void __launch_bounds__(256) k_mfma_reduce(const float* __restrict__ p
 
 inline int mfma_parts(int64_t n) {
   const int64_t tiles = (n + kMfmaCols - 1) / kMfmaCols;
-  int64_t p = 1536 / (tiles > 0 ? tiles : 1);
+  int64_t p = BE_MFMA_WG_TARGET / (tiles > 0 ? tiles : 1);
   return (int)(p < 1 ? 1 : (p > 16 ? 16 : p));
 }
 
