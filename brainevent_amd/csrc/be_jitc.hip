@@ -542,6 +542,10 @@ inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t
   return p;
 }
 
+#ifndef BE_JIT_WG_TARGET
+#define BE_JIT_WG_TARGET 256   // scatter workgroups (classes x pieces x parts): one round over the CUs.  512 (two rounds, twice the
+                               // partial sums) until late in round 2: C3 143 -> 136 us per step; 384 / 1024: 165 / 162
+#endif
 constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators per scatter workgroup (128 KiB); multiples of 256
 
 struct ScatterGeom { int n_classes, pieces, parts; uint32_t piece_len; };
@@ -553,7 +557,7 @@ inline ScatterGeom scatter_geom(const JitP& p, bool scalar, int64_t n_batch = 1)
   g.pieces = (int)std::max<int64_t>(1, (Qmax + cap - 1) / cap);
   const int64_t per_piece = (Qmax + g.pieces - 1) / g.pieces;
   g.piece_len = (uint32_t)std::max<int64_t>(256, (per_piece + 255) & ~255ll);   // multiple of the reduce tile
-  int parts = (int)(512 / std::max<int64_t>(1, (int64_t)g.n_classes * g.pieces * n_batch));
+  int parts = (int)(BE_JIT_WG_TARGET / std::max<int64_t>(1, (int64_t)g.n_classes * g.pieces * n_batch));
   g.parts = std::max(1, std::min(parts, 16));
   return g;
 }
