@@ -783,7 +783,10 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
 #define BE_NT_MFMA16 1
 #endif
 constexpr int kNtChunk = 4096;   // k per mask chunk staged in LDS (256 steps)
-constexpr int kNtRing = 8;
+#ifndef BE_NT_RING
+#define BE_NT_RING 8
+#endif
+constexpr int kNtRing = BE_NT_RING;
 
 template <typename W>
 __global__ void __launch_bounds__(256) k_densemm_nt_mfma(const W* __restrict__ weights, int64_t m, int64_t k,
