@@ -493,8 +493,9 @@ class BinnedScatter:
     def applicable(weights: torch.Tensor, k: int) -> bool:
         if weights.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             return False                  # f64: the bins carry f32 weights (per-entry f64 weights take the planned route)
-        shift = ScatterPlan.default_shift(k, weights.numel() == 1)
-        return ((k + (1 << shift) - 1) >> shift) <= 2048
+        homo = weights.numel() == 1
+        shift = ScatterPlan.default_shift(k, homo)
+        return ((k + (1 << shift) - 1) >> shift) <= fn('be_binned_max_slices', c_int, [c_int])(int(homo))
 
 
 def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes, sd, out) -> None:

@@ -8,438 +8,630 @@ namespace {
 // binned route: event-driven scatter for matrices WITHOUT a plan (or whose rows put too few entries into
 // one output slice for the plan to pay: FixedNumPerPre K=1000 over 10M outputs has 1.6 entries per (row, slice)).
 //
-//   pass B (k_bin_rows)   : persistent workgroups take active rows round-robin, fill an LDS batch of <= kBinBatch
-//                           entries, counting-sort it by output slice ("bin") in LDS, reserve one range per
-//                           (workgroup, bin) in that bin's global region (one returning atomic each) and copy the
-//                           runs out coalesced as (uint16 local column, f32 weight).
-//   pass C (k_bin_accumulate): one workgroup per (bin, part) streams the bin and accumulates in LDS with integer
-//                           atomics exactly like the planned route, then adds its slice to the output.
-//   A bin region that overflows its capacity never corrupts anything: that run is delivered with global float
+//   pass B (k_bin_stream)    : 256 workgroups of 16 waves stream the active rows.  Every workgroup keeps one
+//                              write-combining block of CAP entries per output slice ("bin") in LDS; a wave reads 64
+//                              entries, every lane appends its entry to its bin's block (reserve a slot with a returning
+//                              LDS atomic, write, commit with a second one) and the lane whose commit completes a block
+//                              has its wave copy the block to the workgroup's OWN region of that bin in memory — one
+//                              contiguous store of 48 ... 768 bytes, no global atomics, no workgroup barrier anywhere
+//                              in the stream: loads, LDS traffic and stores of the 16 waves overlap all the time.
+//                              (Rounds 1-2 sorted whole batches of 16384 entries per workgroup: histogram, scan,
+//                              placement and copy-out phases behind barriers left HBM idle 41 % of the kernel.)
+//   pass C (k_bin_accumulate): one workgroup per (bin, part) streams the bin's 256 regions (entry counts from the
+//                              directory pass B leaves behind) and accumulates in LDS with integer atomics exactly
+//                              like the planned route, then writes its slice of the output.
+//   A region that overflows its capacity never corrupts anything: the block is delivered with global float
 //   atomics instead (slow path, still correct).
-//   Every bin has EIGHT regions, one per XCD (the workgroup reads its XCC id): the writers of a 128-byte line then all
-//   sit behind the same L2, which merges their partial writes into whole lines before they leave for HBM — with one
-//   region per bin the short runs of different XCDs met in the same lines and each L2 wrote its own masked copy.
+// Block layout in LDS and in memory: [f32 weight x CAP][u16 local column x CAP] (one weight: [u16 x CAP]).
 // HBM traffic per update (hetero): 8 B read (pass B) + 6 B write + 6 B read = 20 B  vs  8 B algorithmic.
 // =================================================================================================
 #ifndef BE_BIN_U
-#define BE_BIN_U 4       // groups of 8 binned entries in flight per thread of pass C (counted C4: 0.305 -> 0.282 ms; weighted: no change)
+#define BE_BIN_U 4       // groups of 8 binned entries in flight per thread of pass C
 #endif
-constexpr int kMaxBins = 2048;       // 3 x 4 B x 2048 = 24 KiB of LDS bookkeeping (16-wave kernel; the 8-wave one takes 1024)
-constexpr int kBinRegions = 8;       // regions per bin: one per XCD
-constexpr uint16_t kBinPad = 0xffffu; // column marker of a pad entry in a bin of counted entries (local columns are < 2^15)
-
-// phase stamps of k_bin_rows (diagnostic builds only: -DBE_BIN_PROF; BE_HIPCC_FLAGS of brainevent_amd._lib.build)
-#ifdef BE_BIN_PROF
-__device__ unsigned long long g_bin_prof[256 * 8];
-#define BIN_STAMP(i) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t__ - prof_t; prof_t = t__; } } while (0)
-#else
-#define BIN_STAMP(i) do { } while (0)
+#ifndef BE_STREAM_THREADS
+#define BE_STREAM_THREADS 1024
 #endif
+#ifndef BE_STREAM_U
+#define BE_STREAM_U 2    // steps (64 lanes x 4 entries) a wave of pass B keeps in flight next to the ones it is appending
+#endif
+constexpr int kMaxBins = 2048;
+constexpr int kStreamGrid = 256;     // workgroups of pass B = regions per bin (one per CU)
+constexpr int kStreamWaves = 16;
+constexpr uint32_t kSpinLimit = 1u << 14;   // a lane that cannot get a slot for this long adds its entry with a global atomic
 
-__device__ __forceinline__ uint32_t xcc_id() {
-  uint32_t x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  return x & 7u;
-}
+template <bool HOMO, int CAP> struct BinBlock {
+  static constexpr int bytes = CAP * (HOMO ? 2 : 6);
+  static constexpr int dwords = bytes / 4;
+  static constexpr int idx_dw = HOMO ? 0 : CAP;        // dword offset of the u16 columns inside a block
+  static constexpr int groups = CAP / 8;               // groups of 8 entries (pass C: one per thread and round)
+  // a block leaves LDS in units of `vec` dwords (12 B: four weights or eight columns; one weight: 8 B, four columns);
+  // lane gl of the block's `lpf` lanes copies units gl, gl + lpf, ... (nv of them): every store instruction of the
+  // group writes one contiguous piece, and 64 / lpf blocks leave per pass
+  static constexpr int vec = HOMO ? 2 : 3;
+  static constexpr int units = dwords / vec;
+  static constexpr int nv = 1;                         // (4 units per lane, 2 lanes per block: 406 -> 456 us at C4, scattered 24-byte pieces)
+  static constexpr int lpf = units / nv;               // lanes per block in a flush pass (a power of two)
+};
 
-// block-wide inclusive scan over NW waves (wave shuffles + one LDS hop)
-template <int NW>
-__device__ __forceinline__ uint32_t block_scan_nw(uint32_t v, uint32_t* wave_tot /* [NW] in LDS */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += t;
+// exact n / d for 32-bit n by multiply-high (Granlund-Montgomery, round-up method); d >= 1
+struct DivU32 {
+  uint32_t m, sh1, sh2;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
   }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  uint32_t base = 0;
-#pragma unroll
-  for (int w = 0; w < NW; ++w)
-    if (w < wave) base += wave_tot[w];
-  __syncthreads();
-  return base + incl;
+};
+static inline DivU32 make_div(uint32_t d) {
+  uint32_t l = 0;
+  while (l < 32 && (1ull << l) < d) ++l;
+  DivU32 r;
+  r.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  r.sh1 = l < 1 ? l : 1;
+  r.sh2 = l > 1 ? l - 1 : 0;
+  return r;
 }
-// entries per LDS batch of (uint16 column [, f32 weight]) payload
-template <bool HOMO> struct BinBatch { static constexpr int n = HOMO ? 32768 : 16384; };   // 64 / 96 KiB of payload
 
-// one launch instead of three memset nodes: output <- 0, bin cursors <- 0, bin valid extents <- "all of it"
-__global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int64_t k, uint32_t* __restrict__ cursor,
-                                                   uint32_t* __restrict__ valid, int n_bins, uint32_t* __restrict__ count) {
+// one launch instead of several memset nodes: output <- 0 and the spike counter of the compaction that follows <- 0
+__global__ void __launch_bounds__(256) k_bin_reset(float* __restrict__ out, int64_t k, uint32_t* __restrict__ count) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) count[0] = 0u;                       // the spike counter of the compaction that follows
-  float4* o4 = reinterpret_cast<float4*>(out);
-  const int64_t k4 = k >> 2;                       // out comes from the caller's allocator: 16-byte aligned
-  for (int64_t i = t; i < k4; i += stride) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t i = (k4 << 2) + t; i < k; i += stride) out[i] = 0.f;
-  for (int64_t i = t; i < (int64_t)n_bins * kBinRegions; i += stride) { cursor[i] = 0u; valid[i] = 0xffffffffu; }
+  if (t == 0) count[0] = 0u;
+  if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    float4* o4 = reinterpret_cast<float4*>(out);
+    const int64_t k4 = k >> 2;
+    for (int64_t i = t; i < k4; i += stride) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (k4 << 2) + t; i < k; i += stride) out[i] = 0.f;
+  } else {
+    for (int64_t i = t; i < k; i += stride) out[i] = 0.f;
+  }
 }
 
-// A batch is cut into chunks of 64 consecutive entries of one row piece (one per lane); wave w owns chunks
-// w * SLOTS .. w * SLOTS + SLOTS - 1 of the batch and keeps them in REGISTERS from the first read to the placement:
-// every load of the batch is in flight at once (16 / 48 independent 256-byte reads per wave — a row is a random
-// 0.5 .. 4 KB read, and the first version, four chunks in flight and a second pass over the rows for the placement,
-// spent most of a batch waiting for HBM round trips: 28 us per 16384 entries, 2.5 TB/s), and the rows are read once.
-template <bool HOMO> struct BinSlots { static constexpr int n = HOMO ? 32 : 16; };     // registers per lane: 32 / 16 + 16
+// phase stamps of k_bin_stream (diagnostic builds only: -DBE_BIN_PROF; BE_HIPCC_FLAGS of brainevent_amd._lib.build)
+#ifdef BE_BIN_PROF
+__device__ unsigned long long g_bin_prof[256 * 8];
+struct StreamProf {
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t = __builtin_amdgcn_s_memtime();
+  __device__ __forceinline__ void stamp(int i) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc[i] += n - t; t = n; }
+  __device__ __forceinline__ void count(int i, unsigned long long n = 1) { acc[i] += n; }
+  __device__ __forceinline__ void flush_out(int lane) {
+    if (lane == 0 && blockIdx.x < 256)
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_bin_prof[blockIdx.x * 8 + i], acc[i]);
+  }
+};
+#else
+struct StreamProf {
+  __device__ __forceinline__ void stamp(int) {}
+  __device__ __forceinline__ void count(int, unsigned long long = 1) {}
+  __device__ __forceinline__ void flush_out(int) {}
+};
+#endif
 
-// NW = waves per workgroup (16: one workgroup per CU; the bookkeeping arrays and the batch scale with it).
-template <typename W, bool HOMO, int NW>
-__global__ void __launch_bounds__(NW * 64, 4) k_bin_rows(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
-                                                       const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
-                                                       int slice_shift, int n_bins, uint32_t cap_x, uint32_t* __restrict__ bin_cursor,
-                                                       uint32_t* __restrict__ bin_valid, uint16_t* __restrict__ bin_idx,
-                                                       float* __restrict__ bin_w, float* __restrict__ out, uint32_t kChunks,
-                                                       uint32_t payload_entries) {
-  // kChunks = chunks per batch (<= NW * SLOTS, what the registers hold; fewer when many bins leave less LDS for the batch);
-  // payload_entries = kChunks * 64 + 3 * n_bins rounded up to 8: every run is padded to a multiple of 4 entries
-  constexpr int SLOTS = BinSlots<HOMO>::n;
-  const uint32_t kBatch = kChunks * 64u;               // entries per batch
-  constexpr int NT = NW * 64;                          // threads = rows a batch can hold (one thread per row)
-  constexpr int MAXB = NW == 16 ? kMaxBins : kMaxBins / 2;
-  // weighted entries keep the rank the histogram atomic returns (one LDS atomic per entry); counted entries hold twice the
-  // slots per lane and have no registers left for it: they draw the rank with a second atomic at placement time
-  constexpr bool RANKED = !HOMO;
-  __shared__ uint32_t hist[MAXB], offs[MAXB], gpos[MAXB];
-  __shared__ uint32_t fill[RANKED ? 1 : MAXB];
-  extern __shared__ __align__(16) unsigned char bin_payload[];        // [f32 weight x payload_entries][u16 column x payload_entries]
-  float* s_w = reinterpret_cast<float*>(bin_payload);
-  uint16_t* s_idx = reinterpret_cast<uint16_t*>(bin_payload + (HOMO ? 0 : (size_t)payload_entries * 4));
-  __shared__ uint32_t s_lens[NT];         // batch: piece length
-  __shared__ uint32_t s_cstart[NT];       //        first chunk of the piece
-  __shared__ int64_t s_begin[NT];         //        first entry of the piece
-  __shared__ uint32_t s_wtot[NW];
-  __shared__ uint32_t s_nrows, s_nchunks;
-  __shared__ uint64_t s_next;             // next list position of this workgroup
-  __shared__ int64_t s_carry_begin;       // unfinished tail of a long row
-  __shared__ uint32_t s_carry_len;
+__device__ __forceinline__ void lds_fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+// The per-workgroup state of pass B in LDS.  Every bin has a RING OF TWO write-combining blocks of CB entries.  An entry
+// draws a ticket t from its bin's counter: it belongs to block q = t / CB of the bin's stream (position q of the
+// workgroup's region of that bin), slot t % CB, ring slot q & 1 — and may be written once that ring slot's previous
+// occupant (block q - 2) has left: gen[ring slot] == q >> 1.  With one block per bin a full block stalled every later
+// entry of the bin until its flush had finished (one wave in two met such a lane per 64 entries and went round again).
+template <bool HOMO, int CB>
+struct StreamLds {
+  uint32_t* tick;   // [n_bins + 64]      tickets handed out (+ one dummy counter per lane for lanes without an entry)
+  uint32_t* done;   // [2 * n_bins + 64]  entries written into the ring slot's current block (+ dummies)
+  uint32_t* gen;    // [2 * n_bins]       blocks that have left the ring slot
+  uint32_t* ovf;    // [n_bins]           != 0: some entries of the bin went through global atomics
+  uint32_t* dummy;  // [128]              where lanes without a writable entry put their two stores
+  uint32_t* buf;    // [2 * n_bins][B::dwords]
+};
+// LDS words of pass B in front of the per-bin state: per wave a task table (64 row starts as int64, 66 prefix sums of
+// the rows' 4-entry groups, 64 row lengths), a flush list of 64 (ring slot, block number) items, the task ticket, the
+// dummies (128 words + 64 ticket counters + 64 commit counters)
+constexpr int kStreamWl = kStreamWaves * (64 * 2 + 66 + 64);
+constexpr int kStreamFixedWords = kStreamWl + kStreamWaves * 128 + 4 + 256 + 4;   // (+ 4: the blocks start 16-byte aligned)
+
+typedef uint32_t be_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t be_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t be_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float be_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// The wave copies the `n` completed blocks of its flush list (wl[j] = ring slot id, wl[64 + j] = block number) to their places in
+// the workgroup's regions, B::fpp blocks per pass (B::lpf lanes per block, B::vec dwords per lane), and frees the ring slots.
+template <bool HOMO, int CB>
+__device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, const uint32_t* wl, uint32_t n, uint32_t cap_blocks,
+                                                  uint32_t* __restrict__ wg_regions, size_t bin_stride_dw, float* __restrict__ out,
+                                                  int slice_shift, float w0, int lane) {
+  using B = BinBlock<HOMO, CB>;
+  constexpr int LPF = B::lpf, FPP = 64 / LPF, VEC = B::vec, NV = B::nv;
+  const uint32_t g = (uint32_t)lane / LPF, gl = (uint32_t)lane % LPF;
+  for (uint32_t j0 = 0; j0 < n; j0 += FPP) {
+    const bool have = j0 + g < n;
+    const uint32_t slotid = wl[have ? j0 + g : 0u], q = wl[64u + (have ? j0 + g : 0u)];
+    const uint32_t* src = S.buf + (size_t)slotid * B::dwords + gl * VEC;
+    uint32_t v[NV][VEC];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[k][i] = src[k * LPF * VEC + i];
+    uint64_t slow = __ballot(have && q >= cap_blocks);
+    while (slow) {                                  // (rare) the region is full: the block goes out through float atomics
+      const int sl = __ffsll((unsigned long long)slow) - 1;
+      slow &= slow - 1;
+      if ((sl % LPF) != 0) continue;
+      const uint32_t sid = rl(slotid, sl);
+      const uint32_t* blk = S.buf + (size_t)sid * B::dwords;
+      const uint16_t* bi = reinterpret_cast<const uint16_t*>(blk + B::idx_dw);
+      const float* bw = reinterpret_cast<const float*>(blk);
+      float* dst = out + ((int64_t)(sid >> 1) << slice_shift);
+      for (int j = lane; j < CB; j += 64) atomicAdd(dst + bi[j], HOMO ? w0 : bw[j]);
+      if (lane == 0) S.ovf[sid >> 1] = 1u;
+    }
+    // LDS executes a wave's instructions in order: the block has been read before these stores hand the ring slot to
+    // block q + 2 (done first: an entry written after gen moves on must find the count at 0)
+    lds_fence();
+    if (have && gl == 0) __hip_atomic_store(&S.done[slotid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_fence();
+    if (have && gl == 0) __hip_atomic_store(&S.gen[slotid], (q >> 1) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_fence();
+#ifdef BE_DBG_NOSTORE
+    if (have && q == 0xfffffffu) {
+#else
+    if (have && q < cap_blocks) {
+#endif
+      uint32_t* dst = wg_regions + (size_t)(slotid >> 1) * bin_stride_dw + (size_t)q * B::dwords + gl * VEC;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        if (VEC == 3) {
+          be_u32x3_a4 o; o.x = v[k][0]; o.y = v[k][1]; o.z = v[k][VEC > 2 ? 2 : 0];
+          *reinterpret_cast<be_u32x3_a4*>(dst + k * LPF * VEC) = o;
+        } else {
+          be_u32x2_a4 o; o.x = v[k][0]; o.y = v[k][1];
+          *reinterpret_cast<be_u32x2_a4*>(dst + k * LPF * VEC) = o;
+        }
+      }
+    }
+  }
+}
+
+// The NE entries of a lane (a lane's missing entries carry the column 0xffffffff): tickets, then — until every
+// entry is in its block — the stores of the entries whose ring slot is free, their commits, and the flushes of the blocks
+// those commits completed.  All NE entries go through every stage together (independent LDS operations in flight, no
+// branches: a lane without an entry, or with one that has to wait, aims at counters and words of its own that nobody reads).
+template <bool HOMO, int CB, int NE>
+__device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, const uint32_t (&col)[NE],
+                                               const float (&w)[HOMO ? 1 : NE], int slice_shift, uint32_t mask, int n_bins,
+                                               uint32_t cap_blocks, uint32_t* wl, uint32_t* __restrict__ wg_regions,
+                                               size_t bin_stride_dw, float* __restrict__ out, float w0, int lane, uint32_t& n_deferred,
+                                               StreamProf& prof) {
+  using B = BinBlock<HOMO, CB>;
+  constexpr int LOG_CB = CB == 128 ? 7 : CB == 64 ? 6 : CB == 32 ? 5 : CB == 16 ? 4 : 3;
+  // a column >= k (the caller's error) and a missing entry both land on the lane's own dummy counter n_bins + lane
+  const uint32_t dummy_bin = (uint32_t)n_bins + (uint32_t)lane;
+  uint32_t bin[NE], t[NE];
+  uint32_t pend = 0;
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const uint32_t b = col[u] >> slice_shift;
+    bin[u] = b < dummy_bin ? b : dummy_bin;
+    pend |= (b < (uint32_t)n_bins ? 1u : 0u) << u;
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) t[u] = atomicAdd(&S.tick[bin[u]], 1u);
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t spins = 0;
+  for (;;) {
+    uint32_t g[NE], slotid[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      slotid[u] = bin[u] * 2u + ((t[u] >> LOG_CB) & 1u);
+      g[u] = __hip_atomic_load(&S.gen[slotid[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t wr = 0;
+    uint32_t d[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const bool ok = ((pend >> u) & 1u) && g[u] == (t[u] >> (LOG_CB + 1));
+      wr |= (ok ? 1u : 0u) << u;
+      uint32_t* blk = S.buf + (size_t)slotid[u] * B::dwords;
+      const uint32_t s = t[u] & (uint32_t)(CB - 1);
+      uint16_t* pi = ok ? reinterpret_cast<uint16_t*>(blk + B::idx_dw) + s : reinterpret_cast<uint16_t*>(S.dummy + 64 + lane);
+      *pi = (uint16_t)(col[u] & mask);
+      if (!HOMO) {
+        float* pw = ok ? reinterpret_cast<float*>(blk) + s : reinterpret_cast<float*>(S.dummy + lane);
+        *pw = w[HOMO ? 0 : u];
+      }
+    }
+    lds_fence();
+#pragma unroll
+    for (int u = 0; u < NE; ++u) d[u] = atomicAdd(&S.done[(wr >> u) & 1u ? slotid[u] : 2u * (uint32_t)n_bins + (uint32_t)lane], 1u);
+    __builtin_amdgcn_sched_barrier(0);
+    // the blocks these commits completed go on the wave's list (positions from the ballots)
+    uint32_t flm = 0;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) flm |= (((wr >> u) & 1u) && d[u] == (uint32_t)CB - 1u ? 1u : 0u) << u;
+    pend &= ~wr;
+    prof.count(4);
+    // (every completing lane copying its own block, 16 bytes per instruction and no list, measured slower: 406 -> 554 us at
+    //  C4 — a store instruction whose few active lanes write 16 bytes each to unrelated lines costs far more than its issue slot)
+    // the list is NOT flushed here: the caller flushes it at the top of the wave's next round, in front of that round's
+    // loads — the stores then have a whole round of appends to complete in, where stores issued at the end of the round
+    // met the full wait for the next round's loads at once (the counter of outstanding memory operations is one, in order)
+    while (__ballot(flm != 0)) {                     // (one pass, unless the list overflows)
+      if (n_deferred >= 64u) {
+        lds_fence();
+        stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
+        n_deferred = 0;
+      }
+      uint32_t nfl = n_deferred;
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const bool fl = (flm >> u) & 1u;
+        const uint64_t m = __ballot(fl);
+        if (m) {                                     // (wave-uniform)
+          const uint32_t at = nfl + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (fl && at < 64u) {
+            wl[at] = slotid[u];
+            wl[64 + at] = t[u] >> LOG_CB;
+            flm &= ~(1u << u);
+          }
+          nfl += (uint32_t)__popcll((unsigned long long)m);
+        }
+      }
+      prof.count(5, (nfl < 64u ? nfl : 64u) - n_deferred);
+      n_deferred = nfl < 64u ? nfl : 64u;
+    }
+    if (__ballot(pend != 0) == 0) break;
+    // an entry waits for its ring slot: the block in its way may be on this wave's own list
+    if (n_deferred) {
+      lds_fence();
+      stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
+      n_deferred = 0;
+    }
+    if (++spins > kSpinLimit) __builtin_trap();      // never seen: a protocol error ends in a launch failure, not in a hung device
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// pass B.  Tasks of 2^rshift consecutive active rows are handed to the waves by an LDS ticket inside the workgroup's
+// contiguous share of the task list; a wave flattens its task's rows into groups of four consecutive entries (prefix
+// sums of the rows' group counts in a per-wave LDS table), a lane takes one group per step — one 16-byte load of columns
+// and one of weights — and BE_STREAM_U steps are loading while the previous ones are appended.
+template <typename W, bool HOMO, int CB>
+__global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
+                                                     const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
+                                                     int slice_shift, int n_bins, uint32_t cap_blocks,
+                                                     uint32_t* __restrict__ regions, uint32_t* __restrict__ dir,
+                                                     float* __restrict__ out, DivU32 fixdiv) {
+  using B = BinBlock<HOMO, CB>;
+  constexpr int U = BE_STREAM_U;
+  extern __shared__ __align__(16) uint32_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t* tbeg = reinterpret_cast<int64_t*>(lds) + wave * 64;                  // this wave's task table
+  uint32_t* tpre = lds + kStreamWaves * 64 * 2 + wave * 66;
+  uint32_t* tlen = lds + kStreamWaves * (64 * 2 + 66) + wave * 64;
+  uint32_t* wl = lds + kStreamWl + wave * 128;
+  uint32_t* s_ticket = lds + kStreamWl + kStreamWaves * 128;
+  StreamLds<HOMO, CB> S;
+  S.dummy = s_ticket + 4;                        // [128], then the lanes' dummy counters live behind tick / done
+  S.tick = S.dummy + 128;
+  S.done = S.tick + n_bins + 64;
+  S.gen = S.done + 2 * n_bins + 64;
+  S.ovf = S.gen + 2 * n_bins;
+  S.buf = S.ovf + ((n_bins + 3) & ~3);           // 16-byte aligned: blocks are read 16 bytes at a time
+  for (int i = tid; i < 6 * n_bins + 128; i += (int)blockDim.x) S.tick[i] = 0u;
+  if (tid == 0) s_ticket[0] = 0u;
+  __syncthreads();
 
   const uint32_t n_active = *n_active_p;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t mask = (1u << slice_shift) - 1u;
-  const uint32_t xcc = xcc_id();          // this workgroup's XCD: it writes the regions (bin, xcc)
   float w0 = 0.f;
   if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
-  if (tid == 0) { s_next = blockIdx.x; s_carry_len = 0; }
-  __syncthreads();
-#ifdef BE_BIN_PROF
-  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
-#endif
-  // fixed-length rows that fit a batch (at most NT per batch: one thread per row)
-  const bool fixed_rows = rp.p == nullptr && rp.fixed > 0 && rp.fixed <= (int64_t)kBatch;
-  const uint32_t fixed_nch = fixed_rows ? (uint32_t)((rp.fixed + 63) >> 6) : 1u;
-  const uint32_t fixed_per_batch = fixed_rows ? (kChunks / fixed_nch < (uint32_t)NT ? kChunks / fixed_nch : (uint32_t)NT) : 0u;
+  const bool fixed = rp.p == nullptr && rp.fixed > 0 && rp.fixed < (1ll << 26);
+  const uint32_t K = fixed ? (uint32_t)rp.fixed : 0u, K4 = (K + 3u) >> 2;
+  // rows per task: as many as keep every wave of the chip supplied (>= 2 tasks per wave), at most 64
+  int rshift = 6;
+  while (rshift > 0 && (n_active >> rshift) < 8192u) --rshift;
+  while (fixed && rshift > 0 && (rp.fixed << rshift) >= (1ll << 31)) --rshift;
+  const uint32_t R = 1u << rshift;
+  const uint64_t n_tasks = ((uint64_t)n_active + R - 1) >> rshift;
+  const uint64_t per = (n_tasks + gridDim.x - 1) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per;
+  const uint64_t t_end = t_begin + per < n_tasks ? t_begin + per : n_tasks;
+  const size_t bin_stride_dw = (size_t)kStreamGrid * cap_blocks * B::dwords;
+  uint32_t* wg_regions = regions + (size_t)blockIdx.x * cap_blocks * B::dwords;
 
+  StreamProf prof;
+  uint32_t n_deferred = 0;                       // completed blocks on this wave's list, not yet copied out
   for (;;) {
-    // ---- form a batch: thread t looks at this workgroup's t-th next row (loads in parallel), a block scan of
-    //      the rows' chunk counts picks the longest prefix that fits one batch; a row longer than a batch is
-    //      processed alone, one batch-sized piece at a time (carry)
-    for (int b = tid; b < n_bins; b += NT) {
-      hist[b] = 0;
-      if (!RANKED) fill[b] = 0;
+    prof.stamp(7);
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(s_ticket, 1u);
+    tk = rfl(tk);
+    const uint64_t task = t_begin + tk;
+    if (task >= t_end) break;
+    const uint64_t a0 = task << rshift;
+    int64_t rb = 0;
+    uint64_t len = 0;
+    if ((uint32_t)lane < R && a0 + lane < n_active) {
+      const uint32_t r = active[a0 + lane];
+      rb = rp.at(r);
+      len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
     }
-    if (fixed_rows) {                // rows of one length (FixedNumPerPre): the batch is arithmetic — no scan, no search
-      const uint64_t nx = s_next;
-      const uint64_t left = nx < n_active ? (n_active - nx + gridDim.x - 1) / gridDim.x : 0;
-      const uint32_t nr = left < fixed_per_batch ? (uint32_t)left : fixed_per_batch;
-      if ((uint32_t)tid < nr) s_begin[tid] = (int64_t)active[nx + (uint64_t)tid * gridDim.x] * rp.fixed;
-      __syncthreads();
-      if (tid == 0) { s_next = nx + (uint64_t)nr * gridDim.x; s_nrows = nr; s_nchunks = nr * fixed_nch; }
-    } else if (s_carry_len) {        // uniform: shared state
-      __syncthreads();
-      if (tid == 0) {
-        const uint32_t take = s_carry_len < kBatch ? s_carry_len : kBatch;
-        s_begin[0] = s_carry_begin; s_lens[0] = take; s_cstart[0] = 0;
-        s_carry_begin += take; s_carry_len -= take;
-        s_nrows = 1; s_nchunks = (take + 63u) >> 6;
+    const bool huge = __ballot(len >= (1ull << 26)) != 0;     // a row the 32-bit flattening cannot hold: one row at a time
+    const uint32_t n_pieces = huge ? R : 1u;
+    for (uint32_t piece = 0; piece < n_pieces; ++piece) {
+      uint64_t sub_len = 0;            // huge rows: walked in pieces of 2^26 entries
+      int64_t sub_beg = 0;
+      if (huge) {
+        const uint32_t lo = rl((uint32_t)(len & 0xffffffffull), (int)piece), hi = rl((uint32_t)(len >> 32), (int)piece);
+        sub_len = ((uint64_t)hi << 32) | lo;
+        const uint32_t blo = rl((uint32_t)((uint64_t)rb & 0xffffffffull), (int)piece), bhi = rl((uint32_t)((uint64_t)rb >> 32), (int)piece);
+        sub_beg = (int64_t)(((uint64_t)bhi << 32) | blo);
       }
-      __syncthreads();
-    } else {
-      const uint64_t a = s_next + (uint64_t)tid * gridDim.x;
-      int64_t rb = 0; uint64_t len = 0;
-      if (a < n_active) {
-        const uint32_t r = active[a];
-        rb = rp.at(r);
-        len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
-      }
-      // chunk counts saturate at kChunks + 1 per row; NT of them cannot overflow 32 bits
-      const uint32_t nch = len > (uint64_t)kBatch ? kChunks + 1u : (uint32_t)((len + 63u) >> 6);
-      const uint32_t incl = block_scan_nw<NW>(nch, s_wtot);
-      const bool in_list = a < n_active;
-      const bool fits = in_list && incl <= kChunks;
-      const int nfit = __syncthreads_count(fits);          // rows 0 .. nfit-1 (a prefix: the scan is monotone)
-      if (fits) { s_begin[tid] = rb; s_lens[tid] = (uint32_t)len; s_cstart[tid] = incl - nch; }
-      if (fits && tid == nfit - 1) s_nchunks = incl;
-      if (tid == 0) {
-        if (nfit > 0) {
-          s_nrows = nfit;
-          s_next += (uint64_t)nfit * gridDim.x;
-        } else if (in_list) {                               // the first row alone exceeds a batch: start carrying it
-          s_begin[0] = rb; s_lens[0] = kBatch; s_cstart[0] = 0;
-          s_carry_begin = rb + kBatch;
-          s_carry_len = (len - kBatch) > 0xffffffffull ? 0xffffffffu : (uint32_t)(len - kBatch);
-          s_nrows = 1; s_nchunks = kChunks;
-          s_next += gridDim.x;
-        } else {
-          s_nrows = 0; s_nchunks = 0;
-        }
-      }
-      __syncthreads();
-    }
-    if (fixed_rows) __syncthreads();                         // publish s_nrows / s_nchunks of the arithmetic path
-    const uint32_t nrows = s_nrows;
-    if (nrows == 0) break;
-    BIN_STAMP(0);      // batch formed
-
-    // ---- this wave's chunks: lane s < SLOTS finds the piece of chunk wave * SLOTS + s (last piece whose first chunk
-    //      is <= the chunk id: empty pieces share their start with the piece that follows them)
-    int64_t my_e0 = 0;
-    uint32_t my_n = 0;
-    {
-      const uint32_t cid = (uint32_t)wave * SLOTS + (uint32_t)lane;
-      if (fixed_rows) {
-        if (lane < SLOTS && cid < s_nchunks) {
-          const uint32_t pc = cid / fixed_nch;
-          const uint32_t j0 = (cid - pc * fixed_nch) << 6;
-          my_e0 = s_begin[pc] + j0;
-          const uint32_t left = (uint32_t)rp.fixed - j0;
-          my_n = left < 64u ? left : 64u;
-        }
-      } else if (lane < SLOTS && cid < s_nchunks) {
-        uint32_t lo = 0, hi = nrows;                        // first piece with cstart > cid
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_cstart[mid] > cid) hi = mid; else lo = mid + 1;
-        }
-        const uint32_t pc = lo - 1u;
-        const uint32_t j0 = (cid - s_cstart[pc]) << 6;
-        my_e0 = s_begin[pc] + j0;
-        const uint32_t left = s_lens[pc] - j0;
-        my_n = left < 64u ? left : 64u;
-      }
-    }
-    // ---- every load of the batch at once (clamped index + predicate instead of conditional loads)
-    uint32_t col[SLOTS];
-    float wv[HOMO ? 1 : SLOTS];
-    uint32_t cnt_mask_lo = 0, cnt_mask_hi = 0;              // bit s: this lane holds an entry in slot s
+      for (uint64_t sub = 0; sub == 0 || sub < sub_len; sub += (1ull << 26)) {
+        uint32_t T4;                                          // groups of four entries in this (piece of the) task
+        if (!huge) {
+          const uint32_t g4 = ((uint32_t)len + 3u) >> 2;
+          uint32_t incl = g4;
 #pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)my_n, sl);
-      const uint32_t e_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_e0 & 0xffffffffll), sl);
-      const uint32_t e_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_e0 >> 32), sl);
-      const int64_t e0 = (int64_t)(((uint64_t)e_hi << 32) | e_lo);
-      const uint32_t l = n_s ? ((uint32_t)lane < n_s ? (uint32_t)lane : n_s - 1u) : 0u;
-      const int64_t e = n_s ? e0 + l : 0;
-      col[sl] = (uint32_t)indices[e];
-      if (!HOMO) wv[sl] = (float)WTraits<W>::load(weights, e);
-      if ((uint32_t)lane < n_s) { if (sl < 32) cnt_mask_lo |= 1u << (sl & 31); else cnt_mask_hi |= 1u << (sl & 31); }
-    }
-    BIN_STAMP(1);      // loads issued
-    // ---- phase 1: histogram of the batch over the bins; the value the atomic returns is the entry's rank inside its bin
-    //      (weighted entries: one LDS atomic per entry instead of one in a histogram pass and one in the placement pass)
-    uint32_t rank[RANKED ? SLOTS : 1];
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      if (RANKED) rank[sl] = 0u;
-      if ((sl < 32 ? cnt_mask_lo : cnt_mask_hi) >> (sl & 31) & 1u) {
-        if (RANKED) rank[sl] = atomicAdd(&hist[col[sl] >> slice_shift], 1u);
-        else atomicAdd(&hist[col[sl] >> slice_shift], 1u);
-      }
-    }
-    __syncthreads();
-    BIN_STAMP(2);      // loads landed + histogram
-    // ---- phase 2: exclusive scan of hist (two bins per thread) + one range reservation per (bin, XCD)
-    uint32_t g0 = 0u, g1 = 0u;
-    {
-      // runs are padded to multiples of 4 entries in LDS and in the bin (8-byte / 16-byte aligned pieces: the copy-out
-      // moves 4 entries per lane and instruction instead of one).  A pad is (some column of the slice, weight 0) with
-      // weights — it adds zero to an accumulator; the columns are spread because equal addresses serialise an LDS atomic —
-      // and the marker kBinPad without (counted entries: the accumulate pass skips it).
-      const uint32_t v0 = (2 * tid < n_bins) ? hist[2 * tid] : 0u, v1 = (2 * tid + 1 < n_bins) ? hist[2 * tid + 1] : 0u;
-      const uint32_t p0 = (v0 + 3u) & ~3u, p1 = (v1 + 3u) & ~3u;
-      const uint32_t excl = block_scan_nw<NW>(p0 + p1, s_wtot) - (p0 + p1);
-      // the range reservations are returning global atomics (a memory-side round trip of 1-3 us under load): they are
-      // issued here and their values are stored to LDS only after the placement phase, behind a barrier that waits for
-      // LDS traffic alone (__syncthreads() would drain them first)
-      if (2 * tid < n_bins) {
-        offs[2 * tid] = excl;
-        g0 = v0 ? atomicAdd(&bin_cursor[(2 * tid) * kBinRegions + xcc], p0) : 0u;
-        for (uint32_t q = excl + v0; q < excl + p0; ++q) { s_idx[q] = HOMO ? kBinPad : (uint16_t)((q * 40503u) & mask); if (!HOMO) s_w[q] = 0.f; }
-      }
-      if (2 * tid + 1 < n_bins) {
-        offs[2 * tid + 1] = excl + p0;
-        g1 = v1 ? atomicAdd(&bin_cursor[(2 * tid + 1) * kBinRegions + xcc], p1) : 0u;
-        for (uint32_t q = excl + p0 + v1; q < excl + p0 + p1; ++q) { s_idx[q] = HOMO ? kBinPad : (uint16_t)((q * 40503u) & mask); if (!HOMO) s_w[q] = 0.f; }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    BIN_STAMP(3);      // scan + reservations issued
-    // ---- phase 3: place the entries into the LDS batch sorted by bin, straight from the registers
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      if ((sl < 32 ? cnt_mask_lo : cnt_mask_hi) >> (sl & 31) & 1u) {
-        const uint32_t bin = col[sl] >> slice_shift;
-        const uint32_t pos = offs[bin] + (RANKED ? rank[sl] : atomicAdd(&fill[bin], 1u));
-        s_idx[pos] = (uint16_t)(col[sl] & mask);
-        if (!HOMO) s_w[pos] = wv[sl];
-      }
-    }
-    if (2 * tid < n_bins) gpos[2 * tid] = g0;
-    if (2 * tid + 1 < n_bins) gpos[2 * tid + 1] = g1;
-    __syncthreads();
-    BIN_STAMP(4);      // placement
-    // ---- phase 4: copy the padded runs out, 4 entries per lane (one 8-byte column piece + one 16-byte weight piece) and
-    //      8 ... 64 lanes per bin; runs that do not fit their region go through global atomics
-    {
-      const uint32_t run = kBatch / (uint32_t)n_bins;             // expected run length
-      const int lpb_shift = run > 128u ? 6 : (run > 64u ? 5 : (run > 32u ? 4 : 3));
-      const int LPB = 1 << lpb_shift, BPW = 64 >> lpb_shift;      // lanes per bin, bins per wave and iteration
-      const int grp = lane >> lpb_shift, gl = lane & (LPB - 1);
-      for (int bin0 = wave * BPW; bin0 < n_bins; bin0 += NW * BPW) {
-        const int bin = bin0 + grp;
-        uint32_t cnt = 0, o = 0, g = 0;
-        if (bin < n_bins) { cnt = hist[bin]; o = offs[bin]; g = gpos[bin]; }
-        const uint32_t cntp = (cnt + 3u) & ~3u;
-        const bool fits = (uint64_t)g + cntp <= cap_x;
-        // a full region: everything from position g on is NOT in it (later reservations start even higher)
-        if (cnt && !fits && gl == 0) atomicMin(&bin_valid[bin * kBinRegions + xcc], g);
-        const int64_t base = ((int64_t)bin * kBinRegions + xcc) * cap_x + g;
-        if (fits) {
-          uint2* di = reinterpret_cast<uint2*>(bin_idx + base);            // g is a multiple of 4, regions are 128-B aligned
-          float4* dw = reinterpret_cast<float4*>(bin_w + base);
-          const uint2* si = reinterpret_cast<const uint2*>(s_idx + o);     // o is a multiple of 4
-          const float4* sw = reinterpret_cast<const float4*>(s_w + o);
-          for (uint32_t j = gl; j < (cntp >> 2); j += LPB) {
-            di[j] = si[j];
-            if (!HOMO) dw[j] = sw[j];
+          for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
           }
+          T4 = rl(incl, 63);
+          tpre[lane] = incl - g4;
+          tlen[lane] = (uint32_t)len;
+          tbeg[lane] = rb;
         } else {
-          float* dst = out + ((int64_t)bin << slice_shift);
-          for (uint32_t j = gl; j < cnt; j += LPB) atomicAdd(dst + s_idx[o + j], HOMO ? w0 : s_w[o + j]);
+          const uint64_t left = sub_len - sub;
+          const uint32_t l32 = left < (1ull << 26) ? (uint32_t)left : (1u << 26);
+          T4 = (l32 + 3u) >> 2;
+          tpre[lane] = lane == 0 ? 0u : T4;
+          tlen[lane] = l32;
+          tbeg[lane] = sub_beg + (int64_t)sub;
         }
+        if (lane == 0) { tpre[64] = T4; tpre[65] = T4; }
+        lds_fence();
+        const uint32_t n_steps = (T4 + 63u) >> 6;
+        if (n_steps == 0) continue;
+        const bool use_div = fixed && !huge;
+        prof.stamp(0);
+        // ---- the stream: U steps loading while the previous U are appended
+        uint32_t colN[U][4];
+        float wN[U][HOMO ? 1 : 4];
+        uint32_t validN[U];
+#define BE_STREAM_ISSUE(C0)                                                                                          \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
+      const uint32_t e = ((C0) + (uint32_t)u) * 64u + (uint32_t)lane;                                                \
+      const bool ok = e < T4;                                                                                        \
+      const uint32_t ee = ok ? e : 0u;                                                                               \
+      uint32_t i = 0, off, rlen;                                                                                     \
+      if (use_div) {                                                                                                 \
+        i = fixdiv.div(ee);                                                                                          \
+        off = (ee - i * K4) << 2;                                                                                    \
+        rlen = K;                                                                                                    \
+      } else {                                                                                                       \
+        for (uint32_t s = R >> 1; s > 0; s >>= 1)                                                                    \
+          if (tpre[i + s] <= ee) i += s;                                                                             \
+        off = (ee - tpre[i]) << 2;                                                                                   \
+        rlen = tlen[i];                                                                                              \
+      }                                                                                                              \
+      const uint32_t rem = rlen - off;                          /* >= 1 */                                           \
+      const bool shrt = rlen < 4u;                                                                                   \
+      const uint32_t sh = rem >= 4u || shrt ? 0u : 4u - rem;    /* the row's last group: the window moves back */    \
+      const int64_t at = tbeg[i] + (int64_t)off - (int64_t)sh;                                                       \
+      uint32_t vm = rem >= 4u ? 0xfu : (shrt ? (1u << rem) - 1u : (0xfu << sh) & 0xfu);                              \
+      vm = ok ? vm : 0u;                                                                                             \
+      if (__ballot(shrt) == 0) {                                                                                     \
+        const be_u32x4_a4 c4 = *reinterpret_cast<const be_u32x4_a4*>(indices + at);                                  \
+        colN[u][0] = c4.x; colN[u][1] = c4.y; colN[u][2] = c4.z; colN[u][3] = c4.w;                                  \
+        if (!HOMO) {                                                                                                 \
+          if (sizeof(W) == 4) {                                                                                      \
+            const be_f32x4_a4 w4 = *reinterpret_cast<const be_f32x4_a4*>(reinterpret_cast<const float*>(weights) + at); \
+            wN[u][0] = w4.x; wN[u][HOMO ? 0 : 1] = w4.y; wN[u][HOMO ? 0 : 2] = w4.z; wN[u][HOMO ? 0 : 3] = w4.w;      \
+          } else {                                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) wN[u][HOMO ? 0 : j] = (float)WTraits<W>::load(weights, at + j); \
+          }                                                                                                          \
+        }                                                                                                            \
+      } else {                                       /* (rare) rows of fewer than four entries: entry by entry */     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+          const bool pj = (vm >> j) & 1u;                                                                            \
+          colN[u][j] = pj ? (uint32_t)indices[at + j] : 0u;                                                          \
+          if (!HOMO) wN[u][HOMO ? 0 : j] = pj ? (float)WTraits<W>::load(weights, at + j) : 0.f;                      \
+        }                                                                                                            \
+      }                                                                                                              \
+      validN[u] = vm;                                                                                                \
+    }                                                                                                                \
+  } while (0)
+        BE_STREAM_ISSUE(0u);
+        prof.stamp(1);
+        for (uint32_t c0 = 0; c0 < n_steps; c0 += U) {
+          // the loads of this round have been in flight for a whole round of appends; pin them here so that the wait sits
+          // in front of the next round's loads (only one round is ever outstanding: the full wait is the exact one)
+          uint32_t colC[U][4];
+          float wC[U][HOMO ? 1 : 4];
+          uint32_t validC[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              colC[u][j] = colN[u][j];
+              asm volatile("" : "+v"(colC[u][j]));
+              if (!HOMO) { wC[u][HOMO ? 0 : j] = wN[u][HOMO ? 0 : j]; asm volatile("" : "+v"(wC[u][HOMO ? 0 : j])); }
+            }
+            validC[u] = c0 + (uint32_t)u < n_steps ? validN[u] : 0u;
+          }
+          prof.stamp(2);
+          if (n_deferred) {                          // the blocks the previous round completed (see stream_append)
+            lds_fence();
+            stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
+            n_deferred = 0;
+          }
+          if (c0 + U < n_steps) BE_STREAM_ISSUE(c0 + U);
+          prof.stamp(1);
+          {
+            uint32_t colA[U * 4];
+            float wA[HOMO ? 1 : U * 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (__ballot(validC[u] != 0xfu)) {         // (wave-uniform) lanes without all four entries: sentinel columns
+#pragma unroll
+                for (int j = 0; j < 4; ++j) colC[u][j] |= ~(uint32_t)__builtin_amdgcn_sbfe((int)validC[u], j, 1);
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                colA[u * 4 + j] = colC[u][j];
+                if (!HOMO) wA[HOMO ? 0 : u * 4 + j] = wC[u][HOMO ? 0 : j];
+              }
+            }
+#ifdef BE_DBG_NOAPPEND
+            if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
+#endif
+            stream_append<HOMO, CB, U * 4>(S, colA, wA, slice_shift, mask, n_bins, cap_blocks, wl, wg_regions, bin_stride_dw, out, w0,
+                                           lane, n_deferred, prof);
+          }
+          prof.stamp(3);
+          prof.count(6, U);
+        }
+#undef BE_STREAM_ISSUE
+        lds_fence();
       }
     }
-    __syncthreads();
-    BIN_STAMP(5);      // copy-out
   }
-#ifdef BE_BIN_PROF
-  if (tid == 0 && blockIdx.x < 256)
-    for (int i = 0; i < 8; ++i) g_bin_prof[blockIdx.x * 8 + i] += prof_acc[i];
-#endif
+  if (n_deferred) {
+    lds_fence();
+    stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
+  }
+  prof.stamp(7);
+  prof.flush_out(lane);
+  __syncthreads();
+  // ---- drain: tickets are handed out in order, so of a bin's two ring slots only the one of block T / CB (T = the tickets
+  //      drawn) can hold entries now, T % CB of them from slot 0 on; it goes out as it is, and the directory gets T
+  for (int q = tid; q < n_bins * B::dwords; q += (int)blockDim.x) {
+    const int bin = q / B::dwords, l = q - bin * B::dwords;
+    const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
+    if (d > 0 && blk < cap_blocks)
+      regions[(((size_t)bin * kStreamGrid + blockIdx.x) * cap_blocks + blk) * B::dwords + l] = S.buf[(size_t)(bin * 2 + (blk & 1u)) * B::dwords + l];
+  }
+  for (int bin = tid; bin < n_bins; bin += (int)blockDim.x) {
+    const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
+    uint32_t o = S.ovf[bin];
+    if (d > 0 && blk >= cap_blocks) {          // a partly filled block of a full region: float atomics
+      const uint32_t* bp = S.buf + (size_t)(bin * 2 + (blk & 1u)) * B::dwords;
+      const uint16_t* bi = reinterpret_cast<const uint16_t*>(bp + B::idx_dw);
+      const float* bw = reinterpret_cast<const float*>(bp);
+      float* dst = out + ((int64_t)bin << slice_shift);
+      for (uint32_t j = 0; j < d; ++j) atomicAdd(dst + bi[j], HOMO ? w0 : bw[j]);
+      o = 1u;
+    }
+    const uint64_t room = (uint64_t)cap_blocks * CB;
+    dir[(size_t)bin * kStreamGrid + blockIdx.x] = (uint32_t)(T < room ? T : room) | (o ? 0x80000000u : 0u);
+  }
 }
 
-// eight counted entries (uint16 columns, two per dword); pads carry kBinPad and are skipped
-__device__ __forceinline__ void bin_count8(uint32_t* acc, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-  const uint32_t v[4] = {a, b, c, d};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t lo = v[i] & 0xffffu, hi = v[i] >> 16;
-    if (lo != kBinPad) atomicAdd(&acc[lo], 1u);
-    if (hi != kBinPad) atomicAdd(&acc[hi], 1u);
-  }
+// eight counted entries (uint16 columns, two per dword)
+__device__ __forceinline__ void bin_count8(uint32_t* acc, uint4 v) {
+  atomicAdd(&acc[v.x & 0xffffu], 1u); atomicAdd(&acc[v.x >> 16], 1u);
+  atomicAdd(&acc[v.y & 0xffffu], 1u); atomicAdd(&acc[v.y >> 16], 1u);
+  atomicAdd(&acc[v.z & 0xffffu], 1u); atomicAdd(&acc[v.z >> 16], 1u);
+  atomicAdd(&acc[v.w & 0xffffu], 1u); atomicAdd(&acc[v.w >> 16], 1u);
 }
 
-template <bool HOMO>
-__global__ void __launch_bounds__(1024) k_bin_accumulate(const uint16_t* __restrict__ bin_idx, const float* __restrict__ bin_w,
-                                                         const uint32_t* __restrict__ bin_cursor,
-                                                         const uint32_t* __restrict__ bin_valid, uint32_t cap, int slice_shift,
-                                                         int parts, int64_t k, float scale, double inv_scale,
-                                                         const void* __restrict__ w0p, int wdtype, float* __restrict__ out) {
+template <bool HOMO, int CAP>
+__global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restrict__ regions, const uint32_t* __restrict__ dir,
+                                                         uint32_t cap_blocks, int slice_shift, int parts, int64_t k, float scale,
+                                                         double inv_scale, const void* __restrict__ w0p, int wdtype,
+                                                         float* __restrict__ out) {
+  using B = BinBlock<HOMO, CAP>;
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
+  __shared__ uint32_t s_cnt[kStreamGrid], s_pre[kStreamGrid + 1], s_wtot[16];
   const int S = 1 << slice_shift;
   const int bin = blockIdx.x / parts, part = blockIdx.x - bin * parts;
-  // entries of each of the bin's regions (one per XCD); valid = first position that was NOT written (cap if it never overflowed)
-  uint32_t cnts[kBinRegions];
-  uint32_t any = 0;
-  bool overflowed = false;                  // some run of this bin went through global atomics instead
-#pragma unroll
-  for (int x = 0; x < kBinRegions; ++x) {
-    uint32_t c = bin_cursor[bin * kBinRegions + x];
-    const uint32_t valid = bin_valid[bin * kBinRegions + x];
-    overflowed |= valid != 0xffffffffu;
-    c = c < valid ? c : valid;
-    cnts[x] = c < cap ? c : cap;
-    any |= cnts[x];
-  }
+  const int tid = threadIdx.x;
+  // the bin's directory: entries per region -> blocks per region -> prefix sums
+  uint32_t raw = 0;
+  if (tid < kStreamGrid) raw = dir[(size_t)bin * kStreamGrid + tid];
+  const uint32_t cnt_r = raw & 0x7fffffffu;
+  const uint32_t nb_r = (cnt_r + (uint32_t)CAP - 1u) / (uint32_t)CAP;
+  const uint32_t incl = block_scan_1024(nb_r, s_wtot);
+  if (tid < kStreamGrid) { s_cnt[tid] = cnt_r; s_pre[tid + 1] = incl; }
+  if (tid == 0) s_pre[0] = 0u;
+  const bool overflowed = __syncthreads_or((int)(raw >> 31)) != 0;     // some entries of this bin are already in `out`
+  const uint32_t NB = s_pre[kStreamGrid];
   float w0 = 0.f;
   if (HOMO) {
     if (wdtype == BE_F16) w0 = __half2float(static_cast<const __half*>(w0p)[0]);
     else if (wdtype == BE_BF16) w0 = __bfloat162float(static_cast<const __hip_bfloat16*>(w0p)[0]);
     else w0 = static_cast<const float*>(w0p)[0];
   }
-  if (any == 0) return;                     // nothing was binned here (out already holds zeros / overflow adds)
-  for (int i = threadIdx.x; i < S; i += blockDim.x) acc[i] = 0;
+  if (NB == 0) return;                      // nothing was binned here (out already holds zeros / overflow adds)
+  for (int i = tid; i < S; i += 1024) acc[i] = 0;
   __syncthreads();
-  // one flat loop over the groups of 8 entries of all eight regions (all loads independent: a loop per region started
-  // every region with a dependent round trip and left most of the workgroup idle on its tail)
-  uint32_t gstart[kBinRegions + 1];
-  gstart[0] = 0;
-#pragma unroll
-  for (int x = 0; x < kBinRegions; ++x) gstart[x + 1] = gstart[x] + ((cnts[x] + 7u) >> 3);
-  const uint32_t n8 = gstart[kBinRegions];
+  // one flat loop over the groups of 8 entries of all regions, BE_BIN_U groups per thread and round with every load of the
+  // round issued before the first add
+  const uint32_t n8 = NB * (uint32_t)B::groups;
   const uint32_t per = (n8 + parts - 1) / parts;
   const uint32_t g_begin = part * per, g_end = g_begin + per < n8 ? g_begin + per : n8;
-  const uint16_t* bin_i = bin_idx + (int64_t)bin * kBinRegions * cap;
-  const float* bin_f = bin_w + (int64_t)bin * kBinRegions * cap;
-  // BE_BIN_U groups of 8 entries per thread and round, every load of the round issued before the first add: one group per
-  // round left the workgroup waiting a full memory latency per 48 bytes and thread (80 rounds of ~2 us at C4: the kernel
-  // ran at 3.7 TB/s of its 600 MB).  A group that is not a whole one (a region's last, or past the end) loads the bin's
-  // first entries instead — no branch around the loads — and goes through the entry-by-entry tail.
+  const uint32_t* bin_base = regions + (size_t)bin * kStreamGrid * cap_blocks * B::dwords;
   constexpr int U = BE_BIN_U;
-  for (uint32_t g0 = g_begin + threadIdx.x; g0 < g_end; g0 += U * blockDim.x) {
+  for (uint32_t g0 = g_begin + tid; g0 < g_end; g0 += U * 1024) {
     uint4 iv[U];
     float4 wa[U], wb[U];
-    uint32_t e0s[U], cnts_u[U];
-    int xs[U];
-    bool whole[U];
+    uint32_t nv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t g = g0 + (uint32_t)u * blockDim.x;
-      int x = 0;
+      const uint32_t g = g0 + (uint32_t)u * 1024u;
+      const bool in = g < g_end;
+      const uint32_t gg = in ? g : g_begin;
+      const uint32_t blk = gg / (uint32_t)B::groups, sub = gg - blk * (uint32_t)B::groups;
+      uint32_t r = 0;
 #pragma unroll
-      for (int q = 1; q < kBinRegions; ++q) x += g >= gstart[q] ? 1 : 0;
-      uint32_t gs = gstart[0], cnt = cnts[0];
-#pragma unroll
-      for (int q = 1; q < kBinRegions; ++q) if (x == q) { gs = gstart[q]; cnt = cnts[q]; }
-      const uint32_t e0 = (g - gs) * 8u;
-      whole[u] = g < g_end && e0 + 8u <= cnt;        // cap is a multiple of 64: the regions are 128-byte aligned
-      xs[u] = x; e0s[u] = e0; cnts_u[u] = g < g_end ? cnt : 0u;
-      const int64_t at = whole[u] ? (int64_t)x * cap + e0 : 0;
-      iv[u] = *reinterpret_cast<const uint4*>(bin_i + at);
+      for (uint32_t s = kStreamGrid / 2; s > 0; s >>= 1)
+        if (s_pre[r + s] <= blk) r += s;
+      const uint32_t lb = blk - s_pre[r];
+      const uint32_t first = lb * (uint32_t)CAP + sub * 8u, c = s_cnt[r];
+      nv[u] = !in || c <= first ? 0u : (c - first < 8u ? c - first : 8u);
+      const uint32_t* bp = bin_base + ((size_t)r * cap_blocks + lb) * B::dwords;
+      iv[u] = *reinterpret_cast<const uint4*>(bp + B::idx_dw + sub * 4u);
       if (!HOMO) {
-        wa[u] = *reinterpret_cast<const float4*>(bin_f + at);
-        wb[u] = *reinterpret_cast<const float4*>(bin_f + at + 4);
+        wa[u] = *reinterpret_cast<const float4*>(bp + sub * 8u);
+        wb[u] = *reinterpret_cast<const float4*>(bp + sub * 8u + 4u);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (whole[u]) {
+      if (nv[u] == 8u) {
         if (HOMO) {
-          bin_count8(reinterpret_cast<uint32_t*>(acc), iv[u].x, iv[u].y, iv[u].z, iv[u].w);
+          bin_count8(reinterpret_cast<uint32_t*>(acc), iv[u]);
         } else {
           plan_add4<HOMO>(acc, make_uint2(iv[u].x, iv[u].y), wa[u], scale);
           plan_add4<HOMO>(acc, make_uint2(iv[u].z, iv[u].w), wb[u], scale);
         }
-      } else {
-        const uint16_t* bi = bin_i + (int64_t)xs[u] * cap;
-        const float* bw = bin_f + (int64_t)xs[u] * cap;
-        for (uint32_t e = e0s[u]; e < cnts_u[u]; ++e) {
-          if (HOMO) { if (bi[e] != kBinPad) atomicAdd(reinterpret_cast<uint32_t*>(acc) + bi[e], 1u); }
-          else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + bi[e], fixed_from_f32(bw[e], scale));
+      } else if (nv[u]) {                  // the last group of a region
+        const uint32_t ix[4] = {iv[u].x, iv[u].y, iv[u].z, iv[u].w};
+        const float wx[8] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w, wb[u].x, wb[u].y, wb[u].z, wb[u].w};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          if (j < nv[u]) {
+            const uint32_t col = (ix[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (HOMO) atomicAdd(reinterpret_cast<uint32_t*>(acc) + col, 1u);
+            else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + col, fixed_from_f32(wx[j], scale));
+          }
         }
       }
     }
   }
   __syncthreads();
   const int64_t j0 = (int64_t)bin << slice_shift;
-  // parts == 1: this workgroup is the only writer of its slice after k_bin_rows has finished, so a plain store does —
-  // or a plain read-modify-write when an overflowing run has already added into the slice with global atomics
+  // parts == 1: this workgroup is the only writer of its slice after pass B has finished, so a plain store does —
+  // or a plain read-modify-write when an overflowing block has already added into the slice with global atomics
   // (10M contiguous float atomics cost ~30 us at C4; the chip retires them at 1.3 TB/s of added bytes)
   const bool plain = parts == 1;
-  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+  for (int i = tid; i < S; i += 1024) {
     if (j0 + i >= k) break;
     float v;
     if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
@@ -460,6 +652,20 @@ __global__ void __launch_bounds__(256) k_bin_round(const float* __restrict__ src
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) WTraits<W>::store(dst, i, src[i]);
 }
 
+// entries per write-combining block: the largest the LDS of pass B holds for this many bins
+static inline int stream_cap(int n_bins, int homo) {
+  const int64_t budget = 160 * 1024 - 512 - (int64_t)kStreamFixedWords * 4;
+  for (int cap = homo ? 128 : 64; cap >= 8; cap >>= 1) {
+    const int64_t per_bin = 2 * (int64_t)cap * (homo ? 2 : 6) + 24;      // two blocks + ticket, 2 commit counts, 2 generations, flag
+    if (per_bin * n_bins <= budget) return cap;
+  }
+  return 0;
+}
+static inline int64_t stream_cap_blocks(int64_t bin_capacity, int cap) {
+  const int64_t per_region = bin_capacity / kStreamGrid * 5 / 4 + 64;       // the rows are dealt evenly, the columns are not
+  return (per_region + cap - 1) / cap + 2;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -476,14 +682,25 @@ extern "C" int be_debug_bin_prof(unsigned long long* host, int reset) {
 extern "C" {
 
 // ---------------------------------------------------------------- binned route (no plan)
-// entries per (bin, XCD) region: an eighth of the bin's capacity plus slack for the uneven split, in whole 128-byte lines
-static inline int64_t binned_cap_x(int64_t cap) { return ((cap + 7) / 8 * 9 / 8 + 128 + 63) & ~63ll; }
+// output slices the route can serve: pass B keeps two blocks of >= 8 entries per slice in LDS
+int be_binned_max_slices(int homo) {
+  int n = 1;
+  while (n < kMaxBins && stream_cap(n + 1, homo) > 0) ++n;
+  return n;
+}
 
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity) {
   const int64_t n_bins = n_slices_of(k, slice_shift);
-  const int64_t cap = binned_cap_x(bin_capacity) * kBinRegions;
-  return 256 + be_align_up(m * 4, 256) + 2 * be_align_up(n_bins * kBinRegions * 4, 256) + be_align_up(n_bins * cap * 2, 256) +
-         be_align_up(n_bins * cap * 4, 256) + be_align_up(k * 4, 256);      // the tail: f32 image of an f16 / bf16 output
+  // sized for weighted entries (6 B each, blocks of the weighted kernel): a workspace serves one weight or per-entry weights
+  int64_t blocks_bytes = 0;
+  for (int homo = 0; homo < 2; ++homo) {
+    const int cap = stream_cap((int)(n_bins > kMaxBins ? kMaxBins : n_bins), homo);
+    if (cap == 0) continue;
+    const int64_t b = n_bins * kStreamGrid * stream_cap_blocks(bin_capacity, cap) * cap * (homo ? 2 : 6);
+    blocks_bytes = b > blocks_bytes ? b : blocks_bytes;
+  }
+  return 256 + be_align_up(m * 4, 256) + be_align_up(n_bins * kStreamGrid * 4, 256) + be_align_up(blocks_bytes, 256) +
+         be_align_up(k * 4, 256);      // the tail: f32 image of an f16 / bf16 output
 }
 
 int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
@@ -499,12 +716,14 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   const int n_bins = n_slices_of(k, slice_shift);
   BE_REQUIRE(n_bins <= kMaxBins, BE_ERR_RANGE, "too many bins for the binned route");
   BE_REQUIRE(bin_capacity >= 8 && bin_capacity < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
-  const int64_t cap_x = binned_cap_x(bin_capacity);            // per (bin, XCD) region
-  const int64_t cap = cap_x * kBinRegions;
   BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
   const int64_t S = 1ll << slice_shift;
   const size_t lds = (size_t)S * (homo ? 4 : 8);
   BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
+  const int cap = stream_cap(n_bins, homo);
+  BE_REQUIRE(cap > 0, BE_ERR_RANGE, "too many bins for the LDS blocks of the binned route");
+  const int64_t cap_blocks = stream_cap_blocks(bin_capacity, cap);
+  BE_REQUIRE(cap_blocks * cap < (1ll << 31), BE_ERR_RANGE, "bin_capacity too large");
   BE_REQUIRE(workspace != nullptr &&
                  workspace_bytes >= be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity),
              BE_ERR_WORKSPACE, "workspace too small");
@@ -512,78 +731,68 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
-  uint32_t* cursor = reinterpret_cast<uint32_t*>(wsb + 256 + be_align_up(m * 4, 256));
-  uint32_t* valid = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cursor) + be_align_up((int64_t)n_bins * kBinRegions * 4, 256));
-  uint16_t* bin_idx = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(valid) + be_align_up((int64_t)n_bins * kBinRegions * 4, 256));
-  float* bin_w = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_idx) + be_align_up((int64_t)n_bins * cap * 2, 256));
-  float* out32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bin_w) + be_align_up((int64_t)n_bins * cap * 4, 256));
+  uint32_t* dir = reinterpret_cast<uint32_t*>(wsb + 256 + be_align_up(m * 4, 256));
+  uint32_t* regions = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(dir) + be_align_up((int64_t)n_bins * kStreamGrid * 4, 256));
+  // the f32 image sits at the end of the workspace
+  float* out32 = reinterpret_cast<float*>(wsb + be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity) -
+                                          be_align_up(k * 4, 256));
   void* out_user = out;
   if (wdtype != BE_F32) out = out32;                 // accumulate in f32, round once at the end
   RowPtr rp{indptr, indptr_is_i64, row_len};
-  if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, cursor,
-                       valid, n_bins, count);
-    BE_LAUNCH_CHECK();
-  } else {
-    BE_HIP(be_fill_async(out, 0, (size_t)k * 4, st));
-    BE_HIP(be_fill_async(cursor, 0, (size_t)n_bins * kBinRegions * 4, st));
-    BE_HIP(be_fill_async(valid, 0xff, (size_t)n_bins * kBinRegions * 4, st));
-    BE_HIP(be_fill_async(count, 0, 4, st));
-  }
+  hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, count);
+  BE_LAUNCH_CHECK();
   ActiveList al;
   int rc = be_resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, /*zero_first=*/false, &al);
   if (rc != BE_OK) return rc;
   const int prof = be_prof_begin(st);
-  // one 1024-thread workgroup per CU.  (Two 512-thread workgroups with half-size batches, so that one could sort in LDS while
-  // the other has its loads or its copy-out in flight, measured slower at C4 — 533 vs 422 us weighted, 284 vs 204 counted:
-  // twice the batches pay twice the barriers and fixed latencies, and the runs are half as long.)
+  // rows of one length: a lane finds its row by dividing its group index by the row's groups of four
+  const DivU32 fixdiv = make_div(indptr == nullptr && row_len > 0 && row_len < (1ll << 26) ? (uint32_t)((row_len + 3) / 4) : 1u);
   {
-    const void* kern = nullptr;
-#define BE_BIN_KERN(WT) kern = homo ? (const void*)k_bin_rows<WT, true, 16> : (const void*)k_bin_rows<WT, false, 16>
-    if (wdtype == BE_F16) BE_BIN_KERN(__half); else if (wdtype == BE_BF16) BE_BIN_KERN(__hip_bfloat16); else BE_BIN_KERN(float);
-#undef BE_BIN_KERN
-    hipFuncAttributes fa;
-    BE_HIP(hipFuncGetAttributes(&fa, kern));
-    // the batch payload lives in dynamic LDS next to the kernel's static bookkeeping: every run is padded to 4 entries
-    const int64_t budget = 160 * 1024 - (int64_t)fa.sharedSizeBytes - 256;
-    const int64_t per_entry = homo ? 2 : 6;
-    const int64_t max_chunks = 16ll * (homo ? 32 : 16);
-    int64_t chunks = (budget / per_entry - 3ll * n_bins - 8) / 64;
-    chunks = chunks > max_chunks ? max_chunks : chunks;
-    BE_REQUIRE(chunks >= 1, BE_ERR_RANGE, "too many bins for the LDS batch of the binned route");
-    const uint32_t payload_entries = (uint32_t)((chunks * 64 + 3ll * n_bins + 7) & ~7ll);
-    const size_t dyn = (size_t)payload_entries * per_entry;
-    BE_HIP(be_allow_lds(kern, (int)dyn));
-#define BE_BIN_ROWS(WT, HOMO_)                                                                                              \
-  hipLaunchKernelGGL((k_bin_rows<WT, HOMO_, 16>), dim3(256), dim3(1024), dyn, st, static_cast<const WT*>(weights), indices, rp, \
-                     al.ids, al.count, slice_shift, n_bins, (uint32_t)cap_x, cursor, valid, bin_idx, bin_w,                    \
-                     static_cast<float*>(out), (uint32_t)chunks, payload_entries)
-#define BE_BIN_ROWS_W(WT) do { if (homo) BE_BIN_ROWS(WT, true); else BE_BIN_ROWS(WT, false); } while (0)
-    if (wdtype == BE_F16) BE_BIN_ROWS_W(__half); else if (wdtype == BE_BF16) BE_BIN_ROWS_W(__hip_bfloat16); else BE_BIN_ROWS_W(float);
-#undef BE_BIN_ROWS_W
-#undef BE_BIN_ROWS
+    const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_bins * (2 * (size_t)cap * (homo ? 2 : 6) / 4 + 6)) * 4;
+#define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
+  do {                                                                                                                          \
+    auto kern = k_bin_stream<WT, HOMO_, CAP_>;                                                                                  \
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
+    hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, al.ids,      \
+                       al.count, slice_shift, n_bins, (uint32_t)cap_blocks, regions, dir, static_cast<float*>(out), fixdiv);   \
+  } while (0)
+#define BE_BIN_STREAM_W(WT)                                                                                                     \
+  do {                                                                                                                          \
+    if (homo) {                                                                                                                 \
+      if (cap == 128) BE_BIN_STREAM(WT, true, 128); else if (cap == 64) BE_BIN_STREAM(WT, true, 64);                            \
+      else if (cap == 32) BE_BIN_STREAM(WT, true, 32); else if (cap == 16) BE_BIN_STREAM(WT, true, 16);                         \
+      else BE_BIN_STREAM(WT, true, 8);                                                                                          \
+    } else {                                                                                                                    \
+      if (cap == 64) BE_BIN_STREAM(WT, false, 64); else if (cap == 32) BE_BIN_STREAM(WT, false, 32);                            \
+      else if (cap == 16) BE_BIN_STREAM(WT, false, 16); else BE_BIN_STREAM(WT, false, 8);                                       \
+    }                                                                                                                           \
+  } while (0)
+    if (wdtype == BE_F16) BE_BIN_STREAM_W(__half); else if (wdtype == BE_BF16) BE_BIN_STREAM_W(__hip_bfloat16); else BE_BIN_STREAM_W(float);
+#undef BE_BIN_STREAM_W
+#undef BE_BIN_STREAM
   }
   BE_LAUNCH_CHECK();
   // n_bins * parts ~ 256: every workgroup fills a CU (128 KB of LDS) and its slice is merged into the output with float
   // atomics, one per non-zero accumulator, so more parts than CUs only add merge traffic (39 bins: 13 parts took 55 us, 6 take 30).
-  // (Beyond 256 bins the last round of workgroups is partly empty — C4: 611 bins = 2 rounds + 99 — but splitting only its
-  //  bins into parts that fill the round measured nothing, 165 -> 156 us at best: the pass is bound by its byte stream.)
   int parts = 256 / (n_bins > 0 ? n_bins : 1);
   parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
   const unsigned acc_grid = (unsigned)(n_bins * parts);
   const float scale = ldexpf(1.0f, scale_exp - 32);
   const double inv_scale = ldexp(1.0, -scale_exp);
+#define BE_BIN_ACC(HOMO_, CAP_)                                                                                                 \
+  do {                                                                                                                          \
+    auto kern = k_bin_accumulate<HOMO_, CAP_>;                                                                                  \
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
+    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, slice_shift, parts, k,    \
+                       scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out)); \
+  } while (0)
   if (homo) {
-    auto kern = k_bin_accumulate<true>;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
-                       slice_shift, parts, k, scale, inv_scale, weights, wdtype, static_cast<float*>(out));
+    if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
+    else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
   } else {
-    auto kern = k_bin_accumulate<false>;
-    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
-    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, bin_idx, bin_w, cursor, valid, (uint32_t)cap_x,
-                       slice_shift, parts, k, scale, inv_scale, static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out));
+    if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
   }
+#undef BE_BIN_ACC
   be_prof_end(prof, st);
   BE_LAUNCH_CHECK();
   if (wdtype == BE_F16)

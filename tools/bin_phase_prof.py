@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Phase-by-phase time of k_bin_rows (diagnostic build).  On the GPU box:
+"""Phase-by-phase time of k_bin_stream, pass B of the binned route (diagnostic build).  On the GPU box:
     BE_HIPCC_FLAGS=-DBE_BIN_PROF python tools/bin_phase_prof.py [--homo]
-rebuilds the library with the in-kernel stamps (s_memtime, 100 MHz), runs the C4 shape and prints the mean share of each
-phase per batch.  Rebuild without the flag afterwards (the shipped library carries no stamps)."""
+rebuilds the library with the in-kernel stamps (s_memtime, 100 MHz), runs the C4 shape and prints the mean time a wave
+spends in each phase per step, and the append-loop / flush counts per chunk of 64 entries.  Rebuild without the flag afterwards (the shipped library carries no stamps)."""
 import ctypes
 import os
 import sys
@@ -34,9 +34,13 @@ for i in range(steps):
 torch.cuda.synchronize()
 buf = np.zeros(256 * 8, np.uint64)
 f(buf.ctypes.data, 0)
-t = buf.reshape(256, 8).astype(np.float64) / steps / 100.0      # us per step per workgroup (s_memtime ticks at 100 MHz)
-names = ['form batch', 'issue loads', 'loads land + histogram', 'scan + reserve', 'placement', 'copy-out']
-print('homo' if homo else 'hetero', 'per step, mean over workgroups (us):')
-for i, nme in enumerate(names):
-    print(f'  {nme:26s} {t[:, i].mean():8.1f}   (min {t[:, i].min():.1f} max {t[:, i].max():.1f})')
-print(f'  total {t.sum(axis=1).mean():.1f}')
+t = buf.reshape(256, 8).astype(np.float64) / steps
+us = t / 100.0 / 16.0                 # us per step per wave (s_memtime ticks at 100 MHz; 16 waves per workgroup add up)
+names = {0: 'task header (ids, row bounds, scan)', 1: 'issue loads', 2: 'wait for the loads', 3: 'append + flush', 7: 'ticket / tail'}
+print('homo' if homo else 'hetero', 'per step, mean over workgroups, us per wave:')
+for i, nme in names.items():
+    print(f'  {nme:36s} {us[:, i].mean():8.1f}   (min {us[:, i].min():.1f} max {us[:, i].max():.1f})')
+print(f'  total {us[:, [0, 1, 2, 3, 7]].sum(axis=1).mean():.1f}')
+chunks = t[:, 6].mean()
+print(f'  chunks per workgroup {chunks:.0f}; append-loop iterations per chunk {t[:, 4].mean() / max(chunks, 1):.2f}; '
+      f'flushes per chunk {t[:, 5].mean() / max(chunks, 1):.2f}')
