@@ -17,6 +17,7 @@ scatter kernel (see ``csrc/be_csr_plan.hip``; the binned route is ``csrc/be_csr_
 "direct" kernel (global atomics).
 """
 import ctypes
+import os
 import math
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -465,7 +466,9 @@ class BinnedScatter:
                  slice_shift: Optional[int] = None, indices: Optional[torch.Tensor] = None):
         self.m, self.k = int(m), int(k)
         self.homo = weights.numel() == 1
-        self.slice_shift = ScatterPlan.default_shift(k, self.homo) if slice_shift is None else int(slice_shift)
+        if slice_shift is None and os.environ.get('BE_BIN_SHIFT'):      # A/B runs
+            slice_shift = int(os.environ['BE_BIN_SHIFT'])
+        self.slice_shift = self.default_shift(k, self.homo) if slice_shift is None else int(slice_shift)
         self.n_slices = (self.k + (1 << self.slice_shift) - 1) >> self.slice_shift
         expect = max_active_fraction * nnz / max(self.n_slices, 1)
         self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
@@ -490,11 +493,19 @@ class BinnedScatter:
         return (not self.homo) and self.stamp != weights_stamp(weights)
 
     @staticmethod
+    def default_shift(k: int, homo: bool) -> int:
+        """Slice width of the bins: as wide as the LDS accumulators of pass C allow for many outputs, narrower — about 256 to
+        512 bins — otherwise: one workgroup per bin in pass C (plain stores, bitwise reproducible) and less contention on the
+        bins' counters in pass B (one post slice of an 8-way cut of C4, 1.25M outputs, us per step counted / weighted:
+        2^14-wide bins 117 / 135, 2^12 97 / 132, 2^11 164 / 131)."""
+        return max(8, min(ScatterPlan.default_shift(k, homo), (max(int(k), 1) // 256).bit_length() - 1))
+
+    @staticmethod
     def applicable(weights: torch.Tensor, k: int) -> bool:
         if weights.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             return False                  # f64: the bins carry f32 weights (per-entry f64 weights take the planned route)
         homo = weights.numel() == 1
-        shift = ScatterPlan.default_shift(k, homo)
+        shift = BinnedScatter.default_shift(k, homo)
         return ((k + (1 << shift) - 1) >> shift) <= fn('be_binned_max_slices', c_int, [c_int])(int(homo))
 
 

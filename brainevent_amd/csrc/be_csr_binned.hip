@@ -201,8 +201,7 @@ template <bool HOMO, int CB, int NE>
 __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, const uint32_t (&col)[NE],
                                                const float (&w)[HOMO ? 1 : NE], int slice_shift, uint32_t mask, int n_bins,
                                                uint32_t cap_blocks, uint32_t* wl, uint32_t* __restrict__ wg_regions,
-                                               size_t bin_stride_dw, float* __restrict__ out, float w0, int lane, uint32_t& n_deferred,
-                                               StreamProf& prof) {
+                                               size_t bin_stride_dw, float* __restrict__ out, float w0, int lane, StreamProf& prof) {
   using B = BinBlock<HOMO, CB>;
   constexpr int LOG_CB = CB == 128 ? 7 : CB == 64 ? 6 : CB == 32 ? 5 : CB == 16 ? 4 : 3;
   // a column >= k (the caller's error) and a missing entry both land on the lane's own dummy counter n_bins + lane
@@ -254,16 +253,11 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
     prof.count(4);
     // (every completing lane copying its own block, 16 bytes per instruction and no list, measured slower: 406 -> 554 us at
     //  C4 — a store instruction whose few active lanes write 16 bytes each to unrelated lines costs far more than its issue slot)
-    // the list is NOT flushed here: the caller flushes it at the top of the wave's next round, in front of that round's
-    // loads — the stores then have a whole round of appends to complete in, where stores issued at the end of the round
-    // met the full wait for the next round's loads at once (the counter of outstanding memory operations is one, in order)
-    while (__ballot(flm != 0)) {                     // (one pass, unless the list overflows)
-      if (n_deferred >= 64u) {
-        lds_fence();
-        stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
-        n_deferred = 0;
-      }
-      uint32_t nfl = n_deferred;
+    // (Leaving the list to the top of the wave's next round, so that its stores have a round of appends to complete in before
+    //  the full wait for that round's loads, bought nothing at C4 — 412 -> 421 us — and made one post slice of an 8-way cut
+    //  wait for ring slots: 2.3 trips through this loop per round instead of 1.)
+    while (__ballot(flm != 0)) {                     // (one pass, unless more than 64 blocks completed at once)
+      uint32_t nfl = 0;
 #pragma unroll
       for (int u = 0; u < NE; ++u) {
         const bool fl = (flm >> u) & 1u;
@@ -278,16 +272,11 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
           nfl += (uint32_t)__popcll((unsigned long long)m);
         }
       }
-      prof.count(5, (nfl < 64u ? nfl : 64u) - n_deferred);
-      n_deferred = nfl < 64u ? nfl : 64u;
+      prof.count(5, nfl < 64u ? nfl : 64u);
+      lds_fence();
+      stream_flush_list<HOMO, CB>(S, wl, nfl < 64u ? nfl : 64u, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
     }
     if (__ballot(pend != 0) == 0) break;
-    // an entry waits for its ring slot: the block in its way may be on this wave's own list
-    if (n_deferred) {
-      lds_fence();
-      stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
-      n_deferred = 0;
-    }
     if (++spins > kSpinLimit) __builtin_trap();      // never seen: a protocol error ends in a launch failure, not in a hung device
     __builtin_amdgcn_s_sleep(1);
   }
@@ -342,7 +331,6 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   uint32_t* wg_regions = regions + (size_t)blockIdx.x * cap_blocks * B::dwords;
 
   StreamProf prof;
-  uint32_t n_deferred = 0;                       // completed blocks on this wave's list, not yet copied out
   for (;;) {
     prof.stamp(7);
     uint32_t tk = 0;
@@ -464,11 +452,6 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
             validC[u] = c0 + (uint32_t)u < n_steps ? validN[u] : 0u;
           }
           prof.stamp(2);
-          if (n_deferred) {                          // the blocks the previous round completed (see stream_append)
-            lds_fence();
-            stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
-            n_deferred = 0;
-          }
           if (c0 + U < n_steps) BE_STREAM_ISSUE(c0 + U);
           prof.stamp(1);
           {
@@ -490,7 +473,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
             if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
 #endif
             stream_append<HOMO, CB, U * 4>(S, colA, wA, slice_shift, mask, n_bins, cap_blocks, wl, wg_regions, bin_stride_dw, out, w0,
-                                           lane, n_deferred, prof);
+                                           lane, prof);
           }
           prof.stamp(3);
           prof.count(6, U);
@@ -499,10 +482,6 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
         lds_fence();
       }
     }
-  }
-  if (n_deferred) {
-    lds_fence();
-    stream_flush_list<HOMO, CB>(S, wl, n_deferred, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
   }
   prof.stamp(7);
   prof.flush_out(lane);

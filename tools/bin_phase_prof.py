@@ -17,11 +17,13 @@ import brainevent_amd as be
 from bench import gen_fixed_num_on_device
 
 homo = '--homo' in sys.argv
-n, K = 10_000_000, 1000
+n, K = 10_000_000, int(os.environ.get('BE_PROF_K', 1000))
+n_post = int(os.environ.get('BE_PROF_NPOST', n))      # BE_PROF_K=125 BE_PROF_NPOST=1250000: one post slice of an 8-way cut
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev); g.manual_seed(7)
-w, idx = gen_fixed_num_on_device(n, K, n, homo, dev, g)
-conn = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False).prepare()
+w, idx = gen_fixed_num_on_device(n, K, n_post, homo, dev, g)
+conn = be.FixedNumPerPre((w, idx), shape=(n, n_post), check_indices=False).prepare()
+print(type(conn.buffers.get('scatter_plan')).__name__)
 spk = [torch.rand(n, device=dev, generator=g) < 0.01 for _ in range(4)]
 for i in range(5):
     be.BinaryArray(spk[i % 4]) @ conn
