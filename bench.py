@@ -361,8 +361,8 @@ def run_dense(args, dev, g):
 
 def _line(metric, value, args, elapsed, dtype, cfg, roof, kern, step_ms):
     return {'metric': metric, 'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': dtype, 'data': 'synthetic', 'config': cfg, 'roofline': roof,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': args.scaling,
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic', 'config': cfg, 'roofline': roof,
             'kernel_ms': _stats(kern), 'step_ms_hip_events': _stats(step_ms)}
 
 
@@ -464,11 +464,17 @@ def run_scatter(args):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world and world > 1:
         raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
-    n_dev = max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank % n_dev)          # (rehearsals put several ranks on one card; the driver has one GPU per rank)
-    dev = torch.device('cuda', local_rank % n_dev)
+    # BENCH_MOCK_STEP=1: rehearsal of the launcher / partition / exchange / reduction / JSON plumbing on CPU tensors over gloo
+    # (tests/test_bench_launch_cpu.py).  The scatter itself is replaced by a torch index_add: NOT a measurement — the line says
+    # "mock_step": true and its value means nothing.
+    mock = os.environ.get('BENCH_MOCK_STEP') == '1'
+    if mock:
+        os.environ['BENCH_BACKEND'] = 'gloo'
+        dev = torch.device('cpu')
+    else:
+        n_dev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank % n_dev)      # (rehearsals put several ranks on one card; the driver has one GPU per rank)
+        dev = torch.device('cuda', local_rank % n_dev)
     dist = None
     # BENCH_FORCE_DIST=1 / --emulate-world W run the multi-rank code path (process group, all-gather, max-reduce) with a
     # single rank: the only way to exercise it on a one-GPU box
@@ -511,8 +517,10 @@ def run_scatter(args):
         n_post = shape[1]
         n_conn = n_conn_global / p_world               # mean stored synapses per (row, shard); the rows are ragged
     nnz_local = int(indices.numel())
-    csr = be.CSR((weights, indices, indptr), shape=shape, check_structure=False)
-    if args.route == 'plan' and not is_fcn:
+    csr = None if mock else be.CSR((weights, indices, indptr), shape=shape, check_structure=False)
+    if mock:
+        pass
+    elif args.route == 'plan' and not is_fcn:
         # default: LDS-filling accumulator capacity and slices balanced over the 256 CUs; --shift forces full-capacity slices
         csr.buffers['scatter_plan'] = C.ScatterPlan.build(weights, indices, indptr, shape=shape,
                                                           slice_shift=args.shift or None, slice_width=args.width or None,
@@ -523,11 +531,12 @@ def run_scatter(args):
         csr.buffers['scatter_plan'] = None
     else:                                             # the container's own choice (plan / binned / direct)
         csr.prepare()
-    ws_obj = csr.buffers.get('scatter_plan')
-    route = type(ws_obj).__name__ if ws_obj is not None else 'direct'
+    ws_obj = None if mock else csr.buffers.get('scatter_plan')
+    route = 'MOCK (torch index_add on CPU tensors)' if mock else (type(ws_obj).__name__ if ws_obj is not None else 'direct')
     if isinstance(ws_obj, C.ScatterPlan):
         plan, plan_bytes = ws_obj, ws_obj.nbytes()
-    torch.cuda.synchronize()
+    if not mock:
+        torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
     # spike batch: each rank draws the spikes of its own 1/world of the pre population
@@ -539,7 +548,8 @@ def run_scatter(args):
     if use_dist:
         from brainevent_amd._dist import SpikeExchange, NativeSpikeExchange
         # one all-gather per step (RCCL over xGMI); bit-packed by default: 1/8 of the bytes, consumed packed
-        native = (args.exchange_impl == 'native' and args.exchange == 'bits' and os.environ.get('BENCH_BACKEND', 'nccl') == 'nccl')
+        native = (args.exchange_impl == 'native' and args.exchange == 'bits' and os.environ.get('BENCH_BACKEND', 'nccl') == 'nccl'
+                  and not mock)
         exchange = None
         if native:      # the library's own communicator; the id travels over the (already initialised) process group
             box = [None]
@@ -551,8 +561,7 @@ def run_scatter(args):
             ok = 0.0
             if box[0] is not None:
                 # ncclCommInitRank blocks until every rank has joined: run it beside a watchdog so that a rendezvous that
-                # never completes (it has only ever been run with one rank) ends in the torch.distributed exchange
-                # instead of a hung job
+                # never completes ends the job with a message instead of hanging it
                 import threading
                 res = {}
 
@@ -566,10 +575,15 @@ def run_scatter(args):
                 th.start()
                 th.join(timeout=float(os.environ.get('BENCH_NATIVE_INIT_TIMEOUT', 90)))
                 if th.is_alive():
-                    print(f'[bench] rank {rank}: be_exchange_init did not return in time', file=sys.stderr, flush=True)
-                elif 'ex' in res:
+                    # ncclCommInitRank is still blocked on this rank's device: nothing may continue beside it (a fallback
+                    # would share the device with the stuck call).  End the job with a message and a non-zero status;
+                    # `--exchange-impl torch` runs the same measurement without the library's own communicator.
+                    print(f'[bench] rank {rank}: be_exchange_init did not return within BENCH_NATIVE_INIT_TIMEOUT; aborting '
+                          f'(rerun with --exchange-impl torch)', file=sys.stderr, flush=True)
+                    os._exit(3)
+                if 'ex' in res:
                     exchange, ok = res['ex'], 1.0
-                else:
+                else:           # an error every rank can recover from together (the MIN below): torch.distributed instead
                     print(f'[bench] rank {rank}: be_exchange_init failed ({res.get("err")!r})', file=sys.stderr, flush=True)
             flag = torch.tensor([ok], dtype=torch.float64, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
@@ -593,8 +607,14 @@ def run_scatter(args):
     ahead = use_dist and args.exchange == 'bits' and args.exchange_ahead
     ticket = [exchange.post(local_spikes[0])] if ahead else None
 
+    def mock_scatter(full_spikes):
+        ref = reference_for_shard(weights, indices, indptr, full_spikes, n_post, args.homo)
+        return ref.to(torch.float32) * float(weights[0]) if args.homo else ref.to(torch.float32)
+
     def step(i):
         s = local_spikes[i % n_batch]
+        if mock:
+            return mock_scatter(exchange.gather(s) if use_dist else s)
         if ahead:
             # step i's spikes were posted during step i - 1: post step i + 1's now (the collective overlaps with the
             # scatter below), then consume step i's.  Every timed step still issues one exchange and one scatter.
@@ -607,12 +627,24 @@ def run_scatter(args):
         return be.BinaryArray(s) @ csr
 
     def fence():
-        torch.cuda.synchronize()
+        if not mock:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not mock:
+                torch.cuda.synchronize()
 
-    elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup, fence)
+    if mock:
+        for i in range(args.warmup):
+            out = step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(args.warmup + i)
+        fence()
+        elapsed, kern, step_ms = time.perf_counter() - t0, None, np.zeros(0)
+    else:
+        elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup, fence)
     if ahead:      # the exchange posted by the last step (never consumed)
         exchange.wait_events(ticket[0]) if native else ticket[0][1].wait()
     kern_ms = float(np.mean(kern)) if kern is not None else None
@@ -637,7 +669,7 @@ def run_scatter(args):
 
     copy_gbps = None
     line = None
-    if rank == 0 and args.emulate_world <= 1:
+    if rank == 0 and args.emulate_world <= 1 and not mock:
         try:
             src = torch.empty(1 << 29, dtype=torch.float32, device=dev)       # 2 GiB
             dst = torch.empty_like(src)
@@ -659,7 +691,7 @@ def run_scatter(args):
         mean_upd = float(np.mean(upd_per_vec[timed]))
         alg_bytes = bytes_per_upd * mean_upd + n_pre * 1 + n_post * 4 + 16 * mean_active
         plan_kernel = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate')
-        kernel_name = {'ScatterPlan': plan_kernel, 'BinnedScatter': 'k_bin_rows'}.get(route, 'k_csrmv_t_direct')
+        kernel_name = {'ScatterPlan': plan_kernel, 'BinnedScatter': 'k_bin_stream'}.get(route, 'k_csrmv_t_direct')
         roof = hbm_roofline(alg_bytes, kern_ms, traffic=plan_traffic(args, plan, p_world), kernel=kernel_name,
                             extra={'kernel_ms_median': round(float(np.median(kern)), 5) if kern is not None else None,
                                    # the same run's device-copy ceiling (bytes read + written per second
@@ -696,13 +728,16 @@ def run_scatter(args):
                              'expected_stored_synapses': float(n_pre) * n_conn_global if args.emulate_world <= 1 else None},
             'roofline': roof,
         }
+        if mock:
+            line['mock_step'] = True
+            line['data'] = 'synthetic (MOCK STEP: plumbing rehearsal on CPU tensors, not a measurement)'
         default_cfg = (args.n == 1_000_000 and args.conn == 0.01 and args.fire == 0.01 and not args.homo and args.route == 'plan')
-        if world == 1 and not force_dist and not args.no_cpu:
+        if world == 1 and not force_dist and not args.no_cpu and not mock:
             try:
                 line['cpu_baseline'] = cpu_baseline(args, n_post, int(n_conn_global))
             except Exception as e:   # the CPU leg must never sink the GPU number
                 line['cpu_baseline'] = {'error': repr(e)}
-        if world == 1 and not force_dist and not args.no_secondary and default_cfg and args.workload == 'csr':
+        if world == 1 and not force_dist and not args.no_secondary and default_cfg and args.workload == 'csr' and not mock:
             line['secondary'] = 'pending'      # filled in by main() once this call's process group and buffers are gone
     if use_dist:
         if native:
@@ -712,8 +747,27 @@ def run_scatter(args):
     return line
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a CHILD process (torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1), relay what rank 0 prints and return the child's exit code.  Runs before
+    anything in this process has touched the GPU, and never replaces this process (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL between processes needs it on this driver
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and args.emulate_world <= 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     if os.environ.get('BENCH_FAULT_TIMEOUT'):        # rehearsals: where is every rank if the run has not finished by then
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ['BENCH_FAULT_TIMEOUT']), exit=False, file=sys.stderr)

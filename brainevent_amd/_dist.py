@@ -264,6 +264,10 @@ class NativeSpikeExchange:
         from ._lib import fn, check
         self._ct = ctypes
         self.n_pre, self.world, self.rank = int(n_pre), int(world), int(rank)
+        # GPU only (unlike SpikeExchange, which also serves gloo): the receive buffer is handed to ncclAllGather as it is
+        device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError(f"NativeSpikeExchange runs on a HIP device, not on {device} (use SpikeExchange for gloo / CPU)")
         self.device = device
         self._h = ctypes.c_void_p(0)
         buf = ctypes.create_string_buffer(bytes(unique_id), len(unique_id))
@@ -274,10 +278,15 @@ class NativeSpikeExchange:
         f = fn('be_exchange_slice', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                                    ctypes.POINTER(ctypes.c_int64)])
         check(f(self._h, self.rank, ctypes.byref(lo), ctypes.byref(hi)), 'be_exchange_slice')
-        self.lo, self.hi = int(lo.value), int(hi.value)
-        assert (self.lo, self.hi) == word_aligned_bounds(self.n_pre, self.world, self.rank)
-        n_words = int(fn('be_exchange_full_words', ctypes.c_int64, [ctypes.c_void_p])(self._h))
-        self._full_words = torch.zeros(max(n_words, 1), dtype=torch.int32, device=device)
+        try:
+            self.lo, self.hi = int(lo.value), int(hi.value)
+            if (self.lo, self.hi) != word_aligned_bounds(self.n_pre, self.world, self.rank):
+                raise RuntimeError(f"be_exchange_slice disagrees with word_aligned_bounds: {(self.lo, self.hi)}")
+            n_words = int(fn('be_exchange_full_words', ctypes.c_int64, [ctypes.c_void_p])(self._h))
+            self._full_words = torch.zeros(max(n_words, 1), dtype=torch.int32, device=device)
+        except Exception:
+            self.close()                  # the communicator must not outlive a failed constructor
+            raise
 
     @staticmethod
     def unique_id() -> bytes:
@@ -336,6 +345,15 @@ class NativeSpikeExchange:
             n_words = self._full_words.numel()
             view = self._views[slot] = _device_view_i32(out.value, n_words, self._full_words.device)
         return BitPackedBinary.from_packed(view, self.n_pre)
+
+    def release(self, ticket) -> None:
+        """Tell the exchange that the consumer has queued its last read of the ticket's buffer (``be_exchange_release``).
+        Only needed when the products that consume the events run on another stream than the one ``post`` was called on."""
+        from . import _array as A
+        from ._lib import fn, check
+        ct = self._ct
+        check(fn('be_exchange_release', ct.c_int, [ct.c_void_p, ct.c_int, ct.c_void_p])(self._h, ticket[0], A.stream_ptr()),
+              'be_exchange_release')
 
     def close(self) -> None:
         if self._h:

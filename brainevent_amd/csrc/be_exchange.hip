@@ -71,6 +71,8 @@ struct Exchange {
   // pipelined exchange (be_exchange_post / _wait): the library's own stream, two result buffers, their events
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_free[2] = {nullptr, nullptr};  // recorded by be_exchange_release on the consumer's stream
+  bool released[2] = {false, false};
   uint32_t* post_local[2] = {nullptr, nullptr};
   uint32_t* post_full[2] = {nullptr, nullptr};
 };
@@ -180,16 +182,46 @@ int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, 
   Rccl* R = rccl();
   BE_REQUIRE(R != nullptr, BE_ERR_UNSUPPORTED, "librccl.so could not be loaded");
   if (!ex->side) {
-    BE_HIP(hipStreamCreateWithFlags(&ex->side, hipStreamNonBlocking));
-    BE_HIP(hipEventCreateWithFlags(&ex->ev_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) {
-      BE_HIP(hipEventCreateWithFlags(&ex->ev_done[i], hipEventDisableTiming));
-      BE_HIP(hipMalloc(&ex->post_local[i], (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * 4));
-      BE_HIP(hipMalloc(&ex->post_full[i], (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * ex->world * 4));
+    // everything is created into locals and published together: a failure half-way leaves the handle as it was
+    // (a later call starts over) instead of a stream without its buffers
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    uint32_t* pl[2] = {nullptr, nullptr};
+    uint32_t* pf[2] = {nullptr, nullptr};
+    const size_t wl = (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * 4;
+    hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_in, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      e = hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipMalloc(&pl[i], wl);
+      if (e == hipSuccess) e = hipMalloc(&pf[i], wl * ex->world);
     }
+    if (e != hipSuccess) {
+      for (int i = 0; i < 2; ++i) {
+        if (pf[i]) (void)hipFree(pf[i]);
+        if (pl[i]) (void)hipFree(pl[i]);
+        if (ev_free[i]) (void)hipEventDestroy(ev_free[i]);
+        if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+      }
+      if (ev_in) (void)hipEventDestroy(ev_in);
+      if (side) (void)hipStreamDestroy(side);
+      be_set_error(std::string("be_exchange_post: creating the exchange stream / events / buffers -> ") + hipGetErrorString(e));
+      return BE_ERR_HIP;
+    }
+    ex->ev_in = ev_in;
+    for (int i = 0; i < 2; ++i) { ex->ev_done[i] = ev_done[i]; ex->ev_free[i] = ev_free[i]; ex->post_local[i] = pl[i]; ex->post_full[i] = pf[i]; }
+    ex->side = side;
   }
+  // the side stream waits for what the producer's stream has queued so far: the spikes — and, when the consumer works on that
+  // same stream, the consumer's reads of this slot's previous contents.  A consumer on ANOTHER stream says when it is done
+  // with a slot through be_exchange_release; the gather into the slot then waits for that as well.
   BE_HIP(hipEventRecord(ex->ev_in, static_cast<hipStream_t>(producer_stream)));
   BE_HIP(hipStreamWaitEvent(ex->side, ex->ev_in, 0));
+  if (ex->released[slot]) {
+    BE_HIP(hipStreamWaitEvent(ex->side, ex->ev_free[slot], 0));
+    ex->released[slot] = false;
+  }
   const int64_t lo = (int64_t)ex->rank * ex->words_per_rank * 32;
   int64_t n_local = ex->n_pre - lo;
   n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
@@ -216,6 +248,18 @@ int be_exchange_wait(void* exchange, int slot, const uint32_t** full_bits_out, b
   return BE_OK;
 }
 
+// The consumer has queued its last read of the slot's buffer on `consumer_stream`: the next be_exchange_post into that slot
+// waits for it.  Only needed when the consumer's stream is not the stream passed to be_exchange_post as producer_stream.
+int be_exchange_release(void* exchange, int slot, be_stream_t consumer_stream) {
+  BE_REQUIRE(exchange, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(slot == 0 || slot == 1, BE_ERR_INVALID, "slot must be 0 or 1");
+  Exchange* ex = static_cast<Exchange*>(exchange);
+  BE_REQUIRE(ex->side != nullptr, BE_ERR_INVALID, "nothing was posted");
+  BE_HIP(hipEventRecord(ex->ev_free[slot], static_cast<hipStream_t>(consumer_stream)));
+  ex->released[slot] = true;
+  return BE_OK;
+}
+
 int be_exchange_destroy(void* exchange) {
   if (!exchange) return BE_OK;
   Exchange* ex = static_cast<Exchange*>(exchange);
@@ -224,6 +268,7 @@ int be_exchange_destroy(void* exchange) {
     (void)hipStreamSynchronize(ex->side);
     for (int i = 0; i < 2; ++i) {
       if (ex->ev_done[i]) (void)hipEventDestroy(ex->ev_done[i]);
+      if (ex->ev_free[i]) (void)hipEventDestroy(ex->ev_free[i]);
       if (ex->post_local[i]) (void)hipFree(ex->post_local[i]);
       if (ex->post_full[i]) (void)hipFree(ex->post_full[i]);
     }

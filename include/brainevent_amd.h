@@ -134,9 +134,15 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
                                be_stream_t stream);
 /* pipelined form (synaptic delays >= 2 steps): post step t + 1's exchange on the library's own stream — it waits for what
  * producer_stream has queued so far, i.e. the spikes — then scatter step t; wait makes consumer_stream wait for the posted
- * slot (0 / 1, alternate them) and returns its device buffer, valid until that slot is posted again. */
+ * slot (0 / 1, alternate them) and returns its device buffer, valid until that slot is posted again.
+ * Slot reuse: the gather into a slot must not start before the consumer's last read of the slot's previous contents.  When
+ * consumer_stream IS producer_stream (one stream issues the scatters and the posts) that order is implied: post waits for
+ * everything that stream has queued.  A consumer on another stream calls be_exchange_release(ex, slot, consumer_stream)
+ * after queueing its last read of the slot; the next post into the slot then waits for that point too.
+ * A failed be_exchange_post (stream / event / buffer creation) leaves the handle usable: the next call starts over. */
 int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream);
 int be_exchange_wait(void* exchange, int slot, const uint32_t** full_bits_out, be_stream_t consumer_stream);
+int be_exchange_release(void* exchange, int slot, be_stream_t consumer_stream);
 int be_exchange_destroy(void* exchange);
 
 /* ------------------------------------------------------------------------------------------------
