@@ -615,8 +615,8 @@ int densemm_nt_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
 //   (row stride 576 B = 144 dwords = 16 mod 64 banks; the two 16-column groups of a half-wave sit 8 banks apart).
 //   Workgroup = 4 waves = 256 columns x one K range; each wave owns 64 columns (two 32x32 accumulators).
 //   K is split over gridDim.y parts; f32 partials are reduced in fixed order.
-// NOTE: 0 * inf = NaN inside an MFMA, so a non-finite weight in an active row reaches every batch row;
-//       the vector path (which only ever adds selected rows) is used when that matters (n_batch < 8).
+// NOTE: 0 * inf = NaN inside an MFMA, so a non-finite weight in an active row reaches every batch row of its tile;
+//       such outputs are found by their non-finite value and redone by selection (be_nonfinite, k_mfma_reduce, nt_repair_rows).
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 be_v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 be_v8bf __attribute__((ext_vector_type(8)));
@@ -647,6 +647,42 @@ constexpr int kMfmaChunk = 64;   // K-steps whose row ids / masks are staged in 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. every global
 // load in flight — which would serialise the register ring of the MFMA kernel to one HBM round trip per step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- non-finite weights.  Inside an MFMA 0 * inf = NaN, so an inf / NaN weight reaches every batch row of its tile,
+// where the reference (brainevent/_dense/binary.py:589-632) only ever ADDS the rows a batch row selects.  Finite weights
+// cannot produce a non-finite f32 sum here except by a genuine overflow, so a non-finite result marks the outputs to
+// redo: the kernels below recompute exactly those outputs by selection (no products), whatever it costs — the case is rare.
+__device__ __forceinline__ bool be_nonfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
+
+// W @ S.T: the outputs of weight row `row` for the nc batch columns of this pass, by the whole wave
+template <typename W>
+__device__ __forceinline__ void nt_repair_row(const W* __restrict__ weights, int64_t m, int64_t k, int64_t row,
+                                              const uint32_t* __restrict__ mask, W* __restrict__ out_bm, int nc, int b0, int lane) {
+  for (int b8 = 0; b8 < nc; b8 += 8) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t kk = lane; kk < k; kk += 64) {
+      const float w = (float)WTraits<W>::load(weights, row * k + kk);
+      const uint32_t mk = mask[kk] >> b8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((mk >> j) & 1u) a[j] += w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = wave_sum(a[j]);
+      if (lane == 0 && b8 + j < nc) WTraits<W>::store(out_bm, (int64_t)(b0 + b8 + j) * m + row, t);
+    }
+  }
+}
+template <typename W>
+__device__ __forceinline__ void nt_repair_rows(const W* __restrict__ weights, int64_t m, int64_t k, int64_t m0, uint32_t rows_bad,
+                                               const uint32_t* __restrict__ mask, W* __restrict__ out_bm, int nc, int b0, int lane) {
+  while (rows_bad) {                     // (wave-uniform)
+    const int rr = __ffs(rows_bad) - 1;
+    rows_bad &= rows_bad - 1;
+    if (m0 + rr < m) nt_repair_row<W>(weights, m, k, m0 + rr, mask, out_bm, nc, b0, lane);
+  }
+}
 
 template <typename W>
 __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weights, int64_t n,
@@ -837,13 +873,16 @@ __global__ void __launch_bounds__(256) k_densemm_nt_mfma(const W* __restrict__ w
   }
   // C layout: col (batch) = lane & 31, row (weight row) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int b = lane & 31;
-  if (b < nc) {
+  uint32_t rows_bad = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[r]);
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (b < nc && i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[r]);
+    const uint64_t bad = __ballot(b < nc && be_nonfinite(acc[r]));
+    if (bad & 0xffffffffull) rows_bad |= 1u << ((r & 3) + 8 * (r >> 2));
+    if (bad >> 32) rows_bad |= 1u << ((r & 3) + 8 * (r >> 2) + 4);
   }
+  if (rows_bad) nt_repair_rows<W>(weights, m, k, m0, rows_bad, mask, out_bm, nc, b0, lane);
 }
 
 // The same product on v_mfma_f32_16x16x32_{f16,bf16}: an A fragment is 16 weight rows x 32 k, lane (row i = lane % 16,
@@ -919,19 +958,23 @@ __global__ void __launch_bounds__(256) k_densemm_nt_mfma16(const W* __restrict__
     }
   }
   // D layout of a 16x16 tile: column (batch) = lane % 16, rows 4 * (lane / 16) + reg
+  uint32_t rows_bad = 0;
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg) {
       const int b = i_lane + 16 * cg;
-      if (b < nc) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t i = m0 + 16 * rg + 4 * kb + r;
-          if (i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[rg][cg][r]);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = m0 + 16 * rg + 4 * kb + r;
+        if (b < nc && i < m) WTraits<W>::store(out_bm, (int64_t)(b0 + b) * m + i, acc[rg][cg][r]);
+        const uint64_t bad = __ballot(b < nc && be_nonfinite(acc[rg][cg][r]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((bad >> (16 * q)) & 0xffffull) rows_bad |= 1u << (16 * rg + 4 * q + r);
       }
     }
+  if (rows_bad) nt_repair_rows<W>(weights, m, k, m0, rows_bad, mask, out_bm, nc, b0, lane);
 }
 
 // The same kernel for f32 weights: v_mfma_f32_32x32x2_f32 (M = 32 weight rows, N = 32 batch rows, K = 2 per instruction).
@@ -988,13 +1031,16 @@ __global__ void __launch_bounds__(256) k_densemm_nt_mfma_f32(const float* __rest
   }
   // C layout: col (batch) = lane & 31, row (weight row) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int b = lane & 31;
-  if (b < nc) {
+  uint32_t rows_bad = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (i < m) out_bm[(int64_t)(b0 + b) * m + i] = acc[r];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (b < nc && i < m) out_bm[(int64_t)(b0 + b) * m + i] = acc[r];
+    const uint64_t bad = __ballot(b < nc && be_nonfinite(acc[r]));
+    if (bad & 0xffffffffull) rows_bad |= 1u << ((r & 3) + 8 * (r >> 2));
+    if (bad >> 32) rows_bad |= 1u << ((r & 3) + 8 * (r >> 2) + 4);
   }
+  if (rows_bad) nt_repair_rows<float>(weights, m, k, m0, rows_bad, mask, out_bm, nc, b0, lane);
 }
 
 // transpose=True for f32 weights on v_mfma_f32_32x32x2_f32: M = 32 batch rows (A = the 0/1 spike tile), N = 32 weight columns,
@@ -1073,18 +1119,41 @@ __global__ void __launch_bounds__(256) k_densemm_t_mfma_f32(const float* __restr
 
 template <typename W>
 __global__ void __launch_bounds__(256) k_mfma_reduce(const float* __restrict__ partial, int parts, int64_t part_stride,
-                                                     int64_t total, W* __restrict__ out) {
+                                                     int64_t total, W* __restrict__ out, const W* __restrict__ weights, int64_t n,
+                                                     const uint32_t* __restrict__ mask, const uint32_t* __restrict__ ulist,
+                                                     const uint32_t* __restrict__ ucount) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int lane = threadIdx.x & 63;
+  // (whole waves stay in the loop: a non-finite sum is redone by its wave together)
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < total; base += stride) {
+    const int64_t i = base + lane;
+    const bool in = i < total;
+    const int64_t ii = in ? i : total - 1;
     float s = 0.f;
     for (int p0 = 0; p0 < parts; p0 += 8) {      // eight parts' loads in flight; the sum keeps the order of the parts
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(p0 + u < parts ? p0 + u : parts - 1) * part_stride + i];
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(p0 + u < parts ? p0 + u : parts - 1) * part_stride + ii];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += p0 + u < parts ? v[u] : 0.f;
     }
-    WTraits<W>::store(out, i, s);
+    uint64_t bad = __ballot(in && be_nonfinite(s));
+    while (bad) {                                  // (rare: see be_nonfinite) out[b, c] = sum of the rows batch row b selects
+      const int src = __ffsll((unsigned long long)bad) - 1;
+      bad &= bad - 1;
+      const int64_t e = base + src;
+      const int64_t b = e / n, c = e - b * n;
+      const uint32_t n_union = ucount[0];
+      float a = 0.f;
+      for (uint32_t p = (uint32_t)lane; p < n_union; p += 64) {
+        const uint32_t r = ulist[p] & 0x0fffffffu;
+        if ((mask[r] >> b) & 1u) a += (float)WTraits<W>::load(weights, (int64_t)r * n + c);
+      }
+      a = wave_sum(a);
+      const float fixed = __shfl(a, 0, 64);
+      if (lane == src) s = fixed;
+    }
+    if (in) WTraits<W>::store(out, i, s);
   }
 }
 
@@ -1135,7 +1204,7 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
                          n, d.mask, ulist, d.count + kMaxGroups, partial);
     BE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mfma_reduce<W>, dim3(grid_cap((int64_t)nc * n, 256, 2048)), dim3(256), 0, st, partial, parts,
-                       (int64_t)32 * n, (int64_t)nc * n, out_bm + b0 * n);
+                       (int64_t)32 * n, (int64_t)nc * n, out_bm + b0 * n, weights, n, d.mask, ulist, d.count + kMaxGroups);
     BE_LAUNCH_CHECK();
   }
   be_prof_end(prof, st);

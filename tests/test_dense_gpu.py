@@ -239,3 +239,50 @@ def test_batched_no_transpose_with_a_short_contraction(be, k, dtype):
         tol = 1e-5 if dtype == torch.float32 else 2e-2
         assert torch.isfinite(got).all()
         assert float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16, torch.float32])
+def test_mfma_paths_add_only_selected_rows_when_weights_are_not_finite(be, oracle, dtype):
+    """The reference's dense loops only ever ADD the weight rows (columns) a batch row selects
+    (brainevent/_dense/binary.py:589-632): an inf / NaN weight reaches the batch rows that have a spike on it and no other.
+    Inside an MFMA 0 * inf = NaN would reach the whole tile; the library redoes such outputs by selection.  One inf and one
+    NaN in a weight row that is active in ONE batch row of 32, both directions, shapes that take the MFMA kernels."""
+    rng = np.random.default_rng(77)
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 2e-2}[dtype]
+    nb, hot = 32, 5                                    # batch rows; the one that selects the poisoned row / column
+
+    def check(got, ref):
+        got = got.float().cpu().numpy().astype(np.float64)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), 'NaN where the reference has none (or the reverse)'
+        assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref))
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=tol, atol=tol * np.abs(ref[fin]).max())
+        assert (~fin).sum() == 2 and fin[:, [b for b in range(nb) if b != hot]].all()
+
+    # transpose=True: out[n, b] = sum over rows k active in S[k, b] of W[k, n]       (S @ W, union rows, MFMA from 8 batch rows on)
+    k, n = 640, 520
+    Wn = rng.normal(0, 1, (k, n))
+    r0 = 123
+    Wn[r0, 17], Wn[r0, 300] = np.inf, np.nan
+    W = torch.tensor(Wn, dtype=dtype, device='cuda')
+    S = rng.random((k, nb)) < 0.3
+    S[r0, :] = False
+    S[r0, hot] = True
+    got = be.binary_densemm(W, torch.tensor(S, device='cuda'), transpose=True)
+    with np.errstate(invalid='ignore'):
+        ref = oracle.binary_densemm(W.double().cpu().numpy(), S, True)
+    check(got, ref)
+
+    # transpose=False: out[m, b] = sum over columns k active in S[k, b] of W[m, k]    (W @ S.T, MFMA from 4096 weight rows on)
+    m, k = 4100, 264
+    Wn = rng.normal(0, 1, (m, k))
+    c0 = 200
+    Wn[9, c0], Wn[4099, c0] = -np.inf, np.nan
+    W = torch.tensor(Wn, dtype=dtype, device='cuda')
+    S = rng.random((k, nb)) < 0.3
+    S[c0, :] = False
+    S[c0, hot] = True
+    got = be.binary_densemm(W, torch.tensor(S, device='cuda'), transpose=False)
+    with np.errstate(invalid='ignore'):
+        ref = oracle.binary_densemm(W.double().cpu().numpy(), S, False)
+    check(got, ref)
