@@ -302,9 +302,18 @@ def run_jitc(args, dev, g):
         cfg['shard'] = f'walk classes of rank 0 of {args.jit_shard} (no stored state; outputs of the ranks are disjoint)'
     roof = None
     if kern_ms:
-        # no stored matrix: HBM is not the bound; report the bandwidth a stored CSR would have needed (8 B/update)
-        roof = {'bound': 'valu+lds (no HBM matrix traffic)', 'achieved': None, 'peak': None, 'unit': 'GB/s', 'frac': None,
-                'traffic': None, 'kernel_ms': round(kern_ms, 5),
+        # No stored matrix: HBM is not the bound, the walk's vector ALU is.  Issue slots per generated edge, from the ISA of the
+        # inner loops (be_jitc.hip): xorshift32 6 + v_mul_hi_u32 (quarter rate: 4 slots) + address / advance / compare 3 = 13 for the
+        # scatter walk; the gather walk adds the LDS bit test and the count (2 + 2).  Peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
+        slots = 17 if args.jit_gather else 13
+        edges = (n * n * prob) if args.jit_gather else upd
+        peak = 256 * 4 * 16 * 2.4e9 / 1e12
+        ach = edges * slots / (kern_ms * 1e-3) / 1e12
+        roof = {'bound': 'valu', 'achieved': round(ach, 2), 'peak': round(peak, 2), 'unit': 'T lane-ops/s', 'frac': round(ach / peak, 4),
+                'traffic': None, 'kernel': 'k_jit_mv_gather' if args.jit_gather else 'k_jit_mv_scatter', 'kernel_ms': round(kern_ms, 5),
+                'valu_issue_slots_per_edge': slots, 'edges_per_launch': edges,
+                'basis': 'generated edges x vector-ALU issue slots per edge of the walk loop (ISA count); start-up code of a walk '
+                         '(lr_init + stationary start) and idle lanes of walks of unequal length are what the fraction leaves out',
                 'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
     return _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
 

@@ -218,11 +218,23 @@ class ScatterPlan:
         return self.seg.numel() * 4 + self.blob.numel()
 
     def workspace(self, parts: int, n_batch: int = 1) -> torch.Tensor:
-        key = (parts, n_batch)
+        # with room for the pre-gathered segment table only when this plan's blocks are short enough for the step to use it
+        # (up to 8 GiB at 100 slices x 10M rows); if that does not fit the device, the smaller workspace does: the step
+        # then gathers from the plan's own table
+        f = fn('be_binary_csrmm_t_plan_workspace_bytes_for', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int])
+        args = (self.m, self.k, n_batch, self.slice_shift, self.slice_width, parts, int(self.homo))
+        need, base = f(*args, int(self.block_hint)), f(*args, 0)
+        key = (parts, n_batch, need > base)
         ws = self._ws.get(key)
         if ws is None:
-            f = fn('be_binary_csrmm_t_plan_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int])
-            ws = A.workspace(f(self.m, self.k, n_batch, self.slice_shift, self.slice_width, parts, int(self.homo)))
+            oom = getattr(torch, 'OutOfMemoryError', getattr(torch.cuda, 'OutOfMemoryError', RuntimeError))
+            try:
+                ws = A.workspace(need)
+            except oom:
+                if need == base:
+                    raise
+                torch.cuda.empty_cache()
+                ws = A.workspace(base)
             ws[:4 * max(n_batch, 64)].zero_()   # spike counters: zero on entry, re-armed by every call
             # never evicted: a captured HIP graph keeps the raw pointer of the workspace its launches were recorded with,
             # so a workspace that has been handed out must outlive every later call with another (parts, n_batch)

@@ -82,6 +82,20 @@ hipError_t be_allow_lds(const void* kernel, int bytes) {
   return e;
 }
 
+// static LDS bytes of a kernel (hipFuncGetAttributes once per kernel; -1 on error).  Kernels that address their dynamic LDS
+// from address 0 (spike_mask AT0 in be_csr.hip) are only correct while this is 0.
+int be_static_lds_bytes(const void* kernel) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& k : seen)
+    if (k.first == kernel) return k.second;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return -1;
+  seen.emplace_back(kernel, (int)fa.sharedSizeBytes);
+  return (int)fa.sharedSizeBytes;
+}
+
 hipError_t be_fill_async(void* p, int byte_value, size_t bytes, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
   size_t blocks = (bytes / 16 + 255) / 256;

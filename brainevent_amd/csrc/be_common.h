@@ -23,6 +23,8 @@ void be_set_error(const std::string& msg);
 hipError_t be_fill_async(void* p, int byte_value, size_t bytes, hipStream_t st);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): the call costs host time on every launch
 hipError_t be_allow_lds(const void* kernel, int bytes);
+// static LDS bytes of a kernel, cached per kernel (-1: the query failed)
+int be_static_lds_bytes(const void* kernel);
 // optional HIP-event timing of an op's dominant kernel (be_api.hip); slot -1 = profiling off
 int be_prof_begin(hipStream_t st);
 void be_prof_end(int slot, hipStream_t st);

@@ -1091,34 +1091,34 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     const int prof = be_prof_begin(st);
     // bitmap (rounded to 16 bytes) + the 16 waves' result rows
     const size_t vlds = (size_t)((((in_lds ? n_words : n_cwords) + 3) & ~(int64_t)3) * 4) + 16 * 64 * sizeof(typename WTraits<W>::acc);
+    // the kernels address the bitmap from LDS address 0 (spike_mask AT0): true while the very instantiation that is launched
+    // declares no static LDS (checked once per kernel; a static __shared__ added later fails here, loudly, instead of
+    // testing the wrong bits)
+#define BE_NT_VEC_AT0(KERN)                                                                                                 \
+    do {                                                                                                                    \
+      if (be_static_lds_bytes(reinterpret_cast<const void*>(KERN)) != 0) {                                                  \
+        be_set_error("k_csrmv_nt_vec: static LDS in front of the bitmap (spike_mask AT0 addresses it from 0)");             \
+        return BE_ERR_UNSUPPORTED;                                                                                          \
+      }                                                                                                                     \
+    } while (0)
 #define BE_NT_VEC(LPR_)                                                                                                     \
     do {                                                                                                                    \
       const int grid = grid_for(m, 16 * 64, nb >= 8 ? 256 : 512);                                                   \
       if (in_lds) {                                                                                                          \
         auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, true>;                                                                    \
+        BE_NT_VEC_AT0(kern);                                                                                                 \
         BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)vlds));                                               \
         hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), vlds, st, static_cast<const W*>(weights), indices, rp, \
                            bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       } else {                                                                                                               \
         auto kern = k_csrmv_nt_vec<W, HOMO, LPR_, false>;                                                                   \
+        BE_NT_VEC_AT0(kern);                                                                                                 \
         BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)vlds));                                               \
         hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(1024), vlds, st, static_cast<const W*>(weights), indices, rp, \
                            bits, n_words, static_cast<W*>(out), m, coarse, n_cwords, g_shift);                              \
       }                                                                                                                      \
     } while (0)
     // two passes of a row (8 x LPR entries) should hold nearly every row: LPR by the average length
-    {   // the kernels address the bitmap from LDS address 0 (spike_mask AT0): true while they declare no static LDS
-      static bool checked = false;
-      if (!checked) {
-        hipFuncAttributes fa;
-        BE_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_csrmv_nt_vec<W, HOMO, 2, true>)));
-        if (fa.sharedSizeBytes != 0) {
-          be_set_error("k_csrmv_nt_vec: static LDS in front of the bitmap");
-          return BE_ERR_UNSUPPORTED;
-        }
-        checked = true;
-      }
-    }
     // — rows of one known length (no indptr: FixedNumConn) have no long tail to provide for: 8 / 16 lanes up to exactly
     // two passes (64 / 128 entries; measured +5 % at 48 ... 64 per row).  Fewer lanes with both passes in use lose
     // (12 ... 32 per row on 2 / 4 lanes instead of 4 / 8: 0.30-0.33 -> 0.36 ms at 2e8 weighted entries).
@@ -1129,6 +1129,7 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
     else if (avg <= (fixed ? 128 : 100)) BE_NT_VEC(16);
     else BE_NT_VEC(32);
 #undef BE_NT_VEC
+#undef BE_NT_VEC_AT0
     be_prof_end(prof, st);
     BE_LAUNCH_CHECK();
     return BE_OK;

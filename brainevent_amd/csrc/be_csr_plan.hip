@@ -1743,6 +1743,12 @@ static inline int64_t plan_dense_seg_bytes(int64_t m, int64_t n_slices, int64_t 
   return (n_batch == 1 && n_slices >= pregather_min_slices() && bytes <= (8ll << 30)) ? be_align_up(bytes, 256) : 0;
 }
 
+static inline int pregather_max_block() {
+  static const int v = [] { const char* e = getenv("BE_PLAN_PREGATHER_MAX"); return e ? atoi(e) : kPreGatherMaxBlock; }();
+  return v;
+}
+
+// the workspace every form of the planned step needs: counters, active lists, partial sums
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
                                                int parts, int homo) {
   const int64_t n_slices = n_slices_of(k, slice_shift, slice_width);
@@ -1751,7 +1757,16 @@ int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_b
   // rounding any layout applies to the width (h8 / homo u16: up to the next multiple of 4)
   const int64_t task = std::max<int64_t>(1ll << slice_shift, (width_of(slice_shift, slice_width) + 3) & ~3ll);
   return counts_bytes(n_batch) + n_batch * plan_active_stride(m) * 4 +
-         be_align_up(n_batch * n_slices * parts * task * acc_bytes, 256) + plan_dense_seg_bytes(m, n_slices, n_batch);
+         be_align_up(n_batch * n_slices * parts * task * acc_bytes, 256);
+}
+// ... plus room for the pre-gathered segment table when the step would use it: single vector, >= 40 slices, short blocks
+// (block_hint = the plan's average items per block, as passed to the step).  A step that finds only the smaller workspace
+// runs without the table — correct, slower for short blocks.
+int64_t be_binary_csrmm_t_plan_workspace_bytes_for(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
+                                                   int parts, int homo, int block_hint) {
+  const int64_t base = be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo);
+  const bool pre = block_hint > 0 && block_hint <= pregather_max_block();
+  return base + (pre ? plan_dense_seg_bytes(m, n_slices_of(k, slice_shift, slice_width), n_batch) : 0);
 }
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo) {
   return be_binary_csrmm_t_plan_workspace_bytes(m, k, 1, slice_shift, slice_width, parts, homo);
@@ -1825,9 +1840,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
   }
   // short blocks: the segment-table gather dominates the step -> pre-gather it (k_gather_seg, FUSED = 3) instead of fusing
   // the compaction (a workgroup that lists its own rows would have to gather its table entries itself)
-  static const int pre_max_block = [] { const char* e = getenv("BE_PLAN_PREGATHER_MAX"); return e ? atoi(e) : kPreGatherMaxBlock; }();
   const int64_t dense_bytes = plan_dense_seg_bytes(m, n_slices, n_batch);
-  if (dense_bytes > 0 && block_hint > 0 && block_hint <= pre_max_block) fused = 3;
+  if (dense_bytes > 0 && block_hint > 0 && block_hint <= pregather_max_block() &&
+      workspace_bytes >= be_binary_csrmm_t_plan_workspace_bytes(m, k, n_batch, slice_shift, slice_width, parts, homo) + dense_bytes)
+    fused = 3;           // (only with a workspace sized by ..._workspace_bytes_for: the table sits behind the partial sums)
   const uint32_t lds_cap = (fused == 1 || fused == 2) ? (uint32_t)std::min<size_t>(lds_room / 4, 32768) : 0u;
   const uint32_t list_off = (uint32_t)lds;
   const size_t lds_dyn = lds + (size_t)lds_cap * 4;

@@ -234,6 +234,11 @@ __global__ void __launch_bounds__(1024) k_jit_mv_scatter(JitP p, const uint32_t*
   if (q_begin < q_end) {
     const uint32_t qb = (uint32_t)q_begin, qe = (uint32_t)q_end;      // Q < 2^27: 32-bit walk arithmetic
     const uint32_t j0 = (uint32_t)(cs + l);
+    // A wave starts 64 walks together and waits for the longest (31 +- 6 edges per walk at C3: ~70 % of the lanes busy).
+    // Letting idle lanes take their next row early was measured in round 3 and is slower, whatever the threshold: the
+    // start-up code (lr_init + the rejection loop of the stationary start, ~7 rounds until the last of the refilling lanes
+    // accepts) then runs once per 8 ... 32 walks instead of once per 64 — kernel 103 us as it is, 119 / 150 / 177 / 219 us
+    // refilling at 64 (= never early) / 32 / 16 / 8 idle lanes, with the next row id prefetched (tools/ab_c3.sh).
     for (uint64_t a = (uint64_t)part * blockDim.x + threadIdx.x; a < n_active; a += (uint64_t)parts * blockDim.x) {
       const uint32_t row = active[a];
       uint32_t state = lr_init(p.seed, row, chunk, l);

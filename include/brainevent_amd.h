@@ -263,6 +263,11 @@ int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indi
 int64_t be_binary_csrmv_t_plan_workspace_bytes(int64_t m, int64_t k, int slice_shift, int slice_width, int parts, int homo);
 int64_t be_binary_csrmm_t_plan_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
                                                int parts, int homo);
+/* the same plus room for the pre-gathered segment table, which the single-vector step uses for plans of >= 40 slices and short
+ * blocks (block_hint <= 64, the value passed to the step): without it the step gathers from the plan's own table (correct,
+ * slower there); with a block_hint that does not qualify the two sizes are equal */
+int64_t be_binary_csrmm_t_plan_workspace_bytes_for(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int slice_width,
+                                                   int parts, int homo, int block_hint);
 int be_binary_csrmv_t_plan(const void* weights, int homo, int wdtype, const void* blob, const void* seg,
                            const void* spikes, int spike_dtype, void* out, int64_t m, int64_t k, int slice_shift,
                            int slice_width, int layout, int block_hint, int parts, int scale_exp, void* workspace,
