@@ -480,8 +480,12 @@ class BinnedScatter:
         self.homo = weights.numel() == 1
         if slice_shift is None and os.environ.get('BE_BIN_SHIFT'):      # A/B runs
             slice_shift = int(os.environ['BE_BIN_SHIFT'])
-        self.slice_shift = self.default_shift(k, self.homo) if slice_shift is None else int(slice_shift)
-        self.n_slices = (self.k + (1 << self.slice_shift) - 1) >> self.slice_shift
+        # bins at most 2^slice_shift columns wide; the default leaves the width to the library: as wide as the LDS
+        # accumulators of pass C allow, in a multiple of 256 bins (be_binned_bins)
+        self.slice_shift = 16 if slice_shift is None else int(slice_shift)
+        self.n_slices = int(fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(self.k, self.slice_shift, int(self.homo)))
+        if self.n_slices <= 0:
+            raise ValueError(f"the binned route does not serve {self.k} outputs at slice_shift={self.slice_shift}")
         expect = max_active_fraction * nnz / max(self.n_slices, 1)
         self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
         self.scale_exp = 0
@@ -505,20 +509,10 @@ class BinnedScatter:
         return (not self.homo) and self.stamp != weights_stamp(weights)
 
     @staticmethod
-    def default_shift(k: int, homo: bool) -> int:
-        """Slice width of the bins: as wide as the LDS accumulators of pass C allow for many outputs, narrower — about 256 to
-        512 bins — otherwise: one workgroup per bin in pass C (plain stores, bitwise reproducible) and less contention on the
-        bins' counters in pass B (one post slice of an 8-way cut of C4, 1.25M outputs, us per step counted / weighted:
-        2^14-wide bins 117 / 135, 2^12 97 / 132, 2^11 164 / 131)."""
-        return max(8, min(ScatterPlan.default_shift(k, homo), (max(int(k), 1) // 256).bit_length() - 1))
-
-    @staticmethod
     def applicable(weights: torch.Tensor, k: int) -> bool:
         if weights.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             return False                  # f64: the bins carry f32 weights (per-entry f64 weights take the planned route)
-        homo = weights.numel() == 1
-        shift = BinnedScatter.default_shift(k, homo)
-        return ((k + (1 << shift) - 1) >> shift) <= fn('be_binned_max_slices', c_int, [c_int])(int(homo))
+        return fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(int(k), 16, int(weights.numel() == 1)) > 0
 
 
 def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes, sd, out) -> None:

@@ -22,11 +22,14 @@ namespace {
 //                              like the planned route, then writes its slice of the output.
 //   A region that overflows its capacity never corrupts anything: the block is delivered with global float
 //   atomics instead (slow path, still correct).
-// Block layout in LDS and in memory: [f32 weight x CAP][u16 local column x CAP] (one weight: [u16 x CAP]).
+// Block layout in LDS and in memory: CAP / 2 units of [f32 w0][f32 w1][u16 c0 | u16 c1] (one weight: [u16 column x CAP]).
 // HBM traffic per update (hetero): 8 B read (pass B) + 6 B write + 6 B read = 20 B  vs  8 B algorithmic.
 // =================================================================================================
 #ifndef BE_BIN_U
 #define BE_BIN_U 4       // groups of 8 binned entries in flight per thread of pass C
+#endif
+#ifndef BE_FLUSH_PJ
+#define BE_FLUSH_PJ 1    // (2 / 4 passes per LDS round trip measured slower: 418 -> 455 / 464 us at C4, registers)
 #endif
 #ifndef BE_STREAM_THREADS
 #define BE_STREAM_THREADS 1024
@@ -42,21 +45,21 @@ constexpr uint32_t kSpinLimit = 1u << 14;   // a lane that cannot get a slot for
 template <bool HOMO, int CAP> struct BinBlock {
   static constexpr int bytes = CAP * (HOMO ? 2 : 6);
   static constexpr int dwords = bytes / 4;
-  static constexpr int idx_dw = HOMO ? 0 : CAP;        // dword offset of the u16 columns inside a block
+  // weighted entries sit in UNITS of 12 bytes, two entries each: [f32 w0][f32 w1][u16 c0 | u16 c1] — pass C reads the units of a
+  // region as one contiguous stream, a unit per lane and load; one weight: [u16 column x CAP]
+  __device__ static __forceinline__ uint32_t w_dw(uint32_t s) { return 3u * (s >> 1) + (s & 1u); }                 // dword of entry s's weight
+  __device__ static __forceinline__ uint32_t col_hw(uint32_t s) { return HOMO ? s : 6u * (s >> 1) + 4u + (s & 1u); }   // halfword of its column
   static constexpr int groups = CAP / 8;               // groups of 8 entries (pass C: one per thread and round)
-  // a block leaves LDS in units of `vec` dwords (12 B: four weights or eight columns; one weight: 8 B, four columns);
-  // lane gl of the block's `lpf` lanes copies units gl, gl + lpf, ... (nv of them): every store instruction of the
-  // group writes one contiguous piece, and 64 / lpf blocks leave per pass
-  static constexpr int vec = HOMO ? 2 : 3;
-  static constexpr int units = dwords / vec;
-  static constexpr int nv = 1;                         // (4 units per lane, 2 lanes per block: 406 -> 456 us at C4, scattered 24-byte pieces)
-  static constexpr int lpf = units / nv;               // lanes per block in a flush pass (a power of two)
+  // a block leaves LDS 16 bytes per lane (ds_read_b128 + one aligned 16-byte store): `lpf` lanes per block, 64 / lpf blocks
+  // per pass (weighted blocks of 16 entries: 6 lanes, 10 blocks per pass)
+  static constexpr int lpf = bytes / 16;
 };
 
-// exact n / d for 32-bit n by multiply-high (Granlund-Montgomery, round-up method); d >= 1
+// exact n / d for 32-bit n by multiply-high (Granlund-Montgomery, round-up method); d >= 1.  A power of two is a shift (m == 0).
 struct DivU32 {
   uint32_t m, sh1, sh2;
   __device__ __forceinline__ uint32_t div(uint32_t n) const {
+    if (m == 0u) return n >> sh2;                  // (uniform)
     const uint32_t t = __umulhi(m, n);
     return (t + ((n - t) >> sh1)) >> sh2;
   }
@@ -65,6 +68,7 @@ static inline DivU32 make_div(uint32_t d) {
   uint32_t l = 0;
   while (l < 32 && (1ull << l) < d) ++l;
   DivU32 r;
+  if ((1ull << l) == d) { r.m = 0; r.sh1 = 0; r.sh2 = l; return r; }
   r.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
   r.sh1 = l < 1 ? l : 1;
   r.sh2 = l > 1 ? l - 1 : 0;
@@ -140,55 +144,63 @@ typedef float be_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <bool HOMO, int CB>
 __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, const uint32_t* wl, uint32_t n, uint32_t cap_blocks,
                                                   uint32_t* __restrict__ wg_regions, size_t bin_stride_dw, float* __restrict__ out,
-                                                  int slice_shift, float w0, int lane) {
+                                                  uint32_t width, float w0, int lane) {
   using B = BinBlock<HOMO, CB>;
-  constexpr int LPF = B::lpf, FPP = 64 / LPF, VEC = B::vec, NV = B::nv;
+  constexpr int LPF = B::lpf, FPP = 64 / LPF;
+  static_assert(B::bytes % 16 == 0 && LPF >= 1 && LPF <= 64, "blocks are copied 16 bytes per lane");
+  constexpr int PJ = BE_FLUSH_PJ;                           // passes whose list reads, block reads and stores each go out together
   const uint32_t g = (uint32_t)lane / LPF, gl = (uint32_t)lane % LPF;
-  for (uint32_t j0 = 0; j0 < n; j0 += FPP) {
-    const bool have = j0 + g < n;
-    const uint32_t slotid = wl[have ? j0 + g : 0u], q = wl[64u + (have ? j0 + g : 0u)];
-    const uint32_t* src = S.buf + (size_t)slotid * B::dwords + gl * VEC;
-    uint32_t v[NV][VEC];
+  for (uint32_t j0 = 0; j0 < n; j0 += PJ * FPP) {
+    bool have[PJ];
+    uint32_t slotid[PJ], q[PJ];
+    uint4 v[PJ];
 #pragma unroll
-    for (int k = 0; k < NV; ++k)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) v[k][i] = src[k * LPF * VEC + i];
-    uint64_t slow = __ballot(have && q >= cap_blocks);
-    while (slow) {                                  // (rare) the region is full: the block goes out through float atomics
-      const int sl = __ffsll((unsigned long long)slow) - 1;
-      slow &= slow - 1;
-      if ((sl % LPF) != 0) continue;
-      const uint32_t sid = rl(slotid, sl);
-      const uint32_t* blk = S.buf + (size_t)sid * B::dwords;
-      const uint16_t* bi = reinterpret_cast<const uint16_t*>(blk + B::idx_dw);
-      const float* bw = reinterpret_cast<const float*>(blk);
-      float* dst = out + ((int64_t)(sid >> 1) << slice_shift);
-      for (int j = lane; j < CB; j += 64) atomicAdd(dst + bi[j], HOMO ? w0 : bw[j]);
-      if (lane == 0) S.ovf[sid >> 1] = 1u;
+    for (int p = 0; p < PJ; ++p) {
+      const uint32_t j = j0 + (uint32_t)p * FPP + g;
+      have[p] = g < (uint32_t)FPP && j < n;
+      slotid[p] = wl[have[p] ? j : 0u];
+      q[p] = wl[64u + (have[p] ? j : 0u)];
     }
-    // LDS executes a wave's instructions in order: the block has been read before these stores hand the ring slot to
-    // block q + 2 (done first: an entry written after gen moves on must find the count at 0)
-    lds_fence();
-    if (have && gl == 0) __hip_atomic_store(&S.done[slotid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    lds_fence();
-    if (have && gl == 0) __hip_atomic_store(&S.gen[slotid], (q >> 1) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    lds_fence();
-#ifdef BE_DBG_NOSTORE
-    if (have && q == 0xfffffffu) {
-#else
-    if (have && q < cap_blocks) {
-#endif
-      uint32_t* dst = wg_regions + (size_t)(slotid >> 1) * bin_stride_dw + (size_t)q * B::dwords + gl * VEC;
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        if (VEC == 3) {
-          be_u32x3_a4 o; o.x = v[k][0]; o.y = v[k][1]; o.z = v[k][VEC > 2 ? 2 : 0];
-          *reinterpret_cast<be_u32x3_a4*>(dst + k * LPF * VEC) = o;
-        } else {
-          be_u32x2_a4 o; o.x = v[k][0]; o.y = v[k][1];
-          *reinterpret_cast<be_u32x2_a4*>(dst + k * LPF * VEC) = o;
-        }
+    for (int p = 0; p < PJ; ++p)
+      if (p == 0 || j0 + (uint32_t)p * FPP < n)       // (wave-uniform)
+        v[p] = *reinterpret_cast<const uint4*>(S.buf + (size_t)slotid[p] * B::dwords + gl * 4);
+#pragma unroll
+    for (int p = 0; p < PJ; ++p) {
+      if (p > 0 && j0 + (uint32_t)p * FPP >= n) break;
+      uint64_t slow = __ballot(have[p] && q[p] >= cap_blocks);
+      while (slow) {                                  // (rare) the region is full: the block goes out through float atomics
+        const int sl = __ffsll((unsigned long long)slow) - 1;
+        slow &= slow - 1;
+        if ((sl % LPF) != 0) continue;
+        const uint32_t sid = rl(slotid[p], sl);
+        const uint32_t* blk = S.buf + (size_t)sid * B::dwords;
+        const uint16_t* bi = reinterpret_cast<const uint16_t*>(blk);
+        const float* bw = reinterpret_cast<const float*>(blk);
+        float* dst = out + (int64_t)(sid >> 1) * width;
+        for (int j = lane; j < CB; j += 64) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
+        if (lane == 0) S.ovf[sid >> 1] = 1u;
       }
+    }
+    // LDS executes a wave's instructions in order: the blocks have been read before these stores hand their ring slots to
+    // the blocks two further on (done first: an entry written after gen moves on must find the count at 0)
+    lds_fence();
+#pragma unroll
+    for (int p = 0; p < PJ; ++p)
+      if (have[p] && gl == 0) __hip_atomic_store(&S.done[slotid[p]], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_fence();
+#pragma unroll
+    for (int p = 0; p < PJ; ++p)
+      if (have[p] && gl == 0) __hip_atomic_store(&S.gen[slotid[p]], (q[p] >> 1) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_fence();
+#pragma unroll
+    for (int p = 0; p < PJ; ++p) {
+#ifdef BE_DBG_NOSTORE
+      if (have[p] && q[p] == 0xfffffffu)
+#else
+      if (have[p] && q[p] < cap_blocks)
+#endif
+        *reinterpret_cast<uint4*>(wg_regions + (size_t)(slotid[p] >> 1) * bin_stride_dw + (size_t)q[p] * B::dwords + gl * 4) = v[p];
     }
   }
 }
@@ -199,7 +211,7 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
 // branches: a lane without an entry, or with one that has to wait, aims at counters and words of its own that nobody reads).
 template <bool HOMO, int CB, int NE>
 __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, const uint32_t (&col)[NE],
-                                               const float (&w)[HOMO ? 1 : NE], int slice_shift, uint32_t mask, int n_bins,
+                                               const float (&w)[HOMO ? 1 : NE], uint32_t width, DivU32 wdiv, int n_bins,
                                                uint32_t cap_blocks, uint32_t* wl, uint32_t* __restrict__ wg_regions,
                                                size_t bin_stride_dw, float* __restrict__ out, float w0, int lane, StreamProf& prof) {
   using B = BinBlock<HOMO, CB>;
@@ -210,12 +222,16 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
   uint32_t pend = 0;
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    const uint32_t b = col[u] >> slice_shift;
+    const uint32_t b = wdiv.div(col[u]);
     bin[u] = b < dummy_bin ? b : dummy_bin;
     pend |= (b < (uint32_t)n_bins ? 1u : 0u) << u;
   }
 #pragma unroll
+#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 4      // (ablation builds: timing only, the results are garbage)
+  for (int u = 0; u < NE; ++u) t[u] = (col[u] * 2654435761u) >> 8;
+#else
   for (int u = 0; u < NE; ++u) t[u] = atomicAdd(&S.tick[bin[u]], 1u);
+#endif
   __builtin_amdgcn_sched_barrier(0);
   uint32_t spins = 0;
   for (;;) {
@@ -230,25 +246,44 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
     uint32_t d[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
+#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 1
+      const bool ok = ((pend >> u) & 1u) && g[u] != 0xfffffff1u;
+#else
       const bool ok = ((pend >> u) & 1u) && g[u] == (t[u] >> (LOG_CB + 1));
+#endif
       wr |= (ok ? 1u : 0u) << u;
       uint32_t* blk = S.buf + (size_t)slotid[u] * B::dwords;
       const uint32_t s = t[u] & (uint32_t)(CB - 1);
-      uint16_t* pi = ok ? reinterpret_cast<uint16_t*>(blk + B::idx_dw) + s : reinterpret_cast<uint16_t*>(S.dummy + 64 + lane);
-      *pi = (uint16_t)(col[u] & mask);
+      uint16_t* pi = ok ? reinterpret_cast<uint16_t*>(blk) + B::col_hw(s) : reinterpret_cast<uint16_t*>(S.dummy + 64 + lane);
+#if !defined(BE_DBG_LEVEL) || BE_DBG_LEVEL < 3
+      *pi = (uint16_t)(col[u] - __umul24(bin[u], width));
+#else
+      if (pi == nullptr) *pi = 1;
+#endif
       if (!HOMO) {
-        float* pw = ok ? reinterpret_cast<float*>(blk) + s : reinterpret_cast<float*>(S.dummy + lane);
+        float* pw = ok ? reinterpret_cast<float*>(blk) + B::w_dw(s) : reinterpret_cast<float*>(S.dummy + lane);
+#if !defined(BE_DBG_LEVEL) || BE_DBG_LEVEL < 3
         *pw = w[HOMO ? 0 : u];
+#else
+        if (pw == nullptr) *pw = w[HOMO ? 0 : u];
+#endif
       }
     }
     lds_fence();
 #pragma unroll
+#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 2
+    for (int u = 0; u < NE; ++u) d[u] = (t[u] ^ col[u]) & 0xffffu ? 0u : (uint32_t)CB - 1u;
+#else
     for (int u = 0; u < NE; ++u) d[u] = atomicAdd(&S.done[(wr >> u) & 1u ? slotid[u] : 2u * (uint32_t)n_bins + (uint32_t)lane], 1u);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // the blocks these commits completed go on the wave's list (positions from the ballots)
     uint32_t flm = 0;
 #pragma unroll
     for (int u = 0; u < NE; ++u) flm |= (((wr >> u) & 1u) && d[u] == (uint32_t)CB - 1u ? 1u : 0u) << u;
+#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 1
+    if (flm != 0x12345u) flm = 0;
+#endif
     pend &= ~wr;
     prof.count(4);
     // (every completing lane copying its own block, 16 bytes per instruction and no list, measured slower: 406 -> 554 us at
@@ -274,7 +309,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
       }
       prof.count(5, nfl < 64u ? nfl : 64u);
       lds_fence();
-      stream_flush_list<HOMO, CB>(S, wl, nfl < 64u ? nfl : 64u, cap_blocks, wg_regions, bin_stride_dw, out, slice_shift, w0, lane);
+      stream_flush_list<HOMO, CB>(S, wl, nfl < 64u ? nfl : 64u, cap_blocks, wg_regions, bin_stride_dw, out, width, w0, lane);
     }
     if (__ballot(pend != 0) == 0) break;
     if (++spins > kSpinLimit) __builtin_trap();      // never seen: a protocol error ends in a launch failure, not in a hung device
@@ -289,7 +324,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
 template <typename W, bool HOMO, int CB>
 __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
                                                      const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
-                                                     int slice_shift, int n_bins, uint32_t cap_blocks,
+                                                     uint32_t width, DivU32 wdiv, int n_bins, uint32_t cap_blocks,
                                                      uint32_t* __restrict__ regions, uint32_t* __restrict__ dir,
                                                      float* __restrict__ out, DivU32 fixdiv) {
   using B = BinBlock<HOMO, CB>;
@@ -313,7 +348,6 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   __syncthreads();
 
   const uint32_t n_active = *n_active_p;
-  const uint32_t mask = (1u << slice_shift) - 1u;
   float w0 = 0.f;
   if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
   const bool fixed = rp.p == nullptr && rp.fixed > 0 && rp.fixed < (1ll << 26);
@@ -472,7 +506,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
 #ifdef BE_DBG_NOAPPEND
             if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
 #endif
-            stream_append<HOMO, CB, U * 4>(S, colA, wA, slice_shift, mask, n_bins, cap_blocks, wl, wg_regions, bin_stride_dw, out, w0,
+            stream_append<HOMO, CB, U * 4>(S, colA, wA, width, wdiv, n_bins, cap_blocks, wl, wg_regions, bin_stride_dw, out, w0,
                                            lane, prof);
           }
           prof.stamp(3);
@@ -499,10 +533,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
     uint32_t o = S.ovf[bin];
     if (d > 0 && blk >= cap_blocks) {          // a partly filled block of a full region: float atomics
       const uint32_t* bp = S.buf + (size_t)(bin * 2 + (blk & 1u)) * B::dwords;
-      const uint16_t* bi = reinterpret_cast<const uint16_t*>(bp + B::idx_dw);
+      const uint16_t* bi = reinterpret_cast<const uint16_t*>(bp);
       const float* bw = reinterpret_cast<const float*>(bp);
-      float* dst = out + ((int64_t)bin << slice_shift);
-      for (uint32_t j = 0; j < d; ++j) atomicAdd(dst + bi[j], HOMO ? w0 : bw[j]);
+      float* dst = out + (int64_t)bin * width;
+      for (uint32_t j = 0; j < d; ++j) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
       o = 1u;
     }
     const uint64_t room = (uint64_t)cap_blocks * CB;
@@ -520,7 +554,7 @@ __device__ __forceinline__ void bin_count8(uint32_t* acc, uint4 v) {
 
 template <bool HOMO, int CAP>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restrict__ regions, const uint32_t* __restrict__ dir,
-                                                         uint32_t cap_blocks, int slice_shift, int parts, int64_t k, float scale,
+                                                         uint32_t cap_blocks, int width, int map_cap, int parts, int64_t k, float scale,
                                                          double inv_scale, const void* __restrict__ w0p, int wdtype,
                                                          float* __restrict__ out) {
   using B = BinBlock<HOMO, CAP>;
@@ -528,7 +562,10 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   __shared__ uint32_t s_cnt[kStreamGrid], s_pre[kStreamGrid + 1], s_wtot[16];
-  const int S = 1 << slice_shift;
+  // block -> region of the bin, one byte per block, in the LDS the accumulators leave: a group then finds its region with one
+  // LDS read instead of an 8-step binary search over the prefix sums (bins of more than map_cap blocks search)
+  uint8_t* s_map = smem_raw + (((size_t)width * sizeof(acc_t) + 15) & ~(size_t)15);
+  const int S = width;
   const int bin = blockIdx.x / parts, part = blockIdx.x - bin * parts;
   const int tid = threadIdx.x;
   // the bin's directory: entries per region -> blocks per region -> prefix sums
@@ -549,63 +586,97 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   }
   if (NB == 0) return;                      // nothing was binned here (out already holds zeros / overflow adds)
   for (int i = tid; i < S; i += 1024) acc[i] = 0;
+  const bool mapped = NB <= (uint32_t)map_cap;
+  if (mapped && tid < kStreamGrid)
+    for (uint32_t bk = s_pre[tid]; bk < s_pre[tid + 1]; ++bk) s_map[bk] = (uint8_t)tid;
   __syncthreads();
-  // one flat loop over the groups of 8 entries of all regions, BE_BIN_U groups per thread and round with every load of the
-  // round issued before the first add
-  const uint32_t n8 = NB * (uint32_t)B::groups;
-  const uint32_t per = (n8 + parts - 1) / parts;
-  const uint32_t g_begin = part * per, g_end = g_begin + per < n8 ? g_begin + per : n8;
   const uint32_t* bin_base = regions + (size_t)bin * kStreamGrid * cap_blocks * B::dwords;
-  constexpr int U = BE_BIN_U;
-  for (uint32_t g0 = g_begin + tid; g0 < g_end; g0 += U * 1024) {
-    uint4 iv[U];
-    float4 wa[U], wb[U];
-    uint32_t nv[U];
+  if (HOMO) {
+    // one flat loop over the groups of 8 columns (16 bytes) of all regions, BE_BIN_U groups per thread and round with every
+    // load of the round issued before the first add
+    const uint32_t n8 = NB * (uint32_t)B::groups;
+    const uint32_t per = (n8 + parts - 1) / parts;
+    const uint32_t g_begin = part * per, g_end = g_begin + per < n8 ? g_begin + per : n8;
+    constexpr int U = BE_BIN_U;
+    for (uint32_t g0 = g_begin + tid; g0 < g_end; g0 += U * 1024) {
+      uint4 iv[U];
+      uint32_t nv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t g = g0 + (uint32_t)u * 1024u;
-      const bool in = g < g_end;
-      const uint32_t gg = in ? g : g_begin;
-      const uint32_t blk = gg / (uint32_t)B::groups, sub = gg - blk * (uint32_t)B::groups;
-      uint32_t r = 0;
+      for (int u = 0; u < U; ++u) {
+        const uint32_t g = g0 + (uint32_t)u * 1024u;
+        const bool in = g < g_end;
+        const uint32_t gg = in ? g : g_begin;
+        const uint32_t blk = gg / (uint32_t)B::groups, sub = gg - blk * (uint32_t)B::groups;
+        uint32_t r = 0;
+        if (mapped) {
+          r = s_map[blk];
+        } else {
 #pragma unroll
-      for (uint32_t s = kStreamGrid / 2; s > 0; s >>= 1)
-        if (s_pre[r + s] <= blk) r += s;
-      const uint32_t lb = blk - s_pre[r];
-      const uint32_t first = lb * (uint32_t)CAP + sub * 8u, c = s_cnt[r];
-      nv[u] = !in || c <= first ? 0u : (c - first < 8u ? c - first : 8u);
-      const uint32_t* bp = bin_base + ((size_t)r * cap_blocks + lb) * B::dwords;
-      iv[u] = *reinterpret_cast<const uint4*>(bp + B::idx_dw + sub * 4u);
-      if (!HOMO) {
-        wa[u] = *reinterpret_cast<const float4*>(bp + sub * 8u);
-        wb[u] = *reinterpret_cast<const float4*>(bp + sub * 8u + 4u);
+          for (uint32_t s = kStreamGrid / 2; s > 0; s >>= 1)
+            if (s_pre[r + s] <= blk) r += s;
+        }
+        const uint32_t lb = blk - s_pre[r];
+        const uint32_t first = lb * (uint32_t)CAP + sub * 8u, c = s_cnt[r];
+        nv[u] = !in || c <= first ? 0u : (c - first < 8u ? c - first : 8u);
+        iv[u] = *reinterpret_cast<const uint4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::dwords + sub * 4u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (nv[u] == 8u) {
+          bin_count8(reinterpret_cast<uint32_t*>(acc), iv[u]);
+        } else if (nv[u]) {                  // the last group of a region
+          const uint32_t ix[4] = {iv[u].x, iv[u].y, iv[u].z, iv[u].w};
+#pragma unroll
+          for (uint32_t j = 0; j < 8; ++j)
+            if (j < nv[u]) atomicAdd(reinterpret_cast<uint32_t*>(acc) + ((ix[j >> 1] >> (16 * (j & 1))) & 0xffffu), 1u);
+        }
       }
     }
+  } else {
+    // weighted: one flat loop over the 12-byte units (two entries) of all regions; consecutive lanes read consecutive units —
+    // 768 contiguous bytes per load instruction — 2 * BE_BIN_U units per thread and round in flight
+    constexpr uint32_t UB = CAP / 2;                         // units per block
+    const uint32_t n_u = NB * UB;
+    const uint32_t per = (n_u + parts - 1) / parts;
+    const uint32_t g_begin = part * per, g_end = g_begin + per < n_u ? g_begin + per : n_u;
+    constexpr int U = 2 * BE_BIN_U;
+    for (uint32_t g0 = g_begin + tid; g0 < g_end; g0 += U * 1024) {
+      be_u32x3_a4 uv[U];
+      uint32_t nv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (nv[u] == 8u) {
-        if (HOMO) {
-          bin_count8(reinterpret_cast<uint32_t*>(acc), iv[u]);
+      for (int u = 0; u < U; ++u) {
+        const uint32_t g = g0 + (uint32_t)u * 1024u;
+        const bool in = g < g_end;
+        const uint32_t gg = in ? g : g_begin;
+        const uint32_t blk = gg / UB, ub = gg - blk * UB;
+        uint32_t r = 0;
+        if (mapped) {
+          r = s_map[blk];
         } else {
-          plan_add4<HOMO>(acc, make_uint2(iv[u].x, iv[u].y), wa[u], scale);
-          plan_add4<HOMO>(acc, make_uint2(iv[u].z, iv[u].w), wb[u], scale);
-        }
-      } else if (nv[u]) {                  // the last group of a region
-        const uint32_t ix[4] = {iv[u].x, iv[u].y, iv[u].z, iv[u].w};
-        const float wx[8] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w, wb[u].x, wb[u].y, wb[u].z, wb[u].w};
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) {
-          if (j < nv[u]) {
-            const uint32_t col = (ix[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            if (HOMO) atomicAdd(reinterpret_cast<uint32_t*>(acc) + col, 1u);
-            else atomicAdd(reinterpret_cast<unsigned long long*>(acc) + col, fixed_from_f32(wx[j], scale));
-          }
+          for (uint32_t s = kStreamGrid / 2; s > 0; s >>= 1)
+            if (s_pre[r + s] <= blk) r += s;
         }
+        const uint32_t lb = blk - s_pre[r];
+        const uint32_t first = lb * (uint32_t)CAP + ub * 2u, c = s_cnt[r];
+        nv[u] = !in || c <= first ? 0u : (c - first < 2u ? 1u : 2u);
+        uv[u] = *reinterpret_cast<const be_u32x3_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::dwords + ub * 3u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        unsigned long long* a64 = reinterpret_cast<unsigned long long*>(acc);
+#ifdef BE_DBG_C_NOATOMIC
+        if (nv[u] >= 1u && uv[u].z == 0x12345678u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
+        if (nv[u] == 2u && uv[u].x == 0x12345678u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
+#else
+        if (nv[u] >= 1u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
+        if (nv[u] == 2u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
+#endif
       }
     }
   }
   __syncthreads();
-  const int64_t j0 = (int64_t)bin << slice_shift;
+  const int64_t j0 = (int64_t)bin * width;
   // parts == 1: this workgroup is the only writer of its slice after pass B has finished, so a plain store does —
   // or a plain read-modify-write when an overflowing block has already added into the slice with global atomics
   // (10M contiguous float atomics cost ~30 us at C4; the chip retires them at 1.3 TB/s of added bytes)
@@ -645,6 +716,40 @@ static inline int64_t stream_cap_blocks(int64_t bin_capacity, int cap) {
   return (per_region + cap - 1) / cap + 2;
 }
 
+// The bins.  Pass C runs one workgroup per bin, every bin the same work, 256 CUs: a bin count just above a multiple of 256
+// leaves most of the chip idle for a whole round (C4 weighted: 611 bins of 2^14 columns = 2.39 rounds, 190 us; 512 bins of
+// 19532 columns = 2 rounds).  So the output is cut into a multiple of 256 bins of equal width, as few as the accumulators
+// of one bin fit LDS (`slice_shift` caps the width at 2^slice_shift columns; local columns are uint16); outputs of fewer
+// than 256 x 256 columns get bins of 256 columns.
+constexpr int64_t kAccStaticBytes = 4 * (kStreamGrid + kStreamGrid + 1 + 16) + 512;       // pass C: directory, prefix sums, scan, margin
+struct BinGeo { int64_t width; int n_bins, cap, map_cap; };
+static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo) {
+  const int64_t acc_bytes = homo ? 4 : 8;
+  int64_t max_w = (160 * 1024 - kAccStaticBytes) / acc_bytes;
+  max_w = std::min<int64_t>(std::min<int64_t>(max_w, 1ll << slice_shift), 65535) & ~3ll;
+  BinGeo g{0, 0, 0, 0};
+  if (k <= 256 * 256) {
+    g.width = std::min<int64_t>(256, max_w);
+  } else if (!homo && k > 256 * std::min<int64_t>(max_w, 16384)) {
+    // weighted entries over many outputs keep bins of a power of two (2^14 columns at most: C4 = 611 bins): pass C's rounds
+    // were measured not to matter there (512 bins of 19532: 199 us, 611 of 16384: 190 us — it is bound by its byte stream
+    // at ~3.4 TB/s, with or without the LDS atomics), and pass B runs 7 % faster without the division per entry
+    int sh = 14;
+    while ((1ll << sh) > max_w) --sh;
+    g.width = 1ll << sh;
+  } else {
+    const int64_t rounds = (k + 256 * max_w - 1) / (256 * max_w);
+    g.width = ((k + 256 * rounds - 1) / (256 * rounds) + 3) & ~3ll;
+  }
+  const int64_t nb = (k + g.width - 1) / g.width;
+  if (nb > kMaxBins) return g;
+  g.n_bins = (int)nb;
+  g.cap = stream_cap(g.n_bins, homo);
+  g.map_cap = (int)(160 * 1024 - kAccStaticBytes - ((g.width * acc_bytes + 15) & ~15ll));
+  g.map_cap = g.map_cap < 0 ? 0 : g.map_cap;
+  return g;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -661,24 +766,25 @@ extern "C" int be_debug_bin_prof(unsigned long long* host, int reset) {
 extern "C" {
 
 // ---------------------------------------------------------------- binned route (no plan)
-// output slices the route can serve: pass B keeps two blocks of >= 8 entries per slice in LDS
-int be_binned_max_slices(int homo) {
-  int n = 1;
-  while (n < kMaxBins && stream_cap(n + 1, homo) > 0) ++n;
-  return n;
+// bins the route cuts k outputs into for this slice_shift (see binned_geometry); 0: not served (too many bins for pass B's LDS)
+int be_binned_bins(int64_t k, int slice_shift, int homo) {
+  if (k <= 0 || slice_shift < 4 || slice_shift > 16) return 0;
+  const BinGeo g = binned_geometry(k, slice_shift, homo);
+  return g.cap > 0 ? g.n_bins : 0;
 }
 
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity) {
-  const int64_t n_bins = n_slices_of(k, slice_shift);
-  // sized for weighted entries (6 B each, blocks of the weighted kernel): a workspace serves one weight or per-entry weights
-  int64_t blocks_bytes = 0;
+  // sized for the larger of the two entry kinds: a workspace serves one weight or per-entry weights
+  int64_t blocks_bytes = 0, dir_bytes = 0;
   for (int homo = 0; homo < 2; ++homo) {
-    const int cap = stream_cap((int)(n_bins > kMaxBins ? kMaxBins : n_bins), homo);
-    if (cap == 0) continue;
-    const int64_t b = n_bins * kStreamGrid * stream_cap_blocks(bin_capacity, cap) * cap * (homo ? 2 : 6);
+    const BinGeo g = binned_geometry(k, slice_shift, homo);
+    if (g.cap == 0) continue;
+    const int64_t b = (int64_t)g.n_bins * kStreamGrid * stream_cap_blocks(bin_capacity, g.cap) * g.cap * (homo ? 2 : 6);
     blocks_bytes = b > blocks_bytes ? b : blocks_bytes;
+    const int64_t d = (int64_t)g.n_bins * kStreamGrid * 4;
+    dir_bytes = d > dir_bytes ? d : dir_bytes;
   }
-  return 256 + be_align_up(m * 4, 256) + be_align_up(n_bins * kStreamGrid * 4, 256) + be_align_up(blocks_bytes, 256) +
+  return 256 + be_align_up(m * 4, 256) + be_align_up(dir_bytes, 256) + be_align_up(blocks_bytes, 256) +
          be_align_up(k * 4, 256);      // the tail: f32 image of an f16 / bf16 output
 }
 
@@ -686,21 +792,18 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
                              int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
                              int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
                              int64_t workspace_bytes, be_stream_t stream) {
-  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll && k < (1ll << 31), BE_ERR_INVALID, "bad shape");
   BE_REQUIRE(wdtype == BE_F32 || wdtype == BE_F16 || wdtype == BE_BF16, BE_ERR_UNSUPPORTED,
              "the binned route supports f32 / f16 / bf16 weights (its bins carry f32; f64 weights take the planned route)");
-  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 16, BE_ERR_INVALID, "slice_shift must be in [4, 16]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(weights && indices && spikes && out, BE_ERR_INVALID, "null pointer");
-  const int n_bins = n_slices_of(k, slice_shift);
-  BE_REQUIRE(n_bins <= kMaxBins, BE_ERR_RANGE, "too many bins for the binned route");
   BE_REQUIRE(bin_capacity >= 8 && bin_capacity < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
   BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
-  const int64_t S = 1ll << slice_shift;
-  const size_t lds = (size_t)S * (homo ? 4 : 8);
-  BE_REQUIRE(lds <= 160 * 1024, BE_ERR_RANGE, "slice does not fit LDS (hetero: slice_shift <= 14)");
-  const int cap = stream_cap(n_bins, homo);
-  BE_REQUIRE(cap > 0, BE_ERR_RANGE, "too many bins for the LDS blocks of the binned route");
+  const BinGeo geo = binned_geometry(k, slice_shift, homo);
+  const int cap = geo.cap, n_bins = geo.n_bins;
+  BE_REQUIRE(cap > 0, BE_ERR_RANGE, "too many bins for the LDS blocks of the binned route (be_binned_bins)");
+  const size_t lds = (((size_t)geo.width * (homo ? 4 : 8) + 15) & ~(size_t)15) + (size_t)geo.map_cap;
   const int64_t cap_blocks = stream_cap_blocks(bin_capacity, cap);
   BE_REQUIRE(cap_blocks * cap < (1ll << 31), BE_ERR_RANGE, "bin_capacity too large");
   BE_REQUIRE(workspace != nullptr &&
@@ -725,6 +828,7 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   if (rc != BE_OK) return rc;
   const int prof = be_prof_begin(st);
   // rows of one length: a lane finds its row by dividing its group index by the row's groups of four
+  const DivU32 wdiv = make_div((uint32_t)geo.width);
   const DivU32 fixdiv = make_div(indptr == nullptr && row_len > 0 && row_len < (1ll << 26) ? (uint32_t)((row_len + 3) / 4) : 1u);
   {
     const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_bins * (2 * (size_t)cap * (homo ? 2 : 6) / 4 + 6)) * 4;
@@ -733,7 +837,8 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
     auto kern = k_bin_stream<WT, HOMO_, CAP_>;                                                                                  \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, al.ids,      \
-                       al.count, slice_shift, n_bins, (uint32_t)cap_blocks, regions, dir, static_cast<float*>(out), fixdiv);   \
+                       al.count, (uint32_t)geo.width, wdiv, n_bins, (uint32_t)cap_blocks, regions, dir, static_cast<float*>(out), \
+                       fixdiv);                                                                                                 \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \
@@ -762,7 +867,8 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   do {                                                                                                                          \
     auto kern = k_bin_accumulate<HOMO_, CAP_>;                                                                                  \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
-    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, slice_shift, parts, k,    \
+    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
+                       geo.map_cap, parts, k,                                                                                    \
                        scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out)); \
   } while (0)
   if (homo) {

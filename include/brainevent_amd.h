@@ -285,16 +285,19 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * the bin — no global atomics.  Pass C: one workgroup per bin streams the bin's 256 regions and accumulates in LDS
  * (integer atomics, like the planned route).  A region that overflows its share of `bin_capacity` is delivered through
  * global float atomics instead (slower, still correct), so `bin_capacity` is a tuning parameter, not a correctness one:
- * about 1.5 x expected_active_rows x mean_row_length / n_slices.  At most be_binned_max_slices(homo) slices (2048 for one
- * weight, 1146 weighted: two blocks per slice have to fit LDS).  A column index >= k is the caller's error (the entry is dropped).
+ * about 1.5 x expected_active_rows x mean_row_length / be_binned_bins(k, slice_shift, homo).  The library cuts the k outputs
+ * into a multiple of 256 bins of equal width (one workgroup per bin in pass C, 256 CUs), as few as one bin's accumulators fit
+ * LDS and at most 2^slice_shift columns wide (slice_shift in [4, 16]; 16 = as wide as LDS allows); be_binned_bins returns
+ * that count, or 0 when pass B's LDS cannot hold two blocks per bin (more than 2048 / 1146 bins counted / weighted).
+ * A column index >= k is the caller's error (the entry is dropped).
  * Reproducibility: sums are integers (counts, or 64-bit fixed point at 2^scale_exp) converted once, so the result is
- * bitwise identical from call to call as long as (i) no region overflows and (ii) the matrix has more than 128 slices
- * (k > 2^21 weighted / 2^22 counted: one workgroup per slice).  With fewer slices several workgroups share a slice and
+ * bitwise identical from call to call as long as (i) no region overflows and (ii) the matrix has more than 128 bins
+ * (k > 32768: one workgroup per bin).  With fewer bins several workgroups share a bin and
  * merge through float atomics, and an overflowing block is added with float atomics too: both are order dependent in
  * the last bit (still within the 1e-5 tolerance of the path).  The planned route has neither exception.
  * Same role as binary_csrmv_wat_hybrid_* (brainevent/_csr/binary_csrmv_hybrid.cu:619-632): no preprocessing.
  * ---------------------------------------------------------------------------------------------- */
-int be_binned_max_slices(int homo);
+int be_binned_bins(int64_t k, int slice_shift, int homo);
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity);
 int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                              int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out,
