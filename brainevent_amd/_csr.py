@@ -493,6 +493,9 @@ class BinnedScatter:
         self._derive_exponent(weights, indices)
         f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
         self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))
+        f = fn('be_binary_csrmv_t_binned_workspace_init', c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_i64, c_vp])
+        check(f(A.ptr(self.ws), self.ws.numel(), self.m, self.k, self.slice_shift, self.bin_capacity, A.stream_ptr()),
+              'be_binary_csrmv_t_binned_workspace_init')
 
     def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False) -> None:
         self.stamp = weights_stamp(weights)

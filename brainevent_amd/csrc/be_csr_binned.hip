@@ -556,7 +556,8 @@ template <bool HOMO, int CAP>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restrict__ regions, const uint32_t* __restrict__ dir,
                                                          uint32_t cap_blocks, int width, int map_cap, int parts, int64_t k, float scale,
                                                          double inv_scale, const void* __restrict__ w0p, int wdtype,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, float* __restrict__ ovf_img,
+                                                         uint32_t* __restrict__ count_rearm) {
   using B = BinBlock<HOMO, CAP>;
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -576,7 +577,8 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   const uint32_t incl = block_scan_1024(nb_r, s_wtot);
   if (tid < kStreamGrid) { s_cnt[tid] = cnt_r; s_pre[tid + 1] = incl; }
   if (tid == 0) s_pre[0] = 0u;
-  const bool overflowed = __syncthreads_or((int)(raw >> 31)) != 0;     // some entries of this bin are already in `out`
+  const bool overflowed = __syncthreads_or((int)(raw >> 31)) != 0;     // some entries of this bin went to the overflow image
+  if (blockIdx.x == 0 && tid == 0 && count_rearm) count_rearm[0] = 0u;   // the spike counter of the next call's compaction
   const uint32_t NB = s_pre[kStreamGrid];
   float w0 = 0.f;
   if (HOMO) {
@@ -584,7 +586,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
     else if (wdtype == BE_BF16) w0 = __bfloat162float(static_cast<const __hip_bfloat16*>(w0p)[0]);
     else w0 = static_cast<const float*>(w0p)[0];
   }
-  if (NB == 0) return;                      // nothing was binned here (out already holds zeros / overflow adds)
+  if (NB == 0 && parts > 1 && !(overflowed && part == 0)) return;   // nothing to add (several parts per bin: `out` was zeroed up front)
   for (int i = tid; i < S; i += 1024) acc[i] = 0;
   const bool mapped = NB <= (uint32_t)map_cap;
   if (mapped && tid < kStreamGrid)
@@ -677,21 +679,21 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   }
   __syncthreads();
   const int64_t j0 = (int64_t)bin * width;
-  // parts == 1: this workgroup is the only writer of its slice after pass B has finished, so a plain store does —
-  // or a plain read-modify-write when an overflowing block has already added into the slice with global atomics
-  // (10M contiguous float atomics cost ~30 us at C4; the chip retires them at 1.3 TB/s of added bytes)
+  // parts == 1: this workgroup is the only writer of its slice, so a plain store does — every output of the slice is
+  // written, `out` needs no zeroing.  What pass B could not place in a region sits in the overflow image (all zeros
+  // otherwise: read and cleared here only when the bin's flag says so).
   const bool plain = parts == 1;
   for (int i = tid; i < S; i += 1024) {
     if (j0 + i >= k) break;
     float v;
     if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
     else v = (float)((double)(long long)reinterpret_cast<unsigned long long*>(acc)[i] * inv_scale);
-    if (plain) {
-      if (!overflowed) out[j0 + i] = v;
-      else if (v != 0.f) out[j0 + i] += v;
-    } else if (v != 0.f) {
-      atomicAdd(out + j0 + i, v);     // contiguous float atomics: the parts of a bin merge here
+    if (overflowed && part == 0) {
+      const float o = ovf_img[j0 + i];
+      if (o != 0.f) { v += o; ovf_img[j0 + i] = 0.f; }
     }
+    if (plain) out[j0 + i] = v;
+    else if (v != 0.f) atomicAdd(out + j0 + i, v);     // contiguous float atomics: the parts of a bin merge here
   }
 }
 
@@ -785,7 +787,19 @@ int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice
     dir_bytes = d > dir_bytes ? d : dir_bytes;
   }
   return 256 + be_align_up(m * 4, 256) + be_align_up(dir_bytes, 256) + be_align_up(blocks_bytes, 256) +
-         be_align_up(k * 4, 256);      // the tail: f32 image of an f16 / bf16 output
+         2 * be_align_up(k * 4, 256);  // the tail: the overflow image, then the f32 image of an f16 / bf16 output
+}
+
+// Once per workspace, before its first step: the spike counter and the overflow image start at zero (every step leaves them so).
+int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_bytes, int64_t m, int64_t k, int slice_shift,
+                                            int64_t bin_capacity, be_stream_t stream) {
+  const int64_t need = be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity);
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= need, BE_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned char* wsb = static_cast<unsigned char*>(workspace);
+  BE_HIP(be_fill_async(wsb, 0, 256, st));
+  BE_HIP(be_fill_async(wsb + need - 2 * be_align_up(k * 4, 256), 0, (size_t)be_align_up(k * 4, 256), st));
+  return BE_OK;
 }
 
 int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
@@ -815,14 +829,21 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
   uint32_t* dir = reinterpret_cast<uint32_t*>(wsb + 256 + be_align_up(m * 4, 256));
   uint32_t* regions = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(dir) + be_align_up((int64_t)n_bins * kStreamGrid * 4, 256));
-  // the f32 image sits at the end of the workspace
+  // the overflow image and the f32 image sit at the end of the workspace
   float* out32 = reinterpret_cast<float*>(wsb + be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity) -
                                           be_align_up(k * 4, 256));
+  float* ovf_img = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out32) - be_align_up(k * 4, 256));
   void* out_user = out;
   if (wdtype != BE_F32) out = out32;                 // accumulate in f32, round once at the end
   RowPtr rp{indptr, indptr_is_i64, row_len};
-  hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, count);
-  BE_LAUNCH_CHECK();
+  // n_bins * parts ~ 256: every workgroup of pass C fills a CU; with several parts per bin (fewer than 129 bins: k <= 32768)
+  // the parts merge their slices into `out` with float atomics, which then has to start at zero
+  int parts = 256 / (n_bins > 0 ? n_bins : 1);
+  parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+  if (parts > 1) {
+    hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, count);
+    BE_LAUNCH_CHECK();
+  }
   ActiveList al;
   int rc = be_resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, /*zero_first=*/false, &al);
   if (rc != BE_OK) return rc;
@@ -837,8 +858,8 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
     auto kern = k_bin_stream<WT, HOMO_, CAP_>;                                                                                  \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, al.ids,      \
-                       al.count, (uint32_t)geo.width, wdiv, n_bins, (uint32_t)cap_blocks, regions, dir, static_cast<float*>(out), \
-                       fixdiv);                                                                                                 \
+                       al.count, (uint32_t)geo.width, wdiv, n_bins, (uint32_t)cap_blocks, regions, dir, ovf_img, fixdiv);       \
+    (void)0;                                                                                                 \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \
@@ -856,10 +877,6 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
 #undef BE_BIN_STREAM
   }
   BE_LAUNCH_CHECK();
-  // n_bins * parts ~ 256: every workgroup fills a CU (128 KB of LDS) and its slice is merged into the output with float
-  // atomics, one per non-zero accumulator, so more parts than CUs only add merge traffic (39 bins: 13 parts took 55 us, 6 take 30).
-  int parts = 256 / (n_bins > 0 ? n_bins : 1);
-  parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
   const unsigned acc_grid = (unsigned)(n_bins * parts);
   const float scale = ldexpf(1.0f, scale_exp - 32);
   const double inv_scale = ldexp(1.0, -scale_exp);
@@ -869,7 +886,8 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
                        geo.map_cap, parts, k,                                                                                    \
-                       scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out)); \
+                       scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out),  \
+                       ovf_img, spike_dtype == BE_SPIKE_IDS ? static_cast<uint32_t*>(nullptr) : count);                          \
   } while (0)
   if (homo) {
     if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);

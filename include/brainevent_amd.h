@@ -284,7 +284,8 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * per entry, one commit per entry, no workgroup barrier); a completed block is copied to the workgroup's own region of
  * the bin — no global atomics.  Pass C: one workgroup per bin streams the bin's 256 regions and accumulates in LDS
  * (integer atomics, like the planned route).  A region that overflows its share of `bin_capacity` is delivered through
- * global float atomics instead (slower, still correct), so `bin_capacity` is a tuning parameter, not a correctness one:
+ * global float atomics into an overflow image of the output instead (slower, still correct: pass C adds the image in), so
+ * `bin_capacity` is a tuning parameter, not a correctness one:
  * about 1.5 x expected_active_rows x mean_row_length / be_binned_bins(k, slice_shift, homo).  The library cuts the k outputs
  * into a multiple of 256 bins of equal width (one workgroup per bin in pass C, 256 CUs), as few as one bin's accumulators fit
  * LDS and at most 2^slice_shift columns wide (slice_shift in [4, 16]; 16 = as wide as LDS allows); be_binned_bins returns
@@ -299,6 +300,10 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * ---------------------------------------------------------------------------------------------- */
 int be_binned_bins(int64_t k, int slice_shift, int homo);
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity);
+/* once per workspace, before its first step: zeroes the spike counter and the overflow image inside it (every step leaves
+ * both at zero, so the step itself needs no memset and no zeroing of `out`: pass C writes every output) */
+int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_bytes, int64_t m, int64_t k, int slice_shift,
+                                            int64_t bin_capacity, be_stream_t stream);
 int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                              int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out,
                              int64_t m, int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
