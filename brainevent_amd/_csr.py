@@ -491,11 +491,21 @@ class BinnedScatter:
         self.scale_exp = 0
         self.nnz = int(nnz)
         self._derive_exponent(weights, indices)
-        f = fn('be_binary_csrmv_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_int, c_i64])
-        self.ws = A.workspace(f(self.m, self.k, self.slice_shift, self.bin_capacity))
-        f = fn('be_binary_csrmv_t_binned_workspace_init', c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_i64, c_vp])
-        check(f(A.ptr(self.ws), self.ws.numel(), self.m, self.k, self.slice_shift, self.bin_capacity, A.stream_ptr()),
-              'be_binary_csrmv_t_binned_workspace_init')
+        self._ws: Dict = {}
+        self.ws = self.workspace(1)
+
+    def workspace(self, n_batch: int = 1) -> torch.Tensor:
+        """The workspace of steps over ``n_batch`` spike vectors (created and initialised once per batch size; never evicted:
+        a captured HIP graph keeps its raw pointer)."""
+        ws = self._ws.get(int(n_batch))
+        if ws is None:
+            f = fn('be_binary_csrmm_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_i64])
+            ws = A.workspace(f(self.m, self.k, int(n_batch), self.slice_shift, self.bin_capacity))
+            f = fn('be_binary_csrmm_t_binned_workspace_init', c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_vp])
+            check(f(A.ptr(ws), ws.numel(), self.m, self.k, int(n_batch), self.slice_shift, self.bin_capacity, A.stream_ptr()),
+                  'be_binary_csrmm_t_binned_workspace_init')
+            self._ws[int(n_batch)] = ws
+        return ws
 
     def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False) -> None:
         self.stamp = weights_stamp(weights)
@@ -529,13 +539,21 @@ def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes,
 
 
 def binned_batch(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes_bm, sd, out_bm) -> None:
-    """One binned step per batch row on the shared bins (stream ordered) — the reference's batched scatter is a host loop over
-    the columns too (``binary_csrmm_hybrid.cu:16-57``).  An id list is a single vector by construction."""
-    if sd == A.BE_SPIKE_IDS:
+    """The binned step for a batch ``spikes_bm [n_batch, m]`` -> ``out_bm [n_batch, k]`` (``be_binary_csrmm_t_binned``: the rows
+    with a spike in any batch row are read once for up to 32 batch rows at a time where the bins of all of them fit pass B's
+    LDS, else one step per batch row as the reference does, ``binary_csrmm_hybrid.cu:16-57``).  An id list is a single vector."""
+    if sd == A.BE_SPIKE_IDS or spikes_bm.ndim == 1:
         _binned_call(ws, weights, indices, indptr, row_len, spikes_bm, sd, out_bm)
         return
-    for b in range(int(out_bm.shape[0])):
-        _binned_call(ws, weights, indices, indptr, row_len, spikes_bm[b], sd, out_bm[b])
+    nb = int(out_bm.shape[0])
+    wsb = ws.workspace(nb)
+    f = fn('be_binary_csrmm_t_binned', c_int,
+           [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp, c_i64,
+            c_vp])
+    is64 = int(indptr is not None and indptr.dtype == torch.int64)
+    check(f(A.ptr(weights), int(ws.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes_bm), sd,
+            A.ptr(out_bm), ws.m, ws.k, nb, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(wsb), wsb.numel(),
+            A.stream_ptr()), 'be_binary_csrmm_t_binned')
 
 
 def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor, sd: int, out_bm: torch.Tensor,

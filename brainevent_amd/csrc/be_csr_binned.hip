@@ -144,7 +144,7 @@ typedef float be_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <bool HOMO, int CB>
 __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, const uint32_t* wl, uint32_t n, uint32_t cap_blocks,
                                                   uint32_t* __restrict__ wg_regions, size_t bin_stride_dw, float* __restrict__ out,
-                                                  uint32_t width, float w0, int lane) {
+                                                  uint32_t width, int n_bins_b, int64_t k, float w0, int lane) {
   using B = BinBlock<HOMO, CB>;
   constexpr int LPF = B::lpf, FPP = 64 / LPF;
   static_assert(B::bytes % 16 == 0 && LPF >= 1 && LPF <= 64, "blocks are copied 16 bytes per lane");
@@ -177,7 +177,8 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
         const uint32_t* blk = S.buf + (size_t)sid * B::dwords;
         const uint16_t* bi = reinterpret_cast<const uint16_t*>(blk);
         const float* bw = reinterpret_cast<const float*>(blk);
-        float* dst = out + (int64_t)(sid >> 1) * width;
+        const uint32_t vb = sid >> 1, bb = vb / (uint32_t)n_bins_b;          // (batch row, bin) of the virtual bin
+        float* dst = out + (int64_t)bb * k + (int64_t)(vb - bb * (uint32_t)n_bins_b) * width;
         for (int j = lane; j < CB; j += 64) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
         if (lane == 0) S.ovf[sid >> 1] = 1u;
       }
@@ -211,18 +212,21 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
 // branches: a lane without an entry, or with one that has to wait, aims at counters and words of its own that nobody reads).
 template <bool HOMO, int CB, int NE>
 __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, const uint32_t (&col)[NE],
-                                               const float (&w)[HOMO ? 1 : NE], uint32_t width, DivU32 wdiv, int n_bins,
+                                               const float (&w)[HOMO ? 1 : NE], const uint32_t (&boff)[NE / 4], uint32_t width,
+                                               DivU32 wdiv, int n_bins, int n_bins_b, int64_t k,
                                                uint32_t cap_blocks, uint32_t* wl, uint32_t* __restrict__ wg_regions,
                                                size_t bin_stride_dw, float* __restrict__ out, float w0, int lane, StreamProf& prof) {
   using B = BinBlock<HOMO, CB>;
   constexpr int LOG_CB = CB == 128 ? 7 : CB == 64 ? 6 : CB == 32 ? 5 : CB == 16 ? 4 : 3;
   // a column >= k (the caller's error) and a missing entry both land on the lane's own dummy counter n_bins + lane
   const uint32_t dummy_bin = (uint32_t)n_bins + (uint32_t)lane;
-  uint32_t bin[NE], t[NE];
+  uint32_t bin[NE], t[NE], lc[NE];
   uint32_t pend = 0;
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    const uint32_t b = wdiv.div(col[u]);
+    const uint32_t bl = wdiv.div(col[u]);                      // the bin inside its batch row: a missing entry's is huge
+    lc[u] = col[u] - __umul24(bl, width);
+    const uint32_t b = bl < (uint32_t)n_bins_b ? bl + boff[u / 4] : 0xffffffffu;
     bin[u] = b < dummy_bin ? b : dummy_bin;
     pend |= (b < (uint32_t)n_bins ? 1u : 0u) << u;
   }
@@ -256,7 +260,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
       const uint32_t s = t[u] & (uint32_t)(CB - 1);
       uint16_t* pi = ok ? reinterpret_cast<uint16_t*>(blk) + B::col_hw(s) : reinterpret_cast<uint16_t*>(S.dummy + 64 + lane);
 #if !defined(BE_DBG_LEVEL) || BE_DBG_LEVEL < 3
-      *pi = (uint16_t)(col[u] - __umul24(bin[u], width));
+      *pi = (uint16_t)lc[u];
 #else
       if (pi == nullptr) *pi = 1;
 #endif
@@ -309,7 +313,8 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
       }
       prof.count(5, nfl < 64u ? nfl : 64u);
       lds_fence();
-      stream_flush_list<HOMO, CB>(S, wl, nfl < 64u ? nfl : 64u, cap_blocks, wg_regions, bin_stride_dw, out, width, w0, lane);
+      stream_flush_list<HOMO, CB>(S, wl, nfl < 64u ? nfl : 64u, cap_blocks, wg_regions, bin_stride_dw, out, width, n_bins_b, k, w0,
+                                  lane);
     }
     if (__ballot(pend != 0) == 0) break;
     if (++spins > kSpinLimit) __builtin_trap();      // never seen: a protocol error ends in a launch failure, not in a hung device
@@ -326,7 +331,11 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
                                                      const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
                                                      uint32_t width, DivU32 wdiv, int n_bins, uint32_t cap_blocks,
                                                      uint32_t* __restrict__ regions, uint32_t* __restrict__ dir,
-                                                     float* __restrict__ out, DivU32 fixdiv) {
+                                                     float* __restrict__ out, DivU32 fixdiv,
+                                                     const uint32_t* __restrict__ row_masks, int n_bins_b, int64_t k) {
+  // row_masks != NULL: a batch.  `active` lists the rows with a spike in ANY of the (<= 32) batch rows of this pass and
+  // row_masks[j] says in which; the bins are virtual — batch row b's bin i is n_bins_b * b + i of n_bins — and an entry is
+  // appended once per batch row that has its row active (the rows are read once for the whole batch).
   using B = BinBlock<HOMO, CB>;
   constexpr int U = BE_STREAM_U;
   extern __shared__ __align__(16) uint32_t lds[];
@@ -375,8 +384,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
     const uint64_t a0 = task << rshift;
     int64_t rb = 0;
     uint64_t len = 0;
+    uint32_t rmask = 1u;                              // batch rows in which this lane's row is active
     if ((uint32_t)lane < R && a0 + lane < n_active) {
       const uint32_t r = active[a0 + lane];
+      if (row_masks) rmask = row_masks[a0 + lane];
       rb = rp.at(r);
       len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
     }
@@ -422,7 +433,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
         // ---- the stream: U steps loading while the previous U are appended
         uint32_t colN[U][4];
         float wN[U][HOMO ? 1 : 4];
-        uint32_t validN[U];
+        uint32_t validN[U], maskN[U];
 #define BE_STREAM_ISSUE(C0)                                                                                          \
   do {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
@@ -465,6 +476,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
         }                                                                                                            \
       }                                                                                                              \
       validN[u] = vm;                                                                                                \
+      maskN[u] = row_masks ? (huge ? rl(rmask, (int)piece) : (uint32_t)__shfl((int)rmask, (int)i, 64)) : 1u;         \
     }                                                                                                                \
   } while (0)
         BE_STREAM_ISSUE(0u);
@@ -474,9 +486,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
           // in front of the next round's loads (only one round is ever outstanding: the full wait is the exact one)
           uint32_t colC[U][4];
           float wC[U][HOMO ? 1 : 4];
-          uint32_t validC[U];
+          uint32_t validC[U], maskC[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
+            maskC[u] = maskN[u];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               colC[u][j] = colN[u][j];
@@ -489,7 +502,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
           if (c0 + U < n_steps) BE_STREAM_ISSUE(c0 + U);
           prof.stamp(1);
           {
-            uint32_t colA[U * 4];
+            uint32_t colA[U * 4], offA[U];
             float wA[HOMO ? 1 : U * 4];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -497,17 +510,31 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
 #pragma unroll
                 for (int j = 0; j < 4; ++j) colC[u][j] |= ~(uint32_t)__builtin_amdgcn_sbfe((int)validC[u], j, 1);
               }
+              if (!HOMO) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                colA[u * 4 + j] = colC[u][j];
-                if (!HOMO) wA[HOMO ? 0 : u * 4 + j] = wC[u][HOMO ? 0 : j];
+                for (int j = 0; j < 4; ++j) wA[HOMO ? 0 : u * 4 + j] = wC[u][HOMO ? 0 : j];
               }
             }
+            do {                                          // once; a batch: once per batch row some lane's row is active in
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const uint32_t mk = maskC[u];
+                const uint32_t b = mk ? (uint32_t)__ffs(mk) - 1u : 0u;
+                maskC[u] = mk & (mk - 1u);
+                offA[u] = b * (uint32_t)n_bins_b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) colA[u * 4 + j] = mk ? colC[u][j] : 0xffffffffu;
+              }
 #ifdef BE_DBG_NOAPPEND
-            if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
+              if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
 #endif
-            stream_append<HOMO, CB, U * 4>(S, colA, wA, width, wdiv, n_bins, cap_blocks, wl, wg_regions, bin_stride_dw, out, w0,
-                                           lane, prof);
+              stream_append<HOMO, CB, U * 4>(S, colA, wA, offA, width, wdiv, n_bins, n_bins_b, k, cap_blocks, wl, wg_regions,
+                                             bin_stride_dw, out, w0, lane, prof);
+              bool again = false;
+#pragma unroll
+              for (int u = 0; u < U; ++u) again |= maskC[u] != 0u;
+              if (__ballot(again) == 0) break;
+            } while (true);
           }
           prof.stamp(3);
           prof.count(6, U);
@@ -535,7 +562,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
       const uint32_t* bp = S.buf + (size_t)(bin * 2 + (blk & 1u)) * B::dwords;
       const uint16_t* bi = reinterpret_cast<const uint16_t*>(bp);
       const float* bw = reinterpret_cast<const float*>(bp);
-      float* dst = out + (int64_t)bin * width;
+      const uint32_t bb = (uint32_t)bin / (uint32_t)n_bins_b;
+      float* dst = out + (int64_t)bb * k + (int64_t)((uint32_t)bin - bb * (uint32_t)n_bins_b) * width;
       for (uint32_t j = 0; j < d; ++j) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
       o = 1u;
     }
@@ -557,7 +585,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
                                                          uint32_t cap_blocks, int width, int map_cap, int parts, int64_t k, float scale,
                                                          double inv_scale, const void* __restrict__ w0p, int wdtype,
                                                          float* __restrict__ out, float* __restrict__ ovf_img,
-                                                         uint32_t* __restrict__ count_rearm) {
+                                                         uint32_t* __restrict__ count_rearm, int n_bins_b) {
   using B = BinBlock<HOMO, CAP>;
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -678,13 +706,15 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
     }
   }
   __syncthreads();
-  const int64_t j0 = (int64_t)bin * width;
+  // a batch: virtual bin = batch row * n_bins_b + bin; out / ovf_img are [batch row][k]
+  const int64_t j0 = (int64_t)(bin / n_bins_b) * k + (int64_t)(bin % n_bins_b) * width;
+  const int64_t j_end = (int64_t)(bin / n_bins_b) * k + k;
   // parts == 1: this workgroup is the only writer of its slice, so a plain store does — every output of the slice is
   // written, `out` needs no zeroing.  What pass B could not place in a region sits in the overflow image (all zeros
   // otherwise: read and cleared here only when the bin's flag says so).
   const bool plain = parts == 1;
   for (int i = tid; i < S; i += 1024) {
-    if (j0 + i >= k) break;
+    if (j0 + i >= j_end) break;
     float v;
     if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
     else v = (float)((double)(long long)reinterpret_cast<unsigned long long*>(acc)[i] * inv_scale);
@@ -702,6 +732,45 @@ template <typename W>
 __global__ void __launch_bounds__(256) k_bin_round(const float* __restrict__ src, W* __restrict__ dst, int64_t k) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) WTraits<W>::store(dst, i, src[i]);
+}
+
+// A batch of spike vectors [n_batch, m]: the rows with a spike in any of the batch rows [b0, b0 + nb) (nb <= 32) and, per
+// listed row, the mask of those batch rows (bit j = batch row b0 + j).  Same block-aggregated reservation as k_compact_spikes.
+template <int SD /* BE_SPIKE_BOOL / BE_SPIKE_FLOAT / BE_SPIKE_BITS */>
+__global__ void __launch_bounds__(256) k_bin_union(const void* __restrict__ spikes_bm, int64_t m, int64_t row_stride, int nb,
+                                                   uint32_t* __restrict__ active, uint32_t* __restrict__ masks,
+                                                   uint32_t* __restrict__ count) {
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t block_base;
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t mk = 0;
+  if (r < m) {
+    for (int b = 0; b < nb; ++b) {
+      bool on;
+      if (SD == BE_SPIKE_BITS) on = (static_cast<const uint32_t*>(spikes_bm)[(int64_t)b * row_stride + (r >> 5)] >> (r & 31)) & 1u;
+      else if (SD == BE_SPIKE_FLOAT) on = static_cast<const float*>(spikes_bm)[(int64_t)b * row_stride + r] > 0.f;
+      else on = static_cast<const uint8_t*>(spikes_bm)[(int64_t)b * row_stride + r] != 0;
+      mk |= (on ? 1u : 0u) << b;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t bal = __ballot(mk != 0u);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+  if (lane == 0) wave_tot[wave] = (uint32_t)__popcll((unsigned long long)bal);
+  __syncthreads();
+  uint32_t off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) off += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (threadIdx.x == 0) block_base = total ? atomicAdd(count, total) : 0u;
+  __syncthreads();
+  if (mk) {
+    const uint32_t at = block_base + off + rank;
+    active[at] = (uint32_t)r;
+    masks[at] = mk;
+  }
 }
 
 // entries per write-combining block: the largest the LDS of pass B holds for this many bins
@@ -775,91 +844,175 @@ int be_binned_bins(int64_t k, int slice_shift, int homo) {
   return g.cap > 0 ? g.n_bins : 0;
 }
 
-int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity) {
+}  // extern "C"
+
+namespace {
+// A batch reads the rows once for `gb` batch rows at a time: bins as wide as pass C's accumulators allow (few bins per batch
+// row), gb batch rows' bins side by side as long as pass B's LDS holds blocks of 16 (weighted) / 32 (counted) entries for
+// all of them.  gb == 1: the single-vector geometry, one pass per batch row.
+struct BatchGeo { BinGeo g; int gb; };
+static inline BatchGeo binned_geometry_batch(int64_t k, int slice_shift, int homo, int64_t n_batch) {
+  BatchGeo r{binned_geometry(k, slice_shift, homo), 1};
+  if (n_batch <= 1) return r;
+  const int64_t acc_bytes = homo ? 4 : 8;
+  int64_t max_w = (160 * 1024 - kAccStaticBytes) / acc_bytes;
+  max_w = std::min<int64_t>(std::min<int64_t>(max_w, 1ll << slice_shift), 65535) & ~3ll;
+  const int64_t nbb = (k + max_w - 1) / max_w;
+  const int64_t width = ((k + nbb - 1) / nbb + 3) & ~3ll;
+  int gb = (int)std::min<int64_t>(n_batch, 32);
+  while (gb > 1 && (nbb * gb > kMaxBins || stream_cap((int)(nbb * gb), homo) < (homo ? 32 : 16))) --gb;
+  if (gb <= 1) return r;
+  r.gb = gb;
+  r.g.width = width;
+  r.g.n_bins = (int)nbb;                    // bins per batch row; pass B sees n_bins * gb virtual bins
+  r.g.cap = stream_cap((int)(nbb * gb), homo);
+  r.g.map_cap = (int)(160 * 1024 - kAccStaticBytes - ((width * acc_bytes + 15) & ~15ll));
+  r.g.map_cap = r.g.map_cap < 0 ? 0 : r.g.map_cap;
+  return r;
+}
+// entries one bin of this geometry receives when one bin of the single-vector geometry receives bin_capacity
+static inline int64_t batch_bin_capacity(int64_t k, int slice_shift, int homo, int64_t bin_capacity, const BatchGeo& bg) {
+  if (bg.gb <= 1) return bin_capacity;
+  const BinGeo g1 = binned_geometry(k, slice_shift, homo);
+  const int64_t c = (int64_t)((double)bin_capacity * (g1.n_bins > 0 ? g1.n_bins : 1) / (bg.g.n_bins > 0 ? bg.g.n_bins : 1)) + 64;
+  return c < (1ll << 31) ? c : (1ll << 31) - 1;
+}
+struct BinWs { int64_t active_off, masks_off, dir_off, regions_off, ovf_off, out32_off, total; };
+static inline BinWs binned_ws_layout(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity) {
   // sized for the larger of the two entry kinds: a workspace serves one weight or per-entry weights
-  int64_t blocks_bytes = 0, dir_bytes = 0;
+  int64_t blocks_bytes = 0, dir_bytes = 0, gb_max = 1;
   for (int homo = 0; homo < 2; ++homo) {
-    const BinGeo g = binned_geometry(k, slice_shift, homo);
-    if (g.cap == 0) continue;
-    const int64_t b = (int64_t)g.n_bins * kStreamGrid * stream_cap_blocks(bin_capacity, g.cap) * g.cap * (homo ? 2 : 6);
+    const BatchGeo bg = binned_geometry_batch(k, slice_shift, homo, n_batch);
+    if (bg.g.cap == 0) continue;
+    const int64_t vb = (int64_t)bg.g.n_bins * bg.gb;
+    const int64_t cb = stream_cap_blocks(batch_bin_capacity(k, slice_shift, homo, bin_capacity, bg), bg.g.cap);
+    const int64_t b = vb * kStreamGrid * cb * bg.g.cap * (homo ? 2 : 6);
     blocks_bytes = b > blocks_bytes ? b : blocks_bytes;
-    const int64_t d = (int64_t)g.n_bins * kStreamGrid * 4;
-    dir_bytes = d > dir_bytes ? d : dir_bytes;
+    dir_bytes = std::max<int64_t>(dir_bytes, vb * kStreamGrid * 4);
+    gb_max = std::max<int64_t>(gb_max, bg.gb);
   }
-  return 256 + be_align_up(m * 4, 256) + be_align_up(dir_bytes, 256) + be_align_up(blocks_bytes, 256) +
-         2 * be_align_up(k * 4, 256);  // the tail: the overflow image, then the f32 image of an f16 / bf16 output
+  BinWs w;
+  w.active_off = 256;
+  w.masks_off = w.active_off + be_align_up(m * 4, 256);
+  w.dir_off = w.masks_off + (n_batch > 1 ? be_align_up(m * 4, 256) : 0);
+  w.regions_off = w.dir_off + be_align_up(dir_bytes, 256);
+  w.ovf_off = w.regions_off + be_align_up(blocks_bytes, 256);              // overflow image: [gb][k] f32
+  w.out32_off = w.ovf_off + be_align_up(gb_max * k * 4, 256);             // f32 image of an f16 / bf16 output: [n_batch][k]
+  w.total = w.out32_off + be_align_up(n_batch * k * 4, 256);
+  return w;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t be_binary_csrmm_t_binned_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity) {
+  return binned_ws_layout(m, k, n_batch < 1 ? 1 : n_batch, slice_shift, bin_capacity).total;
+}
+int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity) {
+  return be_binary_csrmm_t_binned_workspace_bytes(m, k, 1, slice_shift, bin_capacity);
 }
 
 // Once per workspace, before its first step: the spike counter and the overflow image start at zero (every step leaves them so).
-int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_bytes, int64_t m, int64_t k, int slice_shift,
-                                            int64_t bin_capacity, be_stream_t stream) {
-  const int64_t need = be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity);
-  BE_REQUIRE(workspace != nullptr && workspace_bytes >= need, BE_ERR_WORKSPACE, "workspace too small");
+int be_binary_csrmm_t_binned_workspace_init(void* workspace, int64_t workspace_bytes, int64_t m, int64_t k, int64_t n_batch,
+                                            int slice_shift, int64_t bin_capacity, be_stream_t stream) {
+  const BinWs w = binned_ws_layout(m, k, n_batch < 1 ? 1 : n_batch, slice_shift, bin_capacity);
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= w.total, BE_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   BE_HIP(be_fill_async(wsb, 0, 256, st));
-  BE_HIP(be_fill_async(wsb + need - 2 * be_align_up(k * 4, 256), 0, (size_t)be_align_up(k * 4, 256), st));
+  BE_HIP(be_fill_async(wsb + w.ovf_off, 0, (size_t)(w.out32_off - w.ovf_off), st));
   return BE_OK;
 }
+int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_bytes, int64_t m, int64_t k, int slice_shift,
+                                            int64_t bin_capacity, be_stream_t stream) {
+  return be_binary_csrmm_t_binned_workspace_init(workspace, workspace_bytes, m, k, 1, slice_shift, bin_capacity, stream);
+}
 
-int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
-                             int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
-                             int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
+int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                             int indptr_is_i64, int64_t row_len, const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m,
+                             int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
                              int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0 && m <= 0xffffffffll && k < (1ll << 31), BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(n_batch >= 1 && n_batch <= kMaxBatch, BE_ERR_INVALID, "bad n_batch");
   BE_REQUIRE(wdtype == BE_F32 || wdtype == BE_F16 || wdtype == BE_BF16, BE_ERR_UNSUPPORTED,
              "the binned route supports f32 / f16 / bf16 weights (its bins carry f32; f64 weights take the planned route)");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 16, BE_ERR_INVALID, "slice_shift must be in [4, 16]");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
-  BE_REQUIRE(weights && indices && spikes && out, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(weights && indices && spikes_bm && out_bm, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(bin_capacity >= 8 && bin_capacity < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
   BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
-  const BinGeo geo = binned_geometry(k, slice_shift, homo);
-  const int cap = geo.cap, n_bins = geo.n_bins;
+  BE_REQUIRE(n_batch == 1 || spike_dtype != BE_SPIKE_IDS, BE_ERR_UNSUPPORTED, "BE_SPIKE_IDS takes a single event vector");
+  const BatchGeo bg = binned_geometry_batch(k, slice_shift, homo, n_batch);
+  const BinGeo& geo = bg.g;
+  const int cap = geo.cap, n_bins_b = geo.n_bins, gb = bg.gb;
   BE_REQUIRE(cap > 0, BE_ERR_RANGE, "too many bins for the LDS blocks of the binned route (be_binned_bins)");
   const size_t lds = (((size_t)geo.width * (homo ? 4 : 8) + 15) & ~(size_t)15) + (size_t)geo.map_cap;
-  const int64_t cap_blocks = stream_cap_blocks(bin_capacity, cap);
+  const int64_t cap_blocks = stream_cap_blocks(batch_bin_capacity(k, slice_shift, homo, bin_capacity, bg), cap);
   BE_REQUIRE(cap_blocks * cap < (1ll << 31), BE_ERR_RANGE, "bin_capacity too large");
-  BE_REQUIRE(workspace != nullptr &&
-                 workspace_bytes >= be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity),
-             BE_ERR_WORKSPACE, "workspace too small");
+  const BinWs wl = binned_ws_layout(m, k, n_batch, slice_shift, bin_capacity);
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= wl.total, BE_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
-  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + 256);
-  uint32_t* dir = reinterpret_cast<uint32_t*>(wsb + 256 + be_align_up(m * 4, 256));
-  uint32_t* regions = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(dir) + be_align_up((int64_t)n_bins * kStreamGrid * 4, 256));
-  // the overflow image and the f32 image sit at the end of the workspace
-  float* out32 = reinterpret_cast<float*>(wsb + be_binary_csrmv_t_binned_workspace_bytes(m, k, slice_shift, bin_capacity) -
-                                          be_align_up(k * 4, 256));
-  float* ovf_img = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out32) - be_align_up(k * 4, 256));
-  void* out_user = out;
-  if (wdtype != BE_F32) out = out32;                 // accumulate in f32, round once at the end
+  uint32_t* active = reinterpret_cast<uint32_t*>(wsb + wl.active_off);
+  uint32_t* masks = reinterpret_cast<uint32_t*>(wsb + wl.masks_off);
+  uint32_t* dir = reinterpret_cast<uint32_t*>(wsb + wl.dir_off);
+  uint32_t* regions = reinterpret_cast<uint32_t*>(wsb + wl.regions_off);
+  float* ovf_img = reinterpret_cast<float*>(wsb + wl.ovf_off);
+  float* out32 = reinterpret_cast<float*>(wsb + wl.out32_off);
+  void* out_user = out_bm;
+  float* out = wdtype != BE_F32 ? out32 : static_cast<float*>(out_bm);       // accumulate in f32, round once at the end
   RowPtr rp{indptr, indptr_is_i64, row_len};
-  // n_bins * parts ~ 256: every workgroup of pass C fills a CU; with several parts per bin (fewer than 129 bins: k <= 32768)
-  // the parts merge their slices into `out` with float atomics, which then has to start at zero
-  int parts = 256 / (n_bins > 0 ? n_bins : 1);
-  parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
-  if (parts > 1) {
-    hipLaunchKernelGGL(k_bin_reset, dim3(grid_for(k / 4 + 1, 256, 1024)), dim3(256), 0, st, static_cast<float*>(out), k, count);
-    BE_LAUNCH_CHECK();
-  }
-  ActiveList al;
-  int rc = be_resolve_active(spikes, spike_dtype, m, 1, active, 0, count, st, /*zero_first=*/false, &al);
-  if (rc != BE_OK) return rc;
-  const int prof = be_prof_begin(st);
-  // rows of one length: a lane finds its row by dividing its group index by the row's groups of four
+  const size_t spk_sz = spike_dtype == BE_SPIKE_FLOAT ? 4 : 1;
+  const int64_t row_stride = spike_dtype == BE_SPIKE_BITS ? (m + 31) / 32 : m;            // elements per batch row of spikes
   const DivU32 wdiv = make_div((uint32_t)geo.width);
+  // rows of one length: a lane finds its row by dividing its group index by the row's groups of four
   const DivU32 fixdiv = make_div(indptr == nullptr && row_len > 0 && row_len < (1ll << 26) ? (uint32_t)((row_len + 3) / 4) : 1u);
-  {
-    const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_bins * (2 * (size_t)cap * (homo ? 2 : 6) / 4 + 6)) * 4;
+  const float scale = ldexpf(1.0f, scale_exp - 32);
+  const double inv_scale = ldexp(1.0, -scale_exp);
+  const int prof = be_prof_begin(st);
+  for (int64_t b0 = 0; b0 < n_batch; b0 += gb) {
+    const int nb = (int)std::min<int64_t>(gb, n_batch - b0);
+    const int n_vbins = n_bins_b * nb;
+    float* out_p = out + b0 * k;
+    const unsigned char* spk_p = static_cast<const unsigned char*>(spikes_bm) +
+                                 (size_t)b0 * row_stride * (spike_dtype == BE_SPIKE_BITS ? 4 : spk_sz);
+    // n_vbins * parts ~ 256: every workgroup of pass C fills a CU; with several parts per bin (fewer than 129 bins) the parts
+    // merge their slices into `out` with float atomics, which then has to start at zero
+    int parts = 256 / (n_vbins > 0 ? n_vbins : 1);
+    parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+    if (parts > 1) {
+      hipLaunchKernelGGL(k_bin_reset, dim3(grid_for((int64_t)nb * k / 4 + 1, 256, 1024)), dim3(256), 0, st, out_p, (int64_t)nb * k, count);
+      BE_LAUNCH_CHECK();
+    }
+    ActiveList al;
+    const uint32_t* row_masks = nullptr;
+    if (gb > 1) {               // the rows with a spike in any batch row of this pass + their masks
+      const unsigned ug = (unsigned)((m + 255) / 256);
+      if (spike_dtype == BE_SPIKE_BITS)
+        hipLaunchKernelGGL(k_bin_union<BE_SPIKE_BITS>, dim3(ug), dim3(256), 0, st, spk_p, m, row_stride, nb, active, masks, count);
+      else if (spike_dtype == BE_SPIKE_FLOAT)
+        hipLaunchKernelGGL(k_bin_union<BE_SPIKE_FLOAT>, dim3(ug), dim3(256), 0, st, spk_p, m, row_stride, nb, active, masks, count);
+      else if (spike_dtype == BE_SPIKE_BOOL)
+        hipLaunchKernelGGL(k_bin_union<BE_SPIKE_BOOL>, dim3(ug), dim3(256), 0, st, spk_p, m, row_stride, nb, active, masks, count);
+      else { be_set_error("be_binary_csrmm_t_binned: unknown spike dtype"); return BE_ERR_INVALID; }
+      BE_LAUNCH_CHECK();
+      al.ids = active;
+      al.count = count;
+      row_masks = masks;
+    } else {
+      int rc = be_resolve_active(spk_p, spike_dtype, m, 1, active, 0, count, st, /*zero_first=*/false, &al);
+      if (rc != BE_OK) return rc;
+    }
+    {
+      const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (2 * (size_t)cap * (homo ? 2 : 6) / 4 + 6)) * 4;
 #define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
   do {                                                                                                                          \
     auto kern = k_bin_stream<WT, HOMO_, CAP_>;                                                                                  \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
-    hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, al.ids,      \
-                       al.count, (uint32_t)geo.width, wdiv, n_bins, (uint32_t)cap_blocks, regions, dir, ovf_img, fixdiv);       \
-    (void)0;                                                                                                 \
+    hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
+                       al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \
+                       fixdiv, row_masks, n_bins_b, k);                                                                         \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \
@@ -872,39 +1025,47 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
       else if (cap == 16) BE_BIN_STREAM(WT, false, 16); else BE_BIN_STREAM(WT, false, 8);                                       \
     }                                                                                                                           \
   } while (0)
-    if (wdtype == BE_F16) BE_BIN_STREAM_W(__half); else if (wdtype == BE_BF16) BE_BIN_STREAM_W(__hip_bfloat16); else BE_BIN_STREAM_W(float);
+      if (wdtype == BE_F16) BE_BIN_STREAM_W(__half); else if (wdtype == BE_BF16) BE_BIN_STREAM_W(__hip_bfloat16); else BE_BIN_STREAM_W(float);
 #undef BE_BIN_STREAM_W
 #undef BE_BIN_STREAM
-  }
-  BE_LAUNCH_CHECK();
-  const unsigned acc_grid = (unsigned)(n_bins * parts);
-  const float scale = ldexpf(1.0f, scale_exp - 32);
-  const double inv_scale = ldexp(1.0, -scale_exp);
+    }
+    BE_LAUNCH_CHECK();
+    const unsigned acc_grid = (unsigned)(n_vbins * parts);
+    uint32_t* rearm = spike_dtype == BE_SPIKE_IDS ? static_cast<uint32_t*>(nullptr) : count;
 #define BE_BIN_ACC(HOMO_, CAP_)                                                                                                 \
   do {                                                                                                                          \
     auto kern = k_bin_accumulate<HOMO_, CAP_>;                                                                                  \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
-                       geo.map_cap, parts, k,                                                                                    \
-                       scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype, static_cast<float*>(out),  \
-                       ovf_img, spike_dtype == BE_SPIKE_IDS ? static_cast<uint32_t*>(nullptr) : count);                          \
+                       geo.map_cap, parts, k, scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype,    \
+                       out_p, ovf_img, rearm, n_bins_b);                                                                        \
   } while (0)
-  if (homo) {
-    if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
-    else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
-  } else {
-    if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
-  }
+    if (homo) {
+      if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
+      else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
+    } else {
+      if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
+    }
 #undef BE_BIN_ACC
+    BE_LAUNCH_CHECK();
+  }
   be_prof_end(prof, st);
-  BE_LAUNCH_CHECK();
+  const int64_t total = n_batch * k;
   if (wdtype == BE_F16)
-    hipLaunchKernelGGL(k_bin_round<__half>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st, out32, static_cast<__half*>(out_user), k);
+    hipLaunchKernelGGL(k_bin_round<__half>, dim3(grid_for(total, 256, 2048)), dim3(256), 0, st, out32, static_cast<__half*>(out_user), total);
   else if (wdtype == BE_BF16)
-    hipLaunchKernelGGL(k_bin_round<__hip_bfloat16>, dim3(grid_for(k, 256, 2048)), dim3(256), 0, st, out32,
-                       static_cast<__hip_bfloat16*>(out_user), k);
+    hipLaunchKernelGGL(k_bin_round<__hip_bfloat16>, dim3(grid_for(total, 256, 2048)), dim3(256), 0, st, out32,
+                       static_cast<__hip_bfloat16*>(out_user), total);
   BE_LAUNCH_CHECK();
   return BE_OK;
+}
+
+int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                             int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out, int64_t m,
+                             int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
+                             int64_t workspace_bytes, be_stream_t stream) {
+  return be_binary_csrmm_t_binned(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, spikes, spike_dtype, out, m, k, 1,
+                                  slice_shift, bin_capacity, scale_exp, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -308,6 +308,18 @@ int be_binary_csrmv_t_binned(const void* weights, int homo, int wdtype, const in
                              int indptr_is_i64, int64_t row_len, const void* spikes, int spike_dtype, void* out,
                              int64_t m, int64_t k, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
                              int64_t workspace_bytes, be_stream_t stream);
+/* the same for a batch: spikes_bm [n_batch, m] (bit-packed: [n_batch, ceil(m / 32)] words), out_bm [n_batch, k].  The rows with a
+ * spike in ANY batch row are read once for up to 32 batch rows at a time — each entry is appended once per batch row that has
+ * its row active, into that batch row's own bins — as long as pass B's LDS holds blocks for all their bins (wide bins: few
+ * per batch row); otherwise one single-vector step per batch row, as the reference's batched scatter does
+ * (brainevent/_csr/binary_csrmm_hybrid.cu:16-57, brainevent/_fcn/binary_fcnmm.cu:486-529).  `bin_capacity` as for one vector. */
+int64_t be_binary_csrmm_t_binned_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity);
+int be_binary_csrmm_t_binned_workspace_init(void* workspace, int64_t workspace_bytes, int64_t m, int64_t k, int64_t n_batch,
+                                            int slice_shift, int64_t bin_capacity, be_stream_t stream);
+int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                             int indptr_is_i64, int64_t row_len, const void* spikes_bm, int spike_dtype, void* out_bm,
+                             int64_t m, int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity, int scale_exp,
+                             void* workspace, int64_t workspace_bytes, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * binary_csrmv / binary_csrmm, transpose=False (gather):  out[i] = sum_j w[j] * e(spikes[indices[j]])

@@ -339,3 +339,44 @@ def test_plan_that_does_not_fit_memory_falls_back_to_the_binned_route(be, oracle
     got = be.BinaryArray(spk) @ conn
     got = got.cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     np.testing.assert_allclose(got, oracle.binary_csrmv(w.reshape(-1), idx.reshape(-1), ptr, spk, (m, k), True), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('homo', [False, True])
+@pytest.mark.parametrize('enc', ['bool', 'float', 'bits'])
+def test_binned_batch_reads_the_rows_once_for_the_whole_batch(be, oracle, homo, enc):
+    """be_binary_csrmm_t_binned: the rows with a spike in any batch row are streamed once, every entry appended once per batch
+    row that has its row active (virtual bins = batch row x bin).  Against the oracle per batch row (the reference's batched
+    scatter is a loop over the columns, brainevent/_fcn/binary_fcnmm.cu:486-529), ragged CSR rows including empty ones, batch
+    sizes on both sides of the 32 rows one pass takes, all three spike encodings, bitwise equal between them."""
+    from brainevent_amd._csr import BinnedScatter, binned_batch
+    from brainevent_amd import _array as A
+    rng = np.random.default_rng(5 + int(homo))
+    m, k = 20_000, 300_000
+    lens = rng.integers(0, 40, m)
+    lens[::7] = 0
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rng.integers(0, k, int(ptr[-1])).astype(np.int32)
+    w = np.asarray([1.5], np.float32) if homo else rng.uniform(-1.0, 1.0, idx.size).astype(np.float32)
+    wd, idd, ptd = (torch.tensor(x, device='cuda') for x in (w, idx, ptr))
+    ws = BinnedScatter(wd, m, k, idx.size, max_active_fraction=0.3, indices=idd)
+    for nb in (2, 8, 37):
+        S = rng.random((nb, m)) < 0.1
+        S[1, :] = False                                    # a batch row without a spike
+        if enc == 'bool':
+            sp, sd = torch.tensor(S, device='cuda'), A.BE_SPIKE_BOOL
+        elif enc == 'float':
+            sp, sd = torch.tensor(np.where(S, 0.5, -1.0).astype(np.float32), device='cuda'), A.BE_SPIKE_FLOAT
+        else:
+            words = np.packbits(np.pad(S, ((0, 0), (0, (-m) % 32))), axis=1, bitorder='little').view(np.uint32)
+            sp, sd = torch.tensor(words.view(np.int32), device='cuda'), A.BE_SPIKE_BITS
+        out = torch.full((nb, k), 7.0, dtype=torch.float32, device='cuda')      # every output has to be written
+        binned_batch(ws, wd, idd, ptd, -1, sp, sd, out)
+        ref = np.stack([oracle.binary_csrmv(w.astype(np.float64), idx, ptr, S[b], (m, k), True) for b in range(nb)])
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        out2 = torch.empty_like(out)
+        binned_batch(ws, wd, idd, ptd, -1, sp, sd, out2)
+        # (fewer than 129 virtual bins: several workgroups of pass C share a bin and merge through float atomics, see the header)
+        np.testing.assert_allclose(out2.cpu().numpy(), out.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        if nb >= 32:          # the first pass takes 32 batch rows: 16 bins each = 512 virtual bins, one workgroup per bin
+            assert torch.equal(out[:32], out2[:32]), 'integer sums converted once: bitwise reproducible'
+
