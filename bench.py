@@ -140,7 +140,7 @@ def gen_fixed_num_on_device(n, K, n_post, homo, dev, g):
 # =====================================================================================================================
 # CPU baseline (the oracle's C port of the reference's numba loop; rank 0, N = 1 only)
 # =====================================================================================================================
-def cpu_baseline(args, n_post, n_conn):
+def cpu_baseline(args, n_post, n_conn, parallel=True):
     """The oracle's C restatement of the reference's serial numba scatter loop
     (brainevent/_csr/binary.py:446-451), 1 thread, on a bounded row sample of the same workload:
     same n_post, same row length, same firing rate, fewer pre rows (only active rows are ever touched,
@@ -170,6 +170,8 @@ def cpu_baseline(args, n_post, n_conn):
                   f'{steps} steps, C port of the reference numba loop _csr/binary.py:446-451, gcc -O3 -march=native',
         'host_cpus': os.cpu_count(),
     }
+    if not parallel:
+        return res
     # the all-cores variant next to it (OpenMP over the active rows + atomic adds).  NOT the reference's
     # algorithm (its scatter is serial by construction) — and on this host slower than the serial loop: float atomics on a
     # shared 4 MB vector bounce cache lines between cores.  A few seconds only.
@@ -194,6 +196,51 @@ def cpu_baseline(args, n_post, n_conn):
     except Exception as e:
         res['parallel_atomics_variant'] = {'error': repr(e)}
     return res
+
+
+def cpu_baseline_jitc(n, prob, fire, seconds):
+    """The oracle's C restatement of the reference's serial numba scatter walk (brainevent/_jit_scalar/binary.py:381-416), 1 thread:
+    the same matrix (shape, prob, seed 42), the walks of a bounded sample of active rows (work is proportional to them)."""
+    from oracle import oracle_c
+    oracle_c.build()
+    rng = np.random.default_rng(0)
+    n_act = 4000                                      # ~4000 x n x prob edges per call (C3: 1.6e7): a fraction of a second
+    upd, t_used, calls = 0.0, 0.0, 0
+    while t_used < seconds and calls < 1000:
+        v = np.zeros(n, np.uint8)
+        v[rng.choice(n, n_act, replace=False)] = 1
+        t0 = time.perf_counter()
+        out = oracle_c.jitmv('s', 1.0, 0.0, prob, v, 42, shape=(n, n), transpose=True, corder=False)
+        t_used += time.perf_counter() - t0
+        upd += float(out.sum())
+        calls += 1
+    return {'value': upd / t_used / 1e9, 'unit': 'Geff/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n_act} active rows per call of the same {n} x {n} matrix (prob={prob:g}, seed 42; the full vector fires '
+                      f'{int(n * fire)}), {calls} calls, C port of the reference numba walk _jit_scalar/binary.py:381-416, gcc -O3 -march=native',
+            'host_cpus': os.cpu_count()}
+
+
+def cpu_baseline_dense(n, batch, fire, seconds):
+    """The oracle's C restatement of the reference's numba row-accumulate loop (brainevent/_dense/binary.py:579-606, f32 on the
+    CPU), 1 thread: S[batch, k] @ W[k, n] on a bounded block of weight rows (only rows with a spike are ever read)."""
+    from oracle import oracle_c
+    oracle_c.build()
+    rng = np.random.default_rng(0)
+    rows = max(64, min(n, int(1.0e8 // n)))           # <= 400 MB of f32 weights (their values do not matter to the timing)
+    W = np.full((rows, n), 0.5, dtype=np.float32)
+    S = rng.random((batch, rows)) < fire
+    pairs, t_used, calls = 0, 0.0, 0
+    while t_used < seconds and calls < 1000:
+        t0 = time.perf_counter()
+        for b in range(batch):
+            oracle_c.densemv_f32(W, S[b], True)
+        t_used += time.perf_counter() - t0
+        pairs += int(S.sum())
+        calls += 1
+    return {'value': pairs * n / t_used / 1e9, 'unit': 'Geff/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{rows} of {n} weight rows (f32 on the CPU), {batch} spike vectors, fire={fire:g}, {calls} passes, C port of the '
+                      f'reference numba loop _dense/binary.py:579-606, gcc -O3 -march=native',
+            'host_cpus': os.cpu_count()}
 
 
 # =====================================================================================================================
@@ -315,7 +362,13 @@ def run_jitc(args, dev, g):
                 'basis': 'generated edges x vector-ALU issue slots per edge of the walk loop (ISA count); start-up code of a walk '
                          '(lr_init + stationary start) and idle lanes of walks of unequal length are what the fraction leaves out',
                 'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
-    return _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+    line = _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+    if not args.no_cpu and not args.jit_gather:
+        try:
+            line['cpu_baseline'] = cpu_baseline_jitc(n, prob, args.fire, min(args.cpu_seconds, 6.0))
+        except Exception as e:
+            line['cpu_baseline'] = {'error': repr(e)}
+    return line
 
 
 def run_fcn(args, dev, g):
@@ -345,7 +398,16 @@ def run_fcn(args, dev, g):
     roof = hbm_roofline(alg, whole, kernel='whole step (HIP events): compaction + ' + cfg['route'] + ' kernels',
                         extra={'dominant_kernel_ms': round(kern_ms, 5) if kern_ms else None})
     del conn, w, idx
-    return _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+    line = _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+    if not args.no_cpu:
+        try:      # FixedNumPerPre is a CSR of equal rows: the reference's loop (_fcn/binary.py:167-200) is the CSR scatter loop
+            torch.cuda.empty_cache()
+            a2 = argparse.Namespace(**vars(args))
+            a2.n, a2.cpu_seconds = n, min(args.cpu_seconds, 6.0)
+            line['cpu_baseline'] = cpu_baseline(a2, n_post, K, parallel=False)
+        except Exception as e:
+            line['cpu_baseline'] = {'error': repr(e)}
+    return line
 
 
 def run_dense(args, dev, g):
@@ -365,7 +427,13 @@ def run_dense(args, dev, g):
            'active_pairs': pairs}
     roof = hbm_roofline(union * n * 2 + args.batch * n * 2, kern_ms, kernel='k_densemm_mfma') if kern_ms else None
     del W
-    return _line(metric, value, args, elapsed, 'f16', cfg, roof, kern, step_ms)
+    line = _line(metric, value, args, elapsed, 'f16', cfg, roof, kern, step_ms)
+    if not args.no_cpu:
+        try:
+            line['cpu_baseline'] = cpu_baseline_dense(n, args.batch, args.fire, min(args.cpu_seconds, 6.0))
+        except Exception as e:
+            line['cpu_baseline'] = {'error': repr(e)}
+    return line
 
 
 def _line(metric, value, args, elapsed, dtype, cfg, roof, kern, step_ms):
@@ -389,13 +457,15 @@ def secondary(args, workload=None):
 def secondary_configs(base):
     """C3 / C4 / C5 of BASELINE.json after the headline (one GPU): compact entries for the `secondary` object."""
     out = {}
-    for name, wl, extra in (('C3', 'jitc', []), ('C4', 'fcn', []), ('C4_homo', 'fcn', ['--homo']), ('C5', 'dense', [])):
-        a = parse(['--workload', wl, '--steps', str(base.secondary_steps), '--warmup', '10'] + extra)
+    for name, wl, extra in (('C3', 'jitc', []), ('C4', 'fcn', []), ('C4_homo', 'fcn', ['--homo', '--cpu-seconds', '3']), ('C5', 'dense', [])):
+        a = parse(['--workload', wl, '--steps', str(base.secondary_steps), '--warmup', '10'] + extra + (['--no-cpu'] if base.no_cpu else []))
         try:
             ln = secondary(a, wl)
             out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'kernel_ms',
                                             'step_ms_hip_events', 'roofline')}
             out[name]['config'] = ln['config']
+            if 'cpu_baseline' in ln:
+                out[name]['cpu_baseline'] = ln['cpu_baseline']
         except Exception as e:       # a secondary leg must never sink the headline
             out[name] = {'error': repr(e)}
         torch.cuda.synchronize()
