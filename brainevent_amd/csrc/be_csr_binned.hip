@@ -28,6 +28,9 @@ namespace {
 #ifndef BE_BIN_U
 #define BE_BIN_U 4       // groups of 8 binned entries in flight per thread of pass C
 #endif
+#ifndef BE_RING
+#define BE_RING 2         // write-combining blocks per bin (a ring: an entry of block q waits for block q - BE_RING to leave)
+#endif
 #ifndef BE_FLUSH_PJ
 #define BE_FLUSH_PJ 1    // (2 / 4 passes per LDS round trip measured slower: 418 -> 455 / 464 us at C4, registers)
 #endif
@@ -40,6 +43,8 @@ namespace {
 constexpr int kMaxBins = 2048;
 constexpr int kStreamGrid = 256;     // workgroups of pass B = regions per bin (one per CU)
 constexpr int kStreamWaves = 16;
+constexpr int kRing = BE_RING, kRingLog = BE_RING == 2 ? 1 : 0;
+static_assert(BE_RING == 1 || BE_RING == 2, "ring of one or two blocks per bin");
 constexpr uint32_t kSpinLimit = 1u << 14;   // a lane that cannot get a slot for this long adds its entry with a global atomic
 
 template <bool HOMO, int CAP> struct BinBlock {
@@ -177,10 +182,10 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
         const uint32_t* blk = S.buf + (size_t)sid * B::dwords;
         const uint16_t* bi = reinterpret_cast<const uint16_t*>(blk);
         const float* bw = reinterpret_cast<const float*>(blk);
-        const uint32_t vb = sid >> 1, bb = vb / (uint32_t)n_bins_b;          // (batch row, bin) of the virtual bin
+        const uint32_t vb = sid >> kRingLog, bb = vb / (uint32_t)n_bins_b;          // (batch row, bin) of the virtual bin
         float* dst = out + (int64_t)bb * k + (int64_t)(vb - bb * (uint32_t)n_bins_b) * width;
         for (int j = lane; j < CB; j += 64) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
-        if (lane == 0) S.ovf[sid >> 1] = 1u;
+        if (lane == 0) S.ovf[sid >> kRingLog] = 1u;
       }
     }
     // LDS executes a wave's instructions in order: the blocks have been read before these stores hand their ring slots to
@@ -192,7 +197,7 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
     lds_fence();
 #pragma unroll
     for (int p = 0; p < PJ; ++p)
-      if (have[p] && gl == 0) __hip_atomic_store(&S.gen[slotid[p]], (q[p] >> 1) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (have[p] && gl == 0) __hip_atomic_store(&S.gen[slotid[p]], (q[p] >> kRingLog) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     lds_fence();
 #pragma unroll
     for (int p = 0; p < PJ; ++p) {
@@ -201,7 +206,7 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
 #else
       if (have[p] && q[p] < cap_blocks)
 #endif
-        *reinterpret_cast<uint4*>(wg_regions + (size_t)(slotid[p] >> 1) * bin_stride_dw + (size_t)q[p] * B::dwords + gl * 4) = v[p];
+        *reinterpret_cast<uint4*>(wg_regions + (size_t)(slotid[p] >> kRingLog) * bin_stride_dw + (size_t)q[p] * B::dwords + gl * 4) = v[p];
     }
   }
 }
@@ -242,7 +247,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
     uint32_t g[NE], slotid[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
-      slotid[u] = bin[u] * 2u + ((t[u] >> LOG_CB) & 1u);
+      slotid[u] = bin[u] * (uint32_t)kRing + ((t[u] >> LOG_CB) & (uint32_t)(kRing - 1));
       g[u] = __hip_atomic_load(&S.gen[slotid[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +258,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
 #if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 1
       const bool ok = ((pend >> u) & 1u) && g[u] != 0xfffffff1u;
 #else
-      const bool ok = ((pend >> u) & 1u) && g[u] == (t[u] >> (LOG_CB + 1));
+      const bool ok = ((pend >> u) & 1u) && g[u] == (t[u] >> (LOG_CB + kRingLog));
 #endif
       wr |= (ok ? 1u : 0u) << u;
       uint32_t* blk = S.buf + (size_t)slotid[u] * B::dwords;
@@ -278,7 +283,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
 #if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 2
     for (int u = 0; u < NE; ++u) d[u] = (t[u] ^ col[u]) & 0xffffu ? 0u : (uint32_t)CB - 1u;
 #else
-    for (int u = 0; u < NE; ++u) d[u] = atomicAdd(&S.done[(wr >> u) & 1u ? slotid[u] : 2u * (uint32_t)n_bins + (uint32_t)lane], 1u);
+    for (int u = 0; u < NE; ++u) d[u] = atomicAdd(&S.done[(wr >> u) & 1u ? slotid[u] : (uint32_t)kRing * (uint32_t)n_bins + (uint32_t)lane], 1u);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     // the blocks these commits completed go on the wave's list (positions from the ballots)
@@ -349,10 +354,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   S.dummy = s_ticket + 4;                        // [128], then the lanes' dummy counters live behind tick / done
   S.tick = S.dummy + 128;
   S.done = S.tick + n_bins + 64;
-  S.gen = S.done + 2 * n_bins + 64;
-  S.ovf = S.gen + 2 * n_bins;
+  S.gen = S.done + kRing * n_bins + 64;
+  S.ovf = S.gen + kRing * n_bins;
   S.buf = S.ovf + ((n_bins + 3) & ~3);           // 16-byte aligned: blocks are read 16 bytes at a time
-  for (int i = tid; i < 6 * n_bins + 128; i += (int)blockDim.x) S.tick[i] = 0u;
+  for (int i = tid; i < (2 + 2 * kRing) * n_bins + 128; i += (int)blockDim.x) S.tick[i] = 0u;
   if (tid == 0) s_ticket[0] = 0u;
   __syncthreads();
 
@@ -553,13 +558,13 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
     const int bin = q / B::dwords, l = q - bin * B::dwords;
     const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
     if (d > 0 && blk < cap_blocks)
-      regions[(((size_t)bin * kStreamGrid + blockIdx.x) * cap_blocks + blk) * B::dwords + l] = S.buf[(size_t)(bin * 2 + (blk & 1u)) * B::dwords + l];
+      regions[(((size_t)bin * kStreamGrid + blockIdx.x) * cap_blocks + blk) * B::dwords + l] = S.buf[(size_t)(bin * kRing + (blk & (uint32_t)(kRing - 1))) * B::dwords + l];
   }
   for (int bin = tid; bin < n_bins; bin += (int)blockDim.x) {
     const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
     uint32_t o = S.ovf[bin];
     if (d > 0 && blk >= cap_blocks) {          // a partly filled block of a full region: float atomics
-      const uint32_t* bp = S.buf + (size_t)(bin * 2 + (blk & 1u)) * B::dwords;
+      const uint32_t* bp = S.buf + (size_t)(bin * kRing + (blk & (uint32_t)(kRing - 1))) * B::dwords;
       const uint16_t* bi = reinterpret_cast<const uint16_t*>(bp);
       const float* bw = reinterpret_cast<const float*>(bp);
       const uint32_t bb = (uint32_t)bin / (uint32_t)n_bins_b;
@@ -777,7 +782,7 @@ __global__ void __launch_bounds__(256) k_bin_union(const void* __restrict__ spik
 static inline int stream_cap(int n_bins, int homo) {
   const int64_t budget = 160 * 1024 - 512 - (int64_t)kStreamFixedWords * 4;
   for (int cap = homo ? 128 : 64; cap >= 8; cap >>= 1) {
-    const int64_t per_bin = 2 * (int64_t)cap * (homo ? 2 : 6) + 24;      // two blocks + ticket, 2 commit counts, 2 generations, flag
+    const int64_t per_bin = kRing * (int64_t)cap * (homo ? 2 : 6) + 8 + 8 * kRing;      // two blocks + ticket, 2 commit counts, 2 generations, flag
     if (per_bin * n_bins <= budget) return cap;
   }
   return 0;
@@ -1005,7 +1010,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       if (rc != BE_OK) return rc;
     }
     {
-      const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (2 * (size_t)cap * (homo ? 2 : 6) / 4 + 6)) * 4;
+      const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (kRing * (size_t)cap * (homo ? 2 : 6) / 4 + 2 + 2 * kRing)) * 4;
 #define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
   do {                                                                                                                          \
     auto kern = k_bin_stream<WT, HOMO_, CAP_>;                                                                                  \
