@@ -370,9 +370,7 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
 template <int MODE, typename A, typename T>
 __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
                                                             A* __restrict__ out_bm, int64_t win_cols) {
-  // win_cols: columns of a chunk whose masks LDS holds at a time.  A chunk wider than that is swept in windows; the walks
-  // are sequential generators, so every window re-walks the chunk from its start up to the window's end (W windows cost
-  // (W + 1) / 2 walks of the chunk — still cheaper than a 64-byte sector per edge up to W = 4).
+  // win_cols: columns of a chunk whose masks LDS holds at a time.  A chunk wider than that is swept in windows.
   extern __shared__ __align__(16) unsigned char jit_mm_lds[];
   T* ms = reinterpret_cast<T*>(jit_mm_lds);
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,10 +378,19 @@ __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32
   A acc[NCOL];
 #pragma unroll
   for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
+  constexpr int kMmStride = 4;                               // lane stride of the mm matrix (brainevent/_misc.py:37-38)
   for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
     const int64_t cs = (int64_t)chunk * p.chunk_size;
     const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
     const int64_t width = ce - cs;
+    // the four walks of this row in this chunk keep their generator state across the windows (round 2 restarted every
+    // walk at every window: W windows cost (W + 1) / 2 walks of the chunk, which ruled windows out for wide batches)
+    uint32_t wstate[kMmStride], wq[kMmStride];
+#pragma unroll
+    for (int l = 0; l < kMmStride; ++l) {
+      wstate[l] = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, (uint32_t)l);
+      wq[l] = lr_initial_q(wstate[l], p.cl);
+    }
     for (int64_t w_lo = 0; w_lo < width; w_lo += win_cols) {
       const int64_t w_hi = w_lo + win_cols < width ? w_lo + win_cols : width;
       const int64_t w_n = w_hi - w_lo;
@@ -403,12 +410,12 @@ __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32
       }
       __syncthreads();
       if (row < m) {
-        for (uint32_t l = 0; l < (uint32_t)p.stride; ++l) {
-          uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
-          uint32_t q = lr_initial_q(state, p.cl);
-          uint64_t lj = (uint64_t)l + (uint64_t)p.stride * q;
+#pragma unroll
+        for (int l = 0; l < kMmStride; ++l) {
+          uint32_t state = wstate[l], q = wq[l];
+          uint64_t lj = (uint64_t)l + (uint64_t)kMmStride * q;
           while ((int64_t)lj < w_hi) {
-            uint32_t mk = (int64_t)lj >= w_lo ? (uint32_t)ms[(int64_t)lj - w_lo] : 0u;
+            uint32_t mk = (uint32_t)ms[(int64_t)lj - w_lo];
             if (mk) {
               asm volatile("" : "+v"(mk));                   // keeps the per-column adds behind the branch
               const A w = (MODE == MODE_SCALAR) ? A(1) : edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)(cs + (int64_t)lj));
@@ -417,8 +424,10 @@ __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32
             }
             state = lr_next_nz(state);
             q = q + 1u + lr_bounded(state, p.cl - 1u);
-            lj = (uint64_t)l + (uint64_t)p.stride * q;
+            lj = (uint64_t)l + (uint64_t)kMmStride * q;
           }
+          wstate[l] = state;
+          wq[l] = q;
         }
       }
     }
@@ -709,9 +718,8 @@ int jit_mm_run(const JitP& p, const uint32_t* mask, int64_t rows, int nc, int ga
   const int64_t chunk_cols = std::min<int64_t>(p.chunk_size, p.walk_len);
   const int64_t win_cap = 128 * 1024 / mask_sz;                      // columns whose masks fit LDS
   const int64_t n_win = (chunk_cols + win_cap - 1) / win_cap;
-  // windows only pay for <= 8 batch columns (n = 1M: 3.75 -> 2.87 ms, 2M: 19 -> 15 ms); with 32 columns the re-walks cost
-  // more than the sectors they save (n = 500k: 1.4 -> 3.0 ms), so wider batches use LDS only when a whole chunk fits
-  if ((n_win == 1 || (mask_sz == 1 && n_win <= 4)) && rows > 0) {
+  // (the walks keep their state from window to window, so windows cost two barriers and a staging pass each, nothing else)
+  if (n_win <= 256 && p.stride == 4 && rows > 0) {
     const int64_t win_cols = (chunk_cols + n_win - 1) / n_win;
     const size_t lds = (size_t)be_align_up(win_cols * mask_sz, 16);
     const unsigned grid = (unsigned)((rows + 1023) / 1024);
@@ -868,9 +876,9 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
   if (!gather) BE_HIP(be_fill_async(dst, 0, (size_t)out_len * n_batch * asz, st));
   const size_t spk_sz = (spike_dtype == BE_SPIKE_FLOAT) ? 4 : 1;
   const int prof = be_prof_begin(st);
-  // (Cutting a wide batch into passes of 8 columns, whose 1-byte masks fit LDS in up to four windows, where the masks of 32 columns
-  //  do not, was measured in round 3 and is slower: n = 1M, 32 columns 4.7 ms in one pass against 4 x 2.87 = 11.5 ms — every
-  //  pass re-walks the whole matrix, and a windowed pass re-walks each chunk once per window on top; bit-identical either way.)
+  // (Cutting a wide batch into passes of 8 columns was measured in round 3 and is slower — n = 1M, 32 columns: 4.7 ms in one pass
+  //  against 4 x 2.87 = 11.5 ms, every pass re-walks the whole matrix; what helps is windows whose walks keep their state,
+  //  k_jit_mm_gather_lds.)
   for (int64_t b0 = 0; b0 < n_batch; b0 += 32) {
     const int nc = (int)std::min<int64_t>(32, n_batch - b0);
     const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * in_len * spk_sz;
