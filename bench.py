@@ -596,6 +596,10 @@ def run_scatter(args):
         n_post = shape[1]
         n_conn = n_conn_global / p_world               # mean stored synapses per (row, shard); the rows are ragged
     nnz_local = int(indices.numel())
+    if not mock:
+        torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_setup          # synthetic data (torch generators): not the library's setup
+    t_setup = time.perf_counter()
     csr = None if mock else be.CSR((weights, indices, indptr), shape=shape, check_structure=False)
     if mock:
         pass
@@ -794,7 +798,7 @@ def run_scatter(args):
                                                                   + ('be_exchange_* / RCCL' if native else 'torch.distributed')
                                                                   + (', posted one step ahead' if ahead else '') + ')' if use_dist else '')
                                       + (f' [one process emulating rank 0 of {args.emulate_world}]' if args.emulate_world > 1 else ''),
-                       'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2),
+                       'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2), 'data_gen_s': round(t_gen, 2),
                        'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '
                                        f"layout {({1: 'd8 (5 B/entry)', 2: 'h8 (1 B/entry)'}.get(plan.layout, 'u16'))}" if plan is not None else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},

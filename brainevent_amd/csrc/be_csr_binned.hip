@@ -804,7 +804,10 @@ static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo) {
   int64_t max_w = (160 * 1024 - kAccStaticBytes) / acc_bytes;
   max_w = std::min<int64_t>(std::min<int64_t>(max_w, 1ll << slice_shift), 65535) & ~3ll;
   BinGeo g{0, 0, 0, 0};
-  if (k <= 256 * 256) {
+  static const int forced = [] { const char* e = getenv("BE_BIN_COUNT"); return e ? atoi(e) : 0; }();     // (A/B runs)
+  if (forced > 0 && (k + forced - 1) / forced <= max_w) {
+    g.width = ((k + forced - 1) / forced + 3) & ~3ll;
+  } else if (k <= 256 * 256) {
     g.width = std::min<int64_t>(256, max_w);
   } else if (!homo && k > 256 * std::min<int64_t>(max_w, 16384)) {
     // weighted entries over many outputs keep bins of a power of two (2^14 columns at most: C4 = 611 bins): pass C's rounds
