@@ -55,6 +55,9 @@ def parse(argv=None):
                     'would hold and run the exchange path with a one-rank group (what one rank of W does per step)')
     ap.add_argument('--jit-shard', type=int, default=1, help='jitc workload: run rank 0 of an N-way walk-class partition')
     ap.add_argument('--exchange', choices=['bits', 'bytes'], default='bits', help='payload of the per-step spike all-gather (N > 1)')
+    ap.add_argument('--producer', choices=['words', 'bytes'], default='words', help='N > 1, --exchange bits: the form a rank\'s own '
+                    'spikes arrive in.  words = bit-packed by the producer (what be_lif_coba_step_packed writes): the exchange '
+                    'gathers them from where they lie; bytes = one byte per neuron, packed by the exchange every step')
     ap.add_argument('--exchange-impl', choices=['native', 'torch'], default='native', help='native = the library\'s own RCCL '
                     'all-gather (be_exchange_*: one C call per step); torch = torch.distributed.all_gather_into_tensor '
                     '(about 30 us of host time per call: a 1-of-8 shard step is host-bound behind it)')
@@ -687,8 +690,16 @@ def run_scatter(args):
     upd_per_vec = torch.stack([row_len[f].sum() for f in full]).cpu().numpy()
     active_per_vec = torch.stack([f.sum() for f in full]).cpu().numpy()
 
+    # the local spikes as the producer hands them over: bit-packed words (packed once here, outside the timed steps — the
+    # neuron step writes them that way, be_lif_coba_step_packed) or bytes (the exchange then packs them every step)
+    local_events = [local_spikes[b] for b in range(n_batch)]
+    producer = 'bytes'
+    if use_dist and args.exchange == 'bits' and args.producer == 'words' and not mock:
+        from brainevent_amd import _array as A
+        local_events = [A.PackedSpikes(be.bitpack(local_spikes[b], 0).reshape(-1), n_local) for b in range(n_batch)]
+        producer = 'words'
     ahead = use_dist and args.exchange == 'bits' and args.exchange_ahead
-    ticket = [exchange.post(local_spikes[0])] if ahead else None
+    ticket = [exchange.post(local_events[0])] if ahead else None
 
     def mock_scatter(full_spikes):
         ref = reference_for_shard(weights, indices, indptr, full_spikes, n_post, args.homo)
@@ -701,12 +712,12 @@ def run_scatter(args):
         if ahead:
             # step i's spikes were posted during step i - 1: post step i + 1's now (the collective overlaps with the
             # scatter below), then consume step i's.  Every timed step still issues one exchange and one scatter.
-            nxt = exchange.post(local_spikes[(i + 1) % n_batch])
+            nxt = exchange.post(local_events[(i + 1) % n_batch])
             ev = exchange.wait_events(ticket[0])
             ticket[0] = nxt
             return ev @ csr
         if use_dist:
-            return exchange.gather_events(s) @ csr
+            return exchange.gather_events(local_events[i % n_batch]) @ csr
         return be.BinaryArray(s) @ csr
 
     def fence():
@@ -796,7 +807,10 @@ def run_scatter(args):
                        'synapses_per_row_per_shard': n_conn, 'stored_synapses_total': total_nnz,
                        'parallelism': f'post-slice x{p_world}' + (f' + spike all-gather ({args.exchange}, '
                                                                   + ('be_exchange_* / RCCL' if native else 'torch.distributed')
-                                                                  + (', posted one step ahead' if ahead else '') + ')' if use_dist else '')
+                                                                  + (', posted one step ahead' if ahead else '')
+                                                                  + (', local spikes arrive as packed words' if producer == 'words'
+                                                                     else ', local spikes arrive as bytes and are packed per step')
+                                                                  + ')' if use_dist else '')
                                       + (f' [one process emulating rank 0 of {args.emulate_world}]' if args.emulate_world > 1 else ''),
                        'plan_GB': round(plan_bytes / 1e9, 2), 'setup_s': round(t_setup, 2), 'data_gen_s': round(t_gen, 2),
                        'plan_slices': (f'{plan.n_slices} x {plan.slice_width} columns x {plan.default_parts()} parts, '

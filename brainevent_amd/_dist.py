@@ -162,8 +162,30 @@ class SpikeExchange:
                 self._chunks = [torch.empty(self._pad, dtype=torch.uint8, device=device) for _ in sizes]
 
     # -- packed path ------------------------------------------------------------------------------------
-    def _pack_into(self, local_spikes: torch.Tensor, local_words: torch.Tensor) -> None:
+    def _packed_local(self, local_spikes):
+        """The slice's own words when the producer hands it over packed (``BitPackedBinary`` / ``PackedSpikes``), else None."""
+        from . import _array as A
+        from ._event import BitPackedBinary
+        if isinstance(local_spikes, BitPackedBinary) and local_spikes.ndim == 1:
+            local_spikes = local_spikes._packed_operand()
+        if isinstance(local_spikes, A.PackedSpikes):
+            assert local_spikes.n == self.hi - self.lo
+            return local_spikes.bits if local_spikes.bits.dtype == torch.int32 else local_spikes.bits.view(torch.int32)
+        return None
+
+    def _pack_into(self, local_spikes, local_words: torch.Tensor) -> torch.Tensor:
+        """The words to send: ``local_words`` filled from the spikes — or the producer's own words when they arrive packed and
+        fill the slice (no pack launch, no copy)."""
         n_local = self.hi - self.lo
+        words = self._packed_local(local_spikes)
+        if words is not None:
+            used = (n_local + 31) // 32
+            if used == local_words.numel() and words.device == local_words.device:
+                return words[:used]
+            local_words.zero_()
+            local_words[:used] = words[:used].to(local_words.device)
+            return local_words
+        assert local_spikes.numel() == n_local
         if local_spikes.is_cuda:
             import ctypes
             from . import _array as A
@@ -178,10 +200,11 @@ class SpikeExchange:
             buf = local_words.view(torch.uint8)
             buf.zero_()
             buf[:by.numel()] = by
+        return local_words
 
-    def _gather_words(self, local_spikes: torch.Tensor) -> torch.Tensor:
-        self._pack_into(local_spikes, self._local_words)
-        self.dist.all_gather_into_tensor(self._full_words, self._local_words, group=self.group)
+    def _gather_words(self, local_spikes) -> torch.Tensor:
+        send = self._pack_into(local_spikes, self._local_words)
+        self.dist.all_gather_into_tensor(self._full_words, send, group=self.group)
         return self._full_words
 
     # -- pipelined exchange (packed mode): post step t+1's spikes, then work on step t ---------------------------
@@ -194,7 +217,6 @@ class SpikeExchange:
         steps (the spikes a step delivers were emitted before the previous step started).  Two buffers alternate: at most
         one ticket may be in flight while another is being consumed."""
         assert self.packed, "post()/wait_events() use the bit-packed exchange"
-        assert local_spikes.numel() == self.hi - self.lo
         if not hasattr(self, '_slots'):
             self._slots = [(self._local_words, self._full_words),
                            (torch.zeros_like(self._local_words), torch.zeros_like(self._full_words))]
@@ -202,8 +224,8 @@ class SpikeExchange:
         slot = self._next
         self._next ^= 1
         local_words, full_words = self._slots[slot]
-        self._pack_into(local_spikes, local_words)
-        work = self.dist.all_gather_into_tensor(full_words, local_words, group=self.group, async_op=True)
+        send = self._pack_into(local_spikes, local_words)
+        work = self.dist.all_gather_into_tensor(full_words, send, group=self.group, async_op=True)
         return slot, work
 
     def wait_events(self, ticket):
@@ -219,7 +241,6 @@ class SpikeExchange:
     def gather_events(self, local_spikes: torch.Tensor):
         """This rank's spikes ``[hi - lo]`` -> the full spike vector as an event container usable as ``ev @ shard``."""
         from ._event import BinaryArray, BitPackedBinary
-        assert local_spikes.numel() == self.hi - self.lo
         if self.packed:
             words = self._gather_words(local_spikes)
             if words.is_cuda:
@@ -244,6 +265,24 @@ class SpikeExchange:
             payload = torch.cat([payload, torch.zeros(self._pad - payload.numel(), dtype=torch.uint8, device=payload.device)])
         self.dist.all_gather(self._chunks, payload.contiguous(), group=self.group)
         return torch.cat([c[:b[1] - b[0]].view(torch.bool) for c, b in zip(self._chunks, self.bounds)])
+
+
+def _local_operand(local_spikes, n_local: int):
+    """This rank's spikes as (device buffer, spike dtype code).  A packed-only ``BitPackedBinary`` / ``PackedSpikes`` of the
+    slice — what a producer that emits words delivers (``lif_coba_step(..., spike_bits=...)``) — is handed over as words
+    (``BE_SPIKE_BITS``: the exchange gathers them from where they lie, no pack launch); bits past ``n_local`` must be 0."""
+    from . import _array as A
+    from ._event import BitPackedBinary
+    if isinstance(local_spikes, BitPackedBinary) and local_spikes.ndim == 1:
+        pk = local_spikes._packed_operand()
+        if pk is not None:
+            local_spikes = pk
+    if isinstance(local_spikes, A.PackedSpikes):
+        assert local_spikes.n == n_local
+        return A.to_device(local_spikes.bits), A.BE_SPIKE_BITS
+    assert local_spikes.numel() == n_local
+    return A.spikes_to_device(local_spikes)
+
 
 
 def _device_view_i32(ptr: int, n: int, device) -> torch.Tensor:
@@ -302,8 +341,7 @@ class NativeSpikeExchange:
         from . import _array as A
         from ._event import BitPackedBinary
         from ._lib import fn, check
-        assert local_spikes.numel() == self.hi - self.lo
-        sp, sd = A.spikes_to_device(local_spikes)
+        sp, sd = _local_operand(local_spikes, self.hi - self.lo)
         ct = self._ct
         f = fn('be_exchange_allgather_bits', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p])
         check(f(self._h, A.ptr(sp), sd, A.ptr(self._full_words), A.stream_ptr()), 'be_exchange_allgather_bits')
@@ -320,10 +358,9 @@ class NativeSpikeExchange:
         another is consumed."""
         from . import _array as A
         from ._lib import fn, check
-        assert local_spikes.numel() == self.hi - self.lo
         slot = getattr(self, '_next', 0)
         self._next = slot ^ 1
-        sp, sd = A.spikes_to_device(local_spikes)
+        sp, sd = _local_operand(local_spikes, self.hi - self.lo)
         ct = self._ct
         f = fn('be_exchange_post', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p])
         check(f(self._h, A.ptr(sp), sd, slot, A.stream_ptr()), 'be_exchange_post')

@@ -15,7 +15,8 @@ __all__ = ['lif_coba_step']
 
 
 def lif_coba_step(v: torch.Tensor, g_exc: torch.Tensor, g_inh: torch.Tensor, refractory: torch.Tensor,
-                  in_exc: torch.Tensor, in_inh: torch.Tensor, spikes: torch.Tensor, spike_count: torch.Tensor = None, *,
+                  in_exc: torch.Tensor, in_inh: torch.Tensor, spikes: torch.Tensor = None, spike_count: torch.Tensor = None, *,
+                  spike_bits: torch.Tensor = None,
                   dt: float = 0.1, tau_m: float = 20.0, v_rest: float = -60.0, v_th: float = -50.0, v_reset: float = -60.0,
                   t_ref: float = 5.0, e_exc: float = 0.0, e_inh: float = -80.0, tau_exc: float = 5.0, tau_inh: float = 10.0,
                   i_ext: float = 20.0, syn_scale: float = 1e-3) -> None:
@@ -23,17 +24,27 @@ def lif_coba_step(v: torch.Tensor, g_exc: torch.Tensor, g_inh: torch.Tensor, ref
     this step's spikes (``bool`` / ``uint8``) to ``spikes`` and add them to ``spike_count`` if given.  ``in_exc`` / ``in_inh``
     are this step's synaptic inputs (the outputs of ``BinaryArray(spikes) @ W_exc`` / ``@ W_inh``).  Defaults: the COBA
     benchmark network (Vogels & Abbott 2005).  Every operation is rounded separately, in the order the header states, so the
-    result equals the same formulas written as elementwise tensor ops bit for bit."""
+    result equals the same formulas written as elementwise tensor ops bit for bit.
+
+    ``spike_bits`` (int32 ``[ceil(n / 32)]``, optional): the spikes are also — or, with ``spikes=None``, only — written
+    bit-packed, the form ``BitPackedBinary.from_packed(spike_bits, n) @ conn`` and the multi-GPU spike exchange consume as they
+    are: a step loop that keeps its spikes as words has no pack launch (``be_lif_coba_step_packed``)."""
     n = int(v.numel())
     for t in (v, g_exc, g_inh, refractory, in_exc, in_inh):
         if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
             raise ValueError('lif_coba_step: state and input tensors must be contiguous f32 device tensors of one length.')
-    if spikes.numel() != n or spikes.dtype not in (torch.bool, torch.uint8) or not spikes.is_cuda or not spikes.is_contiguous():
+    if spikes is None and spike_bits is None:
+        raise ValueError('lif_coba_step: give spikes, spike_bits or both.')
+    if spikes is not None and (spikes.numel() != n or spikes.dtype not in (torch.bool, torch.uint8) or not spikes.is_cuda
+                               or not spikes.is_contiguous()):
         raise ValueError('lif_coba_step: spikes must be a contiguous bool / uint8 device tensor of the same length.')
+    if spike_bits is not None and (spike_bits.dtype != torch.int32 or spike_bits.numel() < (n + 31) // 32 or not spike_bits.is_cuda
+                                   or not spike_bits.is_contiguous()):
+        raise ValueError('lif_coba_step: spike_bits must be a contiguous int32 device tensor of ceil(n / 32) words.')
     if spike_count is not None and (spike_count.dtype != torch.float32 or spike_count.numel() != n or not spike_count.is_cuda):
         raise ValueError('lif_coba_step: spike_count must be an f32 device tensor of the same length.')
     c_d, c_vp = ctypes.c_double, ctypes.c_void_p
-    f = fn('be_lif_coba_step', ctypes.c_int, [c_vp] * 8 + [ctypes.c_int64] + [c_d] * 12 + [c_vp])
+    f = fn('be_lif_coba_step_packed', ctypes.c_int, [c_vp] * 9 + [ctypes.c_int64] + [c_d] * 12 + [c_vp])
     check(f(A.ptr(v), A.ptr(g_exc), A.ptr(g_inh), A.ptr(refractory), A.ptr(in_exc), A.ptr(in_inh), A.ptr(spikes),
-            A.ptr(spike_count) if spike_count is not None else None, n, dt, tau_m, v_rest, v_th, v_reset, t_ref, e_exc, e_inh,
-            math.exp(-dt / tau_exc), math.exp(-dt / tau_inh), i_ext, syn_scale, A.stream_ptr()), 'be_lif_coba_step')
+            A.ptr(spike_bits), A.ptr(spike_count), n, dt, tau_m, v_rest, v_th, v_reset, t_ref, e_exc, e_inh,
+            math.exp(-dt / tau_exc), math.exp(-dt / tau_inh), i_ext, syn_scale, A.stream_ptr()), 'be_lif_coba_step_packed')

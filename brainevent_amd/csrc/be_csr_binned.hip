@@ -337,7 +337,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
                                                      uint32_t width, DivU32 wdiv, int n_bins, uint32_t cap_blocks,
                                                      uint32_t* __restrict__ regions, uint32_t* __restrict__ dir,
                                                      float* __restrict__ out, DivU32 fixdiv,
-                                                     const uint32_t* __restrict__ row_masks, int n_bins_b, int64_t k) {
+                                                     const uint32_t* __restrict__ row_masks, int n_bins_b, int64_t k,
+                                                     uint32_t min_tasks, uint32_t task_groups, int64_t m_rows) {
   // row_masks != NULL: a batch.  `active` lists the rows with a spike in ANY of the (<= 32) batch rows of this pass and
   // row_masks[j] says in which; the bins are virtual — batch row b's bin i is n_bins_b * b + i of n_bins — and an entry is
   // appended once per batch row that has its row active (the rows are read once for the whole batch).
@@ -366,9 +367,20 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
   const bool fixed = rp.p == nullptr && rp.fixed > 0 && rp.fixed < (1ll << 26);
   const uint32_t K = fixed ? (uint32_t)rp.fixed : 0u, K4 = (K + 3u) >> 2;
-  // rows per task: as many as keep every wave of the chip supplied (>= 2 tasks per wave), at most 64
+  // rows per task (1 ... 64): about `task_groups` groups of four entries — 12-16 steps of a wave.  Measured (BE_BIN_TASKS /
+  // BE_BIN_TASK_GROUPS): rows of 1000 entries, 8 / 4 / 2 rows per task 0.666 / 0.646 / 0.646 ms per C4 step; rows of ~125
+  // entries (one post slice of an 8-way cut), 64 / 32 / 16 / 8 rows per task 151 / 124 / 124 / 130 us per step: shorter tasks
+  // pay their header (ticket, row ids, row bounds: dependent loads) too often, longer ones leave waves without work and
+  // the others in step with each other.  Fewer active rows than `min_tasks` tasks of that size: smaller tasks.
+  uint64_t avg_g4 = K4;
+  if (!fixed) {
+    const int64_t nnz = rp.at(m_rows) - rp.at(0);
+    avg_g4 = m_rows > 0 ? ((uint64_t)(nnz > 0 ? nnz : 0) / (uint64_t)m_rows + 3u) >> 2 : 1u;
+  }
+  avg_g4 = avg_g4 ? avg_g4 : 1u;
   int rshift = 6;
-  while (rshift > 0 && (n_active >> rshift) < 8192u) --rshift;
+  while (rshift > 0 && (avg_g4 << rshift) > (uint64_t)task_groups) --rshift;
+  while (rshift > 0 && (n_active >> rshift) < min_tasks) --rshift;
   while (fixed && rshift > 0 && (rp.fixed << rshift) >= (1ll << 31)) --rshift;
   const uint32_t R = 1u << rshift;
   const uint64_t n_tasks = ((uint64_t)n_active + R - 1) >> rshift;
@@ -781,7 +793,10 @@ __global__ void __launch_bounds__(256) k_bin_union(const void* __restrict__ spik
 // entries per write-combining block: the largest the LDS of pass B holds for this many bins
 static inline int stream_cap(int n_bins, int homo) {
   const int64_t budget = 160 * 1024 - 512 - (int64_t)kStreamFixedWords * 4;
-  for (int cap = homo ? 128 : 64; cap >= 8; cap >>= 1) {
+  static const int forced = [] { const char* e = getenv("BE_BIN_CAP"); return e ? atoi(e) : 0; }();       // (A/B runs)
+  // (weighted blocks of 128 entries — 768 bytes — serve outputs of fewer than ~85 bins: 10M rows x 1.25M outputs, 125 per row,
+  //  8 % firing, 77 bins: pass B 735 / 567 / 519 / 438 us with blocks of 16 / 32 / 64 / 128, tools/exp_hybrid_estimate.py)
+  for (int cap = forced > 0 ? forced : 128; cap >= 8; cap >>= 1) {
     const int64_t per_bin = kRing * (int64_t)cap * (homo ? 2 : 6) + 8 + 8 * kRing;      // two blocks + ticket, 2 commit counts, 2 generations, flag
     if (per_bin * n_bins <= budget) return cap;
   }
@@ -1013,6 +1028,9 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       if (rc != BE_OK) return rc;
     }
     {
+      // groups of four entries per task, and the tasks a step is cut into at least (k_bin_stream: rows per task)
+      static const uint32_t min_tasks = [] { const char* e = getenv("BE_BIN_TASKS"); return e ? (uint32_t)atoi(e) : 2048u; }();   // (A/B runs)
+      static const uint32_t task_groups = [] { const char* e = getenv("BE_BIN_TASK_GROUPS"); return e ? (uint32_t)atoi(e) : 1024u; }();
       const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (kRing * (size_t)cap * (homo ? 2 : 6) / 4 + 2 + 2 * kRing)) * 4;
 #define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
   do {                                                                                                                          \
@@ -1020,7 +1038,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
                        al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \
-                       fixdiv, row_masks, n_bins_b, k);                                                                         \
+                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m);                                              \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \
@@ -1029,7 +1047,8 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       else if (cap == 32) BE_BIN_STREAM(WT, true, 32); else if (cap == 16) BE_BIN_STREAM(WT, true, 16);                         \
       else BE_BIN_STREAM(WT, true, 8);                                                                                          \
     } else {                                                                                                                    \
-      if (cap == 64) BE_BIN_STREAM(WT, false, 64); else if (cap == 32) BE_BIN_STREAM(WT, false, 32);                            \
+      if (cap == 128) BE_BIN_STREAM(WT, false, 128);                                                                            \
+      else if (cap == 64) BE_BIN_STREAM(WT, false, 64); else if (cap == 32) BE_BIN_STREAM(WT, false, 32);                       \
       else if (cap == 16) BE_BIN_STREAM(WT, false, 16); else BE_BIN_STREAM(WT, false, 8);                                       \
     }                                                                                                                           \
   } while (0)
@@ -1052,7 +1071,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
       else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
     } else {
-      if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
+      if (cap == 128) BE_BIN_ACC(false, 128); else if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
     }
 #undef BE_BIN_ACC
     BE_LAUNCH_CHECK();

@@ -159,14 +159,25 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
   n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
   BE_REQUIRE(n_local == 0 || local_spikes != nullptr, BE_ERR_INVALID, "null pointer");
   const int64_t used = (n_local + 31) / 32;
-  if (used < ex->words_per_rank)      // words of the slice that hold no spike of the population
-    BE_HIP(be_fill_async(ex->local_words + used, 0, (size_t)(ex->words_per_rank - used) * 4, st));
-  if (n_local > 0) {
-    const int rc = be_pack_spikes(local_spikes, spike_dtype, n_local, ex->local_words, stream);
-    if (rc != BE_OK) return rc;
+  // BE_SPIKE_BITS: the producer already emits the slice as words (be_lif_coba_step's spike_bits_out, a BitPackedBinary): a
+  // slice that fills its words is gathered from where it lies — no pack launch, no copy
+  const uint32_t* send = ex->local_words;
+  if (spike_dtype == BE_SPIKE_BITS && used == ex->words_per_rank && n_local > 0) {
+    send = static_cast<const uint32_t*>(local_spikes);
+  } else {
+    if (used < ex->words_per_rank)      // words of the slice that hold no spike of the population
+      BE_HIP(be_fill_async(ex->local_words + used, 0, (size_t)(ex->words_per_rank - used) * 4, st));
+    if (n_local > 0) {
+      if (spike_dtype == BE_SPIKE_BITS) {
+        BE_HIP(hipMemcpyAsync(ex->local_words, local_spikes, (size_t)used * 4, hipMemcpyDeviceToDevice, st));
+      } else {
+        const int rc = be_pack_spikes(local_spikes, spike_dtype, n_local, ex->local_words, stream);
+        if (rc != BE_OK) return rc;
+      }
+    }
   }
   if (ex->words_per_rank > 0)
-    BE_RCCL(R->AllGather(ex->local_words, full_bits, (size_t)ex->words_per_rank, kNcclUint32, ex->comm, st));
+    BE_RCCL(R->AllGather(send, full_bits, (size_t)ex->words_per_rank, kNcclUint32, ex->comm, st));
   return BE_OK;
 }
 
@@ -227,13 +238,23 @@ int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, 
   n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
   BE_REQUIRE(n_local == 0 || local_spikes != nullptr, BE_ERR_INVALID, "null pointer");
   const int64_t used = (n_local + 31) / 32;
-  if (used < ex->words_per_rank) BE_HIP(be_fill_async(ex->post_local[slot] + used, 0, (size_t)(ex->words_per_rank - used) * 4, ex->side));
-  if (n_local > 0) {
-    const int rc = be_pack_spikes(local_spikes, spike_dtype, n_local, ex->post_local[slot], ex->side);
-    if (rc != BE_OK) return rc;
+  // (BE_SPIKE_BITS: see be_exchange_allgather_bits; the caller keeps the words unchanged until the slot's wait has returned)
+  const uint32_t* send = ex->post_local[slot];
+  if (spike_dtype == BE_SPIKE_BITS && used == ex->words_per_rank && n_local > 0) {
+    send = static_cast<const uint32_t*>(local_spikes);
+  } else {
+    if (used < ex->words_per_rank) BE_HIP(be_fill_async(ex->post_local[slot] + used, 0, (size_t)(ex->words_per_rank - used) * 4, ex->side));
+    if (n_local > 0) {
+      if (spike_dtype == BE_SPIKE_BITS) {
+        BE_HIP(hipMemcpyAsync(ex->post_local[slot], local_spikes, (size_t)used * 4, hipMemcpyDeviceToDevice, ex->side));
+      } else {
+        const int rc = be_pack_spikes(local_spikes, spike_dtype, n_local, ex->post_local[slot], ex->side);
+        if (rc != BE_OK) return rc;
+      }
+    }
   }
   if (ex->words_per_rank > 0)
-    BE_RCCL(R->AllGather(ex->post_local[slot], ex->post_full[slot], (size_t)ex->words_per_rank, kNcclUint32, ex->comm, ex->side));
+    BE_RCCL(R->AllGather(send, ex->post_full[slot], (size_t)ex->words_per_rank, kNcclUint32, ex->comm, ex->side));
   BE_HIP(hipEventRecord(ex->ev_done[slot], ex->side));
   return BE_OK;
 }

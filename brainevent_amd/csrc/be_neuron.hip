@@ -17,7 +17,8 @@ struct LifCobaP {
 __global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, float* __restrict__ ge, float* __restrict__ gi,
                                                        float* __restrict__ refr, const float* __restrict__ in_exc,
                                                        const float* __restrict__ in_inh, uint8_t* __restrict__ spikes,
-                                                       float* __restrict__ spike_count, int64_t n, LifCobaP p) {
+                                                       uint32_t* __restrict__ spike_bits, float* __restrict__ spike_count,
+                                                       int64_t n, LifCobaP p) {
 #pragma clang fp contract(off)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -34,7 +35,13 @@ __global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, fl
     refr[i] = s ? p.t_ref : r - p.dt;
     ge[i] = g_e;
     gi[i] = g_i;
-    spikes[i] = s ? 1 : 0;
+    if (spikes != nullptr) spikes[i] = s ? 1 : 0;
+    if (spike_bits != nullptr) {       // the packed form the scatters and the spike exchange consume (BE_SPIKE_BITS): one word per 32 neurons
+      // (lanes past the population have left the loop: the ballot reads them as 0; a word's first lane is inside whenever
+      //  the word holds a neuron, the grid stride is a multiple of 64)
+      const uint64_t bal = __ballot(s);
+      if ((threadIdx.x & 31) == 0) spike_bits[i >> 5] = (uint32_t)(bal >> (threadIdx.x & 32));
+    }
     if (spike_count != nullptr && s) spike_count[i] += 1.f;
   }
 }
@@ -43,22 +50,31 @@ __global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, fl
 
 extern "C" {
 
-int be_lif_coba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
-                     uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
-                     double v_reset, double t_ref, double e_exc, double e_inh, double decay_exc, double decay_inh, double i_ext,
-                     double syn_scale, be_stream_t stream) {
+int be_lif_coba_step_packed(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                            uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
+                            double v_rest, double v_th, double v_reset, double t_ref, double e_exc, double e_inh,
+                            double decay_exc, double decay_inh, double i_ext, double syn_scale, be_stream_t stream) {
   BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
   if (n == 0) return BE_OK;
-  BE_REQUIRE(v && g_exc && g_inh && refractory && in_exc && in_inh && spikes_out, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(v && g_exc && g_inh && refractory && in_exc && in_inh && (spikes_out || spike_bits_out), BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(tau_m > 0. && dt > 0., BE_ERR_INVALID, "dt and tau_m must be positive");
   // derived constants in double, rounded to f32 once (what a host formulation with Python / C doubles hands to f32 arrays)
   const LifCobaP p{(float)dt, (float)(dt / tau_m), (float)v_rest, (float)v_th, (float)v_reset, (float)t_ref, (float)e_exc, (float)e_inh,
                    (float)decay_exc, (float)decay_inh, (float)i_ext, (float)syn_scale};
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
   hipLaunchKernelGGL(k_lif_coba_step, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, g_exc,
-                     g_inh, refractory, in_exc, in_inh, spikes_out, spike_count, n, p);
+                     g_inh, refractory, in_exc, in_inh, spikes_out, spike_bits_out, spike_count, n, p);
   BE_LAUNCH_CHECK();
   return BE_OK;
+}
+
+int be_lif_coba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                     uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
+                     double v_reset, double t_ref, double e_exc, double e_inh, double decay_exc, double decay_inh, double i_ext,
+                     double syn_scale, be_stream_t stream) {
+  BE_REQUIRE(n == 0 || spikes_out, BE_ERR_INVALID, "null pointer");
+  return be_lif_coba_step_packed(v, g_exc, g_inh, refractory, in_exc, in_inh, spikes_out, nullptr, spike_count, n, dt, tau_m, v_rest,
+                                 v_th, v_reset, t_ref, e_exc, e_inh, decay_exc, decay_inh, i_ext, syn_scale, stream);
 }
 
 }  // extern "C"

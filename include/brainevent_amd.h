@@ -93,6 +93,14 @@ int be_lif_coba_step(float* v, float* g_exc, float* g_inh, float* refractory, co
                      uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
                      double v_reset, double t_ref, double e_exc, double e_inh, double decay_exc, double decay_inh, double i_ext,
                      double syn_scale, be_stream_t stream);
+/* The same step; the spikes are ALSO (or only: spikes_out may then be NULL) written bit-packed, spike_bits_out[ceil(n / 32)]
+ * (bit i % 32 of word i / 32; bits past n are 0) — the form every scatter entry point takes as BE_SPIKE_BITS and
+ * be_exchange_allgather_bits / be_exchange_post gather from where it lies: a step loop that keeps its spikes as words has no
+ * pack launch anywhere (the reference packs per call, brainevent/_jit_scalar/binary_jitsmv.cu:107-125). */
+int be_lif_coba_step_packed(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                            uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
+                            double v_rest, double v_th, double v_reset, double t_ref, double e_exc, double e_inh,
+                            double decay_exc, double decay_inh, double i_ext, double syn_scale, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * event vector helpers (replace: brainevent/_jit_scalar/binary_jitsmv.cu:107-125 `_pack_bool_kern`
@@ -121,6 +129,9 @@ int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n,
  *   rank 0: be_exchange_get_unique_id(id)  ->  the binder ships the be_exchange_unique_id_bytes() bytes to every process
  *   all   : be_exchange_init(id, world, rank, n_pre, &ex)        (collective: ncclCommInitRank; current HIP device)
  *   step  : be_exchange_allgather_bits(ex, local_spikes, dtype, full_bits, stream)   full_bits: be_exchange_full_words(ex) words
+ *           dtype BE_SPIKE_BITS: local_spikes are the slice's own words (bits past the slice 0): a slice that fills its w words
+ *           is gathered from where it lies (no pack launch, no copy); with be_exchange_post the words must stay unchanged
+ *           until the slot's be_exchange_wait has been queued
  *   end   : be_exchange_destroy(ex)
  * The handle owns the communicator and one device buffer of w words.  RCCL is loaded with dlopen("librccl.so") on first use
  * (override: environment variable BE_RCCL_LIB); BE_ERR_UNSUPPORTED if it cannot be loaded.

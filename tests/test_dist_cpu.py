@@ -59,6 +59,18 @@ def _worker(rank, world, port, packed, n_pre, n_post, q):
                 got = ds.exchange.wait_events(ticket).value
                 assert np.array_equal(got.numpy(), refs[t]), f"pipelined exchange, step {t}"
                 ticket = nxt
+            # a producer that emits its slice as words (PackedSpikes / packed-only BitPackedBinary): gathered as they are
+            from brainevent_amd import _array as A
+            from brainevent_amd._event import BitPackedBinary
+            ref = np.random.default_rng(900).random(n_pre) < 0.4
+            loc = ref[plo:phi]
+            words = torch.from_numpy(np.packbits(np.pad(loc, (0, (-loc.size) % 32)), bitorder='little').view(np.int32).copy())
+            assert np.array_equal(ds.exchange.gather(A.PackedSpikes(words, phi - plo)).numpy(), ref)
+            if phi > plo:
+                got = ds.exchange.wait_events(ds.exchange.post(BitPackedBinary.from_packed(words, phi - plo))).value
+                assert np.array_equal(got.numpy(), ref)
+            else:
+                ds.exchange.wait_events(ds.exchange.post(A.PackedSpikes(words, 0)))
         q.put((rank, lo, hi, np.stack(outs)))
     finally:
         dist.destroy_process_group()

@@ -108,3 +108,50 @@ def test_native_exchange_through_the_c_abi():
         np.testing.assert_allclose(out.cpu().numpy(), O.binary_csrmv(w, idx, ptr, spikes[t], (n_pre, n_post), True), rtol=1e-5, atol=1e-5)
         ticket = nxt
     ex.close()
+
+
+def test_packed_producer_feeds_the_exchange_without_a_pack_launch(one_rank_group):
+    """A step loop that keeps its spikes as words: `lif_coba_step(..., spike_bits=...)` writes the bit-packed spikes (equal to
+    `be_pack_spikes` of its byte spikes), both exchanges take the packed slice as it is (`BE_SPIKE_BITS`: gathered from where it
+    lies) and the scatter consumes the gathered words — same result as the byte path and as the oracle."""
+    import brainevent_amd as be
+    from brainevent_amd import _dist as D, _array as A
+    from brainevent_amd._csr import ScatterPlan
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(11)
+    dev = torch.device('cuda', 0)
+    for n in (70016, 70001, 37):                       # whole words, a partial last word, less than two words
+        V = torch.from_numpy(rng.uniform(-62, -49.5, n).astype(np.float32)).to(dev)
+        ge, gi = torch.rand(n, device=dev), torch.rand(n, device=dev)
+        refr = torch.from_numpy(np.where(rng.random(n) < 0.2, 1.0, 0.0).astype(np.float32)).to(dev)
+        inp = torch.rand(n, device=dev) * 30
+        st = [t.clone() for t in (V, ge, gi, refr)]
+        spk = torch.zeros(n, dtype=torch.bool, device=dev)
+        bits = torch.full(((n + 31) // 32,), -1, dtype=torch.int32, device=dev)
+        be.lif_coba_step(*st, inp, inp, spk, spike_bits=bits)
+        s = spk.cpu().numpy()
+        assert 0 < s.sum() < n
+        np.testing.assert_array_equal(be.BitPackedBinary.from_packed(bits, n).value.cpu().numpy(), s)
+        np.testing.assert_array_equal(bits.cpu().numpy(), be.BitPackedBinary(spk).packed[0].cpu().numpy().view(np.int32))
+        st2 = [t.clone() for t in (V, ge, gi, refr)]
+        bits2 = torch.zeros_like(bits)
+        be.lif_coba_step(*st2, inp, inp, None, spike_bits=bits2)          # words only
+        assert torch.equal(bits2, bits) and all(torch.equal(a, b) for a, b in zip(st, st2))
+        n_post = 3001
+        lens = rng.integers(0, 30, n)
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        idx = rng.integers(0, n_post, ptr[-1]).astype(np.int32)
+        w = rng.random(ptr[-1]).astype(np.float32)
+        csr = be.CSR((torch.from_numpy(w).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(ptr).to(dev)), shape=(n, n_post))
+        ref = O.binary_csrmv(w, idx, ptr, s, (n, n_post), True)
+        local = be.BitPackedBinary.from_packed(bits, n)
+        ex = D.NativeSpikeExchange(n, 1, 0, D.NativeSpikeExchange.unique_id(), device=dev)
+        ev = ex.gather_events(local)
+        np.testing.assert_array_equal(ev.value.cpu().numpy(), s)
+        np.testing.assert_allclose((ev @ csr).cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        ev = ex.wait_events(ex.post(A.PackedSpikes(bits, n)))
+        np.testing.assert_allclose((ev @ csr).cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        ex.close()
+        tex = D.SpikeExchange(n, packed=True, device=dev)
+        np.testing.assert_array_equal(tex.gather(local).cpu().numpy(), s)
+        np.testing.assert_allclose((tex.wait_events(tex.post(local)) @ csr).cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
