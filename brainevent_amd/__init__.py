@@ -21,6 +21,8 @@ from ._dense import (Dense, binary_densemv, binary_densemm, binary_densemv_p, bi
 from ._convert import (csr_to_coo_index, coo_to_csc_index, coo2csr, csr_to_csc_index, csc_to_csr_index,
                        fixed_conn_num_csr_indptr, fixed_conn_num_csc_structure, fixed_conn_num_to_csc)
 from ._graph import GraphedStep, capture_step
+from ._tuning import (ScatterTuning, DEFAULT_SCATTER_TUNING, get_scatter_tuning, save_scatter_tuning, apply_scatter_tuning,
+                      tune_scatter_routes)
 from ._neuron import lif_coba_step
 from ._op import OpKernel
 XLACustomKernel = OpKernel      # the operator object under the reference's name (no XLA underneath)

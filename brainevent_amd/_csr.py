@@ -483,6 +483,8 @@ class BinnedScatter:
         # bins at most 2^slice_shift columns wide; the default leaves the width to the library: as wide as the LDS
         # accumulators of pass C allow, in a multiple of 256 bins (be_binned_bins)
         self.slice_shift = 16 if slice_shift is None else int(slice_shift)
+        from . import _tuning
+        _tuning.push_to_library()            # pass B's task size from the persisted tuning of this architecture
         self.n_slices = int(fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(self.k, self.slice_shift, int(self.homo)))
         if self.n_slices <= 0:
             raise ValueError(f"the binned route does not serve {self.k} outputs at slice_shift={self.slice_shift}")
@@ -826,6 +828,8 @@ PLAN_MIN_NNZ = 1 << 15          # below this the direct kernel is used (nothing 
 PLAN_MIN_SEGMENT = 8        # entries per (row, slice) from which the planned layout beats the binned route (measured: choose_scatter_route)
 PLAN_MIN_SEGMENT_HOMO = 10  # ... for one shared weight (the binned route moves 2 B per counted entry)
 PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply
+# (the four constants above are the gfx950 defaults; brainevent_amd._tuning replaces them from the persisted per-architecture
+#  store when one exists — applied at the end of this module)
 
 
 class CompressedSparseData(DataRepresentation):
@@ -1131,3 +1135,15 @@ class CSC(CompressedSparseData):
     @property
     def T(self):
         return self.transpose()
+
+
+def _apply_persisted_tuning():
+    try:
+        from . import _tuning
+        _tuning.apply_scatter_tuning()
+    except Exception as e:          # noqa: BLE001 - a bad override must not make the package unimportable: say so, keep the defaults
+        import warnings
+        warnings.warn(f"brainevent_amd: persisted scatter tuning ignored ({e!r}); using the built-in defaults.")
+
+
+_apply_persisted_tuning()

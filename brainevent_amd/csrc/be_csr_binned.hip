@@ -1,5 +1,6 @@
 // be_csr_binned.hip — the binned scatter route (no per-matrix layout) for gfx950; see the section comment below.
 #include "be_csr_shared.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -844,6 +845,10 @@ static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo) {
   return g;
 }
 
+// pass B's task size (be_binned_set_tuning; the environment — BE_BIN_TASK_GROUPS / BE_BIN_TASKS — gives the initial values for A/B runs)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; }
+std::atomic<int> g_task_groups{env_int("BE_BIN_TASK_GROUPS", 1024)}, g_min_tasks{env_int("BE_BIN_TASKS", 2048)};
+
 }  // namespace
 
 // =================================================================================================
@@ -860,6 +865,13 @@ extern "C" int be_debug_bin_prof(unsigned long long* host, int reset) {
 extern "C" {
 
 // ---------------------------------------------------------------- binned route (no plan)
+int be_binned_set_tuning(int task_groups, int min_tasks) {
+  BE_REQUIRE(task_groups >= 1 && min_tasks >= 1, BE_ERR_INVALID, "task_groups and min_tasks must be >= 1");
+  g_task_groups.store(task_groups, std::memory_order_relaxed);
+  g_min_tasks.store(min_tasks, std::memory_order_relaxed);
+  return BE_OK;
+}
+
 // bins the route cuts k outputs into for this slice_shift (see binned_geometry); 0: not served (too many bins for pass B's LDS)
 int be_binned_bins(int64_t k, int slice_shift, int homo) {
   if (k <= 0 || slice_shift < 4 || slice_shift > 16) return 0;
@@ -1029,8 +1041,8 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     }
     {
       // groups of four entries per task, and the tasks a step is cut into at least (k_bin_stream: rows per task)
-      static const uint32_t min_tasks = [] { const char* e = getenv("BE_BIN_TASKS"); return e ? (uint32_t)atoi(e) : 2048u; }();   // (A/B runs)
-      static const uint32_t task_groups = [] { const char* e = getenv("BE_BIN_TASK_GROUPS"); return e ? (uint32_t)atoi(e) : 1024u; }();
+      const uint32_t min_tasks = (uint32_t)g_min_tasks.load(std::memory_order_relaxed);
+      const uint32_t task_groups = (uint32_t)g_task_groups.load(std::memory_order_relaxed);
       const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (kRing * (size_t)cap * (homo ? 2 : 6) / 4 + 2 + 2 * kRing)) * 4;
 #define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
   do {                                                                                                                          \

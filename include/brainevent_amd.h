@@ -310,6 +310,11 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * Same role as binary_csrmv_wat_hybrid_* (brainevent/_csr/binary_csrmv_hybrid.cu:619-632): no preprocessing.
  * ---------------------------------------------------------------------------------------------- */
 int be_binned_bins(int64_t k, int slice_shift, int homo);
+/* Task size of pass B (process-wide, read at every call): a task is about task_groups groups of four consecutive entries, and a
+ * step is cut into at least min_tasks tasks.  Defaults 1024 / 2048 (measured on gfx950); the Python layer sets them from its
+ * persisted per-architecture tuning — the counterpart of the thresholds the reference compiles into its hybrid kernel from
+ * brainevent/_csr/hybrid_config.py:77-88, :256-295. */
+int be_binned_set_tuning(int task_groups, int min_tasks);
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity);
 /* once per workspace, before its first step: zeroes the spike counter and the overflow image inside it (every step leaves
  * both at zero, so the step itself needs no memset and no zeroing of `out`: pass C writes every output) */
