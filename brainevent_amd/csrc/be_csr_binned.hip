@@ -1085,6 +1085,18 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     } else {
       if (cap == 128) BE_BIN_ACC(false, 128); else if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
     }
+    // (experiments, tools/exp_passc_twice.sh: pass C again on the same regions — the 2nd / 3rd launch of a step read settled
+    //  data: C4 weighted 183 -> 154 / 150 us, counted 52 -> 46 / 45: ~30 us of the first launch are the write-back of what pass B
+    //  just wrote, still draining)
+    static const int dbg_twice = [] { const char* e = getenv("BE_DBG_C_TWICE"); return e ? atoi(e) : 0; }();
+    for (int rep = 0; rep < dbg_twice; ++rep) {
+      if (homo) {
+        if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
+        else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
+      } else {
+        if (cap == 128) BE_BIN_ACC(false, 128); else if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
+      }
+    }
 #undef BE_BIN_ACC
     BE_LAUNCH_CHECK();
   }
