@@ -62,6 +62,7 @@ class ScatterPlan:
     #: block layouts (C ABI codes BE_PLAN_U16 / BE_PLAN_D8 / BE_PLAN_H8)
     LAYOUT_U16, LAYOUT_D8, LAYOUT_H8 = 0, 1, 2
     D8_MAX_ROW, D8_MAX_SLICES, D8_CAP, H8_CAP = 16384, 1024, 20000, 40000
+    KEEP_ORDER_MAX_BYTES = 4 << 30      # the rows' column order (2 B per entry) stays with a d8 plan by default up to this size
 
     def __init__(self, m, k, homo, slice_shift, seg, blob, scale_exp, weight_dtype, slice_width=0, layout=0):
         self.m, self.k, self.homo = int(m), int(k), bool(homo)
@@ -215,7 +216,8 @@ class ScatterPlan:
         return (delta, wd) if ok else (U16, w16)
 
     def nbytes(self) -> int:
-        return self.seg.numel() * 4 + self.blob.numel()
+        order = getattr(self, 'order', None)
+        return self.seg.numel() * 4 + self.blob.numel() + (order.numel() * 2 if order is not None else 0)
 
     def workspace(self, parts: int, n_batch: int = 1) -> torch.Tensor:
         # with room for the pre-gathered segment table only when this plan's blocks are short enough for the step to use it
@@ -245,13 +247,19 @@ class ScatterPlan:
     @classmethod
     def build(cls, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], *, shape,
               row_len: int = -1, slice_shift: Optional[int] = None, slice_width: Optional[int] = None,
-              layout: Optional[str] = None) -> 'ScatterPlan':
+              layout: Optional[str] = None, keep_order: Optional[bool] = None) -> 'ScatterPlan':
         """Build the plan on the device.  ``indptr=None`` + ``row_len`` describes fixed-length rows.  ``slice_shift``
         (accumulator capacity) and ``slice_width`` (columns per slice) default to the LDS-filling capacity and the
         balanced width; an explicit ``slice_shift`` alone means full-capacity slices.  ``layout``: ``'u16'`` (uint16
         local columns, 6 B per weighted entry / 2 B per counted one), ``'d8'`` (sorted columns as uint8 deltas, 5 B per
         entry: heterogeneous weights), ``'h8'`` (uint8 advance codes, 1 B per entry: one homogeneous weight) — both for
-        rows of at most 16384 entries and at most 1024 slices — or ``None`` = the delta layout whenever it applies."""
+        rows of at most 16384 entries and at most 1024 slices — or ``None`` = the delta layout whenever it applies.
+
+        The sorted layouts need every row in column order: the count pass stores that order (2 bytes per entry) and the fill
+        reads it back instead of sorting again.  ``keep_order=True`` keeps it with the plan, which makes every later
+        :meth:`refresh_weights` a gather-copy instead of a re-sort (weights updated in place — plasticity); ``False`` frees it
+        after the fill; ``None`` (default) keeps it while it is small next to the plan (``KEEP_ORDER_MAX_BYTES``).  When the
+        order does not fit beside the plan during the build it is simply not used (three sorts, as before)."""
         m, k = int(shape[0]), int(shape[1])
         weights = A.to_device(weights).reshape(-1)
         indices = A.to_device(indices).reshape(-1)
@@ -300,14 +308,28 @@ class ScatterPlan:
         f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
         scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
         blob_bytes = c_i64(0)
-        f_cnt = fn('be_scatter_plan_count', c_int,
+        order = None
+        if lay != cls.LAYOUT_U16 and nnz and keep_order is not False:
+            try:            # the rows' column order, written by the count pass and read back by the fill (one sort instead of two)
+                order = torch.empty(nnz, dtype=torch.int16, device=dev)
+            except getattr(torch, 'OutOfMemoryError', RuntimeError):
+                torch.cuda.empty_cache()
+        f_cnt = fn('be_scatter_plan_count_ordered', c_int,
                    [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64),
-                    c_vp])
+                    c_vp, c_vp])
         check(f_cnt(A.ptr(indices), A.ptr(indptr), is64, row_len, m, k, slice_shift, slice_width, int(homo), lay, A.ptr(seg),
-                    A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st), 'be_scatter_plan_count')
-        blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
+                    A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), A.ptr(order), st), 'be_scatter_plan_count_ordered')
+        try:
+            blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
+        except getattr(torch, 'OutOfMemoryError', RuntimeError):
+            if order is None:
+                raise
+            order = None            # the order and the blocks do not fit together: build without it
+            torch.cuda.empty_cache()
+            blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
         plan = cls(m, k, homo, slice_shift, seg, blob, 0, out_dtype, slice_width, lay)
         plan.nnz = nnz
+        plan.order = order
         if lay == cls.LAYOUT_D8 and nnz:
             # lane-groups of 4 items per block (low 16 bits of the table's second word), over a strided sample of the blocks
             n_blk = m * n_slices
@@ -317,6 +339,10 @@ class ScatterPlan:
         plan.split_f64 = split
         plan._fill(weights, indices, indptr)
         plan.stamp = src_stamp
+        if keep_order is None:
+            keep_order = order is not None and not homo and order.numel() * 2 <= cls.KEEP_ORDER_MAX_BYTES
+        if not keep_order or homo:      # (one shared weight is never re-encoded)
+            plan.order = None
         return plan
 
     def _fill(self, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], keep_exp: bool = False):
@@ -325,17 +351,33 @@ class ScatterPlan:
         an existing plan (:meth:`refresh_weights`)."""
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         maxabs = torch.zeros(2, dtype=torch.int32, device=self.seg.device)   # f32 bits of max |w| / smallest non-zero |w|
-        name = 'be_scatter_plan_refresh_weights' if keep_exp else 'be_scatter_plan_fill'
+        name = 'be_scatter_plan_refresh_weights_ordered' if keep_exp else 'be_scatter_plan_fill_ordered'
         f_fill = fn(name, c_int,
-                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp])
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp])
         check(f_fill(A.ptr(weights), int(self.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, self.row_len,
                      self.m, self.k, self.slice_shift, self.slice_width, self.layout, A.ptr(self.seg), A.ptr(self.blob),
-                     A.ptr(maxabs), A.stream_ptr()), name)
+                     A.ptr(maxabs), A.ptr(getattr(self, 'order', None)), A.stream_ptr()), name)
         self.stamp = weights_stamp(weights)
         if not self.homo:
             # a refresh keeps the exponent it was built with while that still cannot overflow (it is a launch argument: a
-            # captured graph replays with the old one) — unless the new weights need the finer resolution
-            self.scale_exp = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp if keep_exp else None)
+            # captured graph replays with the old one) — unless the new weights need the finer resolution.  The column
+            # statistics come from the plan's own blocks (be_scatter_plan_exponent: a planned step over |w| with every row
+            # active) instead of two passes of global atomics over the raw entries.
+            self.scale_exp = self._plan_exponent(maxabs, keep=self.scale_exp if keep_exp else None)
+
+    def _plan_exponent(self, maxabs: torch.Tensor, keep: Optional[int] = None) -> int:
+        scratch = A.workspace(256)
+        out = c_int(0)
+        f = fn('be_scatter_plan_exponent', c_int,
+               [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_i64, c_vp, c_int, c_int, c_vp, c_i64, ctypes.POINTER(c_int), c_vp])
+        rc = f(A.ptr(self.blob), A.ptr(self.seg), self.m, self.k, self.slice_shift, self.slice_width, self.layout, self.nnz,
+               A.ptr(maxabs), self.MIN_WEIGHT_BITS, -(1 << 31) if keep is None else int(keep), A.ptr(scratch), scratch.numel(),
+               ctypes.byref(out), A.stream_ptr())
+        if rc == -4:               # BE_ERR_RANGE: inf / nan or a dynamic range the sums cannot resolve -> the caller falls back
+            from ._lib import lib
+            raise MathError((lib().be_last_error() or b'').decode())
+        check(rc, 'be_scatter_plan_exponent')
+        return int(out.value)
 
     def refresh_weights(self, weights, indices, indptr) -> None:
         """Re-encode the weights of an unchanged structure into the existing blocks (the reference's cached workspace holds
@@ -444,6 +486,10 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
     return 'direct'
 
 
+PLAN_KEEP_ORDER: Optional[bool] = None    # ScatterPlan.build(keep_order=...) of the plans the containers build by themselves
+                                          # (True: weights that change in place — plasticity — get a gather-copy refresh)
+
+
 def make_scatter_workspace(route: str, weights, indices, indptr, m: int, k: int, nse: int, row_len: int = -1):
     """The scatter workspace of a matrix for the chosen ``route`` (``None`` = direct route).  A plan that does not fit the
     free device memory (128 bytes per (row, slice) block: up to ~3x the raw matrix for short blocks) falls back to the binned
@@ -452,7 +498,7 @@ def make_scatter_workspace(route: str, weights, indices, indptr, m: int, k: int,
     try:
         if route == 'plan':
             try:
-                return ScatterPlan.build(weights, indices, indptr, shape=(m, k), row_len=row_len)
+                return ScatterPlan.build(weights, indices, indptr, shape=(m, k), row_len=row_len, keep_order=PLAN_KEEP_ORDER)
             except oom:
                 torch.cuda.empty_cache()
                 route = 'binned' if BinnedScatter.applicable(weights, k) else 'direct'
@@ -938,9 +984,18 @@ class CompressedSparseData(DataRepresentation):
         self.buffers['scatter_plan'] = plan
         return plan
 
-    def prepare(self, mirror: bool = False):
+    def prepare(self, mirror: bool = False, keep_order: Optional[bool] = None):
         """Build the scatter workspace now (otherwise it is built by the first ``spk @ matrix``).
-        ``mirror=True`` also builds the transposed mirror so that the *gather* direction runs event-driven too."""
+        ``mirror=True`` also builds the transposed mirror so that the *gather* direction runs event-driven too.
+        ``keep_order=True``: a sorted-layout plan keeps its rows' column order (2 bytes per entry), which turns the refresh
+        after an in-place weight update from a re-sort into a gather-copy (``ScatterPlan.build``)."""
+        if keep_order is not None and 'scatter_plan' not in self.buffers:
+            global PLAN_KEEP_ORDER
+            saved, PLAN_KEEP_ORDER = PLAN_KEEP_ORDER, keep_order
+            try:
+                self._scatter_workspace()
+            finally:
+                PLAN_KEEP_ORDER = saved
         self._scatter_workspace()
         if mirror:
             self.build_mirror()

@@ -3,6 +3,8 @@
 // single-launch kernel for small matrices.  Semantics as in be_csr.hip (reference brainevent/_csr/binary.py:387-489,
 // transpose=True); the role of the reference's per-matrix task workspace (brainevent/_csr/main.py:58-88).
 #include "be_csr_shared.h"
+#include <climits>
+#include <cstring>
 #ifndef BE_BLOCK_AUX
 #define BE_BLOCK_AUX 2      // cache policy of the wave-per-block d8 loads: nt — blocks are streamed once per step (C2: kernel 119.6 -> 108-112 us,
                             // 716 -> 750-780 Geff/s; sc0 / sc1 on top change nothing).  NOT on the other decoders: uint16 blocks by part of a wave
@@ -768,11 +770,24 @@ __device__ __forceinline__ void d8_lds_stage(unsigned long long* keys, int n2, i
   }
   __syncthreads();
 }
-// loads the row's (column, position) keys into LDS and sorts them; returns the row length
-__device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32_t* __restrict__ indices, int64_t b, int64_t e) {
+// loads the row's (column, position) keys into LDS and sorts them; returns the row length.  `order_out` (count pass): the
+// sorted order — the row-local position of the i-th smallest column, uint16 — is written to order_out[b + i]; `order_in`
+// (fill / weight refresh): the order is read back instead of sorting again (a gather of the row's columns: the row is one
+// 40-KB window at most).  One of the two sorts of a build and every sort of a weight refresh disappear.
+__device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32_t* __restrict__ indices, int64_t b, int64_t e,
+                                           const uint16_t* __restrict__ order_in = nullptr,
+                                           uint16_t* __restrict__ order_out = nullptr) {
   // caller contract: rows have at most kD8MaxRow entries (the Python side checks it and falls back to the u16 layout);
   // a longer row is cut here rather than written past the LDS array
   const int len = (e - b) > (int64_t)kD8MaxRow ? kD8MaxRow : (int)(e - b);
+  if (order_in != nullptr) {
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      const uint32_t p = order_in[b + i];
+      keys[i] = ((unsigned long long)(uint32_t)indices[b + p] << 16) | (unsigned long long)p;
+    }
+    __syncthreads();
+    return len;
+  }
   int n2 = 2;
   while (n2 < len) n2 <<= 1;
   // a row whose columns already ascend (canonical CSR) needs no sort: (column << 16 | position) ascends with the columns
@@ -781,11 +796,14 @@ __device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32
     keys[i] = i < len ? (((unsigned long long)(uint32_t)indices[b + i] << 16) | (unsigned long long)i) : ~0ull;
     if (i > 0 && i < len && (uint32_t)indices[b + i] < (uint32_t)indices[b + i - 1]) unsorted = 1;
   }
-  if (!__syncthreads_or(unsorted)) return len;
-  // (a thread owning 16 consecutive keys and running the strides below 16 in registers was tried: its strided LDS reads
-  //  conflict 32-way and the build took 1.8 x as long)
-  for (int k2 = 2; k2 <= n2; k2 <<= 1)
-    for (int j = k2 >> 1; j > 0; j >>= 1) d8_lds_stage(keys, n2, k2, j);
+  if (__syncthreads_or(unsorted)) {
+    // (a thread owning 16 consecutive keys and running the strides below 16 in registers was tried: its strided LDS reads
+    //  conflict 32-way and the build took 1.8 x as long)
+    for (int k2 = 2; k2 <= n2; k2 <<= 1)
+      for (int j = k2 >> 1; j > 0; j >>= 1) d8_lds_stage(keys, n2, k2, j);
+  }
+  if (order_out != nullptr)
+    for (int i = threadIdx.x; i < len; i += blockDim.x) order_out[b + i] = (uint16_t)(keys[i] & 0xffffull);
   return len;
 }
 
@@ -817,7 +835,8 @@ __host__ __device__ __forceinline__ uint32_t h8_block_units(uint32_t ng) { retur
 template <bool H8>
 __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
                                                         uint32_t slice_width, int n_slices, uint2* __restrict__ seg,
-                                                        unsigned long long* __restrict__ too_long) {
+                                                        unsigned long long* __restrict__ too_long,
+                                                        uint16_t* __restrict__ order_out) {
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t tot[kD8MaxSlices], base_s[kD8MaxSlices];
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
@@ -825,7 +844,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restric
     const int64_t rb = rp.at(r), re = rp.at(r + 1);
     // a row the LDS sort cannot hold: reported to the host, which fails the build (d8_sort_row would cut it)
     if (threadIdx.x == 0 && re - rb > (int64_t)kD8MaxRow) atomicMax(too_long, (unsigned long long)(re - rb));
-    const int len = d8_sort_row(d8_keys, indices, rb, re);   // ends with a barrier
+    const int len = d8_sort_row(d8_keys, indices, rb, re, nullptr, order_out);   // ends with a barrier
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
       const D8Item it = d8_item<H8>(d8_keys, i, slice_width);
       atomicAdd(&tot[it.s], 1u + it.esc);
@@ -845,7 +864,7 @@ template <typename W>
 __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ weights, const int32_t* __restrict__ indices,
                                                        RowPtr rp, int64_t m, uint32_t slice_width, int n_slices,
                                                        const uint2* __restrict__ seg, unsigned char* __restrict__ blob,
-                                                       uint32_t* __restrict__ maxabs_bits) {
+                                                       uint32_t* __restrict__ maxabs_bits, const uint16_t* __restrict__ order) {
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t first_idx[kD8MaxSlices], e_first[kD8MaxSlices], seg_start[kD8MaxSlices], seg_ng[kD8MaxSlices],
       tot[kD8MaxSlices];
@@ -859,7 +878,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
       tot[s] = 0;
     }
     const int64_t rb = rp.at(r);
-    const int len = d8_sort_row(d8_keys, indices, rb, rp.at(r + 1));
+    const int len = d8_sort_row(d8_keys, indices, rb, rp.at(r + 1), order);
     // inclusive prefix sums of the escape counts over the sorted row: a thread owns `per` consecutive positions
     const int per = (len + 1023) >> 10;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
@@ -1230,7 +1249,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
 // =================================================================================================
 __global__ void __launch_bounds__(1024) k_plan_h8_fill(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
                                                        uint32_t slice_width, int n_slices, const uint2* __restrict__ seg,
-                                                       unsigned char* __restrict__ blob) {
+                                                       unsigned char* __restrict__ blob, const uint16_t* __restrict__ order) {
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t first_idx[kD8MaxSlices], e_first[kD8MaxSlices], seg_start[kD8MaxSlices], seg_ng[kD8MaxSlices],
       tot[kD8MaxSlices];
@@ -1242,7 +1261,7 @@ __global__ void __launch_bounds__(1024) k_plan_h8_fill(const int32_t* __restrict
       seg_ng[s] = sg.y & 0xffffu;
       tot[s] = 0;
     }
-    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1));
+    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1), order);
     const int per = (len + 1023) >> 10;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
     uint32_t mine = 0;
@@ -1537,6 +1556,122 @@ int launch_plan_single(const void* blob, const void* seg, const void* spikes, in
   return BE_OK;
 }
 
+// =================================================================================================
+// Column statistics of a weighted plan, read from its own blocks: what the fixed-point exponent needs — the largest column sum
+// of |w| (overflow bound) and the smallest of the columns' largest |w| (accuracy gate) — without the two passes of global
+// float atomics over the raw entries that be_fixed_point_exponent makes (0.47 s at 1e10 entries: the chip's 21 G/s).  One
+// workgroup per slice owns the slice's accumulators in LDS and walks EVERY row's block of that slice: a planned step with all
+// rows active, over |w|.  MODE 0: 64-bit fixed-point sums at a safe exponent, every addend rounded UP, so the bound never
+// falls short of the true sum; out[0] = the largest.  MODE 1: ds_max of the |w| bit patterns; out[1] = the smallest non-zero one.
+// Build-time code: a wave per block, four blocks in flight per wave, nothing tuned beyond that.
+// =================================================================================================
+template <int MODE> struct StatAcc { using type = unsigned long long; };
+template <> struct StatAcc<1> { using type = uint32_t; };
+template <int MODE>
+__device__ __forceinline__ void stat_add(typename StatAcc<MODE>::type* acc, uint32_t col, uint32_t wbits, float scale) {
+  const uint32_t ab = wbits & 0x7fffffffu;
+  if (ab == 0u) return;
+  if constexpr (MODE == 0) atomicAdd(&acc[col], fixed_from_f32(__uint_as_float(ab), scale) + 1ull);
+  else atomicMax(&acc[col], ab);
+}
+template <int LAYOUT /* BE_PLAN_U16 (weighted) or BE_PLAN_D8 */, int MODE>
+__global__ void __launch_bounds__(1024) k_plan_colstats(const unsigned char* __restrict__ blob, const uint2* __restrict__ seg,
+                                                        int64_t m, int n_slices, int n_slots, float scale,
+                                                        unsigned long long* __restrict__ out) {
+  using acc_t = typename StatAcc<MODE>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  const int slice = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  constexpr int U = 4;
+  // a wave takes 64 consecutive rows at a time: lane l holds the table entry of row r0 + l
+  for (int64_t r0 = (int64_t)wave * 64; r0 < m; r0 += (int64_t)nw * 64) {
+    uint2 sg = make_uint2(0u, 0u);
+    if (r0 + lane < m) sg = seg[(r0 + lane) * n_slices + slice];
+    const int n_rows = (int)(m - r0 < 64 ? m - r0 : 64);
+    for (int i0 = 0; i0 < n_rows; i0 += U) {
+      be_v4u wv[U];
+      uint32_t cv0[U], cv1[U], ngs[U], bases[U];
+      const unsigned char* blks[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {              // the first 64 lane-groups of U blocks: every load issued before the first add
+        const int i = i0 + u < n_rows ? i0 + u : n_rows - 1;
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)sg.x, i), y = (uint32_t)__builtin_amdgcn_readlane((int)sg.y, i);
+        ngs[u] = i0 + u < n_rows ? (LAYOUT == BE_PLAN_D8 ? y & 0xffffu : y) : 0u;
+        bases[u] = y >> 16;
+        blks[u] = blob + ((int64_t)st << 7);
+        wv[u] = be_v4u{0u, 0u, 0u, 0u};
+        cv0[u] = cv1[u] = 0u;
+        if ((uint32_t)lane < ngs[u]) {
+          wv[u] = reinterpret_cast<const be_v4u*>(blks[u])[lane];
+          if (LAYOUT == BE_PLAN_D8) {
+            cv0[u] = reinterpret_cast<const uint32_t*>(blks[u] + (size_t)ngs[u] * 16)[lane];
+          } else {
+            const uint2 c = reinterpret_cast<const uint2*>(blks[u] + (size_t)ngs[u] * 16)[lane];
+            cv0[u] = c.x;
+            cv1[u] = c.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t before = bases[u];                 // d8: the column in front of this pass's first entry
+        for (uint32_t g0 = 0; g0 < ngs[u]; g0 += 64) {
+          be_v4u w = wv[u];
+          uint32_t c0 = cv0[u], c1 = cv1[u];
+          const bool in = g0 + (uint32_t)lane < ngs[u];
+          if (g0 > 0) {                             // (rare) a block of more than 256 items: the later passes load here
+            w = be_v4u{0u, 0u, 0u, 0u};
+            c0 = c1 = 0u;
+            if (in) {
+              w = reinterpret_cast<const be_v4u*>(blks[u])[g0 + lane];
+              if (LAYOUT == BE_PLAN_D8) {
+                c0 = reinterpret_cast<const uint32_t*>(blks[u] + (size_t)ngs[u] * 16)[g0 + lane];
+              } else {
+                const uint2 c = reinterpret_cast<const uint2*>(blks[u] + (size_t)ngs[u] * 16)[g0 + lane];
+                c0 = c.x;
+                c1 = c.y;
+              }
+            }
+          }
+          if (LAYOUT == BE_PLAN_D8) {
+            const uint32_t d = in ? c0 : 0u, mine = d8_sum4(d);
+            const uint32_t incl = wave_incl_scan_u32(mine);
+            const uint32_t b = before + incl - mine;
+            const uint32_t k0 = b + (d & 0xffu), k1 = k0 + ((d >> 8) & 0xffu), k2 = k1 + ((d >> 16) & 0xffu), k3 = k2 + (d >> 24);
+            if (in) {
+              stat_add<MODE>(acc, k0, w.x, scale); stat_add<MODE>(acc, k1, w.y, scale);
+              stat_add<MODE>(acc, k2, w.z, scale); stat_add<MODE>(acc, k3, w.w, scale);
+            }
+            before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          } else if (in) {
+            stat_add<MODE>(acc, c0 & 0xffffu, w.x, scale); stat_add<MODE>(acc, c0 >> 16, w.y, scale);
+            stat_add<MODE>(acc, c1 & 0xffffu, w.z, scale); stat_add<MODE>(acc, c1 >> 16, w.w, scale);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long best = MODE == 0 ? 0ull : ~0ull;
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+    const unsigned long long v = (unsigned long long)acc[i];
+    if (MODE == 0) best = v > best ? v : best;
+    else if (v != 0ull) best = v < best ? v : best;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_down((int)(best >> 32), off, 64) << 32) |
+                                 (uint32_t)__shfl_down((int)(uint32_t)best, off, 64);
+    best = MODE == 0 ? (o > best ? o : best) : (o < best ? o : best);
+  }
+  if (lane == 0) {
+    if (MODE == 0) { if (best) atomicMax(&out[0], best); }
+    else if (best != ~0ull) atomicMin(&out[1], best);
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1605,9 +1740,9 @@ int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int
   return be_align_up((n_blocks + 2) * 8, 256);
 }
 
-int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
-                          int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg, void* scratch,
-                          int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream) {
+int be_scatter_plan_count_ordered(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
+                                  int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg, void* scratch,
+                                  int64_t scratch_bytes, int64_t* blob_bytes_host, uint16_t* order_out, be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
@@ -1633,7 +1768,7 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
     auto kern = layout == BE_PLAN_H8 ? k_plan_d8_count<true> : k_plan_d8_count<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
     hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
-                       (uint32_t)width_of(slice_shift, slice_width), n_slices, sg, too_long);
+                       (uint32_t)width_of(slice_shift, slice_width), n_slices, sg, too_long, order_out);
   } else {
     BE_REQUIRE(layout == BE_PLAN_U16, BE_ERR_INVALID, "unknown plan layout");
     hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m,
@@ -1657,9 +1792,17 @@ int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr
   return BE_OK;
 }
 
-int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
-                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
-                         int layout, const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
+int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
+                          int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg, void* scratch,
+                          int64_t scratch_bytes, int64_t* blob_bytes_host, be_stream_t stream) {
+  return be_scatter_plan_count_ordered(indices, indptr, indptr_is_i64, row_len, m, k, slice_shift, slice_width, homo, layout, seg,
+                                       scratch, scratch_bytes, blob_bytes_host, nullptr, stream);
+}
+
+int be_scatter_plan_fill_ordered(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                                 int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
+                                 int layout, const void* seg, void* blob, uint32_t* maxabs_bits, const uint16_t* order,
+                                 be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
@@ -1679,7 +1822,7 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
     hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
                        (uint32_t)width_of(slice_shift, slice_width), n_slices, static_cast<const uint2*>(seg),
-                       static_cast<unsigned char*>(blob));
+                       static_cast<unsigned char*>(blob), order);
     BE_LAUNCH_CHECK();
     return BE_OK;
   }
@@ -1694,7 +1837,8 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
       BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern),        \
                                  kD8MaxRow * 8));                                                                        \
       hipLaunchKernelGGL(kern, dim3(g8), dim3(1024), kD8MaxRow * 8, st, static_cast<const WT*>(weights), indices, rp, m, \
-                         wdt, n_slices, static_cast<const uint2*>(seg), static_cast<unsigned char*>(blob), maxabs_bits); \
+                         wdt, n_slices, static_cast<const uint2*>(seg), static_cast<unsigned char*>(blob), maxabs_bits,  \
+                         order);                                                                                         \
     }
     switch (wdtype) {
       case BE_F32: BE_D8_FILL(float) break;
@@ -1716,15 +1860,121 @@ int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_
   return BE_OK;
 }
 
+int be_scatter_plan_fill(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                         int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift, int slice_width,
+                         int layout, const void* seg, void* blob, uint32_t* maxabs_bits, be_stream_t stream) {
+  return be_scatter_plan_fill_ordered(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, m, k, slice_shift, slice_width,
+                                      layout, seg, blob, maxabs_bits, nullptr, stream);
+}
+
+int be_scatter_plan_refresh_weights_ordered(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                                            int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
+                                            int slice_width, int layout, const void* seg, void* blob, uint32_t* maxabs_bits,
+                                            const uint16_t* order, be_stream_t stream) {
+  // block starts and lengths (seg) depend on the structure only: re-running the fill over the same seg / blob rewrites
+  // every block with the new weights.  The d8 fill needs every row in column order: with the order the count pass stored it
+  // is a gather-copy, without it the rows are sorted again (positions inside a u16 block may differ from the first fill,
+  // which integer accumulation does not see)
+  return be_scatter_plan_fill_ordered(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, m, k, slice_shift,
+                                      slice_width, layout, seg, blob, maxabs_bits, order, stream);
+}
 int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                                     int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
                                     int slice_width, int layout, const void* seg, void* blob, uint32_t* maxabs_bits,
                                     be_stream_t stream) {
-  // block starts and lengths (seg) depend on the structure only: re-running the fill over the same seg / blob rewrites
-  // every block with the new weights (the d8 fill re-sorts the rows; positions inside a u16 block may differ from the
-  // first fill, which integer accumulation does not see)
-  return be_scatter_plan_fill(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, m, k, slice_shift, slice_width,
-                              layout, seg, blob, maxabs_bits, stream);
+  return be_scatter_plan_refresh_weights_ordered(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, m, k, slice_shift,
+                                                 slice_width, layout, seg, blob, maxabs_bits, nullptr, stream);
+}
+
+// The fixed-point exponent of a weighted plan from the plan itself (k_plan_colstats): same bound, same gate and same keep_exp rule
+// as be_fixed_point_exponent, whose global-atomic passes over the raw entries it replaces for matrices that have a plan.
+// maxabs_bits: what the fill left (max |w| bits, smallest non-zero |w| bits).  scratch >= 256 bytes.  SYNCHRONOUS.
+int be_scatter_plan_exponent(const void* blob, const void* seg, int64_t m, int64_t k, int slice_shift, int slice_width, int layout,
+                             int64_t nnz, const uint32_t* maxabs_bits, int min_weight_bits, int keep_exp, void* scratch,
+                             int64_t scratch_bytes, int* scale_exp_host, be_stream_t stream) {
+  BE_REQUIRE(blob && seg && maxabs_bits && scratch && scale_exp_host, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(m > 0 && k > 0 && nnz >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(layout == BE_PLAN_U16 || layout == BE_PLAN_D8, BE_ERR_INVALID, "a weighted plan has the u16 or the d8 layout");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15 && width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "bad slice geometry");
+  BE_REQUIRE(min_weight_bits >= 0 && min_weight_bits <= 40, BE_ERR_INVALID, "min_weight_bits out of range");
+  BE_REQUIRE(scratch_bytes >= 256, BE_ERR_WORKSPACE, "scratch too small");
+  const int n_slices = n_slices_of(k, slice_shift, slice_width);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned long long* out = static_cast<unsigned long long*>(scratch);           // [0] largest column sum, [1] smallest column maximum
+  uint32_t mb[2];
+  BE_HIP(hipMemcpyAsync(mb, maxabs_bits, 8, hipMemcpyDeviceToHost, st));
+  BE_HIP(hipStreamSynchronize(st));
+  BE_REQUIRE(mb[0] < 0x7f800000u, BE_ERR_RANGE, "weights contain inf / nan: the fixed-point routes do not apply");
+  float wmax, wmin = 0.f;
+  memcpy(&wmax, &mb[0], 4);
+  const bool has_min = mb[1] != 0xffffffffu;
+  if (has_min) memcpy(&wmin, &mb[1], 4);
+  // LDS slots: the u16 layout addresses 2^shift columns + the pad slot, the d8 layout the slice's own columns
+  const int n_slots = layout == BE_PLAN_D8 ? (int)((width_of(slice_shift, slice_width) + 3) & ~3ll) : (1 << slice_shift) + 1;
+  auto launch = [&](int mode, float scale) -> int {
+    const size_t lds = (size_t)n_slots * (mode == 0 ? 8 : 4);
+#define BE_STAT(L_, M_)                                                                                          \
+    {                                                                                                            \
+      auto kern = k_plan_colstats<L_, M_>;                                                                       \
+      BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                       \
+      hipLaunchKernelGGL(kern, dim3(n_slices), dim3(1024), lds, st, static_cast<const unsigned char*>(blob),     \
+                         static_cast<const uint2*>(seg), m, n_slices, n_slots, scale, out);                      \
+    }
+    if (layout == BE_PLAN_D8) { if (mode == 0) BE_STAT(BE_PLAN_D8, 0) else BE_STAT(BE_PLAN_D8, 1) }
+    else { if (mode == 0) BE_STAT(BE_PLAN_U16, 0) else BE_STAT(BE_PLAN_U16, 1) }
+#undef BE_STAT
+    BE_LAUNCH_CHECK();
+    return BE_OK;
+  };
+  double bound = 0.0;
+  if (wmax > 0.f && nnz > 0) {
+    // a safe exponent for the sums of |w| rounded up: nnz * (wmax * 2^e0 + 1) < 2^62
+    int ew = 0, en = 0;
+    (void)frexp((double)wmax, &ew);                                          // wmax < 2^ew
+    (void)frexp((double)nnz, &en);                                           // nnz  < 2^en
+    int e0 = 61 - ew - en;
+    e0 = e0 < -90 ? -90 : (e0 > 150 ? 150 : e0);
+    BE_HIP(be_fill_async(out, 0, 8, st));
+    int rc = launch(0, ldexpf(1.0f, e0 - 32));
+    if (rc != BE_OK) return rc;
+    unsigned long long smax = 0;
+    BE_HIP(hipMemcpyAsync(&smax, out, 8, hipMemcpyDeviceToHost, st));
+    BE_HIP(hipStreamSynchronize(st));
+    bound = ldexp((double)smax + 1.0, -e0);                                 // >= the true largest column sum (addends rounded up)
+  }
+  int eb = 0;
+  if (bound > 0) (void)frexp(bound, &eb);                                    // bound < 2^eb
+  int need = 62 - eb;
+  need = need < -90 ? -90 : (need > 150 ? 150 : need);                       // 2^(e - 32) must be a normal f32
+  bool have_colmax = false;
+  float colmax_min = 0.f;
+  const int cand[2] = {keep_exp, need};
+  for (int c = (keep_exp != INT_MIN && keep_exp <= need) ? 0 : 1; c < 2; ++c) {
+    const int e = cand[c];
+    const double thr = ldexp(1.0, min_weight_bits - e);
+    bool ok = !has_min || (double)wmin >= thr;
+    if (!ok) {
+      if (!have_colmax) {
+        BE_HIP(be_fill_async(out + 1, 0xff, 8, st));
+        int rc = launch(1, 0.f);
+        if (rc != BE_OK) return rc;
+        unsigned long long cm = ~0ull;
+        BE_HIP(hipMemcpyAsync(&cm, out + 1, 8, hipMemcpyDeviceToHost, st));
+        BE_HIP(hipStreamSynchronize(st));
+        have_colmax = true;
+        if (cm == ~0ull) colmax_min = INFINITY;
+        else { const uint32_t b = (uint32_t)cm; memcpy(&colmax_min, &b, 4); }
+      }
+      ok = (double)colmax_min >= thr;
+    }
+    if (ok) {
+      *scale_exp_host = e;
+      return BE_OK;
+    }
+  }
+  be_set_error("be_scatter_plan_exponent: the dynamic range of the weights (" + std::to_string(wmin) + " .. " + std::to_string(wmax) +
+               ") exceeds what 64-bit fixed-point sums resolve; use the direct route");
+  return BE_ERR_RANGE;
 }
 
 // active-list area per batch row: the compacted list (m ids) or, in the fused step, one region per part (its stripes of

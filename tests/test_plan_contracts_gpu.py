@@ -380,3 +380,101 @@ def test_binned_batch_reads_the_rows_once_for_the_whole_batch(be, oracle, homo, 
         if nb >= 32:          # the first pass takes 32 batch rows: 16 bins each = 512 virtual bins, one workgroup per bin
             assert torch.equal(out[:32], out2[:32]), 'integer sums converted once: bitwise reproducible'
 
+
+
+@pytest.mark.parametrize('layout,homo', [('d8', False), ('h8', True)])
+def test_stored_row_order_builds_and_refreshes_the_same_blocks(be, oracle, layout, homo):
+    """The sorted layouts keep the rows' column order from the count pass (`be_scatter_plan_*_ordered`): a build that reads it
+    back in the fill, a build without it, and a weight refresh through the kept order (a gather-copy) or without it (a
+    re-sort) produce the same segment table and bit-identical products; rows are ragged, some empty, some already ascending,
+    columns repeat."""
+    from brainevent_amd._csr import ScatterPlan
+    rng = np.random.default_rng(77)
+    m, k = 700, 90_000
+    lens = rng.integers(0, 900, m)
+    lens[::50] = 0
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    for r in range(0, m, 7):                            # canonical rows: no sort happens, the order is the identity
+        idx[ptr[r]:ptr[r + 1]] = np.sort(idx[ptr[r]:ptr[r + 1]])
+    idx[ptr[3]:ptr[3] + 5] = idx[ptr[3]]                # repeated columns inside a row
+    w = np.ones(1, np.float32) if homo else rng.uniform(0.1, 1.0, ptr[-1]).astype(np.float32)
+    wd, idd, ptd = torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')
+    plans = {ko: ScatterPlan.build(wd, idd, ptd, shape=(m, k), layout=layout, keep_order=ko) for ko in (True, False, None)}
+    assert plans[False].order is None and (plans[True].order is not None) == (not homo)
+    assert (plans[None].order is not None) == (not homo)          # small next to the plan: kept by default (weighted plans only)
+    spikes = [torch.tensor(rng.random(m) < p, device='cuda') for p in (0.3, 1.1, 0.02)]        # (1.1: every row)
+
+    def same_products(wt):       # (the blocks' unwritten alignment padding differs from build to build: compare what they compute)
+        outs = {ko: [be.binary_csrmv(wt, idd, ptd, sv, shape=(m, k), transpose=True, workspace=plans[ko]) for sv in spikes]
+                for ko in plans}
+        for ko in (False, None):
+            assert torch.equal(plans[True].seg, plans[ko].seg)
+            assert all(torch.equal(a, b) for a, b in zip(outs[True], outs[ko])), ko
+    same_products(wd)
+    v = spikes[0]
+    ref = oracle.binary_csrmv(np.broadcast_to(w, idx.shape).astype(np.float64), idx, ptr, v.cpu().numpy(), (m, k), True)
+    out = be.binary_csrmv(wd, idd, ptd, v, shape=(m, k), transpose=True, workspace=plans[True])
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    if homo:
+        return
+    order = plans[True].order.cpu().numpy().view(np.uint16)
+    for r in (1, 2, 8, 14, m - 1):                      # the stored order sorts every row's columns
+        seg = idx[ptr[r]:ptr[r + 1]][order[ptr[r]:ptr[r + 1]]]
+        assert np.all(np.diff(seg) >= 0) and sorted(order[ptr[r]:ptr[r + 1]]) == list(range(ptr[r + 1] - ptr[r]))
+    w2 = rng.uniform(0.1, 1.0, ptr[-1]).astype(np.float32)
+    w2d = torch.tensor(w2, device='cuda')
+    for ko in plans:
+        plans[ko].refresh_weights(w2d, idd, ptd)
+    same_products(w2d)
+    out = be.binary_csrmv(w2d, idd, ptd, v, shape=(m, k), transpose=True, workspace=plans[True])
+    ref2 = oracle.binary_csrmv(w2.astype(np.float64), idx, ptr, v.cpu().numpy(), (m, k), True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref2, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('layout', ['d8', 'u16'])
+def test_plan_exponent_from_its_own_blocks_matches_the_entry_pass(be, oracle, layout):
+    """`be_scatter_plan_exponent` (column statistics from the plan's blocks: a planned step over |w| with every row active)
+    against `be_fixed_point_exponent` (global atomics over the raw entries): the same exponent — or one step more cautious at a
+    power-of-two boundary, since its addends are rounded up — over weight scales, signs, repeated columns and blocks of more
+    than 256 items; the same refusal of weights the sums cannot resolve; keep_exp honoured."""
+    from brainevent_amd._csr import ScatterPlan, fixed_point_exponent, MathError
+    rng = np.random.default_rng(5)
+    m, k = 900, 60_000
+    lens = rng.integers(0, 1500, m)
+    lens[0] = 4000                                    # ~1300 items per (row, slice): several 64-lane-group passes per block
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    idx[ptr[5]:ptr[5] + 300] = 77                     # one column listed 300 times in a row: column sums are not bounded by rows x max
+    idd, ptd = torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')
+    for scale, signed in ((1.0, False), (1e-3, True), (4096.0, True), (2.0 ** -20, False)):
+        w = (rng.uniform(0.25, 1.0, ptr[-1]) * scale).astype(np.float32)
+        if signed:
+            w *= rng.choice([-1.0, 1.0], w.size).astype(np.float32)
+        wd = torch.tensor(w, device='cuda')
+        plan = ScatterPlan.build(wd, idd, ptd, shape=(m, k), layout=layout)
+        e_ref = fixed_point_exponent(wd, idd, k)
+        assert plan.scale_exp in (e_ref, e_ref - 1), (plan.scale_exp, e_ref, scale)
+        # no column can overflow at the chosen exponent with every row active
+        colsum = np.zeros(k)
+        np.add.at(colsum, idx, np.abs(w.astype(np.float64)))
+        assert colsum.max() * 2.0 ** plan.scale_exp < 2.0 ** 62
+        v = torch.ones(m, dtype=torch.bool, device='cuda')
+        out = be.binary_csrmv(wd, idd, ptd, v, shape=(m, k), transpose=True, workspace=plan)
+        ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, np.ones(m, bool), (m, k), True)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL * scale)
+        # a refresh with smaller weights keeps the exponent (it still cannot overflow); larger ones that would overflow move it
+        e0 = plan.scale_exp
+        plan.refresh_weights(wd * 0.5, idd, ptd)
+        assert plan.scale_exp == e0
+        plan.refresh_weights(wd * 64.0, idd, ptd)
+        assert plan.scale_exp <= e0 - 5
+    # a column whose only weights the sums cannot resolve next to huge ones elsewhere: refused like the entry pass refuses it
+    w = rng.uniform(0.5, 1.0, ptr[-1]).astype(np.float32)
+    w[idx == idx[ptr[9]]] = 1e-30
+    w[ptr[20]] = 1e30 if idx[ptr[20]] != idx[ptr[9]] else w[ptr[20]]
+    wd = torch.tensor(w, device='cuda')
+    with pytest.raises(MathError):
+        fixed_point_exponent(wd, idd, k)
+    with pytest.raises(MathError):
+        ScatterPlan.build(wd, idd, ptd, shape=(m, k), layout=layout)

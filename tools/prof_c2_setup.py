@@ -14,6 +14,10 @@ def tick(msg, t0):
 t = time.perf_counter()
 w, idx, ptr = gen_csr_on_device(n, n, nc, False, 1234, dev); t = tick('generate matrix', t)
 plan = C.ScatterPlan.build(w, idx, ptr, shape=(n, n)); t = tick('ScatterPlan.build (count + fill + exponent)', t)
-e = C.fixed_point_exponent(w, idx, n); t = tick(f'fixed_point_exponent alone (e = {e})', t)
+e = C.fixed_point_exponent(w, idx, n); t = tick(f"be_fixed_point_exponent (global atomics over the entries; the plan no longer calls it: e = {e}, plan e = {plan.scale_exp})", t)
 w.mul_(0.5); torch.cuda.synchronize(); t = time.perf_counter()
-plan.refresh_weights(w, idx, ptr); t = tick('refresh_weights after an in-place update', t)
+plan.refresh_weights(w, idx, ptr); t = tick('refresh_weights after an in-place update (order not kept: the rows are sorted again)', t)
+del plan; torch.cuda.synchronize(); t = time.perf_counter()
+plan = C.ScatterPlan.build(w, idx, ptr, shape=(n, n), keep_order=True); t = tick('ScatterPlan.build(keep_order=True)', t)
+w.mul_(0.5); torch.cuda.synchronize(); t = time.perf_counter()
+plan.refresh_weights(w, idx, ptr); t = tick('refresh_weights through the kept order (gather-copy + column statistics from the plan)', t)
