@@ -309,6 +309,8 @@ class ScatterPlan:
         scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
         blob_bytes = c_i64(0)
         order = None
+        if keep_order is None and os.environ.get('BE_PLAN_KEEP_ORDER'):          # (A/B runs)
+            keep_order = os.environ['BE_PLAN_KEEP_ORDER'] == '1'
         if lay != cls.LAYOUT_U16 and nnz and keep_order is not False:
             try:            # the rows' column order, written by the count pass and read back by the fill (one sort instead of two)
                 order = torch.empty(nnz, dtype=torch.int16, device=dev)
