@@ -216,7 +216,7 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
 // entry is in its block — the stores of the entries whose ring slot is free, their commits, and the flushes of the blocks
 // those commits completed.  All NE entries go through every stage together (independent LDS operations in flight, no
 // branches: a lane without an entry, or with one that has to wait, aims at counters and words of its own that nobody reads).
-template <bool HOMO, int CB, int NE>
+template <bool HOMO, int CB, int NE, bool BATCH>
 __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, const uint32_t (&col)[NE],
                                                const float (&w)[HOMO ? 1 : NE], const uint32_t (&boff)[NE / 4], uint32_t width,
                                                DivU32 wdiv, int n_bins, int n_bins_b, int64_t k,
@@ -232,7 +232,9 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
   for (int u = 0; u < NE; ++u) {
     const uint32_t bl = wdiv.div(col[u]);                      // the bin inside its batch row: a missing entry's is huge
     lc[u] = col[u] - __umul24(bl, width);
-    const uint32_t b = bl < (uint32_t)n_bins_b ? bl + boff[u / 4] : 0xffffffffu;
+    // (a single vector has no virtual bins: the bin is the bin — pass B counted 201 -> 188 us, weighted 442 -> 428 at C4 without
+    //  the batch arithmetic in this path)
+    const uint32_t b = !BATCH ? bl : (bl < (uint32_t)n_bins_b ? bl + boff[u / 4] : 0xffffffffu);
     bin[u] = b < dummy_bin ? b : dummy_bin;
     pend |= (b < (uint32_t)n_bins ? 1u : 0u) << u;
   }
@@ -332,7 +334,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
 // contiguous share of the task list; a wave flattens its task's rows into groups of four consecutive entries (prefix
 // sums of the rows' group counts in a per-wave LDS table), a lane takes one group per step — one 16-byte load of columns
 // and one of weights — and BE_STREAM_U steps are loading while the previous ones are appended.
-template <typename W, bool HOMO, int CB>
+template <typename W, bool HOMO, int CB, bool BATCH>
 __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
                                                      const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
                                                      uint32_t width, DivU32 wdiv, int n_bins, uint32_t cap_blocks,
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
     uint32_t rmask = 1u;                              // batch rows in which this lane's row is active
     if ((uint32_t)lane < R && a0 + lane < n_active) {
       const uint32_t r = active[a0 + lane];
-      if (row_masks) rmask = row_masks[a0 + lane];
+      if (BATCH) rmask = row_masks[a0 + lane];
       rb = rp.at(r);
       len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
     }
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
         }                                                                                                            \
       }                                                                                                              \
       validN[u] = vm;                                                                                                \
-      maskN[u] = row_masks ? (huge ? rl(rmask, (int)piece) : (uint32_t)__shfl((int)rmask, (int)i, 64)) : 1u;         \
+      maskN[u] = BATCH ? (huge ? rl(rmask, (int)piece) : (uint32_t)__shfl((int)rmask, (int)i, 64)) : 1u;             \
     }                                                                                                                \
   } while (0)
         BE_STREAM_ISSUE(0u);
@@ -536,17 +538,24 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
             do {                                          // once; a batch: once per batch row some lane's row is active in
 #pragma unroll
               for (int u = 0; u < U; ++u) {
-                const uint32_t mk = maskC[u];
-                const uint32_t b = mk ? (uint32_t)__ffs(mk) - 1u : 0u;
-                maskC[u] = mk & (mk - 1u);
-                offA[u] = b * (uint32_t)n_bins_b;
+                if constexpr (!BATCH) {
+                  maskC[u] = 0u;
+                  offA[u] = 0u;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) colA[u * 4 + j] = mk ? colC[u][j] : 0xffffffffu;
+                  for (int j = 0; j < 4; ++j) colA[u * 4 + j] = colC[u][j];
+                } else {
+                  const uint32_t mk = maskC[u];
+                  const uint32_t b = mk ? (uint32_t)__ffs(mk) - 1u : 0u;
+                  maskC[u] = mk & (mk - 1u);
+                  offA[u] = b * (uint32_t)n_bins_b;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) colA[u * 4 + j] = mk ? colC[u][j] : 0xffffffffu;
+                }
               }
 #ifdef BE_DBG_NOAPPEND
               if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
 #endif
-              stream_append<HOMO, CB, U * 4>(S, colA, wA, offA, width, wdiv, n_bins, n_bins_b, k, cap_blocks, wl, wg_regions,
+              stream_append<HOMO, CB, U * 4, BATCH>(S, colA, wA, offA, width, wdiv, n_bins, n_bins_b, k, cap_blocks, wl, wg_regions,
                                              bin_stride_dw, out, w0, lane, prof);
               bool again = false;
 #pragma unroll
@@ -1046,7 +1055,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (kRing * (size_t)cap * (homo ? 2 : 6) / 4 + 2 + 2 * kRing)) * 4;
 #define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
   do {                                                                                                                          \
-    auto kern = k_bin_stream<WT, HOMO_, CAP_>;                                                                                  \
+    auto kern = row_masks ? k_bin_stream<WT, HOMO_, CAP_, true> : k_bin_stream<WT, HOMO_, CAP_, false>;                         \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
                        al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \
