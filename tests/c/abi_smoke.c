@@ -2,8 +2,9 @@
  * binder of the reference (its FFI replaces `jax.ffi.ffi_call("<module>.<fn>")`, brainevent/_op/kernix_runtime.py:161-189)
  * would do with include/brainevent_amd.h.
  *   1. direct route:   be_binary_csrmv_t_hetero_f32_bool            (no preprocessing, global atomics)
- *   2. planned route:  be_scatter_plan_count -> _fill -> be_fixed_point_exponent -> be_binary_csrmv_t_plan
- *   3. weight refresh: be_scatter_plan_refresh_weights, then step 2's call again
+ *   2. planned route:  be_scatter_plan_count_ordered -> _fill_ordered -> be_scatter_plan_exponent (checked against
+ *                      be_fixed_point_exponent) -> be_binary_csrmv_t_plan
+ *   3. weight refresh: be_scatter_plan_refresh_weights_ordered (a gather-copy through the stored order), then step 2's call again
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
  *   5. neuron step:    be_lif_coba_step
  * Every result is compared with the serial loop of the reference's CPU kernel (brainevent/_csr/binary.py:446-451 /
@@ -92,13 +93,24 @@ int main(void) {
   void *d_seg = dev_copy(NULL, m * n_slices * 8);
   int64_t scr_bytes = be_scatter_plan_scratch_bytes(m, k, shift, width), blob_bytes = 0;
   void *d_scr = dev_copy(NULL, scr_bytes);
-  CHECK_BE(be_scatter_plan_count(d_idx, d_ptr, 0, -1, m, k, shift, width, 0, layout, d_seg, d_scr, scr_bytes, &blob_bytes, NULL));
+  /* the count pass leaves the rows' column order behind (2 bytes per entry): the fill and the refresh below read it back */
+  void *d_order = dev_copy(NULL, nnz * 2);
+  CHECK_BE(be_scatter_plan_count_ordered(d_idx, d_ptr, 0, -1, m, k, shift, width, 0, layout, d_seg, d_scr, scr_bytes, &blob_bytes,
+                                         (uint16_t *)d_order, NULL));
   void *d_blob = dev_copy(NULL, blob_bytes + 128), *d_maxabs = dev_copy(NULL, 8);
-  CHECK_BE(be_scatter_plan_fill(d_w, 0, BE_F32, d_idx, d_ptr, 0, -1, m, k, shift, width, layout, d_seg, d_blob, d_maxabs, NULL));
+  CHECK_BE(be_scatter_plan_fill_ordered(d_w, 0, BE_F32, d_idx, d_ptr, 0, -1, m, k, shift, width, layout, d_seg, d_blob, d_maxabs,
+                                        (const uint16_t *)d_order, NULL));
   int64_t fp_bytes = be_fixed_point_scratch_bytes(k);
   void *d_fp = dev_copy(NULL, fp_bytes);
-  int scale_exp = 0;
-  CHECK_BE(be_fixed_point_exponent(d_w, BE_F32, d_idx, nnz, k, 16, INT_MIN, d_fp, fp_bytes, &scale_exp, NULL));
+  int scale_exp = 0, scale_exp_entries = 0;
+  /* the exponent from the plan's own blocks, and — for comparison — from the raw entries (the call a binned workspace uses) */
+  CHECK_BE(be_scatter_plan_exponent(d_blob, d_seg, m, k, shift, width, layout, nnz, (const uint32_t *)d_maxabs, 16, INT_MIN, d_fp,
+                                    fp_bytes, &scale_exp, NULL));
+  CHECK_BE(be_fixed_point_exponent(d_w, BE_F32, d_idx, nnz, k, 16, INT_MIN, d_fp, fp_bytes, &scale_exp_entries, NULL));
+  if (scale_exp != scale_exp_entries && scale_exp != scale_exp_entries - 1) {
+    printf("FAIL exponent from the plan %d vs from the entries %d\n", scale_exp, scale_exp_entries);
+    ++fails;
+  }
   int64_t pws_bytes = be_binary_csrmv_t_plan_workspace_bytes(m, k, shift, width, parts, 0);
   void *d_pws = dev_copy(NULL, pws_bytes);
   CHECK_HIP(hipMemset(d_pws, 0, 256));                    /* spike counters: zero on entry, zero again on exit */
@@ -114,8 +126,10 @@ int main(void) {
   /* 3. weights updated in place (plasticity): refresh the blocks of the unchanged structure */
   for (int64_t j = 0; j < nnz; ++j) w[j] = w[j] * 0.5f + 0.01f;
   CHECK_HIP(hipMemcpy(d_w, w, nnz * 4, hipMemcpyHostToDevice));
-  CHECK_BE(be_scatter_plan_refresh_weights(d_w, 0, BE_F32, d_idx, d_ptr, 0, -1, m, k, shift, width, layout, d_seg, d_blob, d_maxabs, NULL));
-  CHECK_BE(be_fixed_point_exponent(d_w, BE_F32, d_idx, nnz, k, 16, scale_exp, d_fp, fp_bytes, &scale_exp, NULL));
+  CHECK_BE(be_scatter_plan_refresh_weights_ordered(d_w, 0, BE_F32, d_idx, d_ptr, 0, -1, m, k, shift, width, layout, d_seg, d_blob,
+                                                   d_maxabs, (const uint16_t *)d_order, NULL));
+  CHECK_BE(be_scatter_plan_exponent(d_blob, d_seg, m, k, shift, width, layout, nnz, (const uint32_t *)d_maxabs, 16, scale_exp, d_fp,
+                                    fp_bytes, &scale_exp, NULL));
   memset(ref, 0, k * 8);
   for (int64_t i = 0; i < m; ++i)
     if (spk[i]) for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ref[idx[j]] += (double)w[j];
