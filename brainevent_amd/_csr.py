@@ -19,7 +19,7 @@ scatter kernel (see ``csrc/be_csr_plan.hip``; the binned route is ``csrc/be_csr_
 import ctypes
 import os
 import math
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -245,6 +245,37 @@ class ScatterPlan:
 
     # -- construction ---------------------------------------------------------------------------
     @classmethod
+    def _choose_geometry(cls, m: int, k: int, nnz: int, homo: bool, max_row: Optional[int], slice_shift: Optional[int],
+                         slice_width: Optional[int], layout: Optional[str]):
+        """(layout code, slice_shift, slice_width, n_slices) of a plan: the sorted-delta layouts (d8 / h8) apply to rows the
+        LDS sort holds (``max_row``; None = not asked for) and <= 1024 slices; without explicit choices ``auto_geometry``
+        picks by the measured regime."""
+        if layout not in (None, 'u16', 'd8', 'h8'):
+            raise ValueError(f"layout must be 'u16', 'd8', 'h8' or None, got {layout!r}.")
+        if layout == ('h8', 'd8')[homo]:
+            raise ValueError("d8 is the layout of heterogeneous weights, h8 the one of a homogeneous weight.")
+        if slice_shift is None:
+            slice_shift = cls.default_shift(k, homo)
+        d8_ok = layout != 'u16' and max_row is not None and max_row <= cls.D8_MAX_ROW
+        delta_cap = cls.H8_CAP if homo else cls.D8_CAP
+        if slice_width is None:
+            lay, slice_width = cls.auto_geometry(m, k, nnz, homo, slice_shift, delta_ok=d8_ok,
+                                                 force={'d8': 'delta', 'h8': 'delta', 'u16': 'u16'}.get(layout))
+        else:
+            lay = (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8) if d8_ok else cls.LAYOUT_U16
+            if lay != cls.LAYOUT_U16 and layout is None and slice_width <= (1 << slice_shift):
+                lay = cls.auto_geometry(m, k, nnz, homo, slice_shift)[0]     # the width is given, the layout is not
+        n_slices = (k + slice_width - 1) // slice_width
+        if lay != cls.LAYOUT_U16 and n_slices > cls.D8_MAX_SLICES:
+            lay = cls.LAYOUT_U16
+        if layout in ('d8', 'h8') and lay == cls.LAYOUT_U16:
+            raise ValueError("the d8 / h8 layouts need f32/f16/bf16 weights, rows of at most 16384 entries and at most 1024 "
+                             "slices.")
+        if not (0 < slice_width <= (1 << slice_shift) or (lay != cls.LAYOUT_U16 and 0 < slice_width <= delta_cap)):
+            raise ValueError(f"slice_width {slice_width} exceeds the accumulator capacity of this layout.")
+        return lay, slice_shift, slice_width, n_slices
+
+    @classmethod
     def build(cls, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], *, shape,
               row_len: int = -1, slice_shift: Optional[int] = None, slice_width: Optional[int] = None,
               layout: Optional[str] = None, keep_order: Optional[bool] = None) -> 'ScatterPlan':
@@ -272,38 +303,14 @@ class ScatterPlan:
         src_stamp = weights_stamp(weights)
         if split:       # per-entry f64 weights: every entry becomes two f32 entries (see _split_f64)
             weights, indices, indptr, row_len = _split_f64(weights, indices, indptr, row_len)
-        if layout not in (None, 'u16', 'd8', 'h8'):
-            raise ValueError(f"layout must be 'u16', 'd8', 'h8' or None, got {layout!r}.")
-        if layout == ('h8', 'd8')[homo]:
-            raise ValueError("d8 is the layout of heterogeneous weights, h8 the one of a homogeneous weight.")
-        if slice_shift is None:
-            slice_shift = cls.default_shift(k, homo)
         dev = A.device()
         st = A.stream_ptr()
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
-        # block layout: the sorted-delta layouts (d8 / h8) apply to rows the LDS sort holds and <= 1024 slices; without
-        # explicit choices auto_geometry picks by the measured regime
         nnz = int(indices.numel())
-        d8_ok = layout != 'u16'
-        if d8_ok:
+        max_row = None
+        if layout != 'u16':
             max_row = int(row_len) if indptr is None else (int((indptr[1:] - indptr[:-1]).max().item()) if m > 0 else 0)
-            d8_ok = max_row <= cls.D8_MAX_ROW
-        delta_cap = cls.H8_CAP if homo else cls.D8_CAP
-        if slice_width is None:
-            lay, slice_width = cls.auto_geometry(m, k, nnz, homo, slice_shift, delta_ok=d8_ok,
-                                                 force={'d8': 'delta', 'h8': 'delta', 'u16': 'u16'}.get(layout))
-        else:
-            lay = (cls.LAYOUT_H8 if homo else cls.LAYOUT_D8) if d8_ok else cls.LAYOUT_U16
-            if lay != cls.LAYOUT_U16 and layout is None and slice_width <= (1 << slice_shift):
-                lay = cls.auto_geometry(m, k, nnz, homo, slice_shift)[0]     # the width is given, the layout is not
-        n_slices = (k + slice_width - 1) // slice_width
-        if lay != cls.LAYOUT_U16 and n_slices > cls.D8_MAX_SLICES:
-            lay = cls.LAYOUT_U16
-        if layout in ('d8', 'h8') and lay == cls.LAYOUT_U16:
-            raise ValueError("the d8 / h8 layouts need f32/f16/bf16 weights, rows of at most 16384 entries and at most 1024 "
-                             "slices.")
-        if not (0 < slice_width <= (1 << slice_shift) or (lay != cls.LAYOUT_U16 and 0 < slice_width <= delta_cap)):
-            raise ValueError(f"slice_width {slice_width} exceeds the accumulator capacity of this layout.")
+        lay, slice_shift, slice_width, n_slices = cls._choose_geometry(m, k, nnz, homo, max_row, slice_shift, slice_width, layout)
         seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)   # {uint32 start, uint32 n4} pairs
         f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
         scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
@@ -345,6 +352,81 @@ class ScatterPlan:
             keep_order = order is not None and not homo and order.numel() * 2 <= cls.KEEP_ORDER_MAX_BYTES
         if not keep_order or homo:      # (one shared weight is never re-encoded)
             plan.order = None
+        return plan
+
+    @classmethod
+    def build_from_blocks(cls, get_block: Callable[[int, int], Tuple], block_rows: int, *, shape, nnz: int, max_row_len: int,
+                          homo: bool, weight_dtype: torch.dtype = torch.float32, slice_shift: Optional[int] = None,
+                          slice_width: Optional[int] = None, layout: Optional[str] = None) -> 'ScatterPlan':
+        """Build the plan of a matrix whose raw arrays are **never resident in full**: ``get_block(r0, r1)`` returns the rows
+        ``[r0, r1)`` as ``(weights, indices, indptr)`` on the device — ``indptr`` relative to the block (``indptr[0] == 0``,
+        int32 or int64; or ``None`` with rows of exactly ``max_row_len`` entries) — and is called twice per block: once for the
+        count pass, once for the fill.  Everything the two passes touch is local to a row except the block starts, which one
+        scan over the whole segment table provides in between (``be_scatter_plan_begin / _count_rows / _scan``, then
+        ``be_scatter_plan_fill_ordered`` per block).  The result is the plan :meth:`build` gives for the whole matrix (same
+        segment table, same blocks); a matrix whose raw CSR and plan do not fit the device together — 1.5M x 1.5M with 15 000
+        entries per row: 180 GB + 130 GB — is planned this way and used through :class:`PlannedMatrix`.  ``nnz`` and
+        ``max_row_len`` describe the whole matrix (they pick the geometry); f64 per-entry weights are not served here."""
+        m, k = int(shape[0]), int(shape[1])
+        if weight_dtype == torch.float64 and not homo:
+            raise ValueError("build_from_blocks: per-entry f64 weights are not served (build() splits them; do the same per block).")
+        lay, slice_shift, slice_width, n_slices = cls._choose_geometry(m, k, int(nnz), bool(homo), int(max_row_len), slice_shift,
+                                                                       slice_width, layout)
+        dev, st = A.device(), A.stream_ptr()
+        seg = torch.empty(n_slices * m * 2, dtype=torch.int32, device=dev)
+        f_scr = fn('be_scatter_plan_scratch_bytes', c_i64, [c_i64, c_i64, c_int, c_int])
+        scratch = A.workspace(f_scr(m, k, slice_shift, slice_width))
+        check(fn('be_scatter_plan_begin', c_int, [c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp])(
+            m, k, slice_shift, slice_width, A.ptr(scratch), scratch.numel(), st), 'be_scatter_plan_begin')
+        f_cnt = fn('be_scatter_plan_count_rows', c_int,
+                   [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp])
+        seg_rows = seg.view(m, n_slices * 2)
+
+        def block_args(r0, r1):
+            w, idx, ptr = get_block(r0, r1)
+            w, idx = A.to_device(w).reshape(-1), A.to_device(idx).reshape(-1)
+            assert idx.dtype == torch.int32 and (w.numel() == 1) == bool(homo)
+            ptr = None if ptr is None else A.to_device(ptr)
+            assert ptr is None or ptr.numel() == r1 - r0 + 1
+            is64 = int(ptr is not None and ptr.dtype == torch.int64)
+            return w, idx, ptr, is64, (int(max_row_len) if ptr is None else -1)
+
+        n_seen = 0
+        for r0 in range(0, m, int(block_rows)):
+            r1 = min(m, r0 + int(block_rows))
+            w, idx, ptr, is64, rl = block_args(r0, r1)
+            n_seen += int(idx.numel())
+            check(f_cnt(A.ptr(idx), A.ptr(ptr), is64, rl, r1 - r0, m, k, slice_shift, slice_width, int(homo), lay,
+                        A.ptr(seg_rows[r0]), A.ptr(scratch), scratch.numel(), None, st), 'be_scatter_plan_count_rows')
+            torch.cuda.current_stream().synchronize()         # the block's arrays may be released by the caller's next get_block
+        assert n_seen == int(nnz), f"build_from_blocks: the blocks hold {n_seen} entries, nnz says {nnz}"
+        blob_bytes = c_i64(0)
+        check(fn('be_scatter_plan_scan', c_int, [c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp])(
+            m, k, slice_shift, slice_width, A.ptr(seg), A.ptr(scratch), scratch.numel(), ctypes.byref(blob_bytes), st),
+            'be_scatter_plan_scan')
+        blob = torch.empty(int(blob_bytes.value) + 128, dtype=torch.uint8, device=dev)
+        plan = cls(m, k, bool(homo), slice_shift, seg, blob, 0, weight_dtype, slice_width, lay)
+        plan.nnz, plan.order, plan.row_len, plan.split_f64 = int(nnz), None, -1, False
+        if lay == cls.LAYOUT_D8 and nnz:
+            n_blk = m * n_slices
+            ng = seg.view(n_blk, 2)[::max(1, n_blk >> 22), 1] & 0xffff
+            plan.items_hint = max(1, min(1 << 20, int(round(4.0 * ng.double().mean().item()))))
+        f_fill = fn('be_scatter_plan_fill_ordered', c_int,
+                    [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp])
+        maxabs = torch.zeros(2, dtype=torch.int32, device=dev)
+        stats = torch.tensor([0, 0xffffffff], dtype=torch.int64, device=dev)          # max |w| bits, smallest non-zero |w| bits
+        for r0 in range(0, m, int(block_rows)):
+            r1 = min(m, r0 + int(block_rows))
+            w, idx, ptr, is64, rl = block_args(r0, r1)
+            check(f_fill(A.ptr(w), int(homo), A.wcode(w), A.ptr(idx), A.ptr(ptr), is64, rl, r1 - r0, k, slice_shift, slice_width,
+                         lay, A.ptr(seg_rows[r0]), A.ptr(blob), A.ptr(maxabs), None, st), 'be_scatter_plan_fill_ordered')
+            mb = maxabs.to(torch.int64) & 0xffffffff                                   # (every fill call starts its own statistics)
+            stats = torch.stack([torch.maximum(stats[0], mb[0]), torch.minimum(stats[1], mb[1])])
+            torch.cuda.current_stream().synchronize()
+        plan.stamp = None
+        if not homo:
+            both = torch.where(stats > 0x7fffffff, stats - (1 << 32), stats).to(torch.int32)     # back to the two uint32 bit patterns
+            plan.scale_exp = plan._plan_exponent(both.contiguous())
         return plan
 
     def _fill(self, weights: torch.Tensor, indices: torch.Tensor, indptr: Optional[torch.Tensor], keep_exp: bool = False):
@@ -627,6 +709,36 @@ def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor
 # =====================================================================================================
 # functional ops
 # =====================================================================================================
+class PlannedMatrix:
+    """``events @ M`` through a :class:`ScatterPlan` alone: the raw CSR arrays are not kept (a plan built with
+    :meth:`ScatterPlan.build_from_blocks`, or the plan of a container whose arrays the caller wants to release).  Only the
+    event-driven scatter product exists — vectors and batches, every spike encoding; everything that needs the raw arrays
+    (the gather direction, ``todense``, a weight refresh) does not.  One shared weight is passed as ``weight``."""
+
+    def __init__(self, plan: ScatterPlan, weight=None):
+        if plan.homo and weight is None:
+            raise ValueError("PlannedMatrix: a plan of one shared weight needs that weight.")
+        self.plan = plan
+        self.shape = (plan.m, plan.k)
+        self.weight = None if weight is None else A.to_device(torch.as_tensor(weight)).reshape(-1)[:1].to(plan.weight_dtype)
+
+    def __rmatmul__(self, other):
+        if not is_event(other):
+            raise NotImplementedError("only event operands (BinaryArray, BitPackedBinary, CompactBinary) are served.")
+        v = _event_value(other, scatter=True)
+        if v.ndim not in (1, 2):
+            raise NotImplementedError(f"matmul with object of shape {v.shape}")
+        if v.shape[-1] != self.plan.m:
+            raise MathError(f"shapes {tuple(v.shape)} and {self.shape} not aligned.")
+        sp, sd = A.spikes_to_device(v)
+        spikes_bm = sp.reshape(1, -1) if v.ndim == 1 else sp.contiguous()          # batch-major [n_batch, m] (packed: words)
+        out = torch.empty((1 if v.ndim == 1 else int(v.shape[0]), self.plan.k), dtype=self.plan.weight_dtype, device=A.device())
+        w = self.weight if self.plan.homo else torch.empty(0, dtype=self.plan.weight_dtype, device=A.device())
+        _plan_call(self.plan, w, spikes_bm, sd, out)
+        r = out[0] if v.ndim == 1 else out
+        return r.cpu().numpy() if A.wants_numpy(v) else r
+
+
 def _variant(homo: bool, w: torch.Tensor, sd: int) -> str:
     return f"{'homo' if homo else 'hetero'}_{A.wsuffix(w)}_{'bool' if sd == A.BE_SPIKE_BOOL else 'float'}"
 

@@ -1740,41 +1740,70 @@ int64_t be_scatter_plan_scratch_bytes(int64_t m, int64_t k, int slice_shift, int
   return be_align_up((n_blocks + 2) * 8, 256);
 }
 
-int be_scatter_plan_count_ordered(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
-                                  int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg, void* scratch,
-                                  int64_t scratch_bytes, int64_t* blob_bytes_host, uint16_t* order_out, be_stream_t stream) {
+// ---- the count pass in three pieces, so that a matrix can be planned from BLOCKS OF ROWS that are resident one at a time
+//      (be_scatter_plan_begin, then be_scatter_plan_count_rows per block, then be_scatter_plan_scan; the fill runs per block too:
+//      everything the count and fill kernels touch is local to a row except the block starts, which the scan provides)
+static inline unsigned long long* plan_too_long(void* scratch, int64_t m, int n_slices) {
+  const int64_t n_blocks = ((int64_t)n_slices * m + kScanChunk - 1) / kScanChunk;
+  return reinterpret_cast<unsigned long long*>(static_cast<uint64_t*>(scratch) + n_blocks + 1);   // longest over-long row
+}
+
+int be_scatter_plan_begin(int64_t m, int64_t k, int slice_shift, int slice_width, void* scratch, int64_t scratch_bytes,
+                          be_stream_t stream) {
   BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(scratch && scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift, slice_width), BE_ERR_WORKSPACE, "scratch too small");
+  const int n_slices = n_slices_of(k, slice_shift, slice_width);
+  BE_HIP(be_fill_async(plan_too_long(scratch, m, n_slices), 0, 8, static_cast<hipStream_t>(stream)));
+  return BE_OK;
+}
+
+int be_scatter_plan_count_rows(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m_rows,
+                               int64_t m_total, int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg_rows,
+                               void* scratch, int64_t scratch_bytes, uint16_t* order_out, be_stream_t stream) {
+  BE_REQUIRE(m_rows > 0 && m_rows <= m_total && k > 0, BE_ERR_INVALID, "bad row block");
   BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
   BE_REQUIRE(width_ok(slice_shift, slice_width, layout), BE_ERR_INVALID, "slice_width out of range for this layout");
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   const int n_slices = n_slices_of(k, slice_shift, slice_width);
   BE_REQUIRE(n_slices <= kMaxSlices, BE_ERR_RANGE, "too many slices for the plan kernels");
-  BE_REQUIRE(seg && scratch && blob_bytes_host, BE_ERR_INVALID, "null pointer");
-  BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift, slice_width), BE_ERR_WORKSPACE,
+  BE_REQUIRE(seg_rows && scratch, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m_total, k, slice_shift, slice_width), BE_ERR_WORKSPACE,
              "scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   RowPtr rp{indptr, indptr_is_i64, row_len};
-  const int64_t n = (int64_t)n_slices * m;
-  uint2* sg = static_cast<uint2*>(seg);
-  uint64_t* sums = static_cast<uint64_t*>(scratch);
-  const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
-  BE_REQUIRE(n_blocks < (1ll << 31), BE_ERR_RANGE, "plan index too large");
-  unsigned long long* too_long = reinterpret_cast<unsigned long long*>(sums + n_blocks + 1);   // longest over-long row
-  BE_HIP(be_fill_async(too_long, 0, 8, st));
+  uint2* sg = static_cast<uint2*>(seg_rows);
+  unsigned long long* too_long = plan_too_long(scratch, m_total, n_slices);
   if (layout == BE_PLAN_D8 || layout == BE_PLAN_H8) {
     BE_REQUIRE((layout == BE_PLAN_H8) == (homo != 0), BE_ERR_INVALID, "d8 is the heterogeneous layout, h8 the homogeneous one");
     BE_REQUIRE(indptr != nullptr || row_len <= kD8MaxRow, BE_ERR_RANGE, "d8 / h8 layout: rows of at most 16384 entries");
     BE_REQUIRE(n_slices <= kD8MaxSlices, BE_ERR_RANGE, "too many slices for the d8 / h8 layout");
     auto kern = layout == BE_PLAN_H8 ? k_plan_d8_count<true> : k_plan_d8_count<false>;
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), kD8MaxRow * 8));
-    hipLaunchKernelGGL(kern, dim3(grid_for(m, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m,
+    hipLaunchKernelGGL(kern, dim3(grid_for(m_rows, 1, 256 * 8)), dim3(1024), kD8MaxRow * 8, st, indices, rp, m_rows,
                        (uint32_t)width_of(slice_shift, slice_width), n_slices, sg, too_long, order_out);
   } else {
     BE_REQUIRE(layout == BE_PLAN_U16, BE_ERR_INVALID, "unknown plan layout");
-    hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m,
+    hipLaunchKernelGGL(k_plan_count, dim3(grid_for(m_rows, 1, 256 * 16)), dim3(256), 0, st, indices, rp, m_rows,
                        (uint32_t)width_of(slice_shift, slice_width), n_slices, homo, sg);
   }
   BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+int be_scatter_plan_scan(int64_t m, int64_t k, int slice_shift, int slice_width, void* seg, void* scratch, int64_t scratch_bytes,
+                         int64_t* blob_bytes_host, be_stream_t stream) {
+  BE_REQUIRE(m > 0 && k > 0, BE_ERR_INVALID, "empty matrix has no plan");
+  BE_REQUIRE(slice_shift >= 4 && slice_shift <= 15, BE_ERR_INVALID, "slice_shift must be in [4, 15]");
+  BE_REQUIRE(seg && scratch && blob_bytes_host, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(scratch_bytes >= be_scatter_plan_scratch_bytes(m, k, slice_shift, slice_width), BE_ERR_WORKSPACE, "scratch too small");
+  const int n_slices = n_slices_of(k, slice_shift, slice_width);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)n_slices * m;
+  uint2* sg = static_cast<uint2*>(seg);
+  uint64_t* sums = static_cast<uint64_t*>(scratch);
+  const int64_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
+  BE_REQUIRE(n_blocks < (1ll << 31), BE_ERR_RANGE, "plan index too large");
   hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, st, sg, n, sums);
   BE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, n_blocks);
@@ -1790,6 +1819,18 @@ int be_scatter_plan_count_ordered(const int32_t* indices, const void* indptr, in
   BE_LAUNCH_CHECK();
   *blob_bytes_host = (int64_t)(total_units << 7);
   return BE_OK;
+}
+
+int be_scatter_plan_count_ordered(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
+                                  int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg, void* scratch,
+                                  int64_t scratch_bytes, int64_t* blob_bytes_host, uint16_t* order_out, be_stream_t stream) {
+  BE_REQUIRE(blob_bytes_host, BE_ERR_INVALID, "null pointer");
+  int rc = be_scatter_plan_begin(m, k, slice_shift, slice_width, scratch, scratch_bytes, stream);
+  if (rc != BE_OK) return rc;
+  rc = be_scatter_plan_count_rows(indices, indptr, indptr_is_i64, row_len, m, m, k, slice_shift, slice_width, homo, layout, seg, scratch,
+                                  scratch_bytes, order_out, stream);
+  if (rc != BE_OK) return rc;
+  return be_scatter_plan_scan(m, k, slice_shift, slice_width, seg, scratch, scratch_bytes, blob_bytes_host, stream);
 }
 
 int be_scatter_plan_count(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,

@@ -236,6 +236,24 @@ int be_scatter_plan_refresh_weights(const void* weights, int homo, int wdtype, c
                                     int indptr_is_i64, int64_t row_len, int64_t m, int64_t k, int slice_shift,
                                     int slice_width, int layout, const void* seg, void* blob, uint32_t* maxabs_bits,
                                     be_stream_t stream);
+/* Planning a matrix from BLOCKS OF ROWS that are resident one at a time (a matrix whose raw CSR and plan do not fit the device
+ * together).  Everything the count and the fill touch is local to a row except the block starts, which one scan over the whole
+ * segment table provides:
+ *   be_scatter_plan_begin(m, k, ...)                                once: scratch as for be_scatter_plan_count, whole matrix
+ *   be_scatter_plan_count_rows(block, ..., m_rows, m_total, ..., seg + r0 * n_slices * 8 bytes, scratch, ..., order_blk)   per block:
+ *                          indices / indptr of rows [r0, r0 + m_rows), indptr RELATIVE to the block (indptr[0] == 0)
+ *   be_scatter_plan_scan(m, k, ..., seg, scratch, ..., &blob_bytes)   once, SYNCHRONOUS; the caller allocates blob
+ *   be_scatter_plan_fill_ordered(block, ..., m = m_rows, ..., seg + r0 * n_slices * 8, blob, maxabs, order_blk)           per block;
+ *                          every call restarts maxabs: combine the blocks' (max, min) on the caller's side
+ * be_scatter_plan_count[_ordered] is exactly begin + count_rows over all rows + scan. */
+int be_scatter_plan_begin(int64_t m, int64_t k, int slice_shift, int slice_width, void* scratch, int64_t scratch_bytes,
+                          be_stream_t stream);
+int be_scatter_plan_count_rows(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m_rows,
+                               int64_t m_total, int64_t k, int slice_shift, int slice_width, int homo, int layout, void* seg_rows,
+                               void* scratch, int64_t scratch_bytes, uint16_t* order_out, be_stream_t stream);
+int be_scatter_plan_scan(int64_t m, int64_t k, int slice_shift, int slice_width, void* seg, void* scratch, int64_t scratch_bytes,
+                         int64_t* blob_bytes_host, be_stream_t stream);
+
 /* The sorted layouts (BE_PLAN_D8 / BE_PLAN_H8) need every row in column order.  The *_ordered forms keep that order instead of
  * sorting three times: the count pass writes it — order[nnz] uint16, the row-local position of the i-th smallest column of
  * each row — and the fill and every later weight refresh read it back (a gather-copy: no sort).  order == NULL, or the

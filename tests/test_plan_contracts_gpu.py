@@ -478,3 +478,51 @@ def test_plan_exponent_from_its_own_blocks_matches_the_entry_pass(be, oracle, la
         fixed_point_exponent(wd, idd, k)
     with pytest.raises(MathError):
         ScatterPlan.build(wd, idd, ptd, shape=(m, k), layout=layout)
+
+
+@pytest.mark.parametrize('layout,homo', [('d8', False), ('u16', False), ('h8', True), ('u16', True)])
+def test_plan_built_from_row_blocks_equals_the_resident_build(be, oracle, layout, homo):
+    """`ScatterPlan.build_from_blocks` (the raw arrays resident one block of rows at a time: `be_scatter_plan_begin / _count_rows /
+    _scan`, the fill per block) gives the plan `build` gives for the whole matrix — same segment table, same exponent, bit-identical
+    products — and `PlannedMatrix` serves `events @ M` from the plan alone: vectors, batches, packed words; ragged rows with
+    int32 / int64 row pointers and fixed-length rows; uneven last block."""
+    from brainevent_amd._csr import ScatterPlan, PlannedMatrix
+    rng = np.random.default_rng(123)
+    m, k = 1000, 70_000
+    for fixed in (False, True):
+        lens = np.full(m, 300) if fixed else rng.integers(0, 700, m)
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+        w = np.full(1, 0.75, np.float32) if homo else rng.normal(0, 1, ptr[-1]).astype(np.float32)
+        wd, idd = torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda')
+        ptd = torch.tensor(ptr.astype(np.int32), device='cuda')
+        whole = ScatterPlan.build(wd, idd, None if fixed else ptd, shape=(m, k), row_len=300 if fixed else -1, layout=layout)
+        calls = []
+
+        def get_block(r0, r1, _ptr_dtype=[torch.int32, torch.int64]):
+            calls.append((r0, r1))
+            lo, hi = int(ptr[r0]), int(ptr[r1])
+            pb = None if fixed else torch.tensor(ptr[r0:r1 + 1] - ptr[r0], device='cuda').to(_ptr_dtype[len(calls) % 2])
+            return (wd if homo else wd[lo:hi].clone()), idd[lo:hi].clone(), pb
+        blocked = ScatterPlan.build_from_blocks(get_block, 384, shape=(m, k), nnz=int(ptr[-1]), max_row_len=int(lens.max()),
+                                                homo=homo, layout=layout)
+        assert calls == [(0, 384), (384, 768), (768, 1000)] * 2
+        assert blocked.layout == whole.layout and blocked.slice_width == whole.slice_width
+        assert torch.equal(blocked.seg, whole.seg) and blocked.scale_exp == whole.scale_exp
+        M = PlannedMatrix(blocked, weight=None if not homo else w)
+        for p in (0.2, 1.1):
+            s = rng.random(m) < p
+            sv = torch.tensor(s, device='cuda')
+            ref_out = be.binary_csrmv(wd, idd, ptd, sv, shape=(m, k), transpose=True, workspace=whole)
+            got = be.BinaryArray(sv) @ M
+            assert torch.equal(got, ref_out)
+            assert torch.equal(be.BitPackedBinary(sv) @ M, ref_out)
+            ref = oracle.binary_csrmv(np.broadcast_to(w, idx.shape).astype(np.float64), idx, ptr, s, (m, k), True)
+            np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+        S = torch.tensor(rng.random((3, m)) < 0.3, device='cuda')
+        got = be.BinaryArray(S) @ M
+        for b in range(3):
+            assert torch.equal(got[b], be.binary_csrmv(wd, idd, ptd, S[b], shape=(m, k), transpose=True, workspace=whole))
+        assert isinstance(be.BinaryArray(s) @ M, np.ndarray)                  # numpy events in, numpy out
+        with pytest.raises(Exception):
+            be.BinaryArray(torch.zeros(m + 1, dtype=torch.bool, device='cuda')) @ M
