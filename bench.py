@@ -699,6 +699,12 @@ def run_scatter(args):
         local_events = [A.PackedSpikes(be.bitpack(local_spikes[b], 0).reshape(-1), n_local) for b in range(n_batch)]
         producer = 'words'
     ahead = use_dist and args.exchange == 'bits' and args.exchange_ahead
+    # the rank step with the host path cut to two C calls (brainevent_amd._dist.RankStep; BENCH_RANK_STEP=0: the operator surface,
+    # `exchange.gather_events(s) @ csr`, as in rounds 1-2 — same kernels, ~25 us more host time per step)
+    rank_step = None
+    if use_dist and native and not ahead and not mock and os.environ.get('BENCH_RANK_STEP', '1') != '0':
+        from brainevent_amd._dist import RankStep
+        rank_step = RankStep(exchange, csr)
     ticket = [exchange.post(local_events[0])] if ahead else None
 
     def mock_scatter(full_spikes):
@@ -716,6 +722,8 @@ def run_scatter(args):
             ev = exchange.wait_events(ticket[0])
             ticket[0] = nxt
             return ev @ csr
+        if rank_step is not None:
+            return rank_step(local_events[i % n_batch])
         if use_dist:
             return exchange.gather_events(local_events[i % n_batch]) @ csr
         return be.BinaryArray(s) @ csr
@@ -808,6 +816,7 @@ def run_scatter(args):
                        'parallelism': f'post-slice x{p_world}' + (f' + spike all-gather ({args.exchange}, '
                                                                   + ('be_exchange_* / RCCL' if native else 'torch.distributed')
                                                                   + (', posted one step ahead' if ahead else '')
+                                                                  + (', step issued as two C calls (RankStep)' if rank_step is not None else '')
                                                                   + (', local spikes arrive as packed words' if producer == 'words'
                                                                      else ', local spikes arrive as bytes and are packed per step')
                                                                   + ')' if use_dist else '')

@@ -405,6 +405,70 @@ class NativeSpikeExchange:
             pass
 
 
+class RankStep:
+    """One rank's time step — the exchange of the spikes, then ``events @ shard`` — with the host path cut to two C calls.
+
+    ``exchange.gather_events(local) @ shard`` walks the reference's operator surface on every step (event container, ``@``
+    dispatch, operand validation, workspace lookup): ≈ 40 µs of Python — more than the 35 µs of kernels a 1-of-8 post slice of
+    the 1M x 1M problem runs, so that step was host-bound.  This object resolves once what does not change from step to step
+    (function pointers, the shard's workspace and its constant arguments) and then issues ``be_exchange_allgather_bits`` and
+    the planned / binned step directly.  Same results bit for bit; anything it does not cover — a shard without a fixed-point
+    workspace, weights modified in place since the workspace was filled, an exchange that is not the library's own — takes
+    the general path."""
+
+    def __init__(self, exchange, shard):
+        import ctypes as ct
+        from . import _array as A, _csr as C
+        from ._lib import fn
+        self.exchange, self.shard = exchange, shard
+        self._fast = None
+        ws = shard._scatter_workspace() if hasattr(shard, '_scatter_workspace') else None
+        if (not isinstance(exchange, NativeSpikeExchange) or not isinstance(shard, C.CSR)
+                or not isinstance(ws, (C.ScatterPlan, C.BinnedScatter))):
+            return
+        vp, i64, ci = ct.c_void_p, ct.c_int64, ct.c_int
+        data = shard.data
+        self._gather = fn('be_exchange_allgather_bits', ci, [vp, vp, ci, vp, vp])
+        self._words = exchange._full_words
+        self._n_local = exchange.hi - exchange.lo
+        self._ws_obj, self._data = ws, data
+        m, k = ws.m, ws.k
+        self._out_shape, self._out_dtype, self._dev = (k,), data.dtype, data.device
+        if isinstance(ws, C.ScatterPlan):
+            parts = ws.default_parts()
+            wsp = ws.workspace(parts, 1)
+            f = fn('be_binary_csrmm_t_plan', ci, [vp, ci, ci, vp, vp, vp, ci, vp, i64, i64, i64, ci, ci, ci, ci, ci, ci, vp, i64, vp])
+            head = (A.ptr(data), int(ws.homo), A.wcode(data), A.ptr(ws.blob), A.ptr(ws.seg), A.ptr(self._words), A.BE_SPIKE_BITS)
+            tail = (m, k, 1, ws.slice_shift, ws.slice_width, ws.layout, ws.block_hint, parts)
+            self._keep = (wsp,)
+            self._fast = lambda out_ptr, st: f(*head, out_ptr, *tail, ws.scale_exp, A.ptr(wsp), wsp.numel(), st)
+            self._what = 'be_binary_csrmm_t_plan'
+        else:
+            indices, indptr = shard.indices, getattr(shard, 'indptr', None)
+            row_len = -1 if indptr is not None else int(indices.numel() // max(m, 1))
+            is64 = int(indptr is not None and indptr.dtype == torch.int64)
+            f = fn('be_binary_csrmv_t_binned', ci, [vp, ci, ci, vp, vp, ci, i64, vp, ci, vp, i64, i64, ci, i64, ci, vp, i64, vp])
+            head = (A.ptr(data), int(ws.homo), A.wcode(data), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(self._words),
+                    A.BE_SPIKE_BITS)
+            self._keep = (indices, indptr)
+            self._fast = lambda out_ptr, st: f(*head, out_ptr, m, k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws),
+                                               ws.ws.numel(), st)
+            self._what = 'be_binary_csrmv_t_binned'
+
+    def __call__(self, local_spikes):
+        from . import _array as A
+        from ._lib import check
+        if self._fast is None or self._ws_obj.is_stale(self._data) or self.shard.buffers.get('scatter_plan') is not self._ws_obj:
+            return self.exchange.gather_events(local_spikes) @ self.shard
+        sp, sd = _local_operand(local_spikes, self._n_local)
+        st = A.stream_ptr()
+        ex = self.exchange
+        check(self._gather(ex._h, A.ptr(sp), sd, A.ptr(self._words), st), 'be_exchange_allgather_bits')
+        out = torch.empty(self._out_shape, dtype=self._out_dtype, device=self._dev)
+        check(self._fast(A.ptr(out), st), self._what)
+        return out
+
+
 class DistributedScatter:
     """``spikes @ M`` with ``M`` post-sliced over the ranks of a process group.
 

@@ -155,3 +155,50 @@ def test_packed_producer_feeds_the_exchange_without_a_pack_launch(one_rank_group
         tex = D.SpikeExchange(n, packed=True, device=dev)
         np.testing.assert_array_equal(tex.gather(local).cpu().numpy(), s)
         np.testing.assert_allclose((tex.wait_events(tex.post(local)) @ csr).cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_rank_step_fast_path_equals_the_operator_surface():
+    """`RankStep(exchange, shard)(local)` issues the exchange and the planned / binned step as two C calls; it must give the bits of
+    `exchange.gather_events(local) @ shard`, follow an in-place weight update (it falls back, the general path refreshes the
+    workspace) and serve byte, float and packed local spikes."""
+    import brainevent_amd as be
+    from brainevent_amd import _dist as D, _array as A, _csr as C
+    rng = np.random.default_rng(17)
+    dev = torch.device('cuda', 0)
+    n_pre, n_post = 40_000, 300_000
+    lens = rng.integers(20, 60, n_pre)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, n_post, ptr[-1]).astype(np.int32)
+    w = rng.random(ptr[-1]).astype(np.float32)
+    ex = D.NativeSpikeExchange(n_pre, 1, 0, D.NativeSpikeExchange.unique_id(), device=dev)
+    for route in ('plan', 'binned'):
+        wd = torch.from_numpy(w.copy()).to(dev)
+        csr = be.CSR((wd, torch.from_numpy(idx).to(dev), torch.from_numpy(ptr).to(dev)), shape=(n_pre, n_post))
+        if route == 'plan':
+            csr.buffers['scatter_plan'] = C.ScatterPlan.build(csr.data, csr.indices, csr.indptr, shape=(n_pre, n_post))
+        else:
+            csr.buffers['scatter_plan'] = C.BinnedScatter(csr.data, n_pre, n_post, int(ptr[-1]), indices=csr.indices)
+        step = D.RankStep(ex, csr)
+        assert step._fast is not None
+        for kind in ('bool', 'float', 'words'):
+            s = rng.random(n_pre) < 0.05
+            if kind == 'bool':
+                local = torch.from_numpy(s).to(dev)
+            elif kind == 'float':
+                local = torch.from_numpy(np.where(s, 2.0, 0.0).astype(np.float32)).to(dev)
+            else:
+                local = A.PackedSpikes(be.bitpack(torch.from_numpy(s).to(dev), 0).reshape(-1), n_pre)
+            fast = step(local)
+            slow = ex.gather_events(local) @ csr
+            assert torch.equal(fast, slow), (route, kind)
+        csr.data.mul_(0.5)                                   # in-place update: the fast path notices and hands over
+        local = torch.from_numpy(s).to(dev)
+        got = step(local)
+        from oracle import oracle_np as O
+        np.testing.assert_allclose(got.cpu().numpy(), O.binary_csrmv(w * 0.5, idx, ptr, s, (n_pre, n_post), True), rtol=1e-5, atol=1e-5)
+        assert torch.equal(step(local), got)                 # ... and is fast again on the refreshed workspace, same bits
+    # anything else takes the general path
+    dense_like = be.CSR((torch.ones(1, device=dev), torch.from_numpy(idx[:100]).to(dev), torch.tensor([0, 100], dtype=torch.int32, device=dev)),
+                        shape=(1, n_post))
+    assert D.RankStep(ex, dense_like)._fast is None
+    ex.close()
