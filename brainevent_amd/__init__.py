@@ -12,14 +12,14 @@ from ._error import (BrainEventError, MathError, KernelError, KernelNotAvailable
 from . import config
 from ._registry import get_registry, get_primitives_by_tags, get_all_primitive_names
 from ._event import EventRepresentation, BinaryArray, BitPackedBinary, CompactBinary, bitpack
-from ._csr import (CSR, CSC, ScatterPlan, BinnedScatter, PlannedMatrix, binary_csrmv, binary_csrmm, binary_csrmv_indexed, binary_csrmm_indexed, binary_csrmv_indexed_p, binary_csrmm_indexed_p, binary_csrmv_p, binary_csrmm_p,
+from ._csr import (CSR, CSC, ScatterPlan, BinnedScatter, PlannedMatrix, Mirror, indexed_workspace, build_mirror_of, binary_csrmv, binary_csrmm, binary_csrmv_indexed, binary_csrmm_indexed, binary_csrmv_indexed_p, binary_csrmm_indexed_p, binary_csrmv_p, binary_csrmm_p,
                    binary_csrmv_p_call, binary_csrmm_p_call)
 from ._fcn import (FixedNumConn, FixedNumPerPre, FixedNumPerPost, binary_fcnmv, binary_fcnmm, binary_fcnmv_p,
                    binary_fcnmm_p, binary_fcnmv_p_call, binary_fcnmm_p_call)
 from ._dense import (Dense, binary_densemv, binary_densemm, binary_densemv_p, binary_densemm_p, binary_densemv_p_call,
                      binary_densemm_p_call)
 from ._convert import (csr_to_coo_index, coo_to_csc_index, coo2csr, csr_to_csc_index, csc_to_csr_index,
-                       fixed_conn_num_csr_indptr, fixed_conn_num_csc_structure, fixed_conn_num_to_csc)
+                       fixed_conn_num_csr_indptr, fixed_conn_num_csc_structure, fixed_conn_num_to_csc, CscBuilder)
 from ._graph import GraphedStep, capture_step
 from ._tuning import (ScatterTuning, DEFAULT_SCATTER_TUNING, get_scatter_tuning, save_scatter_tuning, apply_scatter_tuning,
                       tune_scatter_routes)

@@ -32,8 +32,9 @@ from ._lib import check, fn
 from ._misc import _as_indptr, _as_int32_indices, _check_compressed_structure
 from ._op import OpKernel
 
-__all__ = ['CSR', 'CSC', 'ScatterPlan', 'BinnedScatter', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p', 'binary_csrmm_p',
-           'binary_csrmv_p_call', 'binary_csrmm_p_call', 'binary_csrmv_indexed', 'binary_csrmm_indexed']
+__all__ = ['CSR', 'CSC', 'ScatterPlan', 'BinnedScatter', 'Mirror', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p',
+           'binary_csrmm_p', 'binary_csrmv_p_call', 'binary_csrmm_p_call', 'binary_csrmv_indexed', 'binary_csrmm_indexed',
+           'indexed_workspace', 'build_mirror_of']
 
 c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 
@@ -928,25 +929,129 @@ def binary_csrmm(data, indices, indptr, B, *, shape, workspace=None, transpose: 
     return A.to_result(res, as_np)
 
 
-def _indexed_weights(data, perm):
-    w = A.to_device(data)
+def _perm_of(perm, nse: int) -> torch.Tensor:
+    p = A.to_device(perm).reshape(-1)
+    if p.dtype not in (torch.int32, torch.int64):
+        p = p.to(torch.int64 if nse > np.iinfo(np.int32).max else torch.int32)
+    assert p.numel() == nse, f"perm must hold one entry per structural slot ({nse}); got {p.numel()}."
+    return p
+
+
+def _indexed_key(weights: torch.Tensor, perm: torch.Tensor):
+    return weights_stamp(weights), (perm.data_ptr(), perm._version, perm.numel())
+
+
+def indexed_workspace(data, indices, indptr, perm, *, shape, route: Optional[str] = None):
+    """Scatter workspace of the re-indexed structure ``(data[perm], indices, indptr)`` — the per-matrix workspace the
+    reference hands to ``binary_csrmv_indexed`` (``_csr/main.py:1647-1654``: ``_ensure_binary_workspace_and_get(self, "csc",
+    csc_indptr)``).  The permuted weights are gathered ONCE, here (``be_gather_by_perm``); a planned workspace embeds them
+    and the copy is dropped, a binned one keeps it.  The workspace remembers which ``(data, perm)`` it was derived from:
+    :func:`binary_csrmv_indexed` re-derives it when ``data`` was modified in place, and never gathers per call."""
+    from ._convert import gather_by_perm
+    w, idx, ptr_ = A.to_device(data).reshape(-1), A.to_device(indices).reshape(-1), A.to_device(indptr)
+    m, k = int(shape[0]), int(shape[1])
+    nse = int(idx.numel())
     if w.numel() == 1:
-        return w                      # homogeneous weight: perm is ignored, as in the reference
-    p = A.to_device(perm)
-    return w.reshape(-1)[p.long()]
+        return make_scatter_workspace(route or choose_scatter_route(nse, m, k, w), w, idx, ptr_, m, k, nse)
+    p = _perm_of(perm, nse)
+    wp = gather_by_perm(w, p)
+    ws = make_scatter_workspace(route or choose_scatter_route(nse, m, k, wp), wp, idx, ptr_, m, k, nse)
+    if ws is not None:
+        ws.indexed_key = _indexed_key(w, p)
+        ws.indexed_data = wp if isinstance(ws, BinnedScatter) else None
+    return ws
+
+
+def _fresh_indexed_workspace(ws, w, idx, ptr_, p):
+    """``ws`` (built by :func:`indexed_workspace`) brought up to date with the canonical weights ``w``; returns the weights
+    argument of the step (the permuted copy of a binned workspace, unused by a planned one)."""
+    from ._convert import gather_by_perm
+    key = _indexed_key(w, p)
+    if getattr(ws, 'indexed_key', None) != key:
+        wp = gather_by_perm(w, p, out=getattr(ws, 'indexed_data', None))
+        ws.refresh_weights(wp, idx, ptr_)
+        ws.indexed_key = key
+        if isinstance(ws, BinnedScatter):
+            ws.indexed_data = wp
+    return ws.indexed_data if isinstance(ws, BinnedScatter) else w
+
+
+def _csr_batched_indexed(weights, indices, indptr, perm, spikes_bm, sd, *, shape, transpose, workspace=None):
+    """``_csr_batched`` over ``weights[perm]`` without a per-call gather pass."""
+    if weights.numel() == 1 or perm is None:             # one shared weight ignores perm, as in the reference
+        return _csr_batched(weights, indices, indptr, spikes_bm, sd, shape=shape, transpose=transpose, workspace=workspace)
+    m, k = int(shape[0]), int(shape[1])
+    nb = int(spikes_bm.shape[0])
+    out_len = k if transpose else m
+    out = torch.empty((nb, out_len), dtype=weights.dtype, device=weights.device)
+    if out_len == 0 or nb == 0:
+        return out
+    if m == 0 or k == 0 or indices.numel() == 0:
+        return out.zero_()
+    p = _perm_of(perm, int(indices.numel()))
+    if transpose and isinstance(workspace, (ScatterPlan, BinnedScatter)):
+        assert workspace.m == m and workspace.k == k, "workspace was built for another matrix shape"
+        try:
+            w_step = _fresh_indexed_workspace(workspace, weights.reshape(-1), indices, indptr, p)
+        except MathError:
+            workspace = None          # the new weights do not qualify for fixed point: the perm-fused direct kernel
+        else:
+            if isinstance(workspace, ScatterPlan):
+                _plan_call(workspace, w_step, spikes_bm, sd, out)
+            else:
+                binned_batch(workspace, w_step, indices, indptr, -1, spikes_bm, sd, out)
+            return out
+    if transpose:
+        ws = A.workspace(fn('be_binary_csrmm_t_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])(m, k, nb, A.wcode(weights)))
+        name = 'be_binary_csrmm_t_indexed'
+    else:
+        ws = A.workspace(fn('be_binary_csrmm_nt_workspace_bytes', c_i64, [c_i64, c_i64, c_i64])(m, k, nb))
+        name = 'be_binary_csrmm_nt_indexed'
+    f = fn(name, c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_vp,
+                         c_i64, c_vp])
+    check(f(A.ptr(weights), 0, A.wcode(weights), A.ptr(indices), A.ptr(indptr), int(indptr.dtype == torch.int64), -1, A.ptr(p),
+            int(p.dtype == torch.int64), A.ptr(spikes_bm), sd, A.ptr(out), m, k, nb, A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    return out
+
+
+def _binary_csrmv_indexed_hip(data, indices, indptr, perm, vector, *, shape, transpose, workspace=None):
+    spikes, sd = A.spikes_to_device(vector)
+    return _csr_batched_indexed(data, indices, indptr, perm, spikes.reshape(1, -1), sd, shape=shape, transpose=transpose,
+                                workspace=workspace)[0]
+
+
+def _binary_csrmm_indexed_hip(data, indices, indptr, perm, B, *, shape, transpose, workspace=None):
+    Bt, sd = A.spikes_to_device(B)
+    return _csr_batched_indexed(data, indices, indptr, perm, Bt.T.contiguous(), sd, shape=shape, transpose=transpose,
+                                workspace=workspace).T
+
+
+def _indexed_operands(data, indices, indptr, context):
+    w, idx, ptr_ = A.to_device(data), A.to_device(indices), A.to_device(indptr)
+    if idx.dtype != torch.int32:
+        idx = _as_int32_indices(idx, None, context, check_values=False)
+    if ptr_.dtype not in (torch.int32, torch.int64):
+        ptr_ = _as_indptr(ptr_, idx.shape[0], 'auto', context)
+    assert indptr.ndim == 1 and indices.ndim == 1, "indices and indptr must be 1D."
+    assert w.dtype.is_floating_point, 'Weights must be a floating-point type.'
+    return (w.reshape(1) if w.ndim == 0 else w), idx, ptr_
 
 
 def binary_csrmv_indexed(data, indices, indptr, perm, v, *, shape, workspace=None, transpose: bool = False,
                          backend: Optional[str] = None):
     """``binary_csrmv(data[perm], indices, indptr, v, ...)``: the product over a *re-indexed* structure (typically the CSC
     view of a CSR matrix, ``perm`` from :func:`csr_to_csc_index`) with the weights left in their canonical order
-    (reference ``brainevent/_csr/binary_indexed.py:70-140``).  Here the gather ``data[perm]`` is one device pass per call
-    and the product runs the ordinary kernels; when the same structure is used every step, ``CSR.prepare(mirror=True)``
-    keeps a planned copy instead (event-driven, no per-call gather)."""
+    (reference ``brainevent/_csr/binary_indexed.py:70-140``; slot ``j`` reads ``data[perm[j]]``,
+    ``_csr/binary_indexed_csrmv_hybrid.cu:16-23``).  There is no per-call gather pass: ``workspace=None`` runs the perm-fused
+    direct kernels (``be_binary_csrmm_{t,nt}_indexed`` — only the weights of active rows are read); a workspace from
+    :func:`indexed_workspace` embeds (plan) or caches (binned) the permuted weights, keyed on ``(data, perm)``, and is
+    re-derived only when ``data`` was modified in place.  One shared weight ignores ``perm``."""
     as_np = A.wants_numpy(data, indices, indptr, perm, v)
-    res = binary_csrmv(_indexed_weights(data, perm), A.to_device(indices), A.to_device(indptr),
-                       v if isinstance(v, torch.Tensor) else A.to_device(np.asarray(v)), shape=shape, workspace=workspace,
-                       transpose=transpose, backend=backend)
+    w, idx, ptr_ = _indexed_operands(data, indices, indptr, 'binary_csrmv_indexed')
+    vec = v if isinstance(v, torch.Tensor) else np.asarray(v)
+    assert (shape[0] if transpose else shape[1]) == vec.shape[0], "Shape mismatch between the events and the structure."
+    res = binary_csrmv_indexed_p(w, idx, ptr_, None if w.numel() == 1 else A.to_device(perm), vec, shape=tuple(shape),
+                                 transpose=transpose, workspace=workspace, backend=backend)
     return A.to_result(res, as_np)
 
 
@@ -954,20 +1059,13 @@ def binary_csrmm_indexed(data, indices, indptr, perm, B, *, shape, workspace=Non
                          backend: Optional[str] = None):
     """Matrix-operand twin of :func:`binary_csrmv_indexed` (reference ``_csr/binary_indexed.py:615``)."""
     as_np = A.wants_numpy(data, indices, indptr, perm, B)
-    res = binary_csrmm(_indexed_weights(data, perm), A.to_device(indices), A.to_device(indptr),
-                       B if isinstance(B, torch.Tensor) else A.to_device(np.asarray(B)), shape=shape, workspace=workspace,
-                       transpose=transpose, backend=backend)
+    w, idx, ptr_ = _indexed_operands(data, indices, indptr, 'binary_csrmm_indexed')
+    Bm = B if isinstance(B, torch.Tensor) else np.asarray(B)
+    assert Bm.ndim == 2, "B must be 2D."
+    assert (shape[0] if transpose else shape[1]) == Bm.shape[0], "Shape mismatch between the events and the structure."
+    res = binary_csrmm_indexed_p(w, idx, ptr_, None if w.numel() == 1 else A.to_device(perm), Bm, shape=tuple(shape),
+                                 transpose=transpose, workspace=workspace, backend=backend)
     return A.to_result(res, as_np)
-
-
-def _binary_csrmv_indexed_hip(data, indices, indptr, perm, vector, *, shape, transpose, workspace=None):
-    return _binary_csrmv_hip(_indexed_weights(data, perm), indices, indptr, vector, shape=shape, transpose=transpose,
-                             workspace=workspace)
-
-
-def _binary_csrmm_indexed_hip(data, indices, indptr, perm, B, *, shape, transpose, workspace=None):
-    return _binary_csrmm_hip(_indexed_weights(data, perm), indices, indptr, B, shape=shape, transpose=transpose,
-                             workspace=workspace)
 
 
 #: operator objects of the indexed products (reference ``_csr/binary_indexed.py``: ``binary_csrmv_indexed_p`` / ``binary_csrmm_indexed_p``)
@@ -990,6 +1088,172 @@ PLAN_MIN_SEGMENT_HOMO = 10  # ... for one shared weight (the binned route moves 
 PLAN_MIN_SEGMENT_NO_BINNED = 8   # ... and from which it beats the direct route when the binned route does not apply
 # (the four constants above are the gfx950 defaults; brainevent_amd._tuning replaces them from the persisted per-architecture
 #  store when one exists — applied at the end of this module)
+
+
+#: the gather direction of a matrix with at least this many stored entries builds its mirror on first use (None: never
+#: automatically; ``prepare(mirror=True)`` / ``build_mirror()`` always do).  Below it the gather kernel streams the matrix
+#: in less time than a scatter step's launches take (2^24 entries x 8 B at ~6 TB/s = 22 us).
+AUTO_MIRROR_MIN_NNZ: Optional[int] = 1 << 24
+#: raw CSC arrays of a *planned* mirror are released above this many entries unless asked otherwise (the plan alone serves
+#: every step; a weight update then rebuilds the mirror instead of re-encoding it)
+MIRROR_KEEP_RAW_MAX_NNZ = 1 << 28
+#: the permutation (4 / 8 bytes per entry) stays with a mirror whose raw arrays stay, up to this many entries: a weight
+#: update is then one gather-copy (``be_gather_by_perm``) + the workspace's own refresh
+MIRROR_KEEP_PERM_MAX_NNZ = 1 << 28
+
+
+def _free_device_bytes() -> int:
+    """Bytes a new allocation can get: what the driver reports free plus what torch's allocator holds unused."""
+    free, _ = torch.cuda.mem_get_info()
+    return int(free + torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+
+
+def _mirror_bytes(nse: int, data: torch.Tensor, planned: bool) -> int:
+    """Upper estimate of what a mirror of ``nse`` entries holds while it is built (raw CSC arrays + the plan's blocks)."""
+    homo = data.numel() == 1
+    raw = nse * (4 + (0 if homo else data.element_size()))
+    return int(raw + (nse * (2.5 if homo else 7.5) if planned else 0))
+
+
+def auto_mirror_wanted(nse: int, m: int, k: int, data: torch.Tensor) -> bool:
+    """Whether the first gather-direction product of a matrix builds the mirror by itself: large enough for the event-driven
+    route to pay, and the mirror fits in half of the free device memory (otherwise: the gather kernel, and a warning)."""
+    if AUTO_MIRROR_MIN_NNZ is None or nse < AUTO_MIRROR_MIN_NNZ or m <= 0 or k <= 0:
+        return False
+    need = _mirror_bytes(nse, data, planned=True)
+    if need > 0.5 * _free_device_bytes():
+        import warnings
+        warnings.warn(f"brainevent_amd: the event-driven mirror of this matrix ({need / 2**30:.1f} GiB) does not fit beside it; "
+                      f"the gather direction streams the whole matrix on every call (build_mirror() forces the build).")
+        return False
+    return True
+
+
+class Mirror:
+    """The transposed structure of a CSR-like matrix ``A (m, k)`` with a scatter workspace of its own: ``A @ e`` is evaluated as
+    the scatter of the *active columns* (``shape = (k, m)``: mirror row ``j`` lists the rows ``i`` with ``A[i, j]`` stored).
+    ``data`` are the weights in mirror order (moved by the build, or the one shared weight); ``indices`` / ``indptr`` are
+    ``None`` when the raw arrays were released (a planned mirror needs only its plan for the step); ``perm`` (mirror slot ->
+    position in the source arrays) is kept for small mirrors so that a weight update is a gather-copy."""
+
+    def __init__(self, shape, data, indices, indptr, plan, perm, stamp, homo):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.data, self.indices, self.indptr = data, indices, indptr
+        self.plan, self.perm, self.stamp, self.homo = plan, perm, stamp, bool(homo)
+
+    @property
+    def released(self) -> bool:
+        return self.indices is None
+
+    def nbytes(self) -> int:
+        n = 0
+        for t in (self.data, self.indices, self.indptr, self.perm):
+            n += 0 if t is None else t.numel() * t.element_size()
+        if isinstance(self.plan, ScatterPlan):
+            n += self.plan.nbytes()
+        return n
+
+    def is_stale(self, src_data: torch.Tensor) -> bool:
+        return (not self.homo) and self.stamp != weights_stamp(src_data)
+
+    def refreshed(self, src_data, src_indices, src_indptr, row_len, m, k) -> 'Mirror':
+        """This mirror after the source weights changed in place: a gather-copy through ``perm`` into the same buffers + the
+        workspace's own refresh when the permutation was kept, a rebuild otherwise."""
+        if self.perm is None or self.released:
+            return build_mirror_of(src_data, src_indices, src_indptr, row_len, m, k, keep_raw=not self.released,
+                                   keep_perm=self.perm is not None)
+        from ._convert import gather_by_perm
+        gather_by_perm(src_data.reshape(-1), self.perm, out=self.data)      # in place: captured graphs keep the pointer
+        self.stamp = weights_stamp(src_data)
+        self.plan = fresh_scatter_workspace(self.plan, self.data, self.indices, self.indptr)
+        return self
+
+    def apply(self, v, backend=None):
+        """``A @ e(v)`` for an event vector ``v [k]`` or a matrix operand ``v [k, n]`` -> ``[m]`` / ``[m, n]``."""
+        if not self.released:
+            call = binary_csrmv_p_call if v.ndim == 1 else binary_csrmm_p_call
+            return call(self.data, self.indices, self.indptr, v, self.plan, shape=self.shape, transpose=True, backend=backend)[0]
+        sp, sd = A.spikes_to_device(v)
+        spikes_bm = sp.reshape(1, -1) if v.ndim == 1 else sp.T.contiguous()
+        out = torch.empty((int(spikes_bm.shape[0]), self.shape[1]), dtype=self.plan.weight_dtype, device=A.device())
+        _plan_call(self.plan, self.data, spikes_bm, sd, out)
+        return out[0] if v.ndim == 1 else out.T
+
+
+def build_mirror_of(data, indices, indptr, row_len, m: int, k: int, *, keep_raw: Optional[bool] = None,
+                    keep_perm: Optional[bool] = None) -> Mirror:
+    """The :class:`Mirror` of a CSR-like matrix (``indptr=None`` + ``row_len``: fixed-length rows).
+
+    Built by the library's column-block kernels (``_convert.CscBuilder``: one counting pass over the column ids, then the
+    blocks' fills), so there is no entry-count limit: C2 / C4 (1e10 entries) convert on the device.  The route of the mirror's
+    own scatter is chosen like any matrix's (``choose_scatter_route`` over ``k`` stored rows and ``m`` outputs):
+      * planned: when the raw CSC arrays fit beside the plan they are built whole, planned, and released above
+        ``MIRROR_KEEP_RAW_MAX_NNZ`` entries (``keep_raw``); when they do not fit, the plan is built from column blocks that
+        are resident one at a time (``ScatterPlan.build_from_blocks``) and the raw arrays never exist;
+      * binned / direct: the raw CSC arrays are the mirror.
+    ``keep_perm``: keep the permutation (default: up to ``MIRROR_KEEP_PERM_MAX_NNZ`` entries, only with the raw arrays)."""
+    from ._convert import CscBuilder
+    data = A.to_device(data)
+    flat = data.reshape(-1)
+    homo = flat.numel() == 1
+    nse = int(A.to_device(indices).numel())
+    b = CscBuilder(indptr, indices, shape=(m, k), row_len=row_len)
+    stamp = weights_stamp(data)
+    route = choose_scatter_route(nse, k, m, flat) if nse >= PLAN_MIN_NNZ else 'direct'
+    ptr_dtype = torch.int64 if nse > np.iinfo(np.int32).max else torch.int32
+    w1 = flat[:1] if homo else None
+
+    def whole(want_perm: bool):
+        rows, w, perm = b.block(0, k, data=None if homo else flat, perm=want_perm)
+        return (w1 if homo else w), rows, b.csc_indptr.to(ptr_dtype), perm
+
+    oom = getattr(torch, 'OutOfMemoryError', getattr(torch.cuda, 'OutOfMemoryError', RuntimeError))
+    if route == 'plan':
+        need = _mirror_bytes(nse, flat, planned=True) + 2 * nse        # (+ the sorted layouts' row order, 2 B per entry)
+        blocked = need > 0.85 * _free_device_bytes() and not (flat.dtype == torch.float64 and not homo)
+        if keep_raw is None:
+            keep_raw = nse <= MIRROR_KEEP_RAW_MAX_NNZ
+        if not blocked:
+            want_perm = bool(keep_raw and not homo and (keep_perm if keep_perm is not None else nse <= MIRROR_KEEP_PERM_MAX_NNZ))
+            try:
+                t_data, t_idx, t_ptr, perm = whole(want_perm)
+                try:
+                    plan = ScatterPlan.build(t_data, t_idx, t_ptr, shape=(k, m), keep_order=PLAN_KEEP_ORDER if keep_raw else False)
+                except MathError:        # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel
+                    return Mirror((k, m), t_data, t_idx, t_ptr, None, perm, stamp, homo)
+                if keep_raw:
+                    return Mirror((k, m), t_data, t_idx, t_ptr, plan, perm, stamp, homo)
+                plan.order = None
+                return Mirror((k, m), w1 if homo else torch.empty(0, dtype=flat.dtype, device=flat.device), None, None, plan, None,
+                              stamp, homo)
+            except oom:
+                t_data = t_idx = t_ptr = perm = plan = None
+                torch.cuda.empty_cache()
+        # column blocks resident one at a time: each at most a quarter of what is free beside the plan
+        budget = max(1 << 28, int(0.25 * (_free_device_bytes() - _mirror_bytes(nse, flat, planned=True) + _mirror_bytes(nse, flat, False))))
+        n_blocks = max(2, -(-_mirror_bytes(nse, flat, planned=False) // budget))
+        block_cols = -(-k // n_blocks)
+
+        def get_block(c0, c1):
+            rows, w, _ = b.block(c0, c1, data=None if homo else flat)
+            return (w1 if homo else w), rows, b.block_indptr(c0, c1)
+
+        try:
+            plan = ScatterPlan.build_from_blocks(get_block, block_cols, shape=(k, m), nnz=nse, max_row_len=b.max_col_count,
+                                                 homo=homo, weight_dtype=flat.dtype)
+            return Mirror((k, m), w1 if homo else torch.empty(0, dtype=flat.dtype, device=flat.device), None, None, plan, None,
+                          stamp, homo)
+        except MathError:
+            pass                      # fall through: the raw arrays + the direct kernel
+    want_perm = bool(not homo and (keep_perm if keep_perm is not None else nse <= MIRROR_KEEP_PERM_MAX_NNZ))
+    t_data, t_idx, t_ptr, perm = whole(want_perm)
+    ws = None
+    if route == 'binned' or (route == 'plan' and BinnedScatter.applicable(flat, m)):
+        try:
+            ws = BinnedScatter(t_data, k, m, nse, indices=t_idx)
+        except MathError:
+            ws = None
+    return Mirror((k, m), t_data, t_idx, t_ptr, ws, perm, stamp, homo)
 
 
 class CompressedSparseData(DataRepresentation):
@@ -1126,55 +1390,43 @@ class CompressedSparseData(DataRepresentation):
         return self
 
     # -- transposed mirror: makes the unfavourable (gather) direction event-driven -----------------------------
-    def build_mirror(self):
+    def build_mirror(self, *, keep_raw: Optional[bool] = None, keep_perm: Optional[bool] = None):
         """Materialise the transposed structure once (the reference's ``_weight_indices`` / ``csr_to_csc_index`` route,
-        ``brainevent/_csr/main.py:1321-1357``, ``brainevent/_misc.py:1516``) and plan it: afterwards ``CSR @ spk`` /
-        ``spk @ CSC`` scatter over the *active columns* instead of reading the whole matrix.  Costs a second copy of
-        the matrix; built with device sorts (one-off plumbing), so it is limited to matrices whose sort fits in HBM."""
+        ``brainevent/_csr/main.py:1321-1357``, ``brainevent/_misc.py:1516``) and give it a scatter workspace: afterwards
+        ``CSR @ spk`` / ``spk @ CSC`` scatter over the *active columns* instead of reading the whole matrix
+        (:class:`Mirror`, :func:`build_mirror_of`: the library's column-block count / scan / fill kernels, any entry count)."""
         if 'mirror' in self.buffers:
             return self.buffers['mirror']
         m, k = self._plan_shape()                      # stored structure: m rows, k secondary ids
-        nse = self.nse
-        if nse > (1 << 31):
-            raise MemoryError("build_mirror: the device sort of > 2^31 entries is not supported; "
-                              "the gather kernel is used instead")
-        from ._convert import csr_to_csc_index
-        t_indptr, t_indices, order = csr_to_csc_index(self.indptr, self.indices, shape=(m, k))   # secondary ids = rows here
-        t_indptr = t_indptr.to(self.indptr.dtype)
-        t_data = self.data if self.data.numel() == 1 else self.data[order.long()].contiguous()
-        mirror = {'data': t_data, 'indices': t_indices, 'indptr': t_indptr, 'shape': (k, m), 'plan': None,
-                  'order': None if self.data.numel() == 1 else order.to(torch.int32), 'stamp': weights_stamp(self.data)}
-        route = choose_scatter_route(nse, k, m, t_data)
-        try:
-            if route == 'plan':
-                mirror['plan'] = ScatterPlan.build(t_data, t_indices, t_indptr, shape=(k, m))
-            elif route == 'binned':
-                mirror['plan'] = BinnedScatter(t_data, k, m, nse, indices=t_indices)
-        except MathError:            # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel
-            mirror['plan'] = None
-        self.buffers['mirror'] = mirror
-        return mirror
+        self.buffers['mirror'] = build_mirror_of(self.data, self.indices, self.indptr, -1, m, k, keep_raw=keep_raw,
+                                                 keep_perm=keep_perm)
+        return self.buffers['mirror']
 
-    def _fresh_mirror(self):
-        """The mirror holds a permuted copy of the weights: re-gather it when ``self.data`` changed since."""
+    def _fresh_mirror(self, auto: bool = False):
+        """The cached mirror, brought up to date with ``self.data`` (it holds a permuted copy of the weights); with ``auto``
+        a matrix large enough for the event-driven route to pay gets its mirror on first use, like the reference builds
+        its CSC triple on the first ``CSR @ events`` (``_csr/main.py:1321-1357``)."""
         mr = self.buffers.get('mirror')
-        if mr is None or mr['order'] is None or mr['stamp'] == weights_stamp(self.data):
-            return mr
-        torch.index_select(self.data.reshape(-1), 0, mr['order'], out=mr['data'])      # in place: captured graphs keep the pointer
-        mr['stamp'] = weights_stamp(self.data)
-        mr['plan'] = fresh_scatter_workspace(mr['plan'], mr['data'], mr['indices'], mr['indptr'])
+        if mr is None:
+            if not auto or 'mirror' in self.buffers:      # (a cached None: the automatic build was refused once)
+                return None
+            m, k = self._plan_shape()
+            if not auto_mirror_wanted(self.nse, m, k, self.data):
+                self.buffers['mirror'] = None
+                return None
+            return self.build_mirror()
+        if mr.is_stale(self.data):
+            m, k = self._plan_shape()
+            mr = self.buffers['mirror'] = mr.refreshed(self.data, self.indices, self.indptr, -1, m, k)
         return mr
 
     def _gather_via_mirror(self, v):
-        """Event-driven evaluation of the gather direction through the mirror, or ``None`` if there is no mirror."""
-        mr = self._fresh_mirror()
+        """Event-driven evaluation of the gather direction through the mirror, or ``None`` if there is no mirror.  ``v``:
+        the event vector ``[k]`` or a matrix operand ``[k, n]`` (result ``[m, n]``)."""
+        mr = self._fresh_mirror(auto=True)
         if mr is None:
             return None
-        if v.ndim == 1:
-            return binary_csrmv_p_call(mr['data'], mr['indices'], mr['indptr'], v, mr['plan'], shape=mr['shape'],
-                                       transpose=True, backend=self.backend)[0]
-        return binary_csrmm_p_call(mr['data'], mr['indices'], mr['indptr'], v, mr['plan'], shape=mr['shape'],
-                                   transpose=True, backend=self.backend)[0]
+        return mr.apply(v, backend=self.backend)
 
     def _res(self, t):
         return A.to_result(t, self._numpy_result)
@@ -1270,8 +1522,9 @@ class CSC(CompressedSparseData):
             r = None
             if v.ndim == 1:
                 r = self._gather_via_mirror(v)
-            elif v.ndim == 2 and 'mirror' in self.buffers:
-                r = self._gather_via_mirror(v.T).T
+            elif v.ndim == 2:
+                r = self._gather_via_mirror(v.T)
+                r = None if r is None else r.T
             if r is not None:
                 pass
             elif v.ndim == 1:

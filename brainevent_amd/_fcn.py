@@ -11,8 +11,11 @@ Semantics for ``indices[n_rows, n_conn]`` and ``shape = (n_rows, n_cols)`` as th
 
 An ELL matrix is a CSR matrix with an implicit ``indptr`` (``row r = [r*n_conn, (r+1)*n_conn)``), so the
 kernels are the CSR ones (``csrc/be_csr.hip``) reached through the ``be_binary_fcn*`` symbols.  The
-unfavourable direction (``FixedNumPerPre @ spk``, ``spk @ FixedNumPerPost``) runs the gather kernel; the
-reference's CSC-mirror route for it (``_fcn/main.py:317-326``) is listed as "next" in SURVEY.md §8(f).
+unfavourable direction (``FixedNumPerPre @ spk``, ``spk @ FixedNumPerPost``) runs event-driven through the CSC
+mirror (reference ``_fcn/main.py:280-326``: ``_weight_indices`` + the perm-fused CSR kernel) — here a
+:class:`brainevent_amd._csr.Mirror` built by the column-block kernels with the weights moved along, on first use for
+matrices large enough for it to pay (``_csr.AUTO_MIRROR_MIN_NNZ``) or by ``prepare(mirror=True)`` — and the gather
+kernel otherwise.
 """
 import ctypes
 from typing import Dict, Optional
@@ -224,8 +227,11 @@ class FixedNumConn(DataRepresentation):
         self.buffers['scatter_plan'] = plan
         return plan
 
-    def prepare(self):
+    def prepare(self, mirror: bool = False):
+        """Build the scatter workspace now; ``mirror=True`` also the CSC mirror of the unfavourable direction."""
         self._scatter_workspace()
+        if mirror:
+            self.build_mirror()
         return self
 
     def refresh_weights(self):
@@ -233,17 +239,56 @@ class FixedNumConn(DataRepresentation):
         call; needed explicitly only between replays of a captured HIP graph)."""
         if 'scatter_plan' in self.buffers:
             self._scatter_workspace()
+        if self.buffers.get('mirror') is not None:
+            self._fresh_mirror()
         return self
+
+    # -- CSC mirror of the unfavourable direction (reference ``_weight_indices``, ``_fcn/main.py:280-300``) ---------------
+    def build_mirror(self, *, keep_raw: Optional[bool] = None, keep_perm: Optional[bool] = None):
+        """The transposed structure with the weights moved along and a scatter workspace of its own
+        (:func:`brainevent_amd._csr.build_mirror_of` over the implicit ``indptr``): afterwards ``FixedNumPerPre @ spk`` /
+        ``spk @ FixedNumPerPost`` scatter over the active entries of ``spk`` instead of reading every stored row."""
+        if self.buffers.get('mirror') is not None:
+            return self.buffers['mirror']
+        n_rows, n_cols = self._a_shape
+        self.buffers['mirror'] = _csr_mod.build_mirror_of(self.data, self.indices, None, self.num_conn, n_rows, n_cols,
+                                                          keep_raw=keep_raw, keep_perm=keep_perm)
+        return self.buffers['mirror']
+
+    def _fresh_mirror(self, auto: bool = False):
+        mr = self.buffers.get('mirror')
+        n_rows, n_cols = self._a_shape
+        if mr is None:
+            if not auto or 'mirror' in self.buffers:
+                return None
+            if not _csr_mod.auto_mirror_wanted(self.nse, n_rows, n_cols, self.data):
+                self.buffers['mirror'] = None
+                return None
+            return self.build_mirror()
+        if mr.is_stale(self.data):
+            mr = self.buffers['mirror'] = mr.refreshed(self.data, self.indices, None, self.num_conn, n_rows, n_cols)
+        return mr
 
     # -- dispatch (reference ``_binary_matvec`` / ``_binary_matmat`` / ``_dispatch``) -----------------
     def _binary_matvec(self, s, transpose_W: bool):
         ell_t = self._ell_transpose(transpose_W)
+        if not ell_t:
+            mr = self._fresh_mirror(auto=True)
+            if mr is not None:           # unfavourable direction, event-driven (reference ``_fcn/main.py:317-326``)
+                check_fixed_conn_num_shape(self.data, self.indices, s, self._a_shape, False)
+                return mr.apply(s, backend=self.backend)
         ws = self._scatter_workspace() if ell_t else None
         return binary_fcnmv_p_call(self.data, self.indices, s, shape=self._a_shape, transpose=ell_t,
                                    backend=self.backend, workspace=ws)[0]
 
     def _binary_matmat(self, matrix, transpose_W: bool):
         ell_t = self._ell_transpose(transpose_W)
+        if not ell_t:
+            mr = self._fresh_mirror(auto=True)
+            if mr is not None:
+                assert matrix.ndim == 2, "matrix must be 2D."
+                check_fixed_conn_num_shape(self.data, self.indices, matrix, self._a_shape, False)
+                return mr.apply(matrix, backend=self.backend)
         ws = self._scatter_workspace() if ell_t else None
         return binary_fcnmm_p_call(self.data, self.indices, matrix, shape=self._a_shape, transpose=ell_t,
                                    backend=self.backend, workspace=ws)[0]

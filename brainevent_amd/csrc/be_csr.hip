@@ -220,6 +220,52 @@ __global__ void __launch_bounds__(256) k_csrmv_t_direct(const W* __restrict__ we
   }
 }
 
+// the same walk over a RE-INDEXED structure: slot j carries weights[perm[j]] (reference: the perm-fused hybrid kernel,
+// brainevent/_csr/binary_indexed_csrmv_hybrid.cu:16-23) — only the weights of active rows are ever read, no data[perm] pass
+template <typename W, typename ACC, typename PT>
+__global__ void __launch_bounds__(256) k_csrmv_t_direct_indexed(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                                RowPtr rp, const PT* __restrict__ perm,
+                                                                const uint32_t* __restrict__ active,
+                                                                const uint32_t* __restrict__ n_active_p, ACC* __restrict__ out,
+                                                                int64_t active_stride, int64_t k) {
+  active += (int64_t)blockIdx.y * active_stride;
+  out += (int64_t)blockIdx.y * k;
+  const uint32_t n_active = n_active_p[blockIdx.y];
+  const int lane = lane_id();
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t a = wave; a < n_active; a += n_waves) {
+    const int64_t r = active[a];
+    const int64_t b = rp.at(r), e = rp.at(r + 1);
+    for (int64_t j = b + lane; j < e; j += 64) atomicAdd(out + indices[j], (ACC)WTraits<W>::load(weights, (int64_t)perm[j]));
+  }
+}
+
+// gather over a re-indexed structure: one wave per row, the bit-packed input vector read from L2, a weight is loaded only
+// behind its spike test (through perm the weights cannot be streamed with the indices anyway)
+template <typename W, typename PT>
+__global__ void __launch_bounds__(256) k_csrmv_nt_indexed(const W* __restrict__ weights, const int32_t* __restrict__ indices,
+                                                          RowPtr rp, const PT* __restrict__ perm,
+                                                          const uint32_t* __restrict__ bits, int64_t n_words,
+                                                          W* __restrict__ out, int64_t m) {
+  using ACC = typename WTraits<W>::acc;
+  bits += (int64_t)blockIdx.y * n_words;
+  out += (int64_t)blockIdx.y * m;
+  const int lane = lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < m; r += n_waves) {
+    const int64_t b = rp.at(r), e = rp.at(r + 1);
+    ACC acc = ACC(0);
+    for (int64_t j = b + lane; j < e; j += 64) {
+      const uint32_t c = (uint32_t)indices[j];
+      if ((bits[c >> 5] >> (c & 31)) & 1u) acc += (ACC)WTraits<W>::load(weights, (int64_t)perm[j]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) WTraits<W>::store(out, r, acc);
+  }
+}
+
 template <typename W>
 __global__ void __launch_bounds__(256) k_convert_from_f32(const float* __restrict__ src, W* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -993,7 +1039,7 @@ int pack_any(const void* spikes, int sd, int64_t n, int64_t nb, uint32_t* bits, 
 
 template <typename W, bool HOMO>
 int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const void* spikes, int sd, void* out,
-                   int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
+                   int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st, const void* perm = nullptr, int perm64 = 0) {
   unsigned char* wsb = static_cast<unsigned char*>(ws);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + counts_bytes(nb));
@@ -1008,6 +1054,16 @@ int csrmv_t_direct(const void* weights, const int32_t* indices, RowPtr rp, const
   if (m > 0 && k > 0 && nb > 0) {
     const int gx = nb >= 8 ? 512 : 2048;
     const int prof = be_prof_begin(st);
+    if (perm != nullptr && !HOMO) {       // (one shared weight: perm is irrelevant, as in the reference)
+      if (perm64)
+        hipLaunchKernelGGL((k_csrmv_t_direct_indexed<W, ACC, int64_t>), dim3(gx, (unsigned)nb), dim3(256), 0, st,
+                           static_cast<const W*>(weights), indices, rp, static_cast<const int64_t*>(perm), al.ids, al.count, acc,
+                           astride, k);
+      else
+        hipLaunchKernelGGL((k_csrmv_t_direct_indexed<W, ACC, int32_t>), dim3(gx, (unsigned)nb), dim3(256), 0, st,
+                           static_cast<const W*>(weights), indices, rp, static_cast<const int32_t*>(perm), al.ids, al.count, acc,
+                           astride, k);
+    } else
     hipLaunchKernelGGL((k_csrmv_t_direct<W, HOMO, ACC>), dim3(gx, (unsigned)nb), dim3(256), 0, st,
                        static_cast<const W*>(weights), indices, rp, al.ids, al.count, acc, astride, k);
     be_prof_end(prof, st);
@@ -1155,6 +1211,30 @@ int csrmv_nt(const void* weights, const int32_t* indices, RowPtr rp, int64_t nnz
 }
 
 
+template <typename W>
+int csrmv_nt_indexed(const void* weights, const int32_t* indices, RowPtr rp, const void* perm, int perm64, const void* spikes,
+                     int sd, void* out, int64_t m, int64_t k, int64_t nb, void* ws, hipStream_t st) {
+  const int64_t n_words = (k + 31) / 32;
+  const uint32_t* bits = static_cast<const uint32_t*>(spikes);
+  if (sd != BE_SPIKE_BITS) {
+    int rc = pack_any(spikes, sd, k, nb, static_cast<uint32_t*>(ws), n_words, st);
+    if (rc != BE_OK) return rc;
+    bits = static_cast<const uint32_t*>(ws);
+  }
+  if (m == 0 || nb == 0) return BE_OK;
+  const int grid = grid_for(m, 4, nb >= 8 ? 1024 : 4096);
+  const int prof = be_prof_begin(st);
+  if (perm64)
+    hipLaunchKernelGGL((k_csrmv_nt_indexed<W, int64_t>), dim3(grid, (unsigned)nb), dim3(256), 0, st, static_cast<const W*>(weights),
+                       indices, rp, static_cast<const int64_t*>(perm), bits, n_words, static_cast<W*>(out), m);
+  else
+    hipLaunchKernelGGL((k_csrmv_nt_indexed<W, int32_t>), dim3(grid, (unsigned)nb), dim3(256), 0, st, static_cast<const W*>(weights),
+                       indices, rp, static_cast<const int32_t*>(perm), bits, n_words, static_cast<W*>(out), m);
+  be_prof_end(prof, st);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
 }  // namespace
 
 // the single definition of the shared active-list resolver (declared in be_csr_shared.h)
@@ -1280,6 +1360,56 @@ int be_binary_csrmv_nt(const void* weights, int homo, int wdtype, const int32_t*
                        int64_t k, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   return be_binary_csrmm_nt(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, spikes, spike_dtype, out, m,
                             k, 1, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------- perm-fused ("indexed") products
+int be_binary_csrmm_t_indexed(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                              int indptr_is_i64, int64_t row_len, const void* perm, int perm_is_i64, const void* spikes,
+                              int spike_dtype, void* out, int64_t m, int64_t k, int64_t n_batch, void* workspace,
+                              int64_t workspace_bytes, be_stream_t stream) {
+  if (homo || perm == nullptr)
+    return be_binary_csrmm_t(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, spikes, spike_dtype, out, m, k,
+                             n_batch, workspace, workspace_bytes, stream);
+  BE_REQUIRE(m >= 0 && k >= 0 && m <= 0xffffffffll, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
+  BE_REQUIRE(k == 0 || n_batch == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
+  BE_REQUIRE(m == 0 || n_batch == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= direct_ws_bytes(m, k, wdtype, n_batch), BE_ERR_WORKSPACE,
+             "workspace too small");
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  BE_DISPATCH_W(wdtype, 0, return (csrmv_t_direct<W, HOMO>(weights, indices, rp, spikes, spike_dtype, out, m, k, n_batch, workspace, st, perm, perm_is_i64)));
+  return BE_OK;
+}
+
+int be_binary_csrmm_nt_indexed(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                               int indptr_is_i64, int64_t row_len, const void* perm, int perm_is_i64, const void* spikes,
+                               int spike_dtype, void* out, int64_t m, int64_t k, int64_t n_batch, void* workspace,
+                               int64_t workspace_bytes, be_stream_t stream) {
+  if (homo || perm == nullptr)
+    return be_binary_csrmm_nt(weights, homo, wdtype, indices, indptr, indptr_is_i64, row_len, spikes, spike_dtype, out, m, k,
+                              n_batch, workspace, workspace_bytes, stream);
+  BE_REQUIRE(m >= 0 && k >= 0, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "n_batch out of range");
+  BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
+  BE_REQUIRE(weights != nullptr, BE_ERR_INVALID, "weights is NULL");
+  BE_REQUIRE(m == 0 || n_batch == 0 || out != nullptr, BE_ERR_INVALID, "out is NULL");
+  BE_REQUIRE(k == 0 || n_batch == 0 || spikes != nullptr, BE_ERR_INVALID, "spikes is NULL");
+  BE_REQUIRE(spike_dtype == BE_SPIKE_BOOL || spike_dtype == BE_SPIKE_FLOAT || spike_dtype == BE_SPIKE_BITS, BE_ERR_INVALID,
+             "unknown spike dtype");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_binary_csrmm_nt_workspace_bytes(m, k, n_batch),
+             BE_ERR_WORKSPACE, "workspace too small");
+  RowPtr rp{indptr, indptr_is_i64, row_len};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (wdtype) {
+    case BE_F32: return csrmv_nt_indexed<float>(weights, indices, rp, perm, perm_is_i64, spikes, spike_dtype, out, m, k, n_batch, workspace, st);
+    case BE_F64: return csrmv_nt_indexed<double>(weights, indices, rp, perm, perm_is_i64, spikes, spike_dtype, out, m, k, n_batch, workspace, st);
+    case BE_F16: return csrmv_nt_indexed<__half>(weights, indices, rp, perm, perm_is_i64, spikes, spike_dtype, out, m, k, n_batch, workspace, st);
+    case BE_BF16: return csrmv_nt_indexed<__hip_bfloat16>(weights, indices, rp, perm, perm_is_i64, spikes, spike_dtype, out, m, k, n_batch, workspace, st);
+    default: be_set_error("unknown weight dtype"); return BE_ERR_INVALID;
+  }
 }
 
 // ---------------------------------------------------------------- per-variant symbols

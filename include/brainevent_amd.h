@@ -397,6 +397,56 @@ int be_binary_csrmm_nt(const void* weights, int homo, int wdtype, const int32_t*
                        be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * CSR -> CSC structure conversion in column blocks, on the device, 64-bit offsets (no entry-count limit).
+ * replaces: csr_to_csc_count / csr_to_csc_fill_block (brainevent/_csr/csr_to_csc.cu:137-199) and the host loop around them
+ *           (brainevent/_misc.py:1380-1513 `_csr_to_csc_index_gpu_column_block`; public entry brainevent/_misc.py:1516
+ *           `csr_to_csc_index(..., method="gpu_column_block")`), `fixed_conn_num_csc_structure` (brainevent/_misc.py:1255,
+ *           with indptr == NULL and row_len = n_conn).  It is what the mirror of the unfavourable direction is built from
+ *           (brainevent/_csr/main.py:1321-1357 `_weight_indices`, brainevent/_fcn/main.py:280-300).
+ *   1  be_csr_to_csc_count   : counts[n_cols] (int64) <- stored entries per column (one pass over `indices`)
+ *   2  be_csr_to_csc_indptr  : exclusive scan -> csc_indptr[n_cols + 1] (int64 or int32); *nnz_host (may be NULL; when given
+ *                              the call is SYNCHRONOUS; BE_ERR_RANGE if an int32 indptr cannot hold the total)
+ *   3  be_csr_to_csc_fill_block, once per column block [col_lo, col_hi), any partition of the columns: the block's entries go to
+ *        rows_out / weights_out / perm_out — arrays of the BLOCK (csc_indptr[col_hi] - csc_indptr[col_lo] elements), slot =
+ *        csc_indptr[column] - csc_indptr[col_lo] + position inside the column.  csc_indptr is the int64 form of step 2.
+ *        rows_out: the row of every entry (int32);  weights_out: its weight, moved along (weight_bytes = 2 / 4 / 8, or 0: no
+ *        weights — one shared weight);  perm_out: its position in the CSR arrays (int32 or int64; NULL = not wanted: 8 bytes
+ *        per entry is more than the structure itself).  cursor: scratch of (col_hi - col_lo) int64.
+ *   The order of the entries INSIDE a column is unspecified (slots are drawn from per-column cursors with atomics), exactly as
+ *   in the reference's kernel (csr_to_csc.cu:26-27); every product over the result is insensitive to it.
+ *   be_gather_by_perm: out[i] = src[perm[i]] for 2 / 4 / 8-byte elements — how a mirror that kept perm follows a weight update.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t be_csr_to_csc_scratch_bytes(int64_t n_cols);
+int be_csr_to_csc_count(const int32_t* indices, int64_t nnz, int64_t n_cols, int64_t* counts, be_stream_t stream);
+int be_csr_to_csc_indptr(const int64_t* counts, int64_t n_cols, void* csc_indptr_out, int out_is_i64, int64_t* nnz_host,
+                         void* scratch, int64_t scratch_bytes, be_stream_t stream);
+int be_csr_to_csc_fill_block(const int32_t* indices, const void* indptr, int indptr_is_i64, int64_t row_len, int64_t m,
+                             int64_t nnz, int64_t col_lo, int64_t col_hi, const int64_t* csc_indptr, int64_t* cursor,
+                             int32_t* rows_out, void* perm_out, int perm_is_i64, const void* weights, int weight_bytes,
+                             void* weights_out, be_stream_t stream);
+int be_gather_by_perm(const void* src, int elem_bytes, const void* perm, int perm_is_i64, int64_t n, void* out,
+                      be_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * perm-fused ("indexed") products: be_binary_csrmm_{t,nt} over a RE-INDEXED structure whose slot j carries
+ * weights[perm[j]] — the weights stay in their canonical order and only the weights of active rows (t) / of entries whose
+ * input fired (nt) are read; no data[perm] pass per call.
+ * replaces: binary_indexed_csrmv_hybrid / binary_indexed_csrmm_hybrid (brainevent/_csr/binary_indexed_csrmv_hybrid.cu:16-23,
+ *           brainevent/_csr/binary_indexed.py:70, :615).  perm: [nnz] int32 or int64; homo != 0 or perm == NULL: the plain
+ *           product (one shared weight ignores perm, as in the reference).  Workspaces as for be_binary_csrmm_{t,nt}.
+ * These are the preprocessing-free forms (global atomics / one wave per row).  A structure that is used every step is
+ * planned once from the permuted weights instead (be_scatter_plan_*), after which a step reads no weight array at all.
+ * ---------------------------------------------------------------------------------------------- */
+int be_binary_csrmm_t_indexed(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                              int indptr_is_i64, int64_t row_len, const void* perm, int perm_is_i64, const void* spikes_bm,
+                              int spike_dtype, void* out_bm, int64_t m, int64_t k, int64_t n_batch, void* workspace,
+                              int64_t workspace_bytes, be_stream_t stream);
+int be_binary_csrmm_nt_indexed(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
+                               int indptr_is_i64, int64_t row_len, const void* perm, int perm_is_i64, const void* spikes_bm,
+                               int spike_dtype, void* out_bm, int64_t m, int64_t k, int64_t n_batch, void* workspace,
+                               int64_t workspace_bytes, be_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * binary_densemv / binary_densemm  (BinaryArray @ ndarray)
  * replaces: binary_densemv_{transpose,no_transpose}_{f32..bf16}_{bool,float} (brainevent/_dense/binary_densemv.cu:52-149),
  *           binary_densemm_{transpose,no_transpose}_{…} (brainevent/_dense/binary_densemm.cu:50-162) and the cuBLAS

@@ -301,7 +301,7 @@ def test_mirror_makes_gather_direction_event_driven(be, oracle, monkeypatch):
     lens = rng.integers(100, 400, m)
     w, idx, ptr = rand_csr(rng, m, k, lens)
     csr = be.CSR((w, idx, ptr), shape=(m, k)).prepare(mirror=True)
-    assert isinstance(csr.buffers['mirror']['plan'], (C.ScatterPlan, C.BinnedScatter))
+    assert isinstance(csr.buffers['mirror'].plan, (C.ScatterPlan, C.BinnedScatter))
     v = spikes_of(rng, k, 0.05, 'bool')
     ref = oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), False)
     np.testing.assert_allclose(csr @ be.BinaryArray(v), ref, rtol=RTOL, atol=ATOL)
@@ -314,7 +314,7 @@ def test_mirror_makes_gather_direction_event_driven(be, oracle, monkeypatch):
                                rtol=RTOL, atol=ATOL)
     # the mirror is the exact transpose
     mr = csr.buffers['mirror']
-    d = np.zeros((k, m)); np.add.at(d, (np.repeat(np.arange(k), np.diff(mr['indptr'].cpu().numpy())), mr['indices'].cpu().numpy()), mr['data'].cpu().numpy())
+    d = np.zeros((k, m)); np.add.at(d, (np.repeat(np.arange(k), np.diff(mr.indptr.cpu().numpy())), mr.indices.cpu().numpy()), mr.data.cpu().numpy())
     np.testing.assert_allclose(d.T, csr.todense(), rtol=1e-6)
 
 

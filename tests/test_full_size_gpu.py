@@ -12,6 +12,10 @@ so each configuration is checked on the device through size-independent properti
   C5  batched BinaryArray [32, 65536] @ dense fp16 65536^2: MFMA path == vector path (batches of 4 rows) on the same
         inputs within fp16 rounding, a column sample within 2e-3 of a float64 product, row checksums vs float64.
 
+  f1  the unfavourable direction at the same sizes: `CSR @ spk` and `spk @ CSC` at C2 (1e10 entries, int64
+        indptr), `FixedNumPerPre @ spk` at C4, event-driven through the mirror == the gather kernel that streams the whole
+        matrix (exact for one shared weight, 1e-5 with per-entry weights), and within 2x of the scatter step's time.
+
 Set BE_FULL_SIZE=0 to skip them (development runs); the driver's `pytest -m gpu` runs them.
 """
 import os
@@ -69,6 +73,54 @@ def test_c2_csr_1m_by_1m_full_size(be, homo):
             del ref
         del pos, cols, out
     del csr, plan, w, idx, ptr
+    _free()
+
+
+def _step_ms(fn, n=20):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(n):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / n
+
+
+@pytest.mark.parametrize('fmt,homo', [('csr', False), ('csc', True)])
+def test_c2_gather_direction_is_event_driven_through_the_mirror(be, fmt, homo):
+    """`CSR @ spk` (per-entry weights) and `spk @ CSC` (one shared weight) at C2: the mirror is built by the column-block
+    kernels from 1e10 entries behind an int64 indptr, planned, and a step costs what a scatter step costs instead of a pass
+    over 80 / 40 GB (reference: brainevent/_csr/main.py:1647-1654, :2643-2650)."""
+    from brainevent_amd import _csr as C
+    from bench import gen_csr_on_device
+    n, n_conn = 1_000_000, 10_000
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    w, idx, ptr = gen_csr_on_device(n, n, n_conn, homo, 78, dev)
+    assert ptr.dtype == torch.int64 and idx.numel() == 10_000_000_000
+    M = (be.CSR if fmt == 'csr' else be.CSC)((w, idx, ptr), shape=(n, n), check_structure=False)
+    mr = M.build_mirror()
+    assert isinstance(mr.plan, C.ScatterPlan) and mr.released and mr.plan.nnz == idx.numel()
+    assert 'scatter_plan' not in M.buffers                    # the forward workspace is not needed for this direction
+    prod = (lambda e: M @ e) if fmt == 'csr' else (lambda e: e @ M)
+    for step in range(2):
+        spk = torch.rand(n, device=dev, generator=g) < 0.01
+        out = prod(be.BinaryArray(spk))
+        assert torch.equal(out, prod(be.BinaryArray(spk))), 'mirror route is not bitwise repeatable'
+        ref = be.binary_csrmv(w, idx, ptr, spk, shape=(n, n), transpose=False)        # the gather kernel: streams the matrix
+        if homo:
+            assert torch.equal(out, ref)
+        else:
+            rel = ((out.double() - ref.double()).abs() / ref.double().abs().clamp_min(1e-30)).max().item()
+            assert rel <= 1e-5, rel
+    ev = be.BinaryArray(spk)
+    ms = _step_ms(lambda: prod(ev))
+    ms_gather = _step_ms(lambda: be.binary_csrmv(w, idx, ptr, spk, shape=(n, n), transpose=False), n=3)
+    print(f"C2 {fmt} gather direction: mirror {ms:.3f} ms/step, gather kernel {ms_gather:.2f} ms/step")
+    assert ms <= 0.30, ms            # 2 x the 0.14 ms scatter step of the same matrix (the gather kernel: ~13 ms)
+    del M, mr, w, idx, ptr, out, ref
     _free()
 
 
@@ -150,6 +202,37 @@ def test_c4_fixed_num_10m_full_size_and_one_of_eight_shard(be, one_rank_group):
     assert rel <= 1e-5, rel
     assert torch.equal(out, be.BinaryArray(spk) @ conn), 'fixed-point route is not bitwise repeatable'
     del conn, w, idx, out, ref
+    _free()
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_c4_fixed_num_gather_direction_through_the_mirror(be, homo):
+    """`FixedNumPerPre @ spk` at C4 (N = 10M, K = 1000): the CSC mirror (ragged rows, ~1000 each) with the weights moved
+    along, binned route, == the gather kernel over the fixed-length rows (reference: brainevent/_fcn/main.py:317-326)."""
+    from brainevent_amd import _csr as C
+    from bench import gen_fixed_num_on_device
+    n, K = 10_000_000, 1000
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(12)
+    w, idx = gen_fixed_num_on_device(n, K, n, homo, dev, g)
+    conn = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False)
+    mr = conn.build_mirror()
+    assert mr.plan is not None and not mr.released and mr.indptr.dtype == torch.int64 and int(mr.indptr[-1]) == n * K
+    assert mr.perm is None                                    # 8 bytes per entry would be 80 GB: a weight update rebuilds
+    for step in range(2):
+        spk = torch.rand(n, device=dev, generator=g) < 0.01
+        out = conn @ be.BinaryArray(spk)
+        ref = be.binary_fcnmv(w, idx, spk, shape=(n, n), transpose=False)             # gather kernel over all 1e10 entries
+        if homo:
+            assert torch.equal(out, ref)
+        else:
+            rel = ((out.double() - ref.double()).abs() / ref.double().abs().clamp_min(1e-30)).max().item()
+            assert rel <= 1e-5, rel
+    ev = be.BinaryArray(spk)
+    ms = _step_ms(lambda: conn @ ev)
+    print(f"C4 FixedNumPerPre @ spk ({'homo' if homo else 'hetero'}): mirror {ms:.3f} ms/step")
+    assert ms <= (0.60 if homo else 1.30), ms     # 2 x the scatter step of the same matrix (0.27 / 0.63 ms)
+    del conn, mr, w, idx, out, ref
     _free()
 
 
