@@ -1165,7 +1165,11 @@ class Mirror:
         from ._convert import gather_by_perm
         gather_by_perm(src_data.reshape(-1), self.perm, out=self.data)      # in place: captured graphs keep the pointer
         self.stamp = weights_stamp(src_data)
-        self.plan = fresh_scatter_workspace(self.plan, self.data, self.indices, self.indptr)
+        if self.plan is not None:       # (the library wrote through the raw pointer: torch's version counter did not move)
+            try:
+                self.plan.refresh_weights(self.data, self.indices, self.indptr)
+            except MathError:
+                self.plan = None
         return self
 
     def apply(self, v, backend=None):
