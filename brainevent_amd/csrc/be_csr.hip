@@ -444,9 +444,13 @@ __global__ void __launch_bounds__(1024) k_csrmv_nt_wave(const W* __restrict__ we
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int src = (i + q) & 63;
-        gb[q] = (int64_t)(((uint64_t)__builtin_amdgcn_readlane(b_hi, src) << 32) | __builtin_amdgcn_readlane(b_lo, src));
+        // (readlane returns a signed int: without the uint32_t casts a low word >= 2^31 sign-extends over the high word — rows
+        //  starting beyond 2^31 entries read from a wild address; found at C2, 1e10 entries, in round 4)
+        gb[q] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b_hi, src) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b_lo, src));
         gl[q] = (i + q < nvalid)
-                    ? (int64_t)(((uint64_t)__builtin_amdgcn_readlane(l_hi, src) << 32) | __builtin_amdgcn_readlane(l_lo, src))
+                    ? (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)l_hi, src) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)l_lo, src))
                     : 0;
       }
 #pragma unroll
