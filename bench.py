@@ -69,7 +69,7 @@ def parse(argv=None):
     ap.add_argument('--width', type=int, default=0, help='columns per slice of the scatter plan (0 = balanced automatically)')
     ap.add_argument('--layout', choices=['u16', 'd8', 'h8'], default=None, help='block layout of the scatter plan (default: '
                     'the delta layout that applies)')
-    ap.add_argument('--workload', choices=['csr', 'jitc', 'fcn', 'dense'], default='csr',
+    ap.add_argument('--workload', choices=['csr', 'jitc', 'fcn', 'dense', 'gather_mirror'], default='csr',
                     help='csr = the headline C2 config; the others are the secondary BASELINE.json configs')
     ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
     ap.add_argument('--batch', type=int, default=32, help='dense: batch rows')
@@ -250,33 +250,49 @@ def cpu_baseline_dense(n, batch, fire, seconds):
 # timing
 # =====================================================================================================================
 def time_steps(step, steps, warmup, fence=None):
-    """W untimed steps, then exactly K steps bracketed by `fence` (synchronize [+ barrier]) on both sides.
-    Returns (wall seconds of the K steps, per-step dominant-kernel ms [HIP events inside the C ABI, on the op's stream],
-    per-step whole-step ms [HIP events recorded between the steps on the same stream], last output)."""
+    """W untimed steps, then exactly K steps bracketed by `fence` (synchronize [+ barrier]) on both sides — nothing else is
+    issued inside that region: no profiling events, no per-step markers.  `value` / `ms_per_step` come from it.
+    A SECOND pass over the same K steps (same inputs, outside the timed region) then carries the instrumentation: the
+    in-library HIP events around each op's dominant kernel (on the op's own stream) and one HIP event between steps on the
+    stream the calls are issued on (whole step: compaction + kernels + reduce).
+    Returns (wall seconds of the K timed steps, per-step dominant-kernel ms, per-step whole-step ms, last output)."""
     from brainevent_amd import _lib
     fence = fence or torch.cuda.synchronize
     out = None
     for i in range(warmup):
         out = step(i)
-    prof_enable = _lib.fn('be_profile_enable', ctypes.c_int, [ctypes.c_int])
-    prof_read = _lib.fn('be_profile_read', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
-    _lib.check(prof_enable(steps), 'be_profile_enable')
-    # torch.cuda.Event records on torch's current stream — the stream every be_* call of the step is issued on
-    # (brainevent_amd._array.stream_ptr), so consecutive events bracket the whole step (compaction + kernels + reduce)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     fence()
     t0 = time.perf_counter()
-    marks[0].record()
     for i in range(steps):
         out = step(warmup + i)
-        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    # ---- instrumented passes (not part of `value`): each kind of event in a pass of its own, so that neither perturbs the other
+    # (a marker per step costs ~7 us of step time on this runtime: 0.121 ms/step uninstrumented vs 0.128 with both kinds armed)
+    prof_enable = _lib.fn('be_profile_enable', ctypes.c_int, [ctypes.c_int])
+    prof_read = _lib.fn('be_profile_read', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
+    _lib.check(prof_enable(steps), 'be_profile_enable')      # (i) HIP events around each op's dominant kernel, inside the C ABI
+    for i in range(steps):
+        out = step(warmup + i)
+    fence()
     ms = (ctypes.c_float * steps)()
     n_rec = prof_read(ctypes.cast(ms, ctypes.c_void_p), steps)
     prof_enable(0)
     kern = np.array(ms[:n_rec], dtype=np.float64) if n_rec > 0 else None
-    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)], dtype=np.float64)
+    # (ii) whole steps: one HIP event every `blk` steps on the stream the calls are issued on (torch's current stream,
+    # brainevent_amd._array.stream_ptr); the per-step figure of a block is its duration / blk
+    blk = 10 if steps >= 40 else 1
+    n_blk = steps // blk
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_blk + 1)]
+    marks[0].record()
+    for i in range(n_blk * blk):
+        out = step(warmup + i)
+        if (i + 1) % blk == 0:
+            marks[(i + 1) // blk].record()
+    for i in range(n_blk * blk, steps):      # (the last output stays the one of step warmup + steps - 1)
+        out = step(warmup + i)
+    fence()
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) / blk for i in range(n_blk)], dtype=np.float64)
     return elapsed, kern, step_ms, out
 
 
@@ -439,6 +455,70 @@ def run_dense(args, dev, g):
     return line
 
 
+def run_gather_mirror(args, dev, g):
+    """SURVEY.md 8 f1 at the headline's size: `CSR @ BinaryArray` (the unfavourable direction of the C2 matrix) evaluated
+    event-driven through the mirror — built by the column-block kernels from the 1e10-entry CSR behind its int64 indptr —
+    next to the gather kernel that streams the whole matrix (reference: brainevent/_csr/main.py:1647-1654)."""
+    import brainevent_amd as be
+    from brainevent_amd import _csr as C
+    n = args.n
+    n_conn = max(1, int(n * args.conn))
+    w, idx, ptr = gen_csr_on_device(n, n, n_conn, args.homo, 1234, dev)
+    csr = be.CSR((w, idx, ptr), shape=(n, n), check_structure=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mr = csr.build_mirror()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    n_batch = 20
+    spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
+    upd_per_vec = torch.stack([mr.counts[spikes[b]].sum() for b in range(n_batch)]).cpu().numpy()
+    act = spikes.sum(dim=1).cpu().numpy()
+    step = lambda i: csr @ be.BinaryArray(spikes[i % n_batch])
+    elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup)
+    kern_ms = float(np.mean(kern)) if kern is not None else None
+    timed = [(args.warmup + i) % n_batch for i in range(args.steps)]
+    value = float(upd_per_vec[timed].sum()) / elapsed / 1e9
+    last = timed[-1]
+    # the checker: the gather kernel over all stored entries (one pass of the matrix per call)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ref = be.binary_csrmv(w, idx, ptr, spikes[last], shape=(n, n), transpose=False)
+    e0.record()
+    for _ in range(3):
+        ref = be.binary_csrmv(w, idx, ptr, spikes[last], shape=(n, n), transpose=False)
+    e1.record()
+    torch.cuda.synchronize()
+    gather_ms = e0.elapsed_time(e1) / 3
+    if args.homo:
+        err = float((out.double() - ref.double()).abs().max().item())
+    else:
+        err = float(((out.double() - ref.double()).abs() / ref.double().abs().clamp_min(1e-30)).max().item())
+    plan = mr.plan if isinstance(mr.plan, C.ScatterPlan) else None
+    bytes_per_upd = 4 if args.homo else 8
+    alg = bytes_per_upd * float(np.mean(upd_per_vec[timed])) + n + 4 * n + 16 * float(np.mean(act[timed]))
+    kname = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate') if plan else 'k_bin_stream'
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(
+            f"gather_mirror_{'homo' if args.homo else 'hetero'}_n{n}", {}).get('hbm_bytes_per_launch')
+    except Exception:
+        pass
+    roof = hbm_roofline(alg, kern_ms, traffic=traffic, kernel=kname + ' (over the mirror)')
+    cfg = {'workload': f"CSR f32 {'homo' if args.homo else 'hetero'} @ BinaryArray({args.fire:g} fire), {n} x {n}, {n_conn} synapses/row: the "
+                       f"gather direction through the event-driven mirror (route={type(mr.plan).__name__})",
+           'mirror_build_s': round(t_setup, 2), 'mirror_GB': round(mr.nbytes() / 1e9, 2), 'mirror_raw_arrays_released': mr.released,
+           'plan_slices': (f'{plan.n_slices} x {plan.slice_width} x {plan.default_parts()} parts' if plan else None),
+           'gather_kernel_ms_per_step': round(gather_ms, 3),
+           'speedup_over_gather_kernel': round(gather_ms / (elapsed / args.steps * 1e3), 1)}
+    line = _line('synaptic updates/sec (Geff/s), CSR @ BinaryArray through the CSC mirror', value, args, elapsed, 'f32', cfg, roof, kern,
+                 step_ms)
+    line['parity_check'] = {'what': 'last timed step vs the gather kernel over all stored entries (max '
+                                    + ('abs diff)' if args.homo else 'rel err)'), 'error': err,
+                            'ok': bool(err == 0.0 if args.homo else err <= 1e-5)}
+    del csr, mr, w, idx, ptr
+    return line
+
+
 def _line(metric, value, args, elapsed, dtype, cfg, roof, kern, step_ms):
     return {'metric': metric, 'value': round(value, 3), 'unit': 'Geff/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': args.scaling,
@@ -446,7 +526,7 @@ def _line(metric, value, args, elapsed, dtype, cfg, roof, kern, step_ms):
             'kernel_ms': _stats(kern), 'step_ms_hip_events': _stats(step_ms)}
 
 
-SECONDARY = {'jitc': run_jitc, 'fcn': run_fcn, 'dense': run_dense}
+SECONDARY = {'jitc': run_jitc, 'fcn': run_fcn, 'dense': run_dense, 'gather_mirror': run_gather_mirror}
 
 
 def secondary(args, workload=None):
@@ -460,13 +540,16 @@ def secondary(args, workload=None):
 def secondary_configs(base):
     """C3 / C4 / C5 of BASELINE.json after the headline (one GPU): compact entries for the `secondary` object."""
     out = {}
-    for name, wl, extra in (('C3', 'jitc', []), ('C4', 'fcn', []), ('C4_homo', 'fcn', ['--homo', '--cpu-seconds', '3']), ('C5', 'dense', [])):
+    for name, wl, extra in (('C2_gather_mirror', 'gather_mirror', ['--no-cpu']), ('C3', 'jitc', []), ('C4', 'fcn', []),
+                            ('C4_homo', 'fcn', ['--homo', '--cpu-seconds', '3']), ('C5', 'dense', [])):
         a = parse(['--workload', wl, '--steps', str(base.secondary_steps), '--warmup', '10'] + extra + (['--no-cpu'] if base.no_cpu else []))
         try:
             ln = secondary(a, wl)
             out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'kernel_ms',
                                             'step_ms_hip_events', 'roofline')}
             out[name]['config'] = ln['config']
+            if 'parity_check' in ln:
+                out[name]['parity_check'] = ln['parity_check']
             if 'cpu_baseline' in ln:
                 out[name]['cpu_baseline'] = ln['cpu_baseline']
         except Exception as e:       # a secondary leg must never sink the headline

@@ -34,7 +34,7 @@ from ._op import OpKernel
 
 __all__ = ['CSR', 'CSC', 'ScatterPlan', 'BinnedScatter', 'Mirror', 'binary_csrmv', 'binary_csrmm', 'binary_csrmv_p',
            'binary_csrmm_p', 'binary_csrmv_p_call', 'binary_csrmm_p_call', 'binary_csrmv_indexed', 'binary_csrmm_indexed',
-           'indexed_workspace', 'build_mirror_of']
+           'indexed_workspace', 'build_mirror_of', 'hybrid_task_capacity']
 
 c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 
@@ -554,6 +554,8 @@ def choose_scatter_route(nse: int, m: int, k: int, weights: torch.Tensor) -> str
     binned, us/step): homo 20: 51 / 87, 12: 87 / 119, 8: 169 / 148, 4: 845 / 198; hetero 16: 45 / 90, 10: 71 / 105,
     6: 158 / 162, 4: 306 / 236.  The planned layout pays per block (and 128 bytes of memory per block), the binned route per
     entry: they cross at 6-10 entries per block (round 1, before blocks were decoded by part of a wave each: 18)."""
+    from . import _tuning
+    _tuning.ensure_resolved()          # the persisted thresholds of the current device kind (first call only)
     if nse < PLAN_MIN_NNZ or m <= 0 or k <= 0:
         return 'direct'
     homo = weights.numel() == 1
@@ -640,6 +642,13 @@ class BinnedScatter:
             self._ws[int(n_batch)] = ws
         return ws
 
+    def check_status(self, clear: bool = True) -> None:
+        """Raise ``KernelExecutionError`` if a step on one of this object's workspaces gave up on its append protocol
+        (``be_binned_workspace_status``: such a step wrote NaN outputs instead of trapping the device).  Synchronises."""
+        f = fn('be_binned_workspace_status', c_int, [c_vp, c_int, c_vp])
+        for ws in self._ws.values():
+            check(f(A.ptr(ws), int(clear), A.stream_ptr()), 'be_binned_workspace_status')
+
     def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False) -> None:
         self.stamp = weights_stamp(weights)
         if not self.homo:
@@ -705,6 +714,105 @@ def _plan_call(plan: ScatterPlan, weights: torch.Tensor, spikes_bm: torch.Tensor
             plan.scale_exp, A.ptr(ws),
             ws.numel(),
             A.stream_ptr()), 'be_binary_csrmm_t_plan')
+
+
+# =====================================================================================================
+# the reference's task workspace, kept as a name-compatible handle
+# =====================================================================================================
+#: the two constants of the reference's hybrid scheduler that size its task queue (``brainevent/_csr/hybrid_config.py:77-88``)
+HYBRID_TPR_THRESHOLD, HYBRID_TASK_NNZ = 128, 4096
+
+
+def hybrid_task_capacity(indptr) -> int:
+    """Task-queue capacity of the reference's hybrid kernel for ``indptr`` (``brainevent/_csr/hybrid_config.py:298-324``):
+    ``sum over rows longer than 128 of ceil(len / 4096)``, same validation and errors.  Nothing here consumes the number — the
+    per-matrix workspace of this build is a :class:`ScatterPlan` / :class:`BinnedScatter` — it exists so that code written
+    against the reference (``_make_binary_csrmv_workspace(indptr)``, ``workspace.task_capacity``) keeps working."""
+    ptr = indptr.detach().to('cpu').numpy() if isinstance(indptr, torch.Tensor) else np.asarray(indptr)
+    ptr = ptr.astype(np.int64)
+    if ptr.ndim != 1:
+        raise ValueError(f"indptr must be one-dimensional, got shape={ptr.shape}.")
+    if ptr.size == 0:
+        raise ValueError("indptr must contain at least one element.")
+    row_lengths = np.diff(ptr)
+    if np.any(row_lengths < 0):
+        raise ValueError("CSR row lengths must be non-negative.")
+    chunks = np.where(row_lengths > HYBRID_TPR_THRESHOLD, (row_lengths + HYBRID_TASK_NNZ - 1) // HYBRID_TASK_NNZ, 0)
+    cap = int(chunks.sum())
+    if cap > np.iinfo(np.int32).max:
+        raise ValueError("binary task capacity exceeds int32 range.")
+    return cap
+
+
+class _BinaryCsrmvTaskWorkspace:
+    """The reference's explicit task workspace ``(task_capacity, task_begin, task_end, status)``
+    (``brainevent/_csr/binary.py:76-120``, ``_csr/main.py:58-88``) as a handle: the four fields exist with the reference's
+    shapes and dtypes (``task_begin`` / ``task_end``: ``(task_capacity,)`` in the dtype of ``indptr``; ``status``: int32
+    ``(2,)``) so that code which builds, passes, unpacks or checks one keeps working; the kernels of this build do not read
+    them.  Passed as ``workspace=`` to ``binary_csrmv`` / ``binary_csrmm`` it is where the matrix's real scatter workspace is
+    cached after the first call — keyed on the arrays it was derived from, so one handle reused for another matrix of the same
+    ``indptr`` (legal in the reference: its queue depends on ``indptr`` alone) re-derives it."""
+    __slots__ = ('task_capacity', 'task_begin', 'task_end', 'status', '_native', '_native_key')
+
+    def __init__(self, task_capacity, task_begin, task_end, status):
+        self.task_capacity, self.task_begin, self.task_end, self.status = int(task_capacity), task_begin, task_end, status
+        self._native, self._native_key = None, None
+
+    def __iter__(self):
+        return iter((self.task_capacity, self.task_begin, self.task_end, self.status))
+
+    def block_until_ready(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return self
+
+    def native(self, weights, indices, indptr, shape):
+        """The scatter workspace (plan / binned / None = direct) of ``(weights, indices, indptr)``, cached on this handle."""
+        key = (indices.data_ptr(), indptr.data_ptr(), int(indices.numel()), tuple(int(x) for x in shape), weights.numel() == 1,
+               weights.dtype)
+        if self._native_key != key:
+            m, k = int(shape[0]), int(shape[1])
+            nse = int(indices.numel())
+            self._native = make_scatter_workspace(choose_scatter_route(nse, m, k, weights), weights, indices, indptr, m, k, nse)
+            self._native_key = key
+        else:
+            self._native = fresh_scatter_workspace(self._native, weights, indices, indptr)
+        return self._native
+
+
+_BinaryTaskWorkspace = _BinaryCsrmvTaskWorkspace          # the name of the containers' twin (``_csr/main.py:58-88``)
+
+
+def _make_binary_csrmv_workspace(indptr) -> _BinaryCsrmvTaskWorkspace:
+    """Reference ``brainevent/_csr/binary.py:108-120``: an empty task workspace sized by :func:`hybrid_task_capacity`."""
+    cap = hybrid_task_capacity(indptr)
+    if isinstance(indptr, torch.Tensor):
+        mk = lambda n, dt: torch.empty(n, dtype=dt, device=indptr.device)
+        return _BinaryCsrmvTaskWorkspace(cap, mk(cap, indptr.dtype), mk(cap, indptr.dtype), mk(2, torch.int32))
+    dt = np.asarray(indptr).dtype
+    return _BinaryCsrmvTaskWorkspace(cap, np.empty(cap, dt), np.empty(cap, dt), np.empty(2, np.int32))
+
+
+def _make_binary_csrmv_benchmark_workspace(indptr) -> _BinaryCsrmvTaskWorkspace:
+    return _make_binary_csrmv_workspace(indptr)
+
+
+_make_binary_task_workspace = _make_binary_csrmv_workspace
+
+
+def _resolve_workspace(workspace, weights, indices, indptr, shape, transpose):
+    """``workspace=`` of the functional ops: a native workspace as it is; a reference-style task handle -> the native workspace
+    cached on it (scatter direction only: the gather direction needs none); anything else: the direct route."""
+    if isinstance(workspace, _BinaryCsrmvTaskWorkspace):
+        return workspace.native(weights, indices, indptr, shape) if transpose else None
+    return workspace
+
+
+def _task_operands(workspace):
+    """The three task arrays a reference ``*_p_call`` returns next to the result (``brainevent/_csr/binary.py:980-987``)."""
+    if isinstance(workspace, _BinaryCsrmvTaskWorkspace):
+        return workspace.task_begin, workspace.task_end, workspace.status
+    return None, None, None
 
 
 # =====================================================================================================
@@ -813,7 +921,9 @@ def _check_csr_structure_dtypes(indices, indptr):
 
 
 def binary_csrmv_p_call(weights, indices, indptr, vector, workspace=None, *, shape, transpose, backend=None):
-    """Validate, then dispatch (reference ``brainevent/_csr/binary.py:827-987``).  Returns a 1-tuple."""
+    """Validate, then dispatch (reference ``brainevent/_csr/binary.py:827-987``).  Returns the reference's 4-tuple
+    ``(y, task_begin, task_end, status)``: the three task arrays are those of a reference-style ``workspace`` handle
+    (:class:`_BinaryCsrmvTaskWorkspace`), else ``None`` — the kernels here do not produce them."""
     assert indptr.ndim == 1, "Indptr must be 1D."
     assert indices.ndim == 1, "Indices must be 1D."
     _check_csr_structure_dtypes(indices, indptr)
@@ -824,8 +934,9 @@ def binary_csrmv_p_call(weights, indices, indptr, vector, workspace=None, *, sha
     assert weights.dtype.is_floating_point, 'Weights must be a floating-point type.'
     if weights.ndim == 0:
         weights = weights.reshape(1)
-    return (binary_csrmv_p(weights, indices, indptr, vector, shape=shape, transpose=transpose, workspace=workspace,
-                           backend=backend),)
+    native = _resolve_workspace(workspace, weights, indices, indptr, shape, transpose)
+    return (binary_csrmv_p(weights, indices, indptr, vector, shape=shape, transpose=transpose, workspace=native,
+                           backend=backend),) + _task_operands(workspace)
 
 
 binary_csrmv_p.def_call(binary_csrmv_p_call)
@@ -905,8 +1016,9 @@ def binary_csrmm_p_call(weights, indices, indptr, B, workspace=None, *, shape, t
     assert weights.dtype.is_floating_point, 'Weights must be a floating-point type.'
     if weights.ndim == 0:
         weights = weights.reshape(1)
-    return (binary_csrmm_p(weights, indices, indptr, B, shape=shape, transpose=transpose, workspace=workspace,
-                           backend=backend),)
+    native = _resolve_workspace(workspace, weights, indices, indptr, shape, transpose)
+    return (binary_csrmm_p(weights, indices, indptr, B, shape=shape, transpose=transpose, workspace=native,
+                           backend=backend),) + _task_operands(workspace)
 
 
 binary_csrmm_p.def_call(binary_csrmm_p_call)
@@ -1136,10 +1248,11 @@ class Mirror:
     ``None`` when the raw arrays were released (a planned mirror needs only its plan for the step); ``perm`` (mirror slot ->
     position in the source arrays) is kept for small mirrors so that a weight update is a gather-copy."""
 
-    def __init__(self, shape, data, indices, indptr, plan, perm, stamp, homo):
+    def __init__(self, shape, data, indices, indptr, plan, perm, stamp, homo, counts=None):
         self.shape = (int(shape[0]), int(shape[1]))
         self.data, self.indices, self.indptr = data, indices, indptr
         self.plan, self.perm, self.stamp, self.homo = plan, perm, stamp, bool(homo)
+        self.counts = counts            # stored entries per mirror row (int64 [shape[0]]): the work of an event on that row
 
     @property
     def released(self) -> bool:
@@ -1224,12 +1337,12 @@ def build_mirror_of(data, indices, indptr, row_len, m: int, k: int, *, keep_raw:
                 try:
                     plan = ScatterPlan.build(t_data, t_idx, t_ptr, shape=(k, m), keep_order=PLAN_KEEP_ORDER if keep_raw else False)
                 except MathError:        # weights the fixed-point sums cannot resolve: the mirror runs the direct kernel
-                    return Mirror((k, m), t_data, t_idx, t_ptr, None, perm, stamp, homo)
+                    return Mirror((k, m), t_data, t_idx, t_ptr, None, perm, stamp, homo, b.counts)
                 if keep_raw:
-                    return Mirror((k, m), t_data, t_idx, t_ptr, plan, perm, stamp, homo)
+                    return Mirror((k, m), t_data, t_idx, t_ptr, plan, perm, stamp, homo, b.counts)
                 plan.order = None
                 return Mirror((k, m), w1 if homo else torch.empty(0, dtype=flat.dtype, device=flat.device), None, None, plan, None,
-                              stamp, homo)
+                              stamp, homo, b.counts)
             except oom:
                 t_data = t_idx = t_ptr = perm = plan = None
                 torch.cuda.empty_cache()
@@ -1246,7 +1359,7 @@ def build_mirror_of(data, indices, indptr, row_len, m: int, k: int, *, keep_raw:
             plan = ScatterPlan.build_from_blocks(get_block, block_cols, shape=(k, m), nnz=nse, max_row_len=b.max_col_count,
                                                  homo=homo, weight_dtype=flat.dtype)
             return Mirror((k, m), w1 if homo else torch.empty(0, dtype=flat.dtype, device=flat.device), None, None, plan, None,
-                          stamp, homo)
+                          stamp, homo, b.counts)
         except MathError:
             pass                      # fall through: the raw arrays + the direct kernel
     want_perm = bool(not homo and (keep_perm if keep_perm is not None else nse <= MIRROR_KEEP_PERM_MAX_NNZ))
@@ -1257,7 +1370,7 @@ def build_mirror_of(data, indices, indptr, row_len, m: int, k: int, *, keep_raw:
             ws = BinnedScatter(t_data, k, m, nse, indices=t_idx)
         except MathError:
             ws = None
-    return Mirror((k, m), t_data, t_idx, t_ptr, ws, perm, stamp, homo)
+    return Mirror((k, m), t_data, t_idx, t_ptr, ws, perm, stamp, homo, b.counts)
 
 
 class CompressedSparseData(DataRepresentation):
@@ -1564,9 +1677,11 @@ class CSC(CompressedSparseData):
 
 
 def _apply_persisted_tuning():
+    """At import: the environment override or the defaults — never the per-device store, whose lookup would initialise the GPU
+    (``_tuning.ensure_resolved`` does that at the first route choice, once the caller has picked a device)."""
     try:
         from . import _tuning
-        _tuning.apply_scatter_tuning()
+        _tuning.apply_scatter_tuning(_tuning.get_scatter_tuning(resolve_device=False), _resolved_key=('import', None))
     except Exception as e:          # noqa: BLE001 - a bad override must not make the package unimportable: say so, keep the defaults
         import warnings
         warnings.warn(f"brainevent_amd: persisted scatter tuning ignored ({e!r}); using the built-in defaults.")

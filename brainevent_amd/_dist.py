@@ -432,6 +432,7 @@ class RankStep:
         self._words = exchange._full_words
         self._n_local = exchange.hi - exchange.lo
         self._ws_obj, self._data = ws, data
+        self._arrays = (shard.indices, getattr(shard, 'indptr', None))
         m, k = ws.m, ws.k
         self._out_shape, self._out_dtype, self._dev = (k,), data.dtype, data.device
         if isinstance(ws, C.ScatterPlan):
@@ -458,8 +459,13 @@ class RankStep:
     def __call__(self, local_spikes):
         from . import _array as A
         from ._lib import check
-        if self._fast is None or self._ws_obj.is_stale(self._data) or self.shard.buffers.get('scatter_plan') is not self._ws_obj:
-            return self.exchange.gather_events(local_spikes) @ self.shard
+        shard = self.shard
+        # the fast path holds raw pointers of the arrays it was resolved from: it is taken only while the shard still IS those
+        # arrays (a caller may rebind shard.data / indices / indptr to new tensors instead of updating them in place) and its
+        # workspace is the same object and up to date with the weights
+        if (self._fast is None or shard.data is not self._data or any(a is not b for a, b in zip(self._arrays, (shard.indices, getattr(shard, 'indptr', None))))
+                or self._ws_obj.is_stale(self._data) or shard.buffers.get('scatter_plan') is not self._ws_obj):
+            return self.exchange.gather_events(local_spikes) @ shard
         sp, sd = _local_operand(local_spikes, self._n_local)
         st = A.stream_ptr()
         ex = self.exchange

@@ -11,14 +11,13 @@ the current device kind (``gcnArchName`` without feature flags, e.g. ``gfx950``)
 (``BRAINEVENT_AMD_TUNING_FILE`` or ``~/.cache/brainevent_amd/scatter_tuning.json``), then the defaults.  A corrupt or partial
 file never breaks anything: the defaults are used."""
 import dataclasses
-import functools
 import json
 import os
 from pathlib import Path
 from typing import Mapping, Optional, Sequence
 
 __all__ = ['ScatterTuning', 'DEFAULT_SCATTER_TUNING', 'get_scatter_tuning', 'save_scatter_tuning', 'apply_scatter_tuning',
-           'current_device_kind', 'tune_scatter_routes']
+           'current_device_kind', 'tune_scatter_routes', 'ensure_resolved']
 
 _ENV_OVERRIDE = 'BRAINEVENT_AMD_TUNING'
 _ENV_FILE = 'BRAINEVENT_AMD_TUNING_FILE'
@@ -78,21 +77,86 @@ def current_device_kind() -> Optional[str]:
         return None
 
 
-@functools.lru_cache(maxsize=None)
-def get_scatter_tuning() -> ScatterTuning:
-    """The tuning of this process (memoised; never measures anything; safe without a GPU)."""
+_warned = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg)
+
+
+def _env_override() -> Optional[ScatterTuning]:
+    """The tuning of ``BRAINEVENT_AMD_TUNING``, ``None`` when unset.  A malformed value is reported once and ignored (the
+    defaults): a bad override must never break the kernels — neither at import nor at any later resolution."""
     raw = os.environ.get(_ENV_OVERRIDE)
-    if raw:
+    if not raw:
+        return None
+    try:
         return _from_mapping(json.loads(raw))
+    except (ValueError, TypeError, KeyError, AttributeError) as e:
+        _warn_once('env:' + raw, f"brainevent_amd: {_ENV_OVERRIDE} ignored ({e!r}); using the built-in defaults.")
+        return DEFAULT_SCATTER_TUNING
+
+
+_resolved = {}          # device kind (or None) -> ScatterTuning
+
+
+def get_scatter_tuning(resolve_device: bool = True) -> ScatterTuning:
+    """The tuning of this process for the current device kind (memoised per kind; never measures anything).
+
+    ``resolve_device=False`` is what the package import uses: the environment override or the defaults, WITHOUT asking the
+    runtime which device is current — that query initialises the GPU (every torchrun rank importing before ``set_device``
+    would open a context on GPU 0, fork-after-import breaks, an exec-before-GPU re-launch pattern stops being one).  The
+    per-architecture entry of the store is resolved at the first route choice / binned workspace instead
+    (:func:`ensure_resolved`), after the caller has picked its device."""
+    env = _env_override()
+    if env is not None:
+        return env
+    if not resolve_device:
+        return DEFAULT_SCATTER_TUNING
     path = _store_path()
-    if path.exists():
+    if not path.exists():
+        return DEFAULT_SCATTER_TUNING
+    kind = current_device_kind()
+    key = (str(path), kind)
+    if key not in _resolved:
+        t = DEFAULT_SCATTER_TUNING
         try:
-            entry = json.loads(path.read_text(encoding='utf-8')).get(current_device_kind())
+            entry = json.loads(path.read_text(encoding='utf-8')).get(kind)
             if entry is not None:
-                return _from_mapping(entry)
+                t = _from_mapping(entry)
         except (OSError, ValueError, KeyError, TypeError, AttributeError):
             pass               # a corrupt / partial file must never break the kernels: defaults
-    return DEFAULT_SCATTER_TUNING
+        _resolved[key] = t
+    return _resolved[key]
+
+
+def _cache_clear() -> None:
+    _resolved.clear()
+    _applied[0] = None
+
+
+get_scatter_tuning.cache_clear = _cache_clear       # (the name the memoised function of rounds 1-3 offered)
+
+_applied = [None]        # (store path, device kind) whose entry the module constants currently reflect
+
+
+def ensure_resolved() -> None:
+    """Called where a device is certainly in use (route choice, binned workspace): resolve the store entry of the CURRENT
+    device kind once and apply it; later calls are a dictionary lookup.  Without a store, or with an environment override (applied
+    at import already), nothing touches the runtime."""
+    if os.environ.get(_ENV_OVERRIDE):
+        return
+    path = _store_path()
+    if not path.exists():
+        return
+    if _applied[0] == 'explicit':      # the caller applied a tuning of its own (apply_scatter_tuning): that stands
+        return
+    key = (str(path), current_device_kind())
+    if _applied[0] != key:
+        apply_scatter_tuning(get_scatter_tuning(), _resolved_key=key)
 
 
 def save_scatter_tuning(tuning: ScatterTuning, device_kind: Optional[str] = None,
@@ -129,6 +193,10 @@ _pushed = [None]
 
 def push_to_library(tuning: Optional[ScatterTuning] = None) -> None:
     """Hand the binned route's task size to the loaded library (``be_binned_set_tuning``); a no-op when nothing changed."""
+    if tuning is None:
+        ensure_resolved()
+        from . import _csr as C
+        tuning = getattr(C, '_TUNING', None)
     t = tuning or get_scatter_tuning()
     key = (t.binned_task_groups, t.binned_min_tasks)
     if _pushed[0] == key:
@@ -139,11 +207,13 @@ def push_to_library(tuning: Optional[ScatterTuning] = None) -> None:
     _pushed[0] = key
 
 
-def apply_scatter_tuning(tuning: Optional[ScatterTuning] = None) -> ScatterTuning:
+def apply_scatter_tuning(tuning: Optional[ScatterTuning] = None, _resolved_key=None) -> ScatterTuning:
     """Make ``tuning`` (default: the resolved one) what ``choose_scatter_route`` uses: the module constants of
-    ``brainevent_amd._csr`` — and, once the library is loaded, the task size of the binned route."""
+    ``brainevent_amd._csr`` — and, once the library is loaded, the task size of the binned route.  A tuning applied by the caller
+    stands until ``get_scatter_tuning.cache_clear()``; the lazy per-device resolution does not replace it."""
     from . import _csr as C
     t = (tuning or get_scatter_tuning()).validated()
+    _applied[0] = _resolved_key if _resolved_key is not None else ('explicit' if tuning is not None else _applied[0])
     C.PLAN_MIN_NNZ = t.plan_min_nnz
     C.PLAN_MIN_SEGMENT = t.plan_min_segment
     C.PLAN_MIN_SEGMENT_HOMO = t.plan_min_segment_homo

@@ -46,7 +46,13 @@ constexpr int kStreamGrid = 256;     // workgroups of pass B = regions per bin (
 constexpr int kStreamWaves = 16;
 constexpr int kRing = BE_RING, kRingLog = BE_RING == 2 ? 1 : 0;
 static_assert(BE_RING == 1 || BE_RING == 2, "ring of one or two blocks per bin");
-constexpr uint32_t kSpinLimit = 1u << 14;   // a lane that cannot get a slot for this long adds its entry with a global atomic
+// A lane whose ring slot is not freed within kWaitLimitTicks of the constant 100 MHz clock (20 ms — four orders of magnitude
+// above a flush; delayed co-resident waves, a profiler or several processes sharing the card stay far inside it) gives up:
+// it raises the workspace's sticky protocol flag and drops its pending entries.  Pass C then writes NaN into every output of
+// the step and be_binned_workspace_status() reports BE_ERR_HIP with the cause — an error code, never a trap: a device-side
+// abort would poison the HIP context of the whole process (the header promises codes).  Never observed.
+constexpr uint64_t kWaitLimitTicks = 2000000ull;
+constexpr int kBinErrWord = 16;             // word of the workspace head that holds the sticky flag (word 0: the spike counter)
 
 template <bool HOMO, int CAP> struct BinBlock {
   static constexpr int bytes = CAP * (HOMO ? 2 : 6);
@@ -133,6 +139,7 @@ struct StreamLds {
   uint32_t* ovf;    // [n_bins]           != 0: some entries of the bin went through global atomics
   uint32_t* dummy;  // [128]              where lanes without a writable entry put their two stores
   uint32_t* buf;    // [2 * n_bins][B::dwords]
+  uint32_t* err;    // GLOBAL: the workspace's sticky protocol flag (kBinErrWord)
 };
 // LDS words of pass B in front of the per-bin state: per wave a task table (64 row starts as int64, 66 prefix sums of
 // the rows' 4-entry groups, 64 row lengths), a flush list of 64 (ring slot, block number) items, the task ticket, the
@@ -246,6 +253,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
 #endif
   __builtin_amdgcn_sched_barrier(0);
   uint32_t spins = 0;
+  uint64_t t_wait = 0;
   for (;;) {
     uint32_t g[NE], slotid[NE];
 #pragma unroll
@@ -325,7 +333,13 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
                                   lane);
     }
     if (__ballot(pend != 0) == 0) break;
-    if (++spins > kSpinLimit) __builtin_trap();      // never seen: a protocol error ends in a launch failure, not in a hung device
+    if ((++spins & 63u) == 0u) {                     // (wave-uniform) look at the clock every 64 rounds
+      if (spins == 64u) t_wait = wall_clock64();
+      else if (wall_clock64() - t_wait > kWaitLimitTicks) {
+        if (pend != 0) atomicOr(S.err, 1u);          // sticky: pass C poisons the outputs, be_binned_workspace_status names it
+        pend = 0;
+      }
+    }
     __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -341,7 +355,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
                                                      uint32_t* __restrict__ regions, uint32_t* __restrict__ dir,
                                                      float* __restrict__ out, DivU32 fixdiv,
                                                      const uint32_t* __restrict__ row_masks, int n_bins_b, int64_t k,
-                                                     uint32_t min_tasks, uint32_t task_groups, int64_t m_rows) {
+                                                     uint32_t min_tasks, uint32_t task_groups, int64_t m_rows,
+                                                     uint32_t* __restrict__ err_flag) {
   // row_masks != NULL: a batch.  `active` lists the rows with a spike in ANY of the (<= 32) batch rows of this pass and
   // row_masks[j] says in which; the bins are virtual — batch row b's bin i is n_bins_b * b + i of n_bins — and an entry is
   // appended once per batch row that has its row active (the rows are read once for the whole batch).
@@ -360,7 +375,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   S.done = S.tick + n_bins + 64;
   S.gen = S.done + kRing * n_bins + 64;
   S.ovf = S.gen + kRing * n_bins;
-  S.buf = S.ovf + ((n_bins + 3) & ~3);           // 16-byte aligned: blocks are read 16 bytes at a time
+  // the blocks are read 16 bytes at a time (ds_read_b128): their start is rounded up to a 4-word boundary of the allocation —
+  // the arrays in front total 5 * n_bins + constant words, so rounding only the size of `ovf` left C4's 611 bins 12 bytes off
+  S.buf = lds + (((S.ovf + n_bins) - lds + 3) & ~(ptrdiff_t)3);
+  S.err = err_flag;
   for (int i = tid; i < (2 + 2 * kRing) * n_bins + 128; i += (int)blockDim.x) S.tick[i] = 0u;
   if (tid == 0) s_ticket[0] = 0u;
   __syncthreads();
@@ -612,7 +630,8 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
                                                          uint32_t cap_blocks, int width, int map_cap, int parts, int64_t k, float scale,
                                                          double inv_scale, const void* __restrict__ w0p, int wdtype,
                                                          float* __restrict__ out, float* __restrict__ ovf_img,
-                                                         uint32_t* __restrict__ count_rearm, int n_bins_b) {
+                                                         uint32_t* __restrict__ count_rearm, int n_bins_b,
+                                                         const uint32_t* __restrict__ err_flag) {
   using B = BinBlock<HOMO, CAP>;
   using acc_t = typename PlanAcc<HOMO>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -740,11 +759,13 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   // written, `out` needs no zeroing.  What pass B could not place in a region sits in the overflow image (all zeros
   // otherwise: read and cleared here only when the bin's flag says so).
   const bool plain = parts == 1;
+  const bool poisoned = *err_flag != 0u;             // pass B gave up on an entry (kWaitLimitTicks): no output of this step is trusted
   for (int i = tid; i < S; i += 1024) {
     if (j0 + i >= j_end) break;
     float v;
     if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
     else v = (float)((double)(long long)reinterpret_cast<unsigned long long*>(acc)[i] * inv_scale);
+    if (poisoned) v = __int_as_float(0x7fc00000);
     if (overflowed && part == 0) {
       const float o = ovf_img[j0 + i];
       if (o != 0.f) { v += o; ovf_img[j0 + i] = 0.f; }
@@ -972,6 +993,20 @@ int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_b
   return be_binary_csrmm_t_binned_workspace_init(workspace, workspace_bytes, m, k, 1, slice_shift, bin_capacity, stream);
 }
 
+int be_binned_workspace_status(const void* workspace, int clear, be_stream_t stream) {
+  BE_REQUIRE(workspace != nullptr, BE_ERR_INVALID, "workspace is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t flag = 0;
+  const uint32_t* p = static_cast<const uint32_t*>(workspace) + kBinErrWord;
+  BE_HIP(hipMemcpyAsync(&flag, p, 4, hipMemcpyDeviceToHost, st));
+  BE_HIP(hipStreamSynchronize(st));
+  if (flag == 0u) return BE_OK;
+  if (clear) BE_HIP(be_fill_async(const_cast<uint32_t*>(p), 0, 4, st));
+  be_set_error("be_binned_workspace_status: pass B of a binned step gave up on an entry whose ring slot was not freed within 20 ms "
+               "(append protocol stalled); that step's outputs were written as NaN");
+  return BE_ERR_HIP;
+}
+
 int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
                              int indptr_is_i64, int64_t row_len, const void* spikes_bm, int spike_dtype, void* out_bm, int64_t m,
                              int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity, int scale_exp, void* workspace,
@@ -1059,7 +1094,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
                        al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \
-                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m);                                              \
+                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m, count + kBinErrWord);                         \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \
@@ -1086,7 +1121,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
                        geo.map_cap, parts, k, scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype,    \
-                       out_p, ovf_img, rearm, n_bins_b);                                                                        \
+                       out_p, ovf_img, rearm, n_bins_b, count + kBinErrWord);                                                   \
   } while (0)
     if (homo) {
       if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);

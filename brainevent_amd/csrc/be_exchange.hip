@@ -102,6 +102,32 @@ int be_exchange_get_unique_id(void* id_host) {
   return BE_OK;
 }
 
+// The partition of the pre population the exchange rests on, as a pure function of (n_pre, world, rank): every rank owns the same
+// whole number of 32-bit words w = ceil(ceil(n_pre / 32) / world); rank r's slice is [r * w * 32, (r + 1) * w * 32) clipped to
+// n_pre — the last owners may hold fewer spikes, or none.  Everything below (init, slice, gather, post) goes through it.
+struct ExSlice {
+  int64_t words_per_rank, lo, hi, n_local, used_words;
+};
+static inline ExSlice ex_slice_of(int64_t n_pre, int world, int rank) {
+  ExSlice s;
+  s.words_per_rank = (((n_pre + 31) / 32) + world - 1) / world;
+  const int64_t lo = (int64_t)rank * s.words_per_rank * 32, hi = lo + s.words_per_rank * 32;
+  s.lo = lo < n_pre ? lo : n_pre;
+  s.hi = hi < n_pre ? hi : n_pre;
+  s.n_local = s.hi - s.lo;
+  s.used_words = (s.n_local + 31) / 32;
+  return s;
+}
+
+int be_exchange_slice_for(int64_t n_pre, int world, int rank, int64_t* lo_host, int64_t* hi_host, int64_t* words_per_rank_host) {
+  BE_REQUIRE(world >= 1 && rank >= 0 && rank < world && n_pre >= 0, BE_ERR_INVALID, "bad world / rank / n_pre");
+  const ExSlice s = ex_slice_of(n_pre, world, rank);
+  if (lo_host) *lo_host = s.lo;
+  if (hi_host) *hi_host = s.hi;
+  if (words_per_rank_host) *words_per_rank_host = s.words_per_rank;
+  return BE_OK;
+}
+
 int be_exchange_init(const void* id_host, int world, int rank, int64_t n_pre, void** exchange_host_out) {
   BE_REQUIRE(id_host && exchange_host_out, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(world >= 1 && rank >= 0 && rank < world && n_pre >= 0, BE_ERR_INVALID, "bad world / rank / n_pre");
@@ -111,7 +137,7 @@ int be_exchange_init(const void* id_host, int world, int rank, int64_t n_pre, vo
   ex->world = world;
   ex->rank = rank;
   ex->n_pre = n_pre;
-  ex->words_per_rank = (((n_pre + 31) / 32) + world - 1) / world;
+  ex->words_per_rank = ex_slice_of(n_pre, world, rank).words_per_rank;
   ex->local_words = nullptr;
   NcclUniqueId id;
   memcpy(&id, id_host, sizeof(id));
@@ -135,9 +161,9 @@ int be_exchange_slice(const void* exchange, int rank, int64_t* lo_host, int64_t*
   BE_REQUIRE(exchange && lo_host && hi_host, BE_ERR_INVALID, "null pointer");
   const Exchange* ex = static_cast<const Exchange*>(exchange);
   BE_REQUIRE(rank >= 0 && rank < ex->world, BE_ERR_INVALID, "rank out of range");
-  const int64_t lo = (int64_t)rank * ex->words_per_rank * 32, hi = lo + ex->words_per_rank * 32;
-  *lo_host = lo < ex->n_pre ? lo : ex->n_pre;
-  *hi_host = hi < ex->n_pre ? hi : ex->n_pre;
+  const ExSlice sl = ex_slice_of(ex->n_pre, ex->world, rank);
+  *lo_host = sl.lo;
+  *hi_host = sl.hi;
   return BE_OK;
 }
 
@@ -154,11 +180,9 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
   Rccl* R = rccl();
   BE_REQUIRE(R != nullptr, BE_ERR_UNSUPPORTED, "librccl.so could not be loaded");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t lo = (int64_t)ex->rank * ex->words_per_rank * 32;
-  int64_t n_local = ex->n_pre - lo;
-  n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
+  const ExSlice sl = ex_slice_of(ex->n_pre, ex->world, ex->rank);
+  const int64_t n_local = sl.n_local, used = sl.used_words;
   BE_REQUIRE(n_local == 0 || local_spikes != nullptr, BE_ERR_INVALID, "null pointer");
-  const int64_t used = (n_local + 31) / 32;
   // BE_SPIKE_BITS: the producer already emits the slice as words (be_lif_coba_step's spike_bits_out, a BitPackedBinary): a
   // slice that fills its words is gathered from where it lies — no pack launch, no copy
   const uint32_t* send = ex->local_words;
@@ -233,11 +257,9 @@ int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, 
     BE_HIP(hipStreamWaitEvent(ex->side, ex->ev_free[slot], 0));
     ex->released[slot] = false;
   }
-  const int64_t lo = (int64_t)ex->rank * ex->words_per_rank * 32;
-  int64_t n_local = ex->n_pre - lo;
-  n_local = n_local < 0 ? 0 : (n_local > ex->words_per_rank * 32 ? ex->words_per_rank * 32 : n_local);
+  const ExSlice sl = ex_slice_of(ex->n_pre, ex->world, ex->rank);
+  const int64_t n_local = sl.n_local, used = sl.used_words;
   BE_REQUIRE(n_local == 0 || local_spikes != nullptr, BE_ERR_INVALID, "null pointer");
-  const int64_t used = (n_local + 31) / 32;
   // (BE_SPIKE_BITS: see be_exchange_allgather_bits; the caller keeps the words unchanged until the slot's wait has returned)
   const uint32_t* send = ex->post_local[slot];
   if (spike_dtype == BE_SPIKE_BITS && used == ex->words_per_rank && n_local > 0) {

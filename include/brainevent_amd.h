@@ -140,6 +140,9 @@ int be_exchange_unique_id_bytes(void);
 int be_exchange_get_unique_id(void* id_host);
 int be_exchange_init(const void* id_host, int world, int rank, int64_t n_pre, void** exchange_host_out);
 int be_exchange_slice(const void* exchange, int rank, int64_t* lo_host, int64_t* hi_host);
+/* the same partition as a pure function (no handle, no device, no RCCL): rank's slice [lo, hi) of n_pre spikes and the words
+ * every rank owns — what init, slice, allgather and post all compute; any of the three outputs may be NULL */
+int be_exchange_slice_for(int64_t n_pre, int world, int rank, int64_t* lo_host, int64_t* hi_host, int64_t* words_per_rank_host);
 int64_t be_exchange_full_words(const void* exchange);
 int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spike_dtype, uint32_t* full_bits,
                                be_stream_t stream);
@@ -357,6 +360,12 @@ int be_binned_bins(int64_t k, int slice_shift, int homo);
  * persisted per-architecture tuning — the counterpart of the thresholds the reference compiles into its hybrid kernel from
  * brainevent/_csr/hybrid_config.py:77-88, :256-295. */
 int be_binned_set_tuning(int task_groups, int min_tasks);
+/* Sticky protocol flag of a binned workspace.  Pass B's append never blocks for good: a lane whose write-combining slot is not
+ * freed within 20 ms (constant-rate clock; never observed) raises the flag and drops its pending entries, pass C then writes
+ * NaN into every output of that step — the process keeps its HIP context (the reference's device-side check traps instead,
+ * brainevent/include/brainevent/check.h:79-82).  This call reads the flag: BE_OK, or BE_ERR_HIP with the cause in
+ * be_last_error(); clear != 0 re-arms the workspace.  SYNCHRONOUS.  A caller that never sees NaN never needs it. */
+int be_binned_workspace_status(const void* workspace, int clear, be_stream_t stream);
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity);
 /* once per workspace, before its first step: zeroes the spike counter and the overflow image inside it (every step leaves
  * both at zero, so the step itself needs no memset and no zeroing of `out`: pass C writes every output) */

@@ -7,6 +7,10 @@
  *   3. weight refresh: be_scatter_plan_refresh_weights_ordered (a gather-copy through the stored order), then step 2's call again
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
  *   5. neuron step:    be_lif_coba_step
+ *   6. the unfavourable direction made event-driven: be_csr_to_csc_count -> _indptr -> _fill_block (two column
+ *      blocks, weights moved along, perm kept) gives the CSC mirror; the gather product of step 4 is then (a) the direct scatter
+ *      over the mirror, (b) the perm-fused scatter be_binary_csrmm_t_indexed over the mirror's structure with the weights left in
+ *      CSR order, (c) after a weight update: be_gather_by_perm + the same scatter
  * Every result is compared with the serial loop of the reference's CPU kernel (brainevent/_csr/binary.py:446-451 /
  * :466-472), restated inline in double precision; tolerance rtol = atol = 1e-5 (the tolerance of the path).
  * Build:  gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/c/abi_smoke.c \
@@ -177,6 +181,50 @@ int main(void) {
     for (int i = 0; i < 4; ++i) bad += (gsp[i] != rs[i]) || fabs(gv[i] - rv[i]) > 1e-4 || fabs(grf[i] - (rs[i] ? 5.0 : hrf[i] - dt)) > 1e-5;
     printf("%-28s spikes %d%d%d%d %s\n", "neuron step", gsp[0], gsp[1], gsp[2], gsp[3], bad ? "FAIL" : "ok");
     fails += bad ? 1 : 0;
+  }
+
+  /* 6. CSR -> CSC mirror from C, then the gather product of step 4 as a scatter over the active columns */
+  {
+    void *d_counts = dev_copy(NULL, k * 8), *d_cptr = dev_copy(NULL, (k + 1) * 8);
+    int64_t cscr = be_csr_to_csc_scratch_bytes(k), total = 0;
+    void *d_cscr = dev_copy(NULL, cscr);
+    CHECK_BE(be_csr_to_csc_count((const int32_t *)d_idx, nnz, k, (int64_t *)d_counts, NULL));
+    CHECK_BE(be_csr_to_csc_indptr((const int64_t *)d_counts, k, d_cptr, 1, &total, d_cscr, cscr, NULL));
+    if (total != nnz) { printf("FAIL csr_to_csc total %lld != nnz %lld\n", (long long)total, (long long)nnz); ++fails; }
+    int64_t *cptr = malloc((k + 1) * 8);
+    CHECK_HIP(hipMemcpy(cptr, d_cptr, (k + 1) * 8, hipMemcpyDeviceToHost));
+    void *d_rows = dev_copy(NULL, nnz * 4), *d_wt = dev_copy(NULL, nnz * 4), *d_perm = dev_copy(NULL, nnz * 4);
+    void *d_cursor = dev_copy(NULL, k * 8);
+    const int64_t cut = k / 3;                               /* two column blocks: [0, cut) and [cut, k) */
+    const int64_t lo[2] = {0, cut}, hi[2] = {cut, k};
+    for (int b = 0; b < 2; ++b) {
+      const int64_t off = cptr[lo[b]];                       /* a block's arrays start at its first column's offset */
+      CHECK_BE(be_csr_to_csc_fill_block((const int32_t *)d_idx, d_ptr, 0, -1, m, nnz, lo[b], hi[b], (const int64_t *)d_cptr,
+                                        (int64_t *)d_cursor, (int32_t *)d_rows + off, (int32_t *)d_perm + off, 0, d_w, 4,
+                                        (float *)d_wt + off, NULL));
+    }
+    /* (a) direct scatter over the mirror: rows = the k columns, outputs = the m rows; int64 indptr */
+    int64_t mws_bytes = be_binary_csrmv_t_workspace_bytes(k, m, BE_F32);
+    void *d_mws = dev_copy(NULL, mws_bytes);
+    CHECK_BE(be_binary_csrmv_t(d_wt, 0, BE_F32, (const int32_t *)d_rows, d_cptr, 1, -1, d_spk_k, BE_SPIKE_BOOL, d_out, k, m, d_mws,
+                               mws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
+    fails += compare("mirror scatter (moved w)", got, ref, m);
+    /* (b) perm-fused: the weights stay in CSR order, slot j reads w[perm[j]] */
+    CHECK_BE(be_binary_csrmm_t_indexed(d_w, 0, BE_F32, (const int32_t *)d_rows, d_cptr, 1, -1, d_perm, 0, d_spk_k, BE_SPIKE_BOOL,
+                                       d_out, k, m, 1, d_mws, mws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
+    fails += compare("mirror scatter (perm-fused)", got, ref, m);
+    /* (c) weights updated in place: one gather-copy brings the mirror's copy up to date */
+    for (int64_t j = 0; j < nnz; ++j) w[j] = -w[j];
+    CHECK_HIP(hipMemcpy(d_w, w, nnz * 4, hipMemcpyHostToDevice));
+    CHECK_BE(be_gather_by_perm(d_w, 4, d_perm, 0, nnz, d_wt, NULL));
+    for (int64_t i = 0; i < m; ++i) ref[i] = -ref[i];
+    CHECK_BE(be_binary_csrmv_t(d_wt, 0, BE_F32, (const int32_t *)d_rows, d_cptr, 1, -1, d_spk_k, BE_SPIKE_BOOL, d_out, k, m, d_mws,
+                               mws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
+    fails += compare("mirror after gather_by_perm", got, ref, m);
+    free(cptr);
   }
 
   /* error convention: status code + message, never an abort */

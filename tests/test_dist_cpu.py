@@ -177,3 +177,35 @@ def test_jit_walk_class_columns_tile_the_output():
             state = O.lr_next(state)
             q = q + 1 + O.lr_bounded(state, clen - 1)
     assert n_edges > 0
+
+
+def test_native_exchange_slice_arithmetic_matches_the_python_partition():
+    """ranks > 0 of the library's own exchange binding had never executed.  Its partition is a pure function now
+    (``be_exchange_slice_for``: what init / slice / allgather / post all go through); here it is checked for worlds 1 ... 8,
+    even, uneven and degenerate populations (owners of nothing) against ``word_aligned_bounds`` and against the invariants
+    the bit-packed gather rests on: the slices tile [0, n), each starts on a word boundary, every rank contributes the same
+    number of words, and the words gathered are exactly ceil-padded."""
+    import ctypes
+    from brainevent_amd import _lib
+    from brainevent_amd._dist import word_aligned_bounds
+    f = _lib.fn('be_exchange_slice_for', ctypes.c_int,
+                [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                 ctypes.POINTER(ctypes.c_int64)])
+    for world in range(1, 9):
+        for n in (0, 1, 31, 32, 33, 255, 256, 257, 1000, 4096, 1_000_000, 10_000_000, 10_000_019, 32 * world, 32 * world + 1,
+                  32 * (world - 1) + 5):
+            cover, wprs = 0, set()
+            for rank in range(world):
+                lo, hi, wpr = ctypes.c_int64(-1), ctypes.c_int64(-1), ctypes.c_int64(-1)
+                assert f(n, world, rank, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(wpr)) == 0
+                assert (lo.value, hi.value) == word_aligned_bounds(n, world, rank), (n, world, rank)
+                assert lo.value == cover and lo.value <= hi.value <= n            # tiles in rank order, may be empty
+                assert lo.value % 32 == 0 or lo.value == n
+                assert hi.value - lo.value <= wpr.value * 32
+                cover = hi.value
+                wprs.add(wpr.value)
+            assert cover == n and len(wprs) == 1
+            wpr = wprs.pop()
+            assert wpr * world * 32 >= n and (wpr - 1) * world * 32 < max(n, 1) + 32 * world
+    assert f(10, 0, 0, None, None, None) < 0 and f(10, 2, 2, None, None, None) < 0 and f(-1, 1, 0, None, None, None) < 0
+    assert f(10, 2, 1, None, None, None) == 0                                     # outputs are optional

@@ -121,3 +121,43 @@ def test_tuner_measures_and_the_library_takes_the_task_size(tuning_env):
     ref = O.binary_csrmv(w.cpu().numpy().reshape(-1).astype(np.float64), idx.cpu().numpy().reshape(-1), ptr.cpu().numpy(),
                          v.cpu().numpy(), (m, k), True)
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_import_with_a_store_present_does_not_touch_the_gpu(tmp_path):
+    """importing the package must not initialise the GPU even when a tuning store exists (torchrun ranks import
+    before set_device; fork-after-import; exec-before-GPU re-launches).  The per-device entry is resolved at the first route
+    choice instead.  Run in a fresh interpreter so that the import really happens."""
+    import os
+    import subprocess
+    import sys
+    store = tmp_path / 'scatter_tuning.json'
+    store.write_text(json.dumps({'gfx950': {'plan_min_segment': 5}}))
+    code = ("import torch, brainevent_amd, brainevent_amd._csr as C\n"
+            "assert not torch.cuda.is_initialized(), 'import initialised the GPU'\n"
+            "assert C.PLAN_MIN_SEGMENT == 8, C.PLAN_MIN_SEGMENT\n"
+            "from brainevent_amd import _tuning as T\n"
+            "T.current_device_kind = lambda: 'gfx950'\n"
+            "C.choose_scatter_route(10**9, 10**6, 10**6, torch.ones(3))\n"
+            "assert C.PLAN_MIN_SEGMENT == 5, C.PLAN_MIN_SEGMENT\n"
+            "print('ok')\n")
+    env = dict(os.environ, BRAINEVENT_AMD_TUNING_FILE=str(store))
+    env.pop('BRAINEVENT_AMD_TUNING', None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout
+
+
+def test_a_malformed_override_never_breaks_a_later_resolution(monkeypatch):
+    """with a bad BRAINEVENT_AMD_TUNING every later get_scatter_tuning() (e.g. from BinnedScatter's
+    push_to_library) used to raise; it must warn once and keep the defaults."""
+    from brainevent_amd import _tuning as T
+    for junk in ('{ not json', '{"plan_min_segment": "many"}', '[1]', '{"plan_min_segment": 0}'):
+        monkeypatch.setenv('BRAINEVENT_AMD_TUNING', junk)
+        T.get_scatter_tuning.cache_clear()
+        with pytest.warns(UserWarning):
+            T._warned.clear()
+            assert T.get_scatter_tuning() == T.DEFAULT_SCATTER_TUNING
+        assert T.get_scatter_tuning() == T.DEFAULT_SCATTER_TUNING           # and again, without raising
+        T.ensure_resolved()
+    monkeypatch.delenv('BRAINEVENT_AMD_TUNING')
+    T.get_scatter_tuning.cache_clear()
