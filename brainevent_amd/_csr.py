@@ -505,7 +505,8 @@ def weights_stamp(t: torch.Tensor):
     return (t.data_ptr(), t._version, t.numel())
 
 
-def fixed_point_exponent(weights: torch.Tensor, indices: Optional[torch.Tensor], k: int, keep: Optional[int] = None) -> int:
+def fixed_point_exponent(weights: torch.Tensor, indices: Optional[torch.Tensor], k: int, keep: Optional[int] = None,
+                         min_bits: Optional[int] = None) -> int:
     """Fixed-point exponent ``e`` of a weight array (``be_fixed_point_exponent``, chosen inside the library so that a
     non-Python binder can set up the same workspaces).
 
@@ -525,7 +526,8 @@ def fixed_point_exponent(weights: torch.Tensor, indices: Optional[torch.Tensor],
     f = fn('be_fixed_point_exponent', c_int,
            [c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, ctypes.POINTER(c_int), c_vp])
     rc = f(A.ptr(flat_w), A.wcode(flat_w), A.ptr(None if indices is None else indices.reshape(-1)), flat_w.numel(), int(k),
-           ScatterPlan.MIN_WEIGHT_BITS, -(1 << 31) if keep is None else int(keep), A.ptr(scratch), scratch.numel(),
+           ScatterPlan.MIN_WEIGHT_BITS if min_bits is None else int(min_bits), -(1 << 31) if keep is None else int(keep),
+           A.ptr(scratch), scratch.numel(),
            ctypes.byref(out), A.stream_ptr())
     if rc == -4:            # BE_ERR_RANGE: not representable
         from ._lib import lib
@@ -608,7 +610,7 @@ class BinnedScatter:
     """
 
     def __init__(self, weights: torch.Tensor, m: int, k: int, nnz: int, *, max_active_fraction: float = 0.05,
-                 slice_shift: Optional[int] = None, indices: Optional[torch.Tensor] = None):
+                 slice_shift: Optional[int] = None, indices: Optional[torch.Tensor] = None, acc32: Optional[bool] = None):
         self.m, self.k = int(m), int(k)
         self.homo = weights.numel() == 1
         if slice_shift is None and os.environ.get('BE_BIN_SHIFT'):      # A/B runs
@@ -618,16 +620,34 @@ class BinnedScatter:
         self.slice_shift = 16 if slice_shift is None else int(slice_shift)
         from . import _tuning
         _tuning.push_to_library()            # pass B's task size from the persisted tuning of this architecture
-        self.n_slices = int(fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(self.k, self.slice_shift, int(self.homo)))
-        if self.n_slices <= 0:
-            raise ValueError(f"the binned route does not serve {self.k} outputs at slice_shift={self.slice_shift}")
-        expect = max_active_fraction * nnz / max(self.n_slices, 1)
-        self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
+        self.max_active_fraction = float(max_active_fraction)
         self.scale_exp = 0
         self.nnz = int(nnz)
-        self._derive_exponent(weights, indices)
+        self.acc32 = False
+        self._derive_exponent(weights, indices, acc32=acc32)
+        self._set_geometry()
         self._ws: Dict = {}
         self.ws = self.workspace(1)
+
+    #: per-entry weights: take 32-bit sums (twice the bin width: half the bins, one round of pass C) whenever every column's
+    #: largest weight keeps this many bits at the 32-bit exponent — outputs then good to ~2^-20 of their column's weight scale,
+    #: 16 x finer than MIN_WEIGHT_BITS asks of the 64-bit sums.  None: never.
+    ACC32_MIN_WEIGHT_BITS: Optional[int] = 20
+    #: ... and only over at least this many outputs (below, the 64-bit bins already are one round of pass C)
+    ACC32_MIN_OUTPUTS = 256 * 20000
+
+    @property
+    def kind(self) -> int:
+        """The `homo` argument of the binned entry points: 0 per-entry weights / 64-bit sums, 1 one shared weight, 2 per-entry
+        weights / 32-bit sums (BE_BINNED_ACC32)."""
+        return 1 if self.homo else (2 if self.acc32 else 0)
+
+    def _set_geometry(self) -> None:
+        self.n_slices = int(fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(self.k, self.slice_shift, self.kind))
+        if self.n_slices <= 0:
+            raise ValueError(f"the binned route does not serve {self.k} outputs at slice_shift={self.slice_shift}")
+        expect = self.max_active_fraction * self.nnz / max(self.n_slices, 1)
+        self.bin_capacity = int(max(1024, min(2 ** 31, 1.25 * expect + 6 * math.sqrt(max(expect, 1.0)) + 64)))
 
     def workspace(self, n_batch: int = 1) -> torch.Tensor:
         """The workspace of steps over ``n_batch`` spike vectors (created and initialised once per batch size; never evicted:
@@ -635,7 +655,7 @@ class BinnedScatter:
         ws = self._ws.get(int(n_batch))
         if ws is None:
             f = fn('be_binary_csrmm_t_binned_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_i64])
-            ws = A.workspace(f(self.m, self.k, int(n_batch), self.slice_shift, self.bin_capacity))
+            ws = A.workspace(f(self.m, self.k, int(n_batch), self.slice_shift, self.bin_capacity))      # (sized for every kind)
             f = fn('be_binary_csrmm_t_binned_workspace_init', c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_vp])
             check(f(A.ptr(ws), ws.numel(), self.m, self.k, int(n_batch), self.slice_shift, self.bin_capacity, A.stream_ptr()),
                   'be_binary_csrmm_t_binned_workspace_init')
@@ -649,10 +669,42 @@ class BinnedScatter:
         for ws in self._ws.values():
             check(f(A.ptr(ws), int(clear), A.stream_ptr()), 'be_binned_workspace_status')
 
-    def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False) -> None:
+    def _derive_exponent(self, weights: torch.Tensor, indices: Optional[torch.Tensor], keep_exp: bool = False,
+                         acc32: Optional[bool] = None) -> None:
+        """The fixed-point exponent of per-entry weights — and, at construction (``keep_exp=False``), whether the sums are 32 or
+        64 bits wide: 32 when ``ACC32_MIN_WEIGHT_BITS`` allows it (``acc32=None``), or as forced.  A refresh keeps the width (the
+        bins and the workspace were sized for it); weights that no longer qualify for 32-bit sums raise ``MathError`` and the
+        container rebuilds its workspace."""
         self.stamp = weights_stamp(weights)
-        if not self.homo:
-            self.scale_exp = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp if keep_exp else None)
+        if self.homo:
+            return
+        if keep_exp:
+            if self.acc32:
+                try:
+                    e64 = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp + 32,
+                                               min_bits=(self.ACC32_MIN_WEIGHT_BITS or 20) + 32)
+                    self.scale_exp = e64 - 32
+                except MathError:       # no longer fine enough for 32-bit sums: back to 64-bit bins (new geometry, new workspaces)
+                    self.scale_exp = fixed_point_exponent(weights, indices, self.k)
+                    self.acc32 = False
+                    self._set_geometry()
+                    self._ws = {}
+                    self.ws = self.workspace(1)
+            else:
+                self.scale_exp = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp)
+            return
+        want32 = acc32 if acc32 is not None else (self.ACC32_MIN_WEIGHT_BITS is not None and self.k >= self.ACC32_MIN_OUTPUTS
+                                                  and weights.dtype == torch.float32 and not os.environ.get('BE_BIN_NO_ACC32'))
+        if want32:
+            try:        # the 64-bit exponent e leaves 2^62 of headroom; the same bound for 2^30 is e - 32
+                e64 = fixed_point_exponent(weights, indices, self.k, min_bits=(self.ACC32_MIN_WEIGHT_BITS or 20) + 32)
+                self.acc32, self.scale_exp = True, e64 - 32
+                return
+            except MathError:
+                if acc32:
+                    raise
+        self.acc32 = False
+        self.scale_exp = fixed_point_exponent(weights, indices, self.k)
 
     def refresh_weights(self, weights, indices, indptr=None) -> None:
         """The bins are refilled from the matrix on every call; only the fixed-point exponent derives from the weights."""
@@ -667,7 +719,7 @@ class BinnedScatter:
     def applicable(weights: torch.Tensor, k: int) -> bool:
         if weights.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             return False                  # f64: the bins carry f32 weights (per-entry f64 weights take the planned route)
-        return fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(int(k), 16, int(weights.numel() == 1)) > 0
+        return fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(int(k), 16, int(weights.numel() == 1)) > 0      # (kind 0 / 1)
 
 
 def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes, sd, out) -> None:
@@ -675,7 +727,7 @@ def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes,
            [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp, c_i64,
             c_vp])
     is64 = int(indptr is not None and indptr.dtype == torch.int64)
-    check(f(A.ptr(weights), int(ws.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes), sd,
+    check(f(A.ptr(weights), ws.kind, A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes), sd,
             A.ptr(out), ws.m, ws.k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(),
             A.stream_ptr()), 'be_binary_csrmv_t_binned')
 
@@ -693,7 +745,7 @@ def binned_batch(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes_
            [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp, c_i64,
             c_vp])
     is64 = int(indptr is not None and indptr.dtype == torch.int64)
-    check(f(A.ptr(weights), int(ws.homo), A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes_bm), sd,
+    check(f(A.ptr(weights), ws.kind, A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes_bm), sd,
             A.ptr(out_bm), ws.m, ws.k, nb, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(wsb), wsb.numel(),
             A.stream_ptr()), 'be_binary_csrmm_t_binned')
 

@@ -625,7 +625,13 @@ __device__ __forceinline__ void bin_count8(uint32_t* acc, uint4 v) {
   atomicAdd(&acc[v.w & 0xffffu], 1u); atomicAdd(&acc[v.w >> 16], 1u);
 }
 
-template <bool HOMO, int CAP>
+// ACC32 (per-entry weights only): the bin's sums are 32-bit fixed point at 2^scale_exp32 instead of 64-bit — 40000 accumulators
+// fit one workgroup's LDS instead of 20000, so 10M outputs are 256 bins (one round of pass C, blocks of 32 entries in pass B)
+// instead of 611 (2.4 rounds, blocks of 16).  Chosen by the host only when every column's largest weight keeps >= 20 bits at
+// that exponent (be_fixed_point_exponent with min_weight_bits = 20 + 32): an output is then good to ~1e-6 of its column's
+// weight scale — 16 x finer than the gate of the 64-bit sums asks for — and still an integer sum: order independent, bitwise
+// reproducible.  `scale` is then 2^scale_exp32 and inv_scale 2^-scale_exp32.
+template <bool HOMO, int CAP, bool ACC32 = false>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restrict__ regions, const uint32_t* __restrict__ dir,
                                                          uint32_t cap_blocks, int width, int map_cap, int parts, int64_t k, float scale,
                                                          double inv_scale, const void* __restrict__ w0p, int wdtype,
@@ -633,7 +639,8 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
                                                          uint32_t* __restrict__ count_rearm, int n_bins_b,
                                                          const uint32_t* __restrict__ err_flag) {
   using B = BinBlock<HOMO, CAP>;
-  using acc_t = typename PlanAcc<HOMO>::type;
+  using acc_t = typename PlanAcc<HOMO || ACC32>::type;
+  static_assert(!(HOMO && ACC32), "ACC32 is a mode of per-entry weights");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   __shared__ uint32_t s_cnt[kStreamGrid], s_pre[kStreamGrid + 1], s_wtot[16];
@@ -745,8 +752,14 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
         if (nv[u] >= 1u && uv[u].z == 0x12345678u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
         if (nv[u] == 2u && uv[u].x == 0x12345678u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
 #else
-        if (nv[u] >= 1u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
-        if (nv[u] == 2u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
+        if (ACC32) {
+          uint32_t* a32 = reinterpret_cast<uint32_t*>(acc);
+          if (nv[u] >= 1u) atomicAdd(a32 + (uv[u].z & 0xffffu), (uint32_t)__float2int_rn(__uint_as_float(uv[u].x) * scale));
+          if (nv[u] == 2u) atomicAdd(a32 + (uv[u].z >> 16), (uint32_t)__float2int_rn(__uint_as_float(uv[u].y) * scale));
+        } else {
+          if (nv[u] >= 1u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
+          if (nv[u] == 2u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
+        }
 #endif
       }
     }
@@ -764,6 +777,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
     if (j0 + i >= j_end) break;
     float v;
     if (HOMO) v = (float)reinterpret_cast<uint32_t*>(acc)[i] * w0;
+    else if (ACC32) v = (float)((double)(int)reinterpret_cast<uint32_t*>(acc)[i] * inv_scale);
     else v = (float)((double)(long long)reinterpret_cast<unsigned long long*>(acc)[i] * inv_scale);
     if (poisoned) v = __int_as_float(0x7fc00000);
     if (overflowed && part == 0) {
@@ -821,6 +835,11 @@ __global__ void __launch_bounds__(256) k_bin_union(const void* __restrict__ spik
   }
 }
 
+// `kind` of a binned step (the `homo` argument of the entry points): 0 = per-entry weights, 64-bit sums; 1 = one shared weight
+// (counts); 2 = per-entry weights, 32-bit sums (BE_BINNED_ACC32: twice the bin width).  Entries are 2 bytes (counted) or 6.
+static inline bool kind_counted(int kind) { return kind == 1; }
+static inline int64_t kind_acc_bytes(int kind) { return kind == 0 ? 8 : 4; }
+
 // entries per write-combining block: the largest the LDS of pass B holds for this many bins
 static inline int stream_cap(int n_bins, int homo) {
   const int64_t budget = 160 * 1024 - 512 - (int64_t)kStreamFixedWords * 4;
@@ -828,7 +847,7 @@ static inline int stream_cap(int n_bins, int homo) {
   // (weighted blocks of 128 entries — 768 bytes — serve outputs of fewer than ~85 bins: 10M rows x 1.25M outputs, 125 per row,
   //  8 % firing, 77 bins: pass B 735 / 567 / 519 / 438 us with blocks of 16 / 32 / 64 / 128, tools/exp_hybrid_estimate.py)
   for (int cap = forced > 0 ? forced : 128; cap >= 8; cap >>= 1) {
-    const int64_t per_bin = kRing * (int64_t)cap * (homo ? 2 : 6) + 8 + 8 * kRing;      // two blocks + ticket, 2 commit counts, 2 generations, flag
+    const int64_t per_bin = kRing * (int64_t)cap * (kind_counted(homo) ? 2 : 6) + 8 + 8 * kRing;      // two blocks + ticket, 2 commit counts, 2 generations, flag
     if (per_bin * n_bins <= budget) return cap;
   }
   return 0;
@@ -845,8 +864,8 @@ static inline int64_t stream_cap_blocks(int64_t bin_capacity, int cap) {
 // than 256 x 256 columns get bins of 256 columns.
 constexpr int64_t kAccStaticBytes = 4 * (kStreamGrid + kStreamGrid + 1 + 16) + 512;       // pass C: directory, prefix sums, scan, margin
 struct BinGeo { int64_t width; int n_bins, cap, map_cap; };
-static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo) {
-  const int64_t acc_bytes = homo ? 4 : 8;
+static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo /* kind */) {
+  const int64_t acc_bytes = kind_acc_bytes(homo);
   int64_t max_w = (160 * 1024 - kAccStaticBytes) / acc_bytes;
   max_w = std::min<int64_t>(std::min<int64_t>(max_w, 1ll << slice_shift), 65535) & ~3ll;
   BinGeo g{0, 0, 0, 0};
@@ -855,7 +874,7 @@ static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo) {
     g.width = ((k + forced - 1) / forced + 3) & ~3ll;
   } else if (k <= 256 * 256) {
     g.width = std::min<int64_t>(256, max_w);
-  } else if (!homo && k > 256 * std::min<int64_t>(max_w, 16384)) {
+  } else if (homo == 0 && k > 256 * std::min<int64_t>(max_w, 16384)) {
     // weighted entries over many outputs keep bins of a power of two (2^14 columns at most: C4 = 611 bins): pass C's rounds
     // were measured not to matter there (512 bins of 19532: 199 us, 611 of 16384: 190 us — it is bound by its byte stream
     // at ~3.4 TB/s, with or without the LDS atomics), and pass B runs 7 % faster without the division per entry
@@ -904,7 +923,7 @@ int be_binned_set_tuning(int task_groups, int min_tasks) {
 
 // bins the route cuts k outputs into for this slice_shift (see binned_geometry); 0: not served (too many bins for pass B's LDS)
 int be_binned_bins(int64_t k, int slice_shift, int homo) {
-  if (k <= 0 || slice_shift < 4 || slice_shift > 16) return 0;
+  if (k <= 0 || slice_shift < 4 || slice_shift > 16 || homo < 0 || homo > 2) return 0;
   const BinGeo g = binned_geometry(k, slice_shift, homo);
   return g.cap > 0 ? g.n_bins : 0;
 }
@@ -919,13 +938,13 @@ struct BatchGeo { BinGeo g; int gb; };
 static inline BatchGeo binned_geometry_batch(int64_t k, int slice_shift, int homo, int64_t n_batch) {
   BatchGeo r{binned_geometry(k, slice_shift, homo), 1};
   if (n_batch <= 1) return r;
-  const int64_t acc_bytes = homo ? 4 : 8;
+  const int64_t acc_bytes = kind_acc_bytes(homo);
   int64_t max_w = (160 * 1024 - kAccStaticBytes) / acc_bytes;
   max_w = std::min<int64_t>(std::min<int64_t>(max_w, 1ll << slice_shift), 65535) & ~3ll;
   const int64_t nbb = (k + max_w - 1) / max_w;
   const int64_t width = ((k + nbb - 1) / nbb + 3) & ~3ll;
   int gb = (int)std::min<int64_t>(n_batch, 32);
-  while (gb > 1 && (nbb * gb > kMaxBins || stream_cap((int)(nbb * gb), homo) < (homo ? 32 : 16))) --gb;
+  while (gb > 1 && (nbb * gb > kMaxBins || stream_cap((int)(nbb * gb), homo) < (kind_counted(homo) ? 32 : 16))) --gb;
   if (gb <= 1) return r;
   r.gb = gb;
   r.g.width = width;
@@ -946,12 +965,12 @@ struct BinWs { int64_t active_off, masks_off, dir_off, regions_off, ovf_off, out
 static inline BinWs binned_ws_layout(int64_t m, int64_t k, int64_t n_batch, int slice_shift, int64_t bin_capacity) {
   // sized for the larger of the two entry kinds: a workspace serves one weight or per-entry weights
   int64_t blocks_bytes = 0, dir_bytes = 0, gb_max = 1;
-  for (int homo = 0; homo < 2; ++homo) {
+  for (int homo = 0; homo < 3; ++homo) {          // (the three kinds)
     const BatchGeo bg = binned_geometry_batch(k, slice_shift, homo, n_batch);
     if (bg.g.cap == 0) continue;
     const int64_t vb = (int64_t)bg.g.n_bins * bg.gb;
     const int64_t cb = stream_cap_blocks(batch_bin_capacity(k, slice_shift, homo, bin_capacity, bg), bg.g.cap);
-    const int64_t b = vb * kStreamGrid * cb * bg.g.cap * (homo ? 2 : 6);
+    const int64_t b = vb * kStreamGrid * cb * bg.g.cap * (kind_counted(homo) ? 2 : 6);
     blocks_bytes = b > blocks_bytes ? b : blocks_bytes;
     dir_bytes = std::max<int64_t>(dir_bytes, vb * kStreamGrid * 4);
     gb_max = std::max<int64_t>(gb_max, bg.gb);
@@ -1019,14 +1038,19 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(weights && indices && spikes_bm && out_bm, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(bin_capacity >= 8 && bin_capacity < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
-  BE_REQUIRE(homo || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID, "scale_exp out of range");
+  BE_REQUIRE(homo >= 0 && homo <= 2, BE_ERR_INVALID, "homo must be 0 (per-entry weights), 1 (one weight) or 2 (BE_BINNED_ACC32)");
+  const int kind = homo;
+  const bool acc32 = kind == 2;
+  homo = kind == 1;
+  BE_REQUIRE(homo || (acc32 ? (scale_exp > -126 && scale_exp < 127) : (scale_exp - 32 > -126 && scale_exp - 32 < 127)), BE_ERR_INVALID,
+             "scale_exp out of range");
   BE_REQUIRE(n_batch == 1 || spike_dtype != BE_SPIKE_IDS, BE_ERR_UNSUPPORTED, "BE_SPIKE_IDS takes a single event vector");
-  const BatchGeo bg = binned_geometry_batch(k, slice_shift, homo, n_batch);
+  const BatchGeo bg = binned_geometry_batch(k, slice_shift, kind, n_batch);
   const BinGeo& geo = bg.g;
   const int cap = geo.cap, n_bins_b = geo.n_bins, gb = bg.gb;
   BE_REQUIRE(cap > 0, BE_ERR_RANGE, "too many bins for the LDS blocks of the binned route (be_binned_bins)");
-  const size_t lds = (((size_t)geo.width * (homo ? 4 : 8) + 15) & ~(size_t)15) + (size_t)geo.map_cap;
-  const int64_t cap_blocks = stream_cap_blocks(batch_bin_capacity(k, slice_shift, homo, bin_capacity, bg), cap);
+  const size_t lds = (((size_t)geo.width * (size_t)kind_acc_bytes(kind) + 15) & ~(size_t)15) + (size_t)geo.map_cap;
+  const int64_t cap_blocks = stream_cap_blocks(batch_bin_capacity(k, slice_shift, kind, bin_capacity, bg), cap);
   BE_REQUIRE(cap_blocks * cap < (1ll << 31), BE_ERR_RANGE, "bin_capacity too large");
   const BinWs wl = binned_ws_layout(m, k, n_batch, slice_shift, bin_capacity);
   BE_REQUIRE(workspace != nullptr && workspace_bytes >= wl.total, BE_ERR_WORKSPACE, "workspace too small");
@@ -1047,7 +1071,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   const DivU32 wdiv = make_div((uint32_t)geo.width);
   // rows of one length: a lane finds its row by dividing its group index by the row's groups of four
   const DivU32 fixdiv = make_div(indptr == nullptr && row_len > 0 && row_len < (1ll << 26) ? (uint32_t)((row_len + 3) / 4) : 1u);
-  const float scale = ldexpf(1.0f, scale_exp - 32);
+  const float scale = ldexpf(1.0f, acc32 ? scale_exp : scale_exp - 32);      // (ACC32: the multiplier itself; else 2^(e - 32), fixed_from_f32)
   const double inv_scale = ldexp(1.0, -scale_exp);
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < n_batch; b0 += gb) {
@@ -1115,6 +1139,14 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_LAUNCH_CHECK();
     const unsigned acc_grid = (unsigned)(n_vbins * parts);
     uint32_t* rearm = spike_dtype == BE_SPIKE_IDS ? static_cast<uint32_t*>(nullptr) : count;
+#define BE_BIN_ACC32(CAP_)                                                                                                     \
+  do {                                                                                                                          \
+    auto kern = k_bin_accumulate<false, CAP_, true>;                                                                            \
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
+    hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
+                       geo.map_cap, parts, k, scale, inv_scale, static_cast<const void*>(nullptr), wdtype,                      \
+                       out_p, ovf_img, rearm, n_bins_b, count + kBinErrWord);                                                   \
+  } while (0)
 #define BE_BIN_ACC(HOMO_, CAP_)                                                                                                 \
   do {                                                                                                                          \
     auto kern = k_bin_accumulate<HOMO_, CAP_>;                                                                                  \
@@ -1126,6 +1158,9 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     if (homo) {
       if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
       else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
+    } else if (acc32) {
+      if (cap == 128) BE_BIN_ACC32(128); else if (cap == 64) BE_BIN_ACC32(64); else if (cap == 32) BE_BIN_ACC32(32);
+      else if (cap == 16) BE_BIN_ACC32(16); else BE_BIN_ACC32(8);
     } else {
       if (cap == 128) BE_BIN_ACC(false, 128); else if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
     }
@@ -1142,6 +1177,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       }
     }
 #undef BE_BIN_ACC
+#undef BE_BIN_ACC32
     BE_LAUNCH_CHECK();
   }
   be_prof_end(prof, st);

@@ -78,7 +78,7 @@ int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indi
                             int keep_exp, void* scratch, int64_t scratch_bytes, int* scale_exp_host, be_stream_t stream) {
   BE_REQUIRE(weights && scale_exp_host && scratch, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(nnz >= 0 && k > 0 && k <= 0xffffffffll, BE_ERR_INVALID, "bad nnz / k");
-  BE_REQUIRE(min_weight_bits >= 0 && min_weight_bits <= 40, BE_ERR_INVALID, "min_weight_bits out of range");
+  BE_REQUIRE(min_weight_bits >= 0 && min_weight_bits <= 60, BE_ERR_INVALID, "min_weight_bits out of range");
   BE_REQUIRE(scratch_bytes >= be_fixed_point_scratch_bytes(k), BE_ERR_WORKSPACE, "scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   uint32_t* stats = static_cast<uint32_t*>(scratch);                       // 4 words at the head

@@ -225,6 +225,7 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *           (brainevent/_csr/main.py:58-88, :148-161), so weight updates never invalidate it; here the blocks embed the
  *           weights, and this call is what keeps them current.  Re-derive scale_exp from the new maxabs / column sums.
  * ---------------------------------------------------------------------------------------------- */
+#define BE_BINNED_ACC32 2 /* `homo` argument of the binned entry points: per-entry weights, 32-bit fixed-point sums */
 #define BE_PLAN_U16 0 /* uint16 local columns (both weight kinds) */
 #define BE_PLAN_D8 1  /* sorted columns as uint8 deltas (heterogeneous weights) */
 #define BE_PLAN_H8 2  /* sorted columns as uint8 advance codes (one homogeneous weight) */
@@ -353,6 +354,12 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * merge through float atomics, and an overflowing block is added with float atomics too: both are order dependent in
  * the last bit (still within the 1e-5 tolerance of the path).  The planned route has neither exception.
  * Same role as binary_csrmv_wat_hybrid_* (brainevent/_csr/binary_csrmv_hybrid.cu:619-632): no preprocessing.
+ * `homo` of the binned entry points names the KIND of a step: 0 = per-entry weights, sums in 64-bit fixed point at 2^scale_exp;
+ * 1 = one shared weight (counts); BE_BINNED_ACC32 (2) = per-entry weights, sums in 32-bit fixed point at 2^scale_exp — bins twice
+ * as wide (10M outputs: 256 bins, one round of pass C, instead of 611), for matrices whose every column keeps its largest weight
+ * at >= 20 bits at that exponent: scale_exp = be_fixed_point_exponent(..., min_weight_bits = 20 + 32, ...) - 32 (BE_ERR_RANGE:
+ * use kind 0).  The largest column sum of |w| times 2^scale_exp stays below 2^30 by the same call; sums stay integers
+ * (order independent).  be_binned_bins and the workspace sizes take the same kind (a workspace is sized for all three).
  * ---------------------------------------------------------------------------------------------- */
 int be_binned_bins(int64_t k, int slice_shift, int homo);
 /* Task size of pass B (process-wide, read at every call): a task is about task_groups groups of four consecutive entries, and a

@@ -526,3 +526,45 @@ def test_plan_built_from_row_blocks_equals_the_resident_build(be, oracle, layout
         assert isinstance(be.BinaryArray(s) @ M, np.ndarray)                  # numpy events in, numpy out
         with pytest.raises(Exception):
             be.BinaryArray(torch.zeros(m + 1, dtype=torch.bool, device='cuda')) @ M
+
+
+def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle):
+    """BE_BINNED_ACC32: per-entry weights summed in 32-bit fixed point (bins twice as wide) — taken only when every column's
+    largest weight keeps >= 20 bits at the 32-bit exponent; then within 1e-5 of the oracle (measured ~1e-7), bitwise repeatable,
+    and within 2e-6 of the 64-bit sums; weights whose range the 32-bit sums cannot resolve fall back to 64-bit bins."""
+    from brainevent_amd._csr import BinnedScatter, MathError
+    rng = np.random.default_rng(61)
+    m, k, row = 4000, 300_000, 24
+    idx = torch.tensor(rng.integers(0, k, m * row).astype(np.int32), device='cuda')
+    ptr = torch.arange(0, m * row + 1, row, dtype=torch.int32, device='cuda')
+    w = torch.tensor((rng.random(m * row) * 2 - 0.5).astype(np.float32), device='cuda')       # mixed signs
+    v = torch.tensor(rng.random(m) < 0.2, device='cuda')
+    ref = oracle.binary_csrmv(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(), v.cpu().numpy(), (m, k), True)
+    ws32 = BinnedScatter(w, m, k, m * row, indices=idx, acc32=True)
+    ws64 = BinnedScatter(w, m, k, m * row, indices=idx, acc32=False)
+    assert ws32.acc32 and ws32.kind == 2 and not ws64.acc32 and ws64.kind == 0
+    assert ws32.scale_exp == ws64.scale_exp - 32
+    o32 = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws32)
+    o64 = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws64)
+    np.testing.assert_allclose(o32.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o32.cpu().numpy(), o64.cpu().numpy(), rtol=0, atol=2e-6 * float(w.abs().max()) * 8)
+    assert torch.equal(o32, be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws32))
+    # batches go through the same accumulators
+    B = torch.tensor(rng.random((m, 3)) < 0.2, device='cuda')
+    ob = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=ws32)
+    np.testing.assert_allclose(ob.cpu().numpy(), oracle.binary_csrmm(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(),
+                                                                       B.cpu().numpy(), (m, k), True), rtol=1e-5, atol=1e-5)
+    # a column whose only weight is 2^-22 of the largest column sum: 32-bit sums cannot give it 20 bits -> refused / 64-bit
+    w2 = w.clone()
+    w2[::7] *= 1e-6
+    with pytest.raises(MathError):
+        BinnedScatter(w2, m, k, m * row, indices=idx, acc32=True)
+    auto = BinnedScatter(w2, m, k, m * row, indices=idx)
+    assert not auto.acc32                                  # (also: below ACC32_MIN_OUTPUTS the automatic choice is 64-bit)
+    # an in-place update that stops qualifying moves a 32-bit workspace back to 64-bit bins
+    w.copy_(w2)
+    from brainevent_amd._csr import fresh_scatter_workspace
+    assert fresh_scatter_workspace(ws32, w, idx, ptr) is ws32 and not ws32.acc32
+    o = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws32)
+    ref2 = oracle.binary_csrmv(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(), v.cpu().numpy(), (m, k), True)
+    np.testing.assert_allclose(o.cpu().numpy(), ref2, rtol=1e-5, atol=1e-5)
