@@ -579,11 +579,28 @@ PLAN_KEEP_ORDER: Optional[bool] = None    # ScatterPlan.build(keep_order=...) of
                                           # (True: weights that change in place — plasticity — get a gather-copy refresh)
 
 
+#: a matrix with at least this many stored entries that ends up on the direct route (global float atomics: ~21 Geff/s on this
+#: chip, 35x below the planned route at C2) says so once per cause
+DIRECT_ROUTE_WARN_NNZ = 1 << 24
+
+
+def _warn_direct(nse: int, why: str) -> None:
+    if nse >= DIRECT_ROUTE_WARN_NNZ:
+        import warnings
+        warnings.warn(f"brainevent_amd: a matrix of {nse} stored entries runs its scatter product on the direct route (global float "
+                      f"atomics, ~21 G updates/s) because {why}; the fixed-point routes (plan / binned) are 10-40x faster.",
+                      stacklevel=3)
+
+
 def make_scatter_workspace(route: str, weights, indices, indptr, m: int, k: int, nse: int, row_len: int = -1):
     """The scatter workspace of a matrix for the chosen ``route`` (``None`` = direct route).  A plan that does not fit the
     free device memory (128 bytes per (row, slice) block: up to ~3x the raw matrix for short blocks) falls back to the binned
-    route, which needs no per-matrix layout; non-finite weights or an extreme dynamic range fall back to the direct route."""
+    route, which needs no per-matrix layout; non-finite weights or an extreme dynamic range fall back to the direct route —
+    with a warning for large matrices (``DIRECT_ROUTE_WARN_NNZ``): that is a 35x cliff at C2."""
     oom = getattr(torch, 'OutOfMemoryError', getattr(torch.cuda, 'OutOfMemoryError', RuntimeError))
+    if route == 'direct':
+        _warn_direct(nse, "neither the planned layout nor the binned route applies to its shape / weight dtype")
+        return None
     try:
         if route == 'plan':
             try:
@@ -592,11 +609,14 @@ def make_scatter_workspace(route: str, weights, indices, indptr, m: int, k: int,
                 torch.cuda.empty_cache()
                 route = 'binned' if BinnedScatter.applicable(weights, k) else 'direct'
         if route == 'binned':
-            return BinnedScatter(weights, m, k, nse, indices=indices)
-    except MathError:
-        return None           # inf / nan / extreme dynamic range: float atomics (direct route) handle those
+            return BinnedScatter(weights, m, k, nse, indices=indices, indptr=indptr, row_len=row_len)
+    except MathError as e:
+        # inf / nan / extreme dynamic range: float atomics (direct route) handle those
+        _warn_direct(nse, f"its weights do not qualify for fixed-point sums ({e})")
+        return None
     except oom:
         torch.cuda.empty_cache()
+        _warn_direct(nse, "no workspace fits the free device memory")
     return None
 
 
@@ -610,7 +630,8 @@ class BinnedScatter:
     """
 
     def __init__(self, weights: torch.Tensor, m: int, k: int, nnz: int, *, max_active_fraction: float = 0.05,
-                 slice_shift: Optional[int] = None, indices: Optional[torch.Tensor] = None, acc32: Optional[bool] = None):
+                 slice_shift: Optional[int] = None, indices: Optional[torch.Tensor] = None, acc32: Optional[bool] = None,
+                 indptr: Optional[torch.Tensor] = None, row_len: int = -1):
         self.m, self.k = int(m), int(k)
         self.homo = weights.numel() == 1
         if slice_shift is None and os.environ.get('BE_BIN_SHIFT'):      # A/B runs
@@ -630,9 +651,10 @@ class BinnedScatter:
         self.ws = self.workspace(1)
 
     #: per-entry weights: take 32-bit sums (twice the bin width: half the bins, one round of pass C) whenever every column's
-    #: largest weight keeps this many bits at the 32-bit exponent — outputs then good to ~2^-20 of their column's weight scale,
-    #: 16 x finer than MIN_WEIGHT_BITS asks of the 64-bit sums.  None: never.
-    ACC32_MIN_WEIGHT_BITS: Optional[int] = 20
+    #: largest weight keeps this many bits at the 32-bit exponent — every addend is then rounded by at most 2^-19 of its column's
+    #: largest weight, 4 x finer than MIN_WEIGHT_BITS asks of the 64-bit sums (C4: U[0,1) weights, ~1000 per column -> exponent
+    #: 20, 1e-6 of an output in the worst case, ~1e-7 measured).  None: never.
+    ACC32_MIN_WEIGHT_BITS: Optional[int] = 18
     #: ... and only over at least this many outputs (below, the 64-bit bins already are one round of pass C)
     ACC32_MIN_OUTPUTS = 256 * 20000
 
@@ -682,7 +704,7 @@ class BinnedScatter:
             if self.acc32:
                 try:
                     e64 = fixed_point_exponent(weights, indices, self.k, keep=self.scale_exp + 32,
-                                               min_bits=(self.ACC32_MIN_WEIGHT_BITS or 20) + 32)
+                                               min_bits=(self.ACC32_MIN_WEIGHT_BITS or 18) + 32)
                     self.scale_exp = e64 - 32
                 except MathError:       # no longer fine enough for 32-bit sums: back to 64-bit bins (new geometry, new workspaces)
                     self.scale_exp = fixed_point_exponent(weights, indices, self.k)
@@ -697,7 +719,7 @@ class BinnedScatter:
                                                   and weights.dtype == torch.float32 and not os.environ.get('BE_BIN_NO_ACC32'))
         if want32:
             try:        # the 64-bit exponent e leaves 2^62 of headroom; the same bound for 2^30 is e - 32
-                e64 = fixed_point_exponent(weights, indices, self.k, min_bits=(self.ACC32_MIN_WEIGHT_BITS or 20) + 32)
+                e64 = fixed_point_exponent(weights, indices, self.k, min_bits=(self.ACC32_MIN_WEIGHT_BITS or 18) + 32)
                 self.acc32, self.scale_exp = True, e64 - 32
                 return
             except MathError:
@@ -1531,11 +1553,21 @@ class CompressedSparseData(DataRepresentation):
         self.buffers['scatter_plan'] = plan
         return plan
 
-    def prepare(self, mirror: bool = False, keep_order: Optional[bool] = None):
+    def prepare(self, mirror: bool = False, keep_order: Optional[bool] = None, release_raw: bool = False):
         """Build the scatter workspace now (otherwise it is built by the first ``spk @ matrix``).
         ``mirror=True`` also builds the transposed mirror so that the *gather* direction runs event-driven too.
         ``keep_order=True``: a sorted-layout plan keeps its rows' column order (2 bytes per entry), which turns the refresh
-        after an in-place weight update from a re-sort into a gather-copy (``ScatterPlan.build``)."""
+        after an in-place weight update from a re-sort into a gather-copy (``ScatterPlan.build``).
+        ``release_raw=True``: return a :class:`PlannedMatrix` that serves ``events @ M`` from the plan alone — the caller drops
+        this container and with it the raw arrays (C2: 58 GB resident instead of 138 GB).  Needs a planned route (``MathError``
+        / ``ValueError`` otherwise: the binned and the direct route read the raw arrays on every step)."""
+        if release_raw:
+            plan = self._scatter_workspace() if keep_order is None else self.prepare(keep_order=keep_order)._scatter_workspace()
+            if not isinstance(plan, ScatterPlan):
+                raise ValueError("prepare(release_raw=True): this matrix has no scatter plan (route: "
+                                 f"{type(plan).__name__ if plan is not None else 'direct'}); its steps read the raw arrays.")
+            plan.order = None            # (a weight refresh needs the raw arrays anyway)
+            return PlannedMatrix(plan, self.data.reshape(-1)[:1] if plan.homo else None)
         if keep_order is not None and 'scatter_plan' not in self.buffers:
             global PLAN_KEEP_ORDER
             saved, PLAN_KEEP_ORDER = PLAN_KEEP_ORDER, keep_order

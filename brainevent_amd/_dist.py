@@ -475,6 +475,17 @@ class RankStep:
         return out
 
 
+    def captured(self, static_local, warmup: int = 3):
+        """This rank's step as ONE replayable HIP graph: exchange (``ncclAllGather`` on the caller's stream is capturable) +
+        the planned / binned step, recorded once over ``static_local`` — a buffer (tensor or ``PackedSpikes`` words) the producer
+        rewrites in place before every replay.  Returns a :class:`brainevent_amd._graph.GraphedStep`; its output tensor is
+        static too.  Every rank of the group must capture and replay in step (the collective is part of the graph)."""
+        from ._graph import GraphedStep
+        if self._fast is None:
+            raise ValueError("RankStep.captured: this step has no fast path (no fixed-point workspace / not the native exchange).")
+        return GraphedStep(lambda: self(static_local), warmup=warmup)
+
+
 class DistributedScatter:
     """``spikes @ M`` with ``M`` post-sliced over the ranks of a process group.
 

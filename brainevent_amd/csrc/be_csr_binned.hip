@@ -627,10 +627,10 @@ __device__ __forceinline__ void bin_count8(uint32_t* acc, uint4 v) {
 
 // ACC32 (per-entry weights only): the bin's sums are 32-bit fixed point at 2^scale_exp32 instead of 64-bit — 40000 accumulators
 // fit one workgroup's LDS instead of 20000, so 10M outputs are 256 bins (one round of pass C, blocks of 32 entries in pass B)
-// instead of 611 (2.4 rounds, blocks of 16).  Chosen by the host only when every column's largest weight keeps >= 20 bits at
-// that exponent (be_fixed_point_exponent with min_weight_bits = 20 + 32): an output is then good to ~1e-6 of its column's
-// weight scale — 16 x finer than the gate of the 64-bit sums asks for — and still an integer sum: order independent, bitwise
-// reproducible.  `scale` is then 2^scale_exp32 and inv_scale 2^-scale_exp32.
+// instead of 611 (2.4 rounds, blocks of 16).  Chosen by the host only when every column's largest weight keeps >= 18 bits at
+// that exponent (be_fixed_point_exponent with min_weight_bits = 18 + 32): every addend is then rounded by at most 2^-19 of its
+// column's largest weight — 4 x finer than the gate of the 64-bit sums asks for — and the sum is still an integer sum: order
+// independent, bitwise reproducible.  `scale` is then 2^scale_exp32 and inv_scale 2^-scale_exp32.
 template <bool HOMO, int CAP, bool ACC32 = false>
 __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restrict__ regions, const uint32_t* __restrict__ dir,
                                                          uint32_t cap_blocks, int width, int map_cap, int parts, int64_t k, float scale,

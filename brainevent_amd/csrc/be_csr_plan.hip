@@ -774,33 +774,159 @@ __device__ __forceinline__ void d8_lds_stage(unsigned long long* keys, int n2, i
 // sorted order — the row-local position of the i-th smallest column, uint16 — is written to order_out[b + i]; `order_in`
 // (fill / weight refresh): the order is read back instead of sorting again (a gather of the row's columns: the row is one
 // 40-KB window at most).  One of the two sorts of a build and every sort of a weight refresh disappear.
+// Round 4: the sort is a counting sort by column range followed by a rank sort inside each bucket — the row's columns are cut
+// into ~len / 48 equal ranges, every entry draws its place in its bucket from an LDS counter, and a wave then orders a bucket
+// in place by counting, for each of its (at most 4 per lane) keys, the keys of the bucket below it (every key of the bucket is
+// read once by the whole wave: a broadcast LDS read; no barrier inside a bucket).  One bitonic sort of 16384 keys was 105
+// compare-exchange stages with a barrier each (C2: 648 ms of a 850 ms build); this is 4 barriers per row.  Keys are unique
+// (the position is part of the key), so the result is THE sorted order whatever the arrival order at the counters.  Rows
+// whose columns cluster (a bucket above 256 keys) take the bitonic network as before; rows that already ascend skip the sort.
 __device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32_t* __restrict__ indices, int64_t b, int64_t e,
                                            const uint16_t* __restrict__ order_in = nullptr,
-                                           uint16_t* __restrict__ order_out = nullptr) {
+                                           uint16_t* __restrict__ order_out = nullptr, uint32_t col_range = 0) {
   // caller contract: rows have at most kD8MaxRow entries (the Python side checks it and falls back to the u16 layout);
   // a longer row is cut here rather than written past the LDS array
   const int len = (e - b) > (int64_t)kD8MaxRow ? kD8MaxRow : (int)(e - b);
+  constexpr int kPer = kD8MaxRow / 1024;            // entries a thread holds (blockDim.x == 1024)
   if (order_in != nullptr) {
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-      const uint32_t p = order_in[b + i];
-      keys[i] = ((unsigned long long)(uint32_t)indices[b + p] << 16) | (unsigned long long)p;
+    if (blockDim.x == 1024 && len > 0) {
+      // all positions first, then all column gathers: 16 loads in flight per thread instead of a dependent pair per iteration
+      // (a load under `if (i < len)` is waited for on the spot — vmcnt(0) — before the next one is issued)
+      uint32_t pv[kPer], cv[kPer];
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int i = threadIdx.x + q * 1024;
+        pv[q] = order_in[b + (i < len ? i : len - 1)];
+      }
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) cv[q] = (uint32_t)indices[b + pv[q]];
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int i = threadIdx.x + q * 1024;
+        if (i < len) keys[i] = ((unsigned long long)cv[q] << 16) | (unsigned long long)pv[q];
+      }
+    } else {
+      for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint32_t p = order_in[b + i];
+        keys[i] = ((unsigned long long)(uint32_t)indices[b + p] << 16) | (unsigned long long)p;
+      }
     }
     __syncthreads();
     return len;
   }
-  int n2 = 2;
-  while (n2 < len) n2 <<= 1;
-  // a row whose columns already ascend (canonical CSR) needs no sort: (column << 16 | position) ascends with the columns
-  int unsorted = 0;
-  for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-    keys[i] = i < len ? (((unsigned long long)(uint32_t)indices[b + i] << 16) | (unsigned long long)i) : ~0ull;
-    if (i > 0 && i < len && (uint32_t)indices[b + i] < (uint32_t)indices[b + i - 1]) unsorted = 1;
+  __shared__ uint32_t bk_cnt[1024], bk_start[1024], bk_wtot[16];
+  bool sorted_done = false;
+  if (col_range != 0u && len > 256 && blockDim.x == 1024) {
+    // buckets of ~48 keys: the rank sort costs (bucket size) compares per key, and a bucket of up to 64 keys is one key per lane
+    const uint32_t nb = (uint32_t)((len + 47) / 48) < 1024u ? (uint32_t)((len + 47) / 48) : 1024u;
+    const uint32_t bw = (col_range + nb - 1u) / nb;                                                    // columns per bucket
+    const uint32_t magic = (uint32_t)(0xffffffffull / bw);                // floor((2^32 - 1) / bw): the quotient below is <= 1 short
+    bk_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t colv[kPer], rk[kPer], prevv[kPer];
+    int unsorted = 0;
+    // every load of the row is issued before the first use (clamped addresses instead of branches: see above)
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int i = threadIdx.x + q * 1024;
+      const int ii = i < len ? i : len - 1;
+      colv[q] = (uint32_t)indices[b + ii];
+      prevv[q] = (uint32_t)indices[b + (ii > 0 ? ii - 1 : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int i = threadIdx.x + q * 1024;
+      rk[q] = 0u;
+      if (i < len) {
+        const uint32_t c = colv[q];
+        uint32_t sb = __umulhi(c, magic);
+        if (c - sb * bw >= bw) ++sb;
+        sb = sb < nb ? sb : nb - 1u;                  // (a column >= col_range is the caller's error: kept in the last bucket)
+        rk[q] = (sb << 16) | atomicAdd(&bk_cnt[sb], 1u);
+        if (i > 0 && c < prevv[q]) unsorted = 1;
+      }
+    }
+    if (!__syncthreads_or(unsorted)) {                // canonical rows: (column << 16 | position) ascends with the columns
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int i = threadIdx.x + q * 1024;
+        if (i < len) keys[i] = ((unsigned long long)colv[q] << 16) | (unsigned long long)i;
+      }
+      __syncthreads();
+      sorted_done = true;
+    } else {
+      const uint32_t mine = threadIdx.x < nb ? bk_cnt[threadIdx.x] : 0u;
+      const int too_big = mine > 256u ? 1 : 0;
+      const uint32_t incl = block_scan_1024(mine, bk_wtot);              // (two barriers)
+      bk_start[threadIdx.x] = incl - mine;
+      if (!__syncthreads_or(too_big)) {
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const int i = threadIdx.x + q * 1024;
+          if (i < len) keys[bk_start[rk[q] >> 16] + (rk[q] & 0xffffu)] = ((unsigned long long)colv[q] << 16) | (unsigned long long)i;
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (uint32_t bk = (uint32_t)wave; bk < nb; bk += 16u) {        // a wave orders a bucket in place
+          const uint32_t B = bk_cnt[bk];
+          unsigned long long* kb = keys + bk_start[bk];
+          // the bucket's keys are read from LDS once, 64 at a time (one per lane), and handed round the wave by v_readlane: the
+          // inner loop has no memory access (reading key j from LDS per iteration was bound by the LDS latency: 86 us per
+          // 10 000-entry row)
+          if (B <= 64u) {                                                 // nearly every bucket: one key per lane
+            const unsigned long long mk = (uint32_t)lane < B ? kb[lane] : ~0ull;
+            const uint32_t lo = (uint32_t)mk, hi = (uint32_t)(mk >> 32);
+            uint32_t below = 0u;
+            for (uint32_t j = 0; j < B; ++j) {
+              const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)j) << 32) |
+                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, (int)j);
+              below += kj < mk ? 1u : 0u;
+            }
+            __builtin_amdgcn_wave_barrier();                              // (every lane holds its key: nothing reads the bucket any more)
+            if ((uint32_t)lane < B) kb[below] = mk;
+          } else {                                                        // up to 256 keys: four per lane
+            unsigned long long mk[4];
+            uint32_t below[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mk[q] = (uint32_t)(lane + 64 * q) < B ? kb[lane + 64 * q] : ~0ull;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if ((uint32_t)(64 * c) >= B) break;                          // (uniform)
+              const uint32_t lo = (uint32_t)mk[c], hi = (uint32_t)(mk[c] >> 32);
+              const uint32_t nj = B - 64u * (uint32_t)c < 64u ? B - 64u * (uint32_t)c : 64u;
+              for (uint32_t j = 0; j < nj; ++j) {
+                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)j) << 32) |
+                                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, (int)j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) below[q] += kj < mk[q] ? 1u : 0u;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if ((uint32_t)(lane + 64 * q) < B) kb[below[q]] = mk[q];
+          }
+        }
+        __syncthreads();
+        sorted_done = true;
+      }
+    }
   }
-  if (__syncthreads_or(unsorted)) {
-    // (a thread owning 16 consecutive keys and running the strides below 16 in registers was tried: its strided LDS reads
-    //  conflict 32-way and the build took 1.8 x as long)
-    for (int k2 = 2; k2 <= n2; k2 <<= 1)
-      for (int j = k2 >> 1; j > 0; j >>= 1) d8_lds_stage(keys, n2, k2, j);
+  if (!sorted_done) {
+    int n2 = 2;
+    while (n2 < len) n2 <<= 1;
+    // a row whose columns already ascend (canonical CSR) needs no sort: (column << 16 | position) ascends with the columns
+    int unsorted = 0;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+      keys[i] = i < len ? (((unsigned long long)(uint32_t)indices[b + i] << 16) | (unsigned long long)i) : ~0ull;
+      if (i > 0 && i < len && (uint32_t)indices[b + i] < (uint32_t)indices[b + i - 1]) unsorted = 1;
+    }
+    if (__syncthreads_or(unsorted)) {
+      // (a thread owning 16 consecutive keys and running the strides below 16 in registers was tried: its strided LDS reads
+      //  conflict 32-way and the build took 1.8 x as long)
+      for (int k2 = 2; k2 <= n2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) d8_lds_stage(keys, n2, k2, j);
+    }
   }
   if (order_out != nullptr)
     for (int i = threadIdx.x; i < len; i += blockDim.x) order_out[b + i] = (uint16_t)(keys[i] & 0xffffull);
@@ -811,17 +937,25 @@ __device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32
 struct D8Item { uint32_t s, loc, esc, rem; bool first; };
 // H8 = the homogeneous-weight variant of the encoding (see "h8" below): code 255 is reserved for the escape itself,
 // so a gap is esc x 255 + rem with rem in [0, 254]; d8 keeps rem in [1, 255] for a non-zero gap.
+// col / W without the ~35-instruction integer division (three loops of the fill walk every sorted position through it, twice):
+// the quotient by floor((2^32 - 1) / W) is at most one short
+__device__ __forceinline__ uint32_t d8_div(uint32_t col, uint32_t W) {
+  const uint32_t magic = (uint32_t)(0xffffffffull / W);        // (W is uniform: computed once per wave by the compiler's hoisting)
+  uint32_t q = __umulhi(col, magic);
+  if (col - q * W >= W) ++q;
+  return q;
+}
 template <bool H8 = false>
 __device__ __forceinline__ D8Item d8_item(const unsigned long long* keys, int i, uint32_t W) {
   D8Item it;
   const uint32_t col = (uint32_t)(keys[i] >> 16);
-  it.s = col / W;
+  it.s = d8_div(col, W);
   it.loc = col - it.s * W;
   uint32_t gap = 0;
   it.first = true;
   if (i > 0) {
     const uint32_t prev = (uint32_t)(keys[i - 1] >> 16);
-    if (prev / W == it.s) {
+    if (d8_div(prev, W) == it.s) {
       it.first = false;
       gap = col - prev;
     }
@@ -844,7 +978,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restric
     const int64_t rb = rp.at(r), re = rp.at(r + 1);
     // a row the LDS sort cannot hold: reported to the host, which fails the build (d8_sort_row would cut it)
     if (threadIdx.x == 0 && re - rb > (int64_t)kD8MaxRow) atomicMax(too_long, (unsigned long long)(re - rb));
-    const int len = d8_sort_row(d8_keys, indices, rb, re, nullptr, order_out);   // ends with a barrier
+    const int len = d8_sort_row(d8_keys, indices, rb, re, nullptr, order_out, slice_width * (uint32_t)n_slices);   // ends with a barrier
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
       const D8Item it = d8_item<H8>(d8_keys, i, slice_width);
       atomicAdd(&tot[it.s], 1u + it.esc);
@@ -878,7 +1012,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
       tot[s] = 0;
     }
     const int64_t rb = rp.at(r);
-    const int len = d8_sort_row(d8_keys, indices, rb, rp.at(r + 1), order);
+    const int len = d8_sort_row(d8_keys, indices, rb, rp.at(r + 1), order, nullptr, slice_width * (uint32_t)n_slices);
     // inclusive prefix sums of the escape counts over the sorted row: a thread owns `per` consecutive positions
     const int per = (len + 1023) >> 10;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
@@ -892,8 +1026,22 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
       if (it.first) { first_idx[it.s] = (uint32_t)i; e_first[it.s] = run; }
     }
     __syncthreads();
+    // the thread's weights first, all in flight together (clamped positions instead of a branch per load: a gather under
+    // `if` is waited for on the spot, one memory round trip per entry — 16 per row and thread)
+    constexpr int kOwn = kD8MaxRow / 1024;
+    float wown[kOwn];
+    if (len > 0) {
+#pragma unroll
+      for (int t = 0; t < kOwn; ++t) {
+        const int i = i0 + t < i1 ? i0 + t : (i1 > i0 ? i1 - 1 : len - 1);
+        wown[t] = (float)WTraits<W>::load(weights, rb + (int64_t)(d8_keys[i] & 0xffffull));
+      }
+    }
     run = excl;
-    for (int i = i0; i < i1; ++i) {
+#pragma unroll
+    for (int t = 0; t < kOwn; ++t) {
+      const int i = i0 + t;
+      if (i >= i1) break;
       const D8Item it = d8_item(d8_keys, i, slice_width);
       run += it.esc;
       const uint32_t pos = ((uint32_t)i - first_idx[it.s]) + (run - e_first[it.s]);
@@ -901,7 +1049,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
       float* wp = reinterpret_cast<float*>(blk);
       unsigned char* dp = blk + (size_t)seg_ng[it.s] * 16;
       for (uint32_t q = pos - it.esc; q < pos; ++q) { wp[q] = 0.f; dp[q] = 255; }
-      const float w = (float)WTraits<W>::load(weights, rb + (int64_t)(d8_keys[i] & 0xffffull));
+      const float w = wown[t];
       wp[pos] = w;
       dp[pos] = (unsigned char)it.rem;
       atomicMax(&tot[it.s], pos + 1u);
@@ -1261,7 +1409,7 @@ __global__ void __launch_bounds__(1024) k_plan_h8_fill(const int32_t* __restrict
       seg_ng[s] = sg.y & 0xffffu;
       tot[s] = 0;
     }
-    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1), order);
+    const int len = d8_sort_row(d8_keys, indices, rp.at(r), rp.at(r + 1), order, nullptr, slice_width * (uint32_t)n_slices);
     const int per = (len + 1023) >> 10;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
     uint32_t mine = 0;

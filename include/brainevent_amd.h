@@ -357,7 +357,7 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * `homo` of the binned entry points names the KIND of a step: 0 = per-entry weights, sums in 64-bit fixed point at 2^scale_exp;
  * 1 = one shared weight (counts); BE_BINNED_ACC32 (2) = per-entry weights, sums in 32-bit fixed point at 2^scale_exp — bins twice
  * as wide (10M outputs: 256 bins, one round of pass C, instead of 611), for matrices whose every column keeps its largest weight
- * at >= 20 bits at that exponent: scale_exp = be_fixed_point_exponent(..., min_weight_bits = 20 + 32, ...) - 32 (BE_ERR_RANGE:
+ * at >= 18 bits at that exponent: scale_exp = be_fixed_point_exponent(..., min_weight_bits = 18 + 32, ...) - 32 (BE_ERR_RANGE:
  * use kind 0).  The largest column sum of |w| times 2^scale_exp stays below 2^30 by the same call; sums stay integers
  * (order independent).  be_binned_bins and the workspace sizes take the same kind (a workspace is sized for all three).
  * ---------------------------------------------------------------------------------------------- */

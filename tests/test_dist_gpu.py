@@ -191,6 +191,21 @@ def test_rank_step_fast_path_equals_the_operator_surface():
             fast = step(local)
             slow = ex.gather_events(local) @ csr
             assert torch.equal(fast, slow), (route, kind)
+        # the whole rank step (exchange + scatter) as one replayed HIP graph over a static local buffer: same bits
+        static = torch.zeros(n_pre, dtype=torch.bool, device=dev)
+        graphed = step.captured(static)
+        for _ in range(3):
+            s = rng.random(n_pre) < 0.05
+            static.copy_(torch.from_numpy(s).to(dev))
+            assert torch.equal(graphed(), step(static)), route
+        del graphed
+        # a caller that REBINDS shard.data (instead of updating it in place) must not get the old weights through the raw pointers
+        old_data = csr.data
+        csr.data = (old_data * 3.0).contiguous()
+        assert torch.equal(step(static), ex.gather_events(static) @ csr), route
+        csr.data = old_data
+        csr.buffers['scatter_plan'] = C.fresh_scatter_workspace(csr.buffers['scatter_plan'], csr.data, csr.indices, csr.indptr)
+        step = D.RankStep(ex, csr)
         csr.data.mul_(0.5)                                   # in-place update: the fast path notices and hands over
         local = torch.from_numpy(s).to(dev)
         got = step(local)

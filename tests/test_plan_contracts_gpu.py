@@ -530,14 +530,14 @@ def test_plan_built_from_row_blocks_equals_the_resident_build(be, oracle, layout
 
 def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle):
     """BE_BINNED_ACC32: per-entry weights summed in 32-bit fixed point (bins twice as wide) — taken only when every column's
-    largest weight keeps >= 20 bits at the 32-bit exponent; then within 1e-5 of the oracle (measured ~1e-7), bitwise repeatable,
+    largest weight keeps >= 18 bits at the 32-bit exponent; then within 1e-5 of the oracle (measured ~1e-7), bitwise repeatable,
     and within 2e-6 of the 64-bit sums; weights whose range the 32-bit sums cannot resolve fall back to 64-bit bins."""
     from brainevent_amd._csr import BinnedScatter, MathError
     rng = np.random.default_rng(61)
     m, k, row = 4000, 300_000, 24
     idx = torch.tensor(rng.integers(0, k, m * row).astype(np.int32), device='cuda')
     ptr = torch.arange(0, m * row + 1, row, dtype=torch.int32, device='cuda')
-    w = torch.tensor((rng.random(m * row) * 2 - 0.5).astype(np.float32), device='cuda')       # mixed signs
+    w = torch.tensor((rng.uniform(0.25, 1.0, m * row) * rng.choice([-1.0, 1.0], m * row)).astype(np.float32), device='cuda')   # mixed signs
     v = torch.tensor(rng.random(m) < 0.2, device='cuda')
     ref = oracle.binary_csrmv(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(), v.cpu().numpy(), (m, k), True)
     ws32 = BinnedScatter(w, m, k, m * row, indices=idx, acc32=True)
@@ -554,7 +554,7 @@ def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle):
     ob = be.binary_csrmm(w, idx, ptr, B, shape=(m, k), transpose=True, workspace=ws32)
     np.testing.assert_allclose(ob.cpu().numpy(), oracle.binary_csrmm(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(),
                                                                        B.cpu().numpy(), (m, k), True), rtol=1e-5, atol=1e-5)
-    # a column whose only weight is 2^-22 of the largest column sum: 32-bit sums cannot give it 20 bits -> refused / 64-bit
+    # columns whose only weight is ~1e-6 of the largest column sum: 32-bit sums cannot give them 18 bits -> refused / 64-bit
     w2 = w.clone()
     w2[::7] *= 1e-6
     with pytest.raises(MathError):
@@ -568,3 +568,53 @@ def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle):
     o = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws32)
     ref2 = oracle.binary_csrmv(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(), v.cpu().numpy(), (m, k), True)
     np.testing.assert_allclose(o.cpu().numpy(), ref2, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_row_sort_of_the_sorted_layouts_by_counting(be, oracle, monkeypatch, homo):
+    """Round 4: the d8 / h8 build orders a row by a counting sort over column ranges + a rank sort inside each bucket instead of
+    one bitonic network.  Rows that exercise every branch — uniform columns (buckets of ~128), columns clustered into a few
+    hundred ids (buckets above 256: the bitonic fallback), many duplicates of one column, already ascending rows, rows at the
+    16384 limit, short rows — must give the products of the unsorted uint16 layout bit for bit and match the oracle."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(71)
+    k = 90_000
+    rows = []
+    rows.append(rng.integers(0, k, 10_000))                              # uniform
+    rows.append(rng.integers(40_000, 40_300, 6_000))                     # clustered: one or two buckets hold everything
+    rows.append(np.concatenate([np.full(3_000, 777), rng.integers(0, k, 2_000)]))      # many duplicates
+    rows.append(np.sort(rng.integers(0, k, 9_000)))                      # ascending already
+    rows.append(rng.integers(0, k, 16_384))                              # the longest row the layouts take
+    rows.append(rng.integers(0, k, 300))
+    rows.append(rng.integers(0, k, 257))
+    rows.append(np.array([5, 3, 3, 89_999, 0]))
+    rows.append(np.array([], dtype=np.int64))
+    rows += [rng.integers(0, k, int(n)) for n in rng.integers(200, 3000, 40)]
+    lens = np.array([len(r) for r in rows])
+    m = len(rows)
+    idx = np.concatenate(rows).astype(np.int32)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    w = np.array([0.5], np.float32) if homo else rng.uniform(-1, 1, idx.size).astype(np.float32)
+    dw, di, dp = torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')
+    sorted_plan = C.ScatterPlan.build(dw, di, dp, shape=(m, k), layout='h8' if homo else 'd8', keep_order=True)
+    plain_plan = C.ScatterPlan.build(dw, di, dp, shape=(m, k), layout='u16', slice_shift=sorted_plan.slice_shift)
+    for trial in range(3):
+        v = rng.random(m) < (1.0 if trial == 0 else 0.4)
+        dv = torch.tensor(v, device='cuda')
+        a = be.binary_csrmv(dw, di, dp, dv, shape=(m, k), transpose=True, workspace=sorted_plan)
+        b = be.binary_csrmv(dw, di, dp, dv, shape=(m, k), transpose=True, workspace=plain_plan)
+        if homo:
+            assert torch.equal(a, b)
+        else:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-6)   # (exponents of the two plans may differ)
+        ref = oracle.binary_csrmv(np.asarray(w, np.float64), idx, ptr, v, (m, k), True)
+        np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    # the stored order really is the ascending column order of every row (ties by position)
+    if homo:          # (one shared weight is never re-encoded: its plan does not keep the order)
+        return
+    order = sorted_plan.order.cpu().numpy().astype(np.int64) & 0xffff
+    for r in (0, 1, 2, 4, 7):
+        seg = slice(ptr[r], ptr[r + 1])
+        want = np.lexsort((np.arange(lens[r]), idx[seg]))
+        np.testing.assert_array_equal(order[seg], want)
