@@ -398,7 +398,11 @@ def run_fcn(args, dev, g):
     n_post = args.n_post or n
     w, idx = gen_fixed_num_on_device(n, K, n_post, args.homo, dev, g)
     conn = be.FixedNumPerPre((w, idx), shape=(n, n_post), check_indices=False)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter()
     conn.prepare()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
     spikes = torch.rand((n_batch, n), device=dev, generator=g) < args.fire
     act = spikes.sum(dim=1).cpu().numpy()
     step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ conn
@@ -410,7 +414,9 @@ def run_fcn(args, dev, g):
     ws = conn.buffers.get('scatter_plan')
     cfg = {'workload': f"BinaryArray({args.fire:g}) @ FixedNumPerPre K={K} {n} pre x {n_post} post "
                        f"{'homo' if args.homo else 'hetero'} f32, 1 GPU",
-           'route': type(ws).__name__ if ws is not None else 'direct (global atomics)'}
+           'route': (type(ws).__name__ + (' (32-bit fixed-point sums, BE_BINNED_ACC32)' if getattr(ws, 'acc32', False) else ''))
+                    if ws is not None else 'direct (global atomics)',
+           'setup_s': round(t_setup, 3)}
     alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n_post
     # the step is several kernels of similar weight on this route: the whole-step HIP-event time is the honest divisor
     whole = float(np.median(step_ms))

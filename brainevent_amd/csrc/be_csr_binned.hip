@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
                                                      float* __restrict__ out, DivU32 fixdiv,
                                                      const uint32_t* __restrict__ row_masks, int n_bins_b, int64_t k,
                                                      uint32_t min_tasks, uint32_t task_groups, int64_t m_rows,
-                                                     uint32_t* __restrict__ err_flag) {
+                                                     uint32_t* __restrict__ err_flag, uint32_t sign_mask) {
   // row_masks != NULL: a batch.  `active` lists the rows with a spike in ANY of the (<= 32) batch rows of this pass and
   // row_masks[j] says in which; the bins are virtual — batch row b's bin i is n_bins_b * b + i of n_bins — and an entry is
   // appended once per batch row that has its row active (the rows are read once for the whole batch).
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
               }
               if (!HOMO) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wA[HOMO ? 0 : u * 4 + j] = wC[u][HOMO ? 0 : j];
+                for (int j = 0; j < 4; ++j) wA[HOMO ? 0 : u * 4 + j] = __uint_as_float(__float_as_uint(wC[u][HOMO ? 0 : j]) & sign_mask);
               }
             }
             do {                                          // once; a batch: once per batch row some lane's row is active in
@@ -1038,6 +1038,10 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   BE_REQUIRE(check_rows(indptr, row_len), BE_ERR_INVALID, "indptr is NULL and row_len < 0");
   BE_REQUIRE(weights && indices && spikes_bm && out_bm, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(bin_capacity >= 8 && bin_capacity < (1ll << 32), BE_ERR_INVALID, "bin_capacity out of range");
+  // BE_BINNED_ABS (bit 2, per-entry weights): the step sums |w| (pass B clears the sign of every weight it reads) — the column
+  // statistics a fixed-point exponent is derived from
+  const uint32_t sign_mask = (homo & 4) ? 0x7fffffffu : 0xffffffffu;
+  homo &= ~4;
   BE_REQUIRE(homo >= 0 && homo <= 2, BE_ERR_INVALID, "homo must be 0 (per-entry weights), 1 (one weight) or 2 (BE_BINNED_ACC32)");
   const int kind = homo;
   const bool acc32 = kind == 2;
@@ -1118,7 +1122,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
                        al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \
-                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m, count + kBinErrWord);                         \
+                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m, count + kBinErrWord, sign_mask);              \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \

@@ -939,23 +939,23 @@ struct D8Item { uint32_t s, loc, esc, rem; bool first; };
 // so a gap is esc x 255 + rem with rem in [0, 254]; d8 keeps rem in [1, 255] for a non-zero gap.
 // col / W without the ~35-instruction integer division (three loops of the fill walk every sorted position through it, twice):
 // the quotient by floor((2^32 - 1) / W) is at most one short
-__device__ __forceinline__ uint32_t d8_div(uint32_t col, uint32_t W) {
-  const uint32_t magic = (uint32_t)(0xffffffffull / W);        // (W is uniform: computed once per wave by the compiler's hoisting)
+__device__ __forceinline__ uint32_t d8_magic(uint32_t W) { return (uint32_t)(0xffffffffull / W); }     // once per kernel
+__device__ __forceinline__ uint32_t d8_div(uint32_t col, uint32_t W, uint32_t magic) {
   uint32_t q = __umulhi(col, magic);
   if (col - q * W >= W) ++q;
   return q;
 }
 template <bool H8 = false>
-__device__ __forceinline__ D8Item d8_item(const unsigned long long* keys, int i, uint32_t W) {
+__device__ __forceinline__ D8Item d8_item(const unsigned long long* keys, int i, uint32_t W, uint32_t magic) {
   D8Item it;
   const uint32_t col = (uint32_t)(keys[i] >> 16);
-  it.s = d8_div(col, W);
+  it.s = d8_div(col, W, magic);
   it.loc = col - it.s * W;
   uint32_t gap = 0;
   it.first = true;
   if (i > 0) {
     const uint32_t prev = (uint32_t)(keys[i - 1] >> 16);
-    if (d8_div(prev, W) == it.s) {
+    if (d8_div(prev, W, magic) == it.s) {
       it.first = false;
       gap = col - prev;
     }
@@ -971,6 +971,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restric
                                                         uint32_t slice_width, int n_slices, uint2* __restrict__ seg,
                                                         unsigned long long* __restrict__ too_long,
                                                         uint16_t* __restrict__ order_out) {
+  const uint32_t wmagic = d8_magic(slice_width);
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t tot[kD8MaxSlices], base_s[kD8MaxSlices];
   for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
@@ -980,7 +981,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_count(const int32_t* __restric
     if (threadIdx.x == 0 && re - rb > (int64_t)kD8MaxRow) atomicMax(too_long, (unsigned long long)(re - rb));
     const int len = d8_sort_row(d8_keys, indices, rb, re, nullptr, order_out, slice_width * (uint32_t)n_slices);   // ends with a barrier
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
-      const D8Item it = d8_item<H8>(d8_keys, i, slice_width);
+      const D8Item it = d8_item<H8>(d8_keys, i, slice_width, wmagic);
       atomicAdd(&tot[it.s], 1u + it.esc);
       if (it.first) base_s[it.s] = it.loc;
     }
@@ -999,6 +1000,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
                                                        RowPtr rp, int64_t m, uint32_t slice_width, int n_slices,
                                                        const uint2* __restrict__ seg, unsigned char* __restrict__ blob,
                                                        uint32_t* __restrict__ maxabs_bits, const uint16_t* __restrict__ order) {
+  const uint32_t wmagic = d8_magic(slice_width);
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t first_idx[kD8MaxSlices], e_first[kD8MaxSlices], seg_start[kD8MaxSlices], seg_ng[kD8MaxSlices],
       tot[kD8MaxSlices];
@@ -1017,11 +1019,11 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
     const int per = (len + 1023) >> 10;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
     uint32_t mine = 0;
-    for (int i = i0; i < i1; ++i) mine += d8_item(d8_keys, i, slice_width).esc;
+    for (int i = i0; i < i1; ++i) mine += d8_item(d8_keys, i, slice_width, wmagic).esc;
     const uint32_t excl = block_scan_1024(mine, wtot) - mine;
     uint32_t run = excl;
     for (int i = i0; i < i1; ++i) {
-      const D8Item it = d8_item(d8_keys, i, slice_width);
+      const D8Item it = d8_item(d8_keys, i, slice_width, wmagic);
       run += it.esc;
       if (it.first) { first_idx[it.s] = (uint32_t)i; e_first[it.s] = run; }
     }
@@ -1042,7 +1044,7 @@ __global__ void __launch_bounds__(1024) k_plan_d8_fill(const W* __restrict__ wei
     for (int t = 0; t < kOwn; ++t) {
       const int i = i0 + t;
       if (i >= i1) break;
-      const D8Item it = d8_item(d8_keys, i, slice_width);
+      const D8Item it = d8_item(d8_keys, i, slice_width, wmagic);
       run += it.esc;
       const uint32_t pos = ((uint32_t)i - first_idx[it.s]) + (run - e_first[it.s]);
       unsigned char* blk = blob + ((int64_t)seg_start[it.s] << 7);
@@ -1398,6 +1400,7 @@ __global__ void __launch_bounds__(1024) k_plan_accumulate_d8(const unsigned char
 __global__ void __launch_bounds__(1024) k_plan_h8_fill(const int32_t* __restrict__ indices, RowPtr rp, int64_t m,
                                                        uint32_t slice_width, int n_slices, const uint2* __restrict__ seg,
                                                        unsigned char* __restrict__ blob, const uint16_t* __restrict__ order) {
+  const uint32_t wmagic = d8_magic(slice_width);
   extern __shared__ unsigned long long d8_keys[];
   __shared__ uint32_t first_idx[kD8MaxSlices], e_first[kD8MaxSlices], seg_start[kD8MaxSlices], seg_ng[kD8MaxSlices],
       tot[kD8MaxSlices];
@@ -1413,18 +1416,18 @@ __global__ void __launch_bounds__(1024) k_plan_h8_fill(const int32_t* __restrict
     const int per = (len + 1023) >> 10;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < len) ? i0 + per : len;
     uint32_t mine = 0;
-    for (int i = i0; i < i1; ++i) mine += d8_item<true>(d8_keys, i, slice_width).esc;
+    for (int i = i0; i < i1; ++i) mine += d8_item<true>(d8_keys, i, slice_width, wmagic).esc;
     const uint32_t excl = block_scan_1024(mine, wtot) - mine;
     uint32_t run = excl;
     for (int i = i0; i < i1; ++i) {
-      const D8Item it = d8_item<true>(d8_keys, i, slice_width);
+      const D8Item it = d8_item<true>(d8_keys, i, slice_width, wmagic);
       run += it.esc;
       if (it.first) { first_idx[it.s] = (uint32_t)i; e_first[it.s] = run; }
     }
     __syncthreads();
     run = excl;
     for (int i = i0; i < i1; ++i) {
-      const D8Item it = d8_item<true>(d8_keys, i, slice_width);
+      const D8Item it = d8_item<true>(d8_keys, i, slice_width, wmagic);
       run += it.esc;
       const uint32_t pos = ((uint32_t)i - first_idx[it.s]) + (run - e_first[it.s]);
       unsigned char* blk = blob + ((int64_t)seg_start[it.s] << 7);

@@ -226,6 +226,8 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
  *           weights, and this call is what keeps them current.  Re-derive scale_exp from the new maxabs / column sums.
  * ---------------------------------------------------------------------------------------------- */
 #define BE_BINNED_ACC32 2 /* `homo` argument of the binned entry points: per-entry weights, 32-bit fixed-point sums */
+#define BE_BINNED_ABS 4   /* ... OR-ed to 0 / 2: the step sums |w| (column statistics: how a caller derives scale_exp with a few
+                            binned steps over all the rows instead of a pass of global atomics over the entries) */
 #define BE_PLAN_U16 0 /* uint16 local columns (both weight kinds) */
 #define BE_PLAN_D8 1  /* sorted columns as uint8 deltas (heterogeneous weights) */
 #define BE_PLAN_H8 2  /* sorted columns as uint8 advance codes (one homogeneous weight) */

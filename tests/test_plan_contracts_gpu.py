@@ -618,3 +618,44 @@ def test_row_sort_of_the_sorted_layouts_by_counting(be, oracle, monkeypatch, hom
         seg = slice(ptr[r], ptr[r + 1])
         want = np.lexsort((np.arange(lens[r]), idx[seg]))
         np.testing.assert_array_equal(order[seg], want)
+
+
+@pytest.mark.parametrize('fixed_rows', [True, False])
+def test_binned_exponent_from_binned_steps_equals_the_atomic_pass(be, oracle, monkeypatch, fixed_rows):
+    """Round 4: the column statistics behind a binned workspace's exponent (largest column sum of |w|, the accuracy gate) come
+    from binned steps over |w| and over counts (BE_BINNED_ABS) instead of passes of global atomics over the entries.  Same
+    exponent as ``be_fixed_point_exponent`` (the step sums are exact to 2^-29 of a weight, the atomic float sums are not: the
+    bound may land on the other side of a power of two only when it sits within 1e-3 of one), products within 1e-5."""
+    from brainevent_amd._csr import BinnedScatter, fixed_point_exponent
+    rng = np.random.default_rng(81)
+    m, k, row = 30_000, 400_000, 40
+    if fixed_rows:
+        idx = torch.tensor(rng.integers(0, k, (m, row)).astype(np.int32), device='cuda')
+        ptr, rl = None, row
+        ptr_np = np.arange(0, m * row + 1, row, dtype=np.int32)
+    else:
+        lens = rng.integers(0, 2 * row, m)
+        ptr_np = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        idx = torch.tensor(rng.integers(0, k, int(ptr_np[-1])).astype(np.int32), device='cuda')
+        ptr, rl = torch.tensor(ptr_np, device='cuda'), -1
+    nnz = int(idx.numel())
+    w = torch.tensor((rng.uniform(0.2, 1.0, nnz) * rng.choice([-1.0, 1.0], nnz)).astype(np.float32), device='cuda')
+    flat_idx = idx.reshape(-1)
+    e_atomic = fixed_point_exponent(w, flat_idx, k)
+    monkeypatch.setattr(BinnedScatter, 'STATS_BY_STEPS_MIN_NNZ', 1)
+    ws = BinnedScatter(w, m, k, nnz, indices=flat_idx, indptr=ptr, row_len=rl, acc32=False)
+    assert ws._stats is not None and ws.scale_exp == e_atomic
+    colsum = np.zeros(k); np.add.at(colsum, flat_idx.cpu().numpy(), np.abs(w.cpu().numpy().astype(np.float64)))
+    np.testing.assert_allclose(ws._stats[0], colsum.max(), rtol=1e-6)
+    v = rng.random(m) < 0.05
+    got = be.binary_csrmv(w, flat_idx, torch.tensor(ptr_np, device='cuda'), torch.tensor(v, device='cuda'), shape=(m, k), transpose=True,
+                          workspace=ws)
+    ref = oracle.binary_csrmv(w.cpu().numpy().astype(np.float64), flat_idx.cpu().numpy(), ptr_np, v, (m, k), True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    # 32-bit sums decided from the same statistics
+    ws32 = BinnedScatter(w, m, k, nnz, indices=flat_idx, indptr=ptr, row_len=rl, acc32=True)
+    assert ws32.acc32 and ws32.scale_exp == e_atomic - 32
+    # inf / nan are refused before any step runs
+    w_bad = w.clone(); w_bad[5] = float('inf')
+    with pytest.raises(be.MathError):
+        BinnedScatter(w_bad, m, k, nnz, indices=flat_idx, indptr=ptr, row_len=rl)
