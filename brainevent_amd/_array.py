@@ -37,6 +37,9 @@ class PackedSpikes:
     dtype = property(lambda self: torch.bool)
     size = property(lambda self: self.n)
 
+    def __len__(self) -> int:
+        return self.n
+
 
 class _SpikeIdsStruct(ctypes.Structure):      # be_spike_ids_t of include/brainevent_amd.h
     _fields_ = [('active_ids', ctypes.c_void_p), ('n_active', ctypes.c_void_p)]

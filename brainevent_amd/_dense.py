@@ -38,6 +38,11 @@ def _dense_batched(weights: torch.Tensor, spikes_bm: torch.Tensor, sd: int, tran
         return out
     f_ws = fn('be_binary_densemm_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int, c_int])
     ws = A.workspace(f_ws(rows_w, cols_w, nb, int(transpose), A.wcode(weights)))
+    if sd == A.BE_SPIKE_BITS:      # bit-packed rows [nb, ceil(k / 32)] words: the generic entry point (the per-variant names cover bool / float)
+        f = fn('be_binary_densemm', c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_vp])
+        check(f(A.ptr(weights), A.wcode(weights), A.ptr(spikes_bm), sd, A.ptr(out), rows_w, cols_w, nb, int(transpose), A.ptr(ws),
+                ws.numel(), A.stream_ptr()), 'be_binary_densemm')
+        return out
     name = (f"be_binary_densemm_{'transpose' if transpose else 'no_transpose'}_{A.wsuffix(weights)}_"
             f"{'bool' if sd == A.BE_SPIKE_BOOL else 'float'}")
     f = fn(name, c_int, _MM_ARGS)
@@ -97,7 +102,7 @@ binary_densemm_p.def_call(binary_densemm_p_call)
 
 
 def _as_arr(x):
-    return x if isinstance(x, torch.Tensor) else np.asarray(x)
+    return x if isinstance(x, (torch.Tensor, A.PackedSpikes)) else np.asarray(x)
 
 
 def _float_weights(w):
@@ -169,7 +174,7 @@ class Dense(DataRepresentation):
         from ._event import is_event, event_operand
         if not is_event(other):
             raise NotImplementedError("only event operands are on the accelerated path (plain dense matmul is out of scope).")
-        return event_operand(other, allow_packed=False)
+        return event_operand(other)        # (1-D bit-packed containers hand their words over: BE_SPIKE_BITS)
 
     def __matmul__(self, other):          # dense @ events
         ev = self._event(other)

@@ -117,8 +117,8 @@ class BinaryArray(EventRepresentation):
                                   f"Got {oc.ndim}D array.")
             assert self.shape[-1] == oc.shape[0], (f"Incompatible dimensions for matrix multiplication: "
                                                    f"{self.shape[-1]} and {oc.shape[0]}.")
-            if self.ndim == 1:
-                return binary_densemv(oc, self.value, transpose=True)
+            if self.ndim == 1:        # (a 1-D bit-packed / compacted container hands its words over: BE_SPIKE_BITS, no unpack)
+                return binary_densemv(oc, event_operand(self), transpose=True)
             return binary_densemm(oc, self.value.T, transpose=True).T
         return oc.__rmatmul__(self)
 
@@ -132,7 +132,7 @@ class BinaryArray(EventRepresentation):
             assert oc.shape[-1] == self.shape[0], (f"Incompatible dimensions for matrix multiplication: "
                                                    f"{oc.shape[-1]} and {self.shape[0]}.")
             if self.ndim == 1:
-                return binary_densemv(oc, self.value, transpose=False)
+                return binary_densemv(oc, event_operand(self), transpose=False)
             return binary_densemm(oc, self.value, transpose=False)
         return oc.__matmul__(self)
 

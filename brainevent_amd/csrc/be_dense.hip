@@ -137,6 +137,82 @@ __global__ void __launch_bounds__(256) k_dense_masks_count(const typename SP::ty
   if (threadIdx.x == 0) tile_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// BE_SPIKE_BITS operands (a batch of bit-packed event vectors, nc rows of ceil(k / 32) words — what BitPackedBinary holds and
+// what the spike exchange delivers): the same masks by a bit transpose, read from the words as they are.  The reference's
+// kernels pack on entry (brainevent/_jit_scalar/binary_jitsmm.cu:15-26); here a packed operand is never unpacked.
+__global__ void __launch_bounds__(256) k_dense_masks_bits(const uint32_t* __restrict__ words, int64_t k, int nc,
+                                                          uint32_t* __restrict__ mask) {
+  const int64_t n_words = (k + 31) / 32;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) {
+    uint32_t mk = 0;
+    for (int b0 = 0; b0 < nc; b0 += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = words[(int64_t)(b0 + u < nc ? b0 + u : nc - 1) * n_words + (i >> 5)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) mk |= (b0 + u < nc ? (v[u] >> (i & 31)) & 1u : 0u) << (b0 + u);
+    }
+    mask[i] = mk;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dense_masks_count_bits(const uint32_t* __restrict__ words, int64_t k, int nc,
+                                                                uint32_t* __restrict__ mask, uint32_t* __restrict__ tile_cnt) {
+  __shared__ uint32_t red[4];
+  const int64_t n_words = (k + 31) / 32;
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * 8;      // 8 consecutive rows: one byte of a word
+  uint32_t mk[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (base < k) {
+    for (int b0 = 0; b0 < nc; b0 += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = words[(int64_t)(b0 + u < nc ? b0 + u : nc - 1) * n_words + (base >> 5)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t byte = b0 + u < nc ? (v[u] >> (base & 31)) & 0xffu : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mk[i] |= ((byte >> i) & 1u) << (b0 + u);
+      }
+    }
+  }
+  uint32_t c = 0;
+  if (base + 8 <= k) {
+    *reinterpret_cast<uint4*>(mask + base) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+    *reinterpret_cast<uint4*>(mask + base + 4) = make_uint4(mk[4], mk[5], mk[6], mk[7]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c += mk[i] ? 1u : 0u;
+  } else {
+    for (int i = 0; i < 8 && base + i < k; ++i) { mask[base + i] = mk[i]; c += mk[i] ? 1u : 0u; }
+  }
+  c = wave_sum(c);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// bytes of one batch row of a spike operand
+static inline size_t spike_row_bytes(int sd, int64_t k) {
+  return sd == BE_SPIKE_BITS ? (size_t)((k + 31) / 32) * 4 : (size_t)k * (sd == BE_SPIKE_FLOAT ? 4 : 1);
+}
+static inline int grid_cap_fwd(int64_t n, int block, int cap) { int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
+// masks of a chunk of batch rows, any spike encoding
+static inline void launch_dense_masks(const void* chunk, int sd, int64_t k, int nc, uint32_t* mask, hipStream_t st) {
+  const dim3 grid(grid_cap_fwd(k, 256, 2048));
+  if (sd == BE_SPIKE_BITS) hipLaunchKernelGGL(k_dense_masks_bits, grid, dim3(256), 0, st, static_cast<const uint32_t*>(chunk), k, nc, mask);
+  else if (sd == BE_SPIKE_FLOAT) hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, grid, dim3(256), 0, st, static_cast<const float*>(chunk), k, nc, mask);
+  else hipLaunchKernelGGL(k_dense_masks<SpikeBool>, grid, dim3(256), 0, st, static_cast<const uint8_t*>(chunk), k, nc, mask);
+}
+static inline void launch_dense_masks_count(const void* chunk, int sd, int64_t k, int nc, uint32_t* mask, uint32_t* tile_cnt, int64_t nt,
+                                            hipStream_t st) {
+  if (sd == BE_SPIKE_BITS)
+    hipLaunchKernelGGL(k_dense_masks_count_bits, dim3((unsigned)nt), dim3(256), 0, st, static_cast<const uint32_t*>(chunk), k, nc, mask, tile_cnt);
+  else if (sd == BE_SPIKE_FLOAT)
+    hipLaunchKernelGGL(k_dense_masks_count<SpikeFloat>, dim3((unsigned)nt), dim3(256), 0, st, static_cast<const float*>(chunk), k, nc, mask, tile_cnt);
+  else
+    hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st, static_cast<const uint8_t*>(chunk), k, nc, mask, tile_cnt);
+}
+
 // one workgroup per group: exclusive scan of that group's tile counts; count[g] = total
 __global__ void __launch_bounds__(1024) k_gl_scan(uint32_t* __restrict__ tile_cnt, int64_t n_tiles, uint32_t* __restrict__ count) {
   __shared__ uint32_t part[1024];
@@ -509,10 +585,8 @@ inline DenseWs carve(void* ws, int64_t k) {
   return d;
 }
 
-template <typename SP>
-int build_lists(const void* spikes_chunk, int64_t k, int nc, int n_groups, const DenseWs& d, hipStream_t st) {
-  hipLaunchKernelGGL(k_dense_masks<SP>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                     static_cast<const typename SP::type*>(spikes_chunk), k, nc, d.mask);
+int build_lists(const void* spikes_chunk, int sd, int64_t k, int nc, int n_groups, const DenseWs& d, hipStream_t st) {
+  launch_dense_masks(spikes_chunk, sd, k, nc, d.mask, st);
   BE_LAUNCH_CHECK();
   const int64_t nt = n_tiles_of(k);
   hipLaunchKernelGGL(k_gl_count<false>, dim3((unsigned)nt, n_groups), dim3(256), 0, st, d.mask, k, d.tile_cnt);
@@ -531,7 +605,6 @@ int densemm_t_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, in
   using ACC = typename WTraits<W>::acc;
   DenseWs d = carve(ws, k);
   ACC* partial = static_cast<ACC*>(d.partial);
-  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
   int parts_used = 1;
   // parts must be the same for every chunk so that one reduce pass serves the whole batch
   parts_used = parts_for(n, VEC, (int)((std::min<int64_t>(nb, kMaxChunk) + kGroup - 1) / kGroup));
@@ -539,9 +612,8 @@ int densemm_t_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, in
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
     const int n_groups = (nc + kGroup - 1) / kGroup;
-    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
-    int rc = (sd == BE_SPIKE_FLOAT) ? build_lists<SpikeFloat>(chunk, k, nc, n_groups, d, st)
-                                    : build_lists<SpikeBool>(chunk, k, nc, n_groups, d, st);
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * spike_row_bytes(sd, k);
+    int rc = build_lists(chunk, sd, k, nc, n_groups, d, st);
     if (rc != BE_OK) return rc;
     const int64_t tasks = ((n + 64 * VEC - 1) / (64 * VEC)) * n_groups;
     hipLaunchKernelGGL((k_densemm_t<W, VEC>), dim3((unsigned)((tasks + 3) / 4), parts_used), dim3(256), 0, st, weights, n,
@@ -567,22 +639,16 @@ template <typename W, int VEC>
 int densemm_nt_vec(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t m, int64_t k, int64_t nb, void* ws,
                    hipStream_t st) {
   DenseWs d = carve(ws, k);
-  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
   const int64_t nt = n_tiles_of(k);
   uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;          // union list in the last slot
   uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
-    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * spike_row_bytes(sd, k);
     // masks + per-tile counts of the active columns in one launch, scan, ordered union list: three launches (five before:
     // masks, 0/1 flags, count, scan, write — 16 us more per call at C5)
-    if (sd == BE_SPIKE_FLOAT)
-      hipLaunchKernelGGL(k_dense_masks_count<SpikeFloat>, dim3((unsigned)nt), dim3(256), 0, st,
-                         static_cast<const float*>(chunk), k, nc, d.mask, utile);
-    else
-      hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st,
-                         static_cast<const uint8_t*>(chunk), k, nc, d.mask, utile);
+    launch_dense_masks_count(chunk, sd, k, nc, d.mask, utile, nt, st);
     BE_LAUNCH_CHECK();
     if (nt <= 1024) {      // every workgroup of the write sums the tiles in front of it: no scan launch
       hipLaunchKernelGGL((k_gl_write<true, true>), dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k,
@@ -1168,7 +1234,6 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
                    hipStream_t st) {
   DenseWs d = carve(ws, k);
   float* partial = static_cast<float*>(d.partial);     // sized for 16 * nb * n floats >= parts * 32 * n when nb >= 8 ... see ws
-  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
   const int64_t nt = n_tiles_of(k);
   uint32_t* ulist = d.lists + (int64_t)kMaxGroups * k;
   uint32_t* utile = d.tile_cnt + (int64_t)kMaxGroups * nt;
@@ -1176,15 +1241,10 @@ int densemm_t_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, i
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
-    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * spike_row_bytes(sd, k);
     // masks + per-tile counts of the active columns in one launch, scan, ordered union list: three launches (five before:
     // masks, 0/1 flags, count, scan, write — 16 us more per call at C5)
-    if (sd == BE_SPIKE_FLOAT)
-      hipLaunchKernelGGL(k_dense_masks_count<SpikeFloat>, dim3((unsigned)nt), dim3(256), 0, st,
-                         static_cast<const float*>(chunk), k, nc, d.mask, utile);
-    else
-      hipLaunchKernelGGL(k_dense_masks_count<SpikeBool>, dim3((unsigned)nt), dim3(256), 0, st,
-                         static_cast<const uint8_t*>(chunk), k, nc, d.mask, utile);
+    launch_dense_masks_count(chunk, sd, k, nc, d.mask, utile, nt, st);
     BE_LAUNCH_CHECK();
     if (nt <= 1024) {      // every workgroup of the write sums the tiles in front of it: no scan launch
       hipLaunchKernelGGL((k_gl_write<true, true>), dim3((unsigned)nt, 1), dim3(256), 0, st, d.mask, k, utile, ulist, k,
@@ -1215,17 +1275,11 @@ template <typename W>
 int densemm_nt_mfma(const W* weights, const void* spikes_bm, int sd, W* out_bm, int64_t m, int64_t k, int64_t nb, void* ws,
                     hipStream_t st) {
   DenseWs d = carve(ws, k);
-  const size_t spk_sz = (sd == BE_SPIKE_FLOAT) ? 4 : 1;
   const int prof = be_prof_begin(st);
   for (int64_t b0 = 0; b0 < nb; b0 += kMaxChunk) {
     const int nc = (int)std::min<int64_t>(kMaxChunk, nb - b0);
-    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * k * spk_sz;
-    if (sd == BE_SPIKE_FLOAT)
-      hipLaunchKernelGGL(k_dense_masks<SpikeFloat>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                         static_cast<const float*>(chunk), k, nc, d.mask);
-    else
-      hipLaunchKernelGGL(k_dense_masks<SpikeBool>, dim3(grid_cap(k, 256, 2048)), dim3(256), 0, st,
-                         static_cast<const uint8_t*>(chunk), k, nc, d.mask);
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * spike_row_bytes(sd, k);
+    launch_dense_masks(chunk, sd, k, nc, d.mask, st);
     BE_LAUNCH_CHECK();
     if constexpr (std::is_same<W, float>::value)
       hipLaunchKernelGGL(k_densemm_nt_mfma_f32<0>, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, weights, m, k, d.mask,
@@ -1291,7 +1345,8 @@ int be_binary_densemm(const void* weights, int wdtype, const void* spikes_bm, in
     return BE_OK;
   }
   BE_REQUIRE(weights && spikes_bm, BE_ERR_INVALID, "null pointer");
-  BE_REQUIRE(spike_dtype == BE_SPIKE_BOOL || spike_dtype == BE_SPIKE_FLOAT, BE_ERR_INVALID, "unknown spike dtype");
+  BE_REQUIRE(spike_dtype == BE_SPIKE_BOOL || spike_dtype == BE_SPIKE_FLOAT || spike_dtype == BE_SPIKE_BITS, BE_ERR_INVALID,
+             "unknown spike dtype");
   BE_REQUIRE(workspace != nullptr && workspace_bytes >= dense_ws_bytes(rows_w, cols_w, n_batch, transpose, wdtype),
              BE_ERR_WORKSPACE, "workspace too small");
   switch (wdtype) {

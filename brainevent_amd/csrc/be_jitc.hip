@@ -326,14 +326,47 @@ __global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename Scatt
 // gather : one thread per generator row; spike matrix as per-column masks (<= 32 batch columns per pass):
 //          out_bm[c, row] = sum over edges j of row with bit c of mask[j] set
 // scatter: the residue-class kernel above with lane stride 4 and gridDim.y = batch column (jit_scatter_batched)
+// Scalar-weight mm gather: the per-column counts of a generator row are kept BIT-SLICED — plane[b] holds bit b of all (<= 32)
+// column counters, one column per bit position — so adding an edge's column mask is a ripple-carry add of one word: on average
+// two plane updates (and / xor / move) instead of one predicated add per batch column (32 columns: ~100 vector operations per
+// generated edge that hits, with some lane of the wave hitting on nearly every edge at 1 % firing).  The carry chain stops as soon
+// as no lane carries any more; its length is log2 of the largest count so far.  Counts are exact integers either way.
+struct SlicedCounts {
+  uint32_t plane[32];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int b = 0; b < 32; ++b) plane[b] = 0u;
+  }
+  __device__ __forceinline__ void add(uint32_t mk) {
+    uint32_t carry = mk;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      if (__ballot(carry != 0u) == 0ull) break;          // (wave-uniform exit)
+      const uint32_t t = plane[b] & carry;
+      plane[b] ^= carry;
+      carry = t;
+    }
+  }
+  __device__ __forceinline__ uint32_t count(int c) const {
+    uint32_t n = 0u;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) n |= ((plane[b] >> c) & 1u) << b;
+    return n;
+  }
+};
+
 template <int MODE, typename A, int NCOL>
 __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* __restrict__ mask, int64_t m, int nc,
                                                        A* __restrict__ out_bm) {
   const int64_t stride_t = (int64_t)gridDim.x * blockDim.x;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < m; row += stride_t) {
-    A acc[NCOL];                                   // NCOL = 8 / 16 / 32 >= nc: the columns the masks can hold
+    A acc[MODE == MODE_SCALAR ? 1 : NCOL];         // NCOL = 8 / 16 / 32 >= nc: the columns the masks can hold
+    SlicedCounts sc;                               // (scalar weights: bit-sliced counts instead)
+    if constexpr (MODE == MODE_SCALAR) sc.clear();
+    else {
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
+      for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
+    }
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
       const int64_t cs = (int64_t)chunk * p.chunk_size;
       const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
@@ -345,8 +378,10 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
         while ((int64_t)lj < width) {
           const int64_t j = cs + (int64_t)lj;
           const uint32_t mk = mask[j];
-          if (mk) {
-            const A w = (MODE == MODE_SCALAR) ? A(1) : edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)j);
+          if constexpr (MODE == MODE_SCALAR) {
+            sc.add(mk);
+          } else if (mk) {
+            const A w = edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)j);
 #pragma unroll
             for (int c = 0; c < NCOL; ++c) acc_add_inplace(acc[c], ((mk >> c) & 1u) ? w : A(0));
           }
@@ -358,7 +393,10 @@ __global__ void __launch_bounds__(256) k_jit_mm_gather(JitP p, const uint32_t* _
     }
 #pragma unroll
     for (int c = 0; c < NCOL; ++c)
-      if (c < nc) out_bm[(int64_t)c * m + row] = (MODE == MODE_SCALAR) ? (A)(acc[c] * (A)p.w0) : acc[c];
+      if (c < nc) {
+        if constexpr (MODE == MODE_SCALAR) out_bm[(int64_t)c * m + row] = (A)((A)sc.count(c) * (A)p.w0);
+        else out_bm[(int64_t)c * m + row] = acc[c];
+      }
   }
 }
 
@@ -375,9 +413,13 @@ __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32
   T* ms = reinterpret_cast<T*>(jit_mm_lds);
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   constexpr int NCOL = 8 * (int)sizeof(T);                 // batch columns a mask of type T holds
-  A acc[NCOL];
+  A acc[MODE == MODE_SCALAR ? 1 : NCOL];
+  SlicedCounts sc;                                         // (scalar weights: bit-sliced counts instead)
+  if constexpr (MODE == MODE_SCALAR) sc.clear();
+  else {
 #pragma unroll
-  for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
+    for (int c = 0; c < NCOL; ++c) acc[c] = A(0);
+  }
   constexpr int kMmStride = 4;                               // lane stride of the mm matrix (brainevent/_misc.py:37-38)
   for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
     const int64_t cs = (int64_t)chunk * p.chunk_size;
@@ -416,9 +458,11 @@ __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32
           uint64_t lj = (uint64_t)l + (uint64_t)kMmStride * q;
           while ((int64_t)lj < w_hi) {
             uint32_t mk = (uint32_t)ms[(int64_t)lj - w_lo];
-            if (mk) {
+            if constexpr (MODE == MODE_SCALAR) {
+              sc.add(mk);
+            } else if (mk) {
               asm volatile("" : "+v"(mk));                   // keeps the per-column adds behind the branch
-              const A w = (MODE == MODE_SCALAR) ? A(1) : edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)(cs + (int64_t)lj));
+              const A w = edge_weight<MODE, A>(p, (uint32_t)row, (uint32_t)(cs + (int64_t)lj));
 #pragma unroll
               for (int c = 0; c < NCOL; ++c) acc_add_inplace(acc[c], ((mk >> c) & 1u) ? w : A(0));
             }
@@ -435,7 +479,28 @@ __global__ void __launch_bounds__(1024) k_jit_mm_gather_lds(JitP p, const uint32
   if (row < m) {
 #pragma unroll
     for (int c = 0; c < NCOL; ++c)
-      if (c < nc) out_bm[(int64_t)c * m + row] = (MODE == MODE_SCALAR) ? (A)(acc[c] * (A)p.w0) : acc[c];
+      if (c < nc) {
+        if constexpr (MODE == MODE_SCALAR) out_bm[(int64_t)c * m + row] = (A)((A)sc.count(c) * (A)p.w0);
+        else out_bm[(int64_t)c * m + row] = acc[c];
+      }
+  }
+}
+
+// the same masks from a bit-packed batch (nc rows of ceil(len / 32) words): a bit transpose, no unpack
+__global__ void __launch_bounds__(256) k_jit_masks_bits(const uint32_t* __restrict__ words, int64_t len, int nc,
+                                                        uint32_t* __restrict__ mask) {
+  const int64_t n_words = (len + 31) / 32;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    uint32_t mk = 0;
+    for (int b0 = 0; b0 < nc; b0 += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = words[(int64_t)(b0 + u < nc ? b0 + u : nc - 1) * n_words + (i >> 5)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) mk |= (b0 + u < nc ? (v[u] >> (i & 31)) & 1u : 0u) << (b0 + u);
+    }
+    mask[i] = mk;
   }
 }
 
@@ -594,8 +659,12 @@ int jit_mv_gather(const JitP& p, const void* spikes, int sd, void* out, int64_t 
   uint32_t* bits = reinterpret_cast<uint32_t*>(wsb);
   const int64_t n_words = (p.walk_len + 31) / 32;
   AccT* partial = reinterpret_cast<AccT*>(wsb + be_align_up((n_words + 2) * 4, 256));
-  int rc = be_pack_spikes(spikes, sd, p.walk_len, bits, st);
-  if (rc != BE_OK) return rc;
+  if (sd == BE_SPIKE_BITS) {      // already the kernels' format (a BitPackedBinary, the words the spike exchange delivers): no pack launch
+    bits = const_cast<uint32_t*>(static_cast<const uint32_t*>(spikes));
+  } else {
+    int rc = be_pack_spikes(spikes, sd, p.walk_len, bits, st);
+    if (rc != BE_OK) return rc;
+  }
   const size_t lds = (size_t)(((std::min<int64_t>(p.chunk_size, p.walk_len) + 31) / 32) + 2) * 4;
   const dim3 grid(gcap(m, 32, 512), p.n_chunks);
   const int prof = be_prof_begin(st);
@@ -874,15 +943,19 @@ int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, ui
   void* dst = direct ? out_bm : scratch;
   const size_t asz = f64 ? 8 : 4;
   if (!gather) BE_HIP(be_fill_async(dst, 0, (size_t)out_len * n_batch * asz, st));
-  const size_t spk_sz = (spike_dtype == BE_SPIKE_FLOAT) ? 4 : 1;
+  const size_t row_bytes = spike_dtype == BE_SPIKE_BITS ? (size_t)((in_len + 31) / 32) * 4
+                                                         : (size_t)in_len * (spike_dtype == BE_SPIKE_FLOAT ? 4 : 1);
   const int prof = be_prof_begin(st);
   // (Cutting a wide batch into passes of 8 columns was measured in round 3 and is slower — n = 1M, 32 columns: 4.7 ms in one pass
   //  against 4 x 2.87 = 11.5 ms, every pass re-walks the whole matrix; what helps is windows whose walks keep their state,
   //  k_jit_mm_gather_lds.)
   for (int64_t b0 = 0; b0 < n_batch; b0 += 32) {
     const int nc = (int)std::min<int64_t>(32, n_batch - b0);
-    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * in_len * spk_sz;
-    if (spike_dtype == BE_SPIKE_FLOAT)
+    const void* chunk = static_cast<const unsigned char*>(spikes_bm) + (size_t)b0 * row_bytes;
+    if (spike_dtype == BE_SPIKE_BITS)
+      hipLaunchKernelGGL(k_jit_masks_bits, dim3(gcap(in_len, 256, 2048)), dim3(256), 0, st, static_cast<const uint32_t*>(chunk),
+                         in_len, nc, mask);
+    else if (spike_dtype == BE_SPIKE_FLOAT)
       hipLaunchKernelGGL(k_jit_masks<SpikeFloat>, dim3(gcap(in_len, 256, 2048)), dim3(256), 0, st,
                          static_cast<const float*>(chunk), in_len, nc, mask);
     else

@@ -269,3 +269,96 @@ def test_compacted_ids_on_fixed_num_and_abi_contract(be):
     rc = f(A.ptr(M.data), 0, A.BE_F32, A.ptr(M.indices), None, 0, nc, ctypes.c_void_p(ids.data_ptr()), A.BE_SPIKE_IDS,
            A.ptr(out), n_pre, n_post, 2, A.ptr(ws), ws.numel(), A.stream_ptr())
     assert rc == -5
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: packed events into the dense and JITC kernels (the reference's kernels pack on entry,
+# brainevent/_jit_scalar/binary_jitsmv.cu:107-125, _jit_scalar/binary_jitsmm.cu:15-26; here words that exist — a
+# BitPackedBinary, what the spike exchange delivers — are consumed as they are: BE_SPIKE_BITS, no unpack launch)
+# ---------------------------------------------------------------------------------------------------
+def _packed_only(be, x):
+    """A 1-D container that exists ONLY as words on the device (what `exchange.gather_events` returns)."""
+    xt = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    return be.BitPackedBinary.from_packed(be.bitpack(xt, 0).reshape(-1), x.shape[0])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_packed_vector_into_dense_products_without_unpacking(be, dtype):
+    rng = np.random.default_rng(41)
+    k, n = 1000, 777
+    W = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).cuda().to(dtype)
+    for fire in (0.02, 0.6):
+        s_rows, s_cols = rng.random(k) < fire, rng.random(n) < fire
+        for x, prod, plain in ((s_rows, lambda e: e @ W, lambda v: be.BinaryArray(v) @ W),
+                               (s_cols, lambda e: W @ e, lambda v: W @ be.BinaryArray(v))):
+            ev = _packed_only(be, x)
+            got = prod(ev)
+            assert ev._value is None, 'the packed-only operand was unpacked'
+            want = plain(torch.from_numpy(x).cuda())
+            assert torch.equal(got, want)
+    # Dense container, and a CompactBinary built on the device (it carries packed words too)
+    D = be.Dense(W)
+    ev = _packed_only(be, s_rows)
+    assert torch.equal(ev @ D, be.BinaryArray(torch.from_numpy(s_rows).cuda()) @ W) and ev._value is None
+
+
+def test_packed_batches_through_the_c_abi_of_dense_and_jitc(be):
+    """be_binary_densemm / be_binary_jitmm with spike_dtype = BE_SPIKE_BITS: batch rows of ceil(k / 32) words, 1 ... 40 rows,
+    both directions — the same bits as the byte operand (the masks are the same; only how they are built differs)."""
+    import ctypes as ct
+    from brainevent_amd import _array as A, _lib
+    rng = np.random.default_rng(42)
+    k, n = 333, 450
+    W = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).cuda()
+    f_ws = _lib.fn('be_binary_densemm_workspace_bytes', ct.c_int64, [ct.c_int64, ct.c_int64, ct.c_int64, ct.c_int, ct.c_int])
+    f = _lib.fn('be_binary_densemm', ct.c_int, [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int64, ct.c_int64,
+                                               ct.c_int64, ct.c_int, ct.c_void_p, ct.c_int64, ct.c_void_p])
+    for nb in (1, 7, 32, 40):
+        for transpose in (1, 0):
+            in_len, out_len = (k, n) if transpose else (n, k)
+            S = torch.from_numpy(rng.random((nb, in_len)) < 0.15).cuda()
+            words = be.bitpack(S, 1).contiguous()
+            assert words.shape == (nb, (in_len + 31) // 32)
+            ws = A.workspace(f_ws(k, n, nb, transpose, A.BE_F32))
+            outs = []
+            for sp, sd in ((S, A.BE_SPIKE_BOOL), (words, A.BE_SPIKE_BITS)):
+                out = torch.empty((nb, out_len), dtype=torch.float32, device='cuda')
+                _lib.check(f(A.ptr(W), A.BE_F32, A.ptr(sp), sd, A.ptr(out), k, n, nb, transpose, A.ptr(ws), ws.numel(), A.stream_ptr()))
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (nb, transpose)
+    # JITC mm, both kernels (gather / scatter), scalar and uniform weights
+    f_ws = _lib.fn('be_binary_jitmm_workspace_bytes', ct.c_int64, [ct.c_int64] * 4 + [ct.c_int])
+    f = _lib.fn('be_binary_jitmm', ct.c_int, [ct.c_int, ct.c_double, ct.c_double, ct.c_int, ct.c_int64, ct.c_uint32, ct.c_void_p, ct.c_int,
+                                             ct.c_void_p, ct.c_int64, ct.c_int64, ct.c_int64, ct.c_int64, ct.c_int, ct.c_void_p,
+                                             ct.c_int64, ct.c_void_p])
+    shape1, in_len, out_len, clen = 900, 900, 700, 20
+    for mode, w0, w1 in ((0, 0.5, 0.0), (1, 0.1, 0.8)):
+        for gather in (1, 0):
+            for nb in (3, 33):
+                S = torch.from_numpy(rng.random((nb, in_len)) < 0.2).cuda()
+                words = be.bitpack(S, 1).contiguous()
+                ws = A.workspace(f_ws(shape1, in_len, out_len, nb, gather))
+                outs = []
+                for sp, sd in ((S, A.BE_SPIKE_BOOL), (words, A.BE_SPIKE_BITS)):
+                    out = torch.empty((nb, out_len), dtype=torch.float32, device='cuda')
+                    _lib.check(f(mode, w0, w1, A.BE_F32, clen, 17, A.ptr(sp), sd, A.ptr(out), shape1, in_len, out_len, nb, gather,
+                                 A.ptr(ws), ws.numel(), A.stream_ptr()))
+                    outs.append(out)
+                assert torch.equal(outs[0], outs[1]), (mode, gather, nb)
+
+
+@pytest.mark.parametrize('cls_name,params', [('JITCScalarR', (np.float32(0.5), 0.05, 11)), ('JITCScalarC', (np.float32(0.5), 0.05, 11)),
+                                             ('JITCUniformR', (np.float32(0.1), np.float32(0.9), 0.05, 12)),
+                                             ('JITCNormalC', (np.float32(0.2), np.float32(1.1), 0.05, 13))])
+@pytest.mark.parametrize('corder', [False, True])
+def test_packed_vector_into_jitc_products_without_unpacking(be, cls_name, params, corder):
+    rng = np.random.default_rng(43)
+    shape = (600, 850)
+    M = getattr(be, cls_name)(params, shape=shape, corder=corder)
+    sr, sc = rng.random(shape[0]) < 0.1, rng.random(shape[1]) < 0.1
+    for x, prod in ((sr, lambda e: e @ M), (sc, lambda e: M @ e)):
+        ev = _packed_only(be, x)
+        got = prod(ev)
+        assert ev._value is None, 'the packed-only operand was unpacked'
+        want = prod(be.BinaryArray(torch.from_numpy(x).cuda()))
+        assert torch.equal(torch.as_tensor(got), torch.as_tensor(want))

@@ -354,3 +354,53 @@ def test_jit_randomized_against_oracle(be, oracle, seed):
     got = fmm(*args, prob, B, rseed, shape=shape, transpose=transpose, corder=corder)
     ref = oracle.binary_jitmm(family, w0, w1, prob, B, rseed, shape=shape, transpose=transpose, corder=corder)
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+@pytest.mark.parametrize('cls_kind,corder', [('R', False), ('R', True), ('C', False)])
+def test_prepare_serves_both_directions_from_the_stored_matrix(be, oracle, family, cls_kind, corder, monkeypatch):
+    """`JITC*.prepare()` (round 4): the drawn connectivity is materialised once and `spk @ M` / `M @ spk` (vectors) then run
+    event-driven on the stored matrix — the reference's default object walks the whole matrix per step in one of the two
+    directions (brainevent/_jit_scalar/main.py:990-1007).  Same numbers as on the fly: exact for the scalar family, 1e-5
+    otherwise; `prepare('mm')` does the same for matrix operands (a different draw)."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    monkeypatch.setattr(C, 'AUTO_MIRROR_MIN_NNZ', 1000)
+    name = {'s': 'JITCScalar', 'u': 'JITCUniform', 'n': 'JITCNormal'}[family] + cls_kind
+    params = {'s': (np.float32(0.5), 0.04, 21), 'u': (np.float32(0.1), np.float32(0.9), 0.04, 22),
+              'n': (np.float32(0.3), np.float32(0.8), 0.04, 23)}[family]
+    shape = (1100, 1400)
+    rng = np.random.default_rng(51)
+    fly = getattr(be, name)(params, shape=shape, corder=corder)
+    stored = getattr(be, name)(params, shape=shape, corder=corder).prepare('mv').prepare('mm')
+    assert stored.buffers['materialized_mv'] is not None and stored.buffers['materialized_mm'] is not None
+    assert not any(k.startswith('materialized') for k in stored.T.buffers)          # a transposed object materialises its own
+    sr, sc = rng.random(shape[0]) < 0.05, rng.random(shape[1]) < 0.05
+    Br, Bc = rng.random((3, shape[0])) < 0.05, rng.random((shape[1], 3)) < 0.05
+    cmp = (np.testing.assert_array_equal if family == 's' else
+           (lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)))
+    cmp(be.BinaryArray(sr) @ stored, be.BinaryArray(sr) @ fly)
+    cmp(stored @ be.BinaryArray(sc), fly @ be.BinaryArray(sc))
+    cmp(be.BinaryArray(Br) @ stored, be.BinaryArray(Br) @ fly)
+    cmp(stored @ be.BinaryArray(Bc), fly @ be.BinaryArray(Bc))
+    # both directions of the vector product are event-driven on the stored matrix: a scatter workspace and a mirror exist
+    S = stored.buffers['materialized_mv']
+    assert S.buffers.get('scatter_plan') is not None and isinstance(S.buffers.get('mirror'), C.Mirror)
+    # refused (with a warning) when the stored form does not fit beside what is resident
+    monkeypatch.setattr(C, '_free_device_bytes', lambda: 1 << 10)
+    with pytest.warns(UserWarning, match='does not fit'):
+        tight = getattr(be, name)(params, shape=shape, corder=corder).prepare()
+    assert tight.buffers.get('materialized_mv') is None
+    cmp(be.BinaryArray(sr) @ tight, be.BinaryArray(sr) @ fly)
+
+
+def test_scalar_mm_gather_counts_are_bit_sliced_and_exact(be, oracle):
+    """Round 4: the scalar mm gather keeps its per-column counts bit-sliced (a ripple-carry add of the edge's column mask);
+    32 batch columns at 50 % firing drive the counts through several carries — still the oracle's integers times the weight,
+    for the LDS-mask kernel and (one wide chunk) the global-mask kernel, narrow and wide batches."""
+    rng = np.random.default_rng(52)
+    for shape, prob, n in (((300, 2000), 0.2, 32), ((64, 900), 0.5, 17), ((500, 700), 0.1, 8), ((200, 40000), 0.01, 32)):
+        B = rng.random((shape[1], n)) < 0.5
+        got = be.binary_jitsmm(np.float32(0.25), prob, B, 99, shape=shape, transpose=False, corder=True)
+        ref = oracle.binary_jitmm('s', 0.25, 0.0, prob, B, 99, shape=shape, transpose=False, corder=True)
+        np.testing.assert_array_equal(got, ref.astype(np.float32))
