@@ -331,6 +331,14 @@ def hbm_roofline(alg_bytes, kern_ms, traffic=None, kernel=None, extra=None):
     return roof
 
 
+def traffic_lookup(key):
+    """HBM bytes per launch / step of a configuration from profiles/traffic.json (separate rocprofv3 --pmc passes), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(key, {}).get('hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
 def plan_traffic(args, plan, world):
     """PMC bytes per launch of the dominant kernel, looked up (they come from a separate rocprofv3 --pmc pass)."""
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -420,7 +428,9 @@ def run_fcn(args, dev, g):
     alg = (4 if args.homo else 8) * float(np.mean(act)) * K + n + 4 * n_post
     # the step is several kernels of similar weight on this route: the whole-step HIP-event time is the honest divisor
     whole = float(np.median(step_ms))
-    roof = hbm_roofline(alg, whole, kernel='whole step (HIP events): compaction + ' + cfg['route'] + ' kernels',
+    default_c4 = n == 10_000_000 and K == 1000 and n_post == n and args.fire == 0.01
+    roof = hbm_roofline(alg, whole, traffic=traffic_lookup('c4_homo' if args.homo else 'c4_hetero') if default_c4 else None,
+                        kernel='whole step (HIP events): compaction + ' + cfg['route'] + ' kernels',
                         extra={'dominant_kernel_ms': round(kern_ms, 5) if kern_ms else None})
     del conn, w, idx
     line = _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
@@ -450,7 +460,8 @@ def run_dense(args, dev, g):
     union = float(spikes.any(dim=1).sum().item()) / n_batch
     cfg = {'workload': f'BinaryArray({args.fire:g}) [{args.batch},{n}] @ dense fp16 [{n},{n}]', 'union_rows': union,
            'active_pairs': pairs}
-    roof = hbm_roofline(union * n * 2 + args.batch * n * 2, kern_ms, kernel='k_densemm_mfma') if kern_ms else None
+    roof = hbm_roofline(union * n * 2 + args.batch * n * 2, kern_ms, kernel='k_densemm_mfma',
+                        traffic=traffic_lookup('c5') if (n == 65536 and args.batch == 32 and args.fire == 0.01) else None) if kern_ms else None
     del W
     line = _line(metric, value, args, elapsed, 'f16', cfg, roof, kern, step_ms)
     if not args.no_cpu:
@@ -503,12 +514,7 @@ def run_gather_mirror(args, dev, g):
     bytes_per_upd = 4 if args.homo else 8
     alg = bytes_per_upd * float(np.mean(upd_per_vec[timed])) + n + 4 * n + 16 * float(np.mean(act[timed]))
     kname = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate') if plan else 'k_bin_stream'
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(
-            f"gather_mirror_{'homo' if args.homo else 'hetero'}_n{n}", {}).get('hbm_bytes_per_launch')
-    except Exception:
-        pass
+    traffic = traffic_lookup(f"gather_mirror_{'homo' if args.homo else 'hetero'}_n{n}") if (args.conn == 0.01 and args.fire == 0.01) else None
     roof = hbm_roofline(alg, kern_ms, traffic=traffic, kernel=kname + ' (over the mirror)')
     cfg = {'workload': f"CSR f32 {'homo' if args.homo else 'hetero'} @ BinaryArray({args.fire:g} fire), {n} x {n}, {n_conn} synapses/row: the "
                        f"gather direction through the event-driven mirror (route={type(mr.plan).__name__})",
@@ -883,7 +889,13 @@ def run_scatter(args):
         alg_bytes = bytes_per_upd * mean_upd + n_pre * 1 + n_post * 4 + 16 * mean_active
         plan_kernel = {1: 'k_plan_accumulate_d8', 2: 'k_plan_accumulate_h8'}.get(getattr(plan, 'layout', 0), 'k_plan_accumulate')
         kernel_name = {'ScatterPlan': plan_kernel, 'BinnedScatter': 'k_bin_stream'}.get(route, 'k_csrmv_t_direct')
-        roof = hbm_roofline(alg_bytes, kern_ms, traffic=plan_traffic(args, plan, p_world), kernel=kernel_name,
+        traffic = plan_traffic(args, plan, p_world)
+        if traffic is None and args.emulate_world == 8 and args.fire == 0.01 and not args.homo:
+            if is_fcn and n_pre == 10_000_000 and args.k == 1000:
+                traffic = traffic_lookup('c4_rank_of_8')
+            elif not is_fcn and args.n == 1_000_000 and args.conn == 0.01:
+                traffic = traffic_lookup('c2_rank_of_8')
+        roof = hbm_roofline(alg_bytes, kern_ms, traffic=traffic, kernel=kernel_name,
                             extra={'kernel_ms_median': round(float(np.median(kern)), 5) if kern is not None else None,
                                    # the same run's device-copy ceiling (bytes read + written per second
                                    # of a 2 GiB device-to-device copy) next to the nominal peak
