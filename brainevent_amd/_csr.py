@@ -706,15 +706,16 @@ class BinnedScatter:
         indptr, row_len = self._rows
         m, k, dev = self.m, self.k, weights.device
         flat = weights.reshape(-1)
-        wmax, wmin = 0.0, float('inf')
-        for lo in range(0, flat.numel(), 1 << 28):          # (chunked: no 40-GB temporary)
-            a = flat[lo:lo + (1 << 28)].abs().float()
-            if not bool(torch.isfinite(a).all()):
-                raise MathError("weights contain inf / nan: the fixed-point routes do not apply")
-            wmax = max(wmax, float(a.max()))
-            nz = a[a > 0]
-            if nz.numel():
-                wmin = min(wmin, float(nz.min()))
+        mx, mn = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        scr = A.workspace(256)
+        check(fn('be_weight_stats', c_int, [c_vp, c_int, c_i64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), c_vp,
+                                            c_i64, c_vp])(A.ptr(flat), A.wcode(flat), flat.numel(), ctypes.byref(mx), ctypes.byref(mn),
+                                                          A.ptr(scr), scr.numel(), A.stream_ptr()), 'be_weight_stats')
+        if mx.value >= 0x7f800000:
+            raise MathError("weights contain inf / nan: the fixed-point routes do not apply")
+        as_f32 = lambda b: float(np.array([b], dtype=np.uint32).view(np.float32)[0])
+        wmax = as_f32(mx.value)
+        wmin = as_f32(mn.value) if mn.value != 0xffffffff else float('inf')
         if wmax == 0.0:
             return 0.0, float('inf'), 0.0, float('inf')
         e0 = 62 - math.frexp(wmax * (self.nnz + 1) * 1.001)[1]             # every entry in one column could not overflow this

@@ -74,6 +74,37 @@ extern "C" {
 
 int64_t be_fixed_point_scratch_bytes(int64_t k) { return 256 + be_align_up((k > 0 ? k : 1) * 4, 256); }
 
+// max |w| and the smallest non-zero |w| of a weight array, as f32 bit patterns (0 / 0xffffffff when there is none): one streaming
+// pass, no atomics per entry.  A max at or above 0x7f800000 means inf / nan.  scratch >= 256 bytes.  SYNCHRONOUS.
+int be_weight_stats(const void* weights, int wdtype, int64_t n, uint32_t* max_bits_host, uint32_t* min_nonzero_bits_host,
+                    void* scratch, int64_t scratch_bytes, be_stream_t stream) {
+  BE_REQUIRE(weights && max_bits_host && min_nonzero_bits_host && scratch && scratch_bytes >= 256, BE_ERR_INVALID, "null pointer / scratch");
+  BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t* stats = static_cast<uint32_t*>(scratch);
+  BE_HIP(be_fill_async(stats, 0, 16, st));
+  BE_HIP(be_fill_async(stats + 1, 0xff, 4, st));
+  if (n > 0) {
+    const int grid = grid_for(n, 256, 256 * 16);
+    const int32_t* no_idx = nullptr;
+    float* no_col = nullptr;
+    switch (wdtype) {
+      case BE_F32: hipLaunchKernelGGL(k_fp_colsum<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(weights), no_idx, n, no_col, stats); break;
+      case BE_F64: hipLaunchKernelGGL(k_fp_colsum<double>, dim3(grid), dim3(256), 0, st, static_cast<const double*>(weights), no_idx, n, no_col, stats); break;
+      case BE_F16: hipLaunchKernelGGL(k_fp_colsum<__half>, dim3(grid), dim3(256), 0, st, static_cast<const __half*>(weights), no_idx, n, no_col, stats); break;
+      case BE_BF16: hipLaunchKernelGGL(k_fp_colsum<__hip_bfloat16>, dim3(grid), dim3(256), 0, st, static_cast<const __hip_bfloat16*>(weights), no_idx, n, no_col, stats); break;
+      default: be_set_error("unknown weight dtype"); return BE_ERR_INVALID;
+    }
+    BE_LAUNCH_CHECK();
+  }
+  uint32_t h[2];
+  BE_HIP(hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, st));
+  BE_HIP(hipStreamSynchronize(st));
+  *max_bits_host = h[0];
+  *min_nonzero_bits_host = h[1];
+  return BE_OK;
+}
+
 int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indices, int64_t nnz, int64_t k, int min_weight_bits,
                             int keep_exp, void* scratch, int64_t scratch_bytes, int* scale_exp_host, be_stream_t stream) {
   BE_REQUIRE(weights && scale_exp_host && scratch, BE_ERR_INVALID, "null pointer");

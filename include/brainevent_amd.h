@@ -288,6 +288,10 @@ int be_scatter_plan_refresh_weights_ordered(const void* weights, int homo, int w
  * range 64-bit sums cannot resolve.  scratch >= be_fixed_point_scratch_bytes(k).  No reference counterpart: its GPU kernels
  * add floats with global atomics (brainevent/_csr/binary_csrmv_hybrid.cu:199-234). */
 int64_t be_fixed_point_scratch_bytes(int64_t k);
+/* max |w| and the smallest non-zero |w| of a weight array as f32 bit patterns (0 / 0xffffffff when there is none; a max at or
+ * above 0x7f800000 means inf / nan): one streaming pass.  scratch >= 256 bytes.  SYNCHRONOUS. */
+int be_weight_stats(const void* weights, int wdtype, int64_t n, uint32_t* max_bits_host, uint32_t* min_nonzero_bits_host,
+                    void* scratch, int64_t scratch_bytes, be_stream_t stream);
 int be_fixed_point_exponent(const void* weights, int wdtype, const int32_t* indices, int64_t nnz, int64_t k,
                             int min_weight_bits, int keep_exp, void* scratch, int64_t scratch_bytes, int* scale_exp_host,
                             be_stream_t stream);
