@@ -32,7 +32,8 @@ __all__ = [
     'binary_jitsmv', 'binary_jitsmm', 'binary_jitumv', 'binary_jitumm', 'binary_jitnmv', 'binary_jitnmm',
     'binary_jitsmv_p', 'binary_jitsmm_p', 'binary_jitumv_p', 'binary_jitumm_p', 'binary_jitnmv_p', 'binary_jitnmm_p',
     'binary_jitsmv_p_call', 'binary_jitsmm_p_call', 'binary_jitumv_p_call', 'binary_jitumm_p_call',
-    'binary_jitnmv_p_call', 'binary_jitnmm_p_call', 'JITCScatterShard', 'jit_scatter_class_columns', 'jit_edge_weights',
+    'binary_jitnmv_p_call', 'binary_jitnmm_p_call', 'JITCScatterShard', 'JITCGatherShard', 'jit_scatter_class_columns',
+    'jit_edge_weights',
 ]
 
 c_i64, c_int, c_vp, c_dbl, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_uint32
@@ -441,6 +442,10 @@ class JITCMatrix(DataRepresentation):
         """This rank's share of ``events @ self`` for a multi-GPU run (nothing is stored; see :class:`JITCScatterShard`)."""
         return JITCScatterShard(self, world, rank)
 
+    def gather_shard(self, world: int, rank: int, side: str = 'left') -> 'JITCGatherShard':
+        """This rank's output rows of the product whose orientation is the gather kernel (see :class:`JITCGatherShard`)."""
+        return JITCGatherShard(self, world, rank, side)
+
     # -- materialisation (reference: ``mat.mv.tocsr()`` / ``mat.mm.tocsr()``, ``_jit_scalar/main.py`` mode views) ----
     # -- materialisation views: ``mat.mv`` / ``mat.mm`` (reference ``_jit_scalar/main.py:40-110``, ``:404-413``) ----------
     @property
@@ -699,3 +704,65 @@ class JITCScatterShard:
                 sd, A.ptr(out), self.shape1, in_len, out_len, self.class_begin, self.class_end - self.class_begin,
                 _fixed_scale_exp(wmax, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()), 'be_binary_jitmv_sharded')
         return m._out(out, v)
+
+
+class JITCGatherShard:
+    """Rank ``rank`` of ``world``'s share of a JIT-connectivity product in its *gather* orientation, sharded by OUTPUT ROWS
+    (open until round 4): the generator rows are the outputs there and a row's walk is keyed by
+    ``(seed, row, chunk, lane)`` alone, so a rank that owns the output rows ``[lo, hi)`` (``post_slice_bounds``) computes
+    exactly those outputs from the full spike vector — nothing stored, no reduction, the ranks' slices concatenate to the
+    unsharded result bit for bit.  ``side='left'``: ``events @ M`` (``M.__rmatmul__``); ``side='right'``: ``M @ events``.
+    Whichever side is asked for must run the gather kernel for this object's ``corder`` (the other orientation shards by
+    walk class: :class:`JITCScatterShard`).  ``shard.apply(events)`` returns this rank's ``hi - lo`` outputs; 1-D events."""
+
+    def __init__(self, mat: JITCMatrix, world: int, rank: int, side: str = 'left'):
+        from ._dist import post_slice_bounds
+        if side not in ('left', 'right'):
+            raise ValueError("side must be 'left' (events @ M) or 'right' (M @ events).")
+        left = side == 'left'
+        if mat._is_row:       # the (shape, transpose, corder) mapping of JITCMatrix.__rmatmul__ / __matmul__
+            shape, transpose, corder = (mat.shape, True, not mat.corder) if left else (mat.shape, False, mat.corder)
+        else:
+            shape, transpose, corder = (mat.shape[::-1], False, not mat.corder) if left else (mat.shape[::-1], True, mat.corder)
+        if not corder:
+            raise ValueError("this side of the product runs the scatter kernel for this corder: shard it by walk class "
+                             "(JITCScatterShard / scatter_shard).")
+        self.mat, self.world, self.rank, self.side = mat, int(world), int(rank), side
+        self.in_len = int(shape[0] if transpose else shape[1])
+        self.out_len = int(shape[1] if transpose else shape[0])
+        self.shape1 = int(shape[1])
+        self.lo, self.hi = post_slice_bounds(self.out_len, self.world, self.rank)
+
+    def apply(self, other):
+        if not is_event(other):
+            raise NotImplementedError("only event operands are on the accelerated path.")
+        v = event_operand(other)
+        if v.ndim != 1:
+            raise NotImplementedError("JITCGatherShard takes 1-D events.")
+        m = self.mat
+        assert v.shape[0] == self.in_len, f"vector length {v.shape[0]} != {self.in_len}"
+        spikes, sd = A.spikes_to_device(v)
+        n_rows = self.hi - self.lo
+        out = torch.empty(n_rows, dtype=m.dtype, device=A.device())
+        if n_rows == 0:
+            return m._out(out, v)
+        a = m._weights[0]
+        b = m._weights[1] if m._family != 's' else 0.0
+        w0, w1, _ = _jit_params(m._family, a, b)
+        f_ws = fn('be_binary_jitmv_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
+        ws = A.workspace(f_ws(self.shape1, self.in_len, n_rows, 1))
+        f = fn('be_binary_jitmv_rows', c_int,
+               [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp])
+        check(f(_FAMILY[m._family], w0, w1, A.wcode(out), _initialize_conn_length(m.prob), m.seed & 0xFFFFFFFF, A.ptr(spikes), sd,
+                A.ptr(out), self.shape1, self.in_len, self.lo, n_rows, A.ptr(ws), ws.numel(), A.stream_ptr()), 'be_binary_jitmv_rows')
+        return m._out(out, v)
+
+    def __rmatmul__(self, other):          # events @ shard
+        if self.side != 'left':
+            raise ValueError("this shard was cut for M @ events (side='right').")
+        return self.apply(other)
+
+    def __matmul__(self, other):           # shard @ events
+        if self.side != 'right':
+            raise ValueError("this shard was cut for events @ M (side='left').")
+        return self.apply(other)

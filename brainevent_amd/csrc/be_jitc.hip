@@ -104,6 +104,7 @@ struct JitP {
   int stride;               // 32 (mv) or 4 (mm)
   double w0, w1;            // scalar: weight, -- | uniform: low, span | normal: loc, scale
   int cls_begin, cls_count; // scatter: the (chunk, lane) classes [cls_begin, cls_begin + cls_count) this call owns
+  uint32_t row0;            // gather: generator row of output 0 (a rank of a row-sharded gather computes rows [row0, row0 + m))
 };
 
 // edge weight in the arithmetic type A (float or double); (row, col) are the RNG-orientation coordinates
@@ -151,7 +152,8 @@ __global__ void __launch_bounds__(1024) k_jit_mv_gather(JitP p, const uint32_t* 
     if (row < m) {
       // the walk in the q domain: lane l visits chunk-local columns l + 32 q, i.e. always bit ((cs + l) & 31) of
       // consecutive 32-bit words of the packed spike vector — one LDS word per step, no 64-bit arithmetic
-      uint32_t state = lr_init(p.seed, (uint32_t)row, (uint32_t)chunk, l);
+      const uint32_t grow = (uint32_t)row + p.row0;          // the generator row (the RNG is keyed by it; `row` indexes the output)
+      uint32_t state = lr_init(p.seed, grow, (uint32_t)chunk, l);
       uint32_t q = lr_initial_q(state, p.cl);
       const uint32_t qmax = width > (int64_t)l ? (uint32_t)((width - l + 31) >> 5) : 0u;   // l + 32 q < width
       const int64_t bit0 = cs + l;
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(1024) k_jit_mv_gather(JitP p, const uint32_t* 
         const bool on = (wp[q] >> sh) & 1u;
         if (on) {
           if (MODE == MODE_SCALAR) acc += 1;
-          else acc += (AccT)edge_weight<MODE, float>(p, (uint32_t)row, (uint32_t)(bit0 + 32ll * q));
+          else acc += (AccT)edge_weight<MODE, float>(p, grow, (uint32_t)(bit0 + 32ll * q));
         }
         state = lr_next_nz(state);
         q = q + 1u + lr_bounded(state, p.cl - 1u);
@@ -617,6 +619,7 @@ inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t
   p.w0 = w0;
   p.w1 = w1;
   p.cls_begin = 0;
+  p.row0 = 0u;
   p.cls_count = p.n_chunks * stride;
   return p;
 }
@@ -830,13 +833,25 @@ int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t 
 
 static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                       int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
-                      int class_begin, int class_count, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+                      int class_begin, int class_count, int64_t row_begin, void* workspace, int64_t workspace_bytes, be_stream_t stream);
 
 int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                     int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
                     void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   return jitmv_impl(mode, w0, w1, wdtype, clen, seed, spikes, spike_dtype, out, shape1, in_len, out_len, gather, scale_exp, 0,
-                    -1, workspace, workspace_bytes, stream);
+                    -1, 0, workspace, workspace_bytes, stream);
+}
+
+// The gather ("notrans") orientation sharded by OUTPUT ROWS: the generator rows are the outputs there and a row's walk is keyed
+// by (seed, row, chunk, lane) alone, so a rank that owns the rows [row_begin, row_begin + row_count) computes exactly those
+// outputs from the full (all-gathered) spike vector — nothing stored, outputs disjoint, their concatenation is the unsharded
+// result bit for bit.  out: row_count elements.  Workspace: be_binary_jitmv_workspace_bytes(shape1, in_len, row_count, 1).
+int be_binary_jitmv_rows(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                         int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t row_begin, int64_t row_count,
+                         void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count < (1ll << 32), BE_ERR_INVALID, "bad row range");
+  return jitmv_impl(mode, w0, w1, wdtype, clen, seed, spikes, spike_dtype, out, shape1, in_len, row_count, /*gather=*/1, 0, 0, -1,
+                    row_begin, workspace, workspace_bytes, stream);
 }
 
 int be_jit_scatter_classes(int64_t shape1, int64_t out_len, int stride) {
@@ -850,12 +865,12 @@ int be_binary_jitmv_sharded(int mode, double w0, double w1, int wdtype, int64_t 
                             int class_count, int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(class_begin >= 0 && class_count >= 0, BE_ERR_INVALID, "bad class range");
   return jitmv_impl(mode, w0, w1, wdtype, clen, seed, spikes, spike_dtype, out, shape1, in_len, out_len, /*gather=*/0,
-                    scale_exp, class_begin, class_count, workspace, workspace_bytes, stream);
+                    scale_exp, class_begin, class_count, 0, workspace, workspace_bytes, stream);
 }
 
 static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                       int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather, int scale_exp,
-                      int class_begin, int class_count, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+                      int class_begin, int class_count, int64_t row_begin, void* workspace, int64_t workspace_bytes, be_stream_t stream) {
   BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
   BE_REQUIRE(in_len >= 0 && out_len >= 0 && shape1 >= 0, BE_ERR_INVALID, "bad shape");
   BE_REQUIRE(in_len < (1ll << 32) && out_len < (1ll << 32), BE_ERR_RANGE, "dimensions must fit uint32 for the RNG keys");
@@ -873,6 +888,7 @@ static int jitmv_impl(int mode, double w0, double w1, int wdtype, int64_t clen, 
   BE_REQUIRE(gather || mode == MODE_SCALAR || (scale_exp - 32 > -126 && scale_exp - 32 < 127), BE_ERR_INVALID,
              "scale_exp out of range");
   JitP p = make_params(shape1, gather ? in_len : out_len, seed, clen, 32, w0, w1);
+  p.row0 = (uint32_t)row_begin;
   if (class_count >= 0) {      // sharded scatter: only the classes [class_begin, class_begin + class_count)
     BE_REQUIRE(class_begin + class_count <= p.cls_count, BE_ERR_RANGE, "class range exceeds be_jit_scatter_classes()");
     p.cls_begin = class_begin;

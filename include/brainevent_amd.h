@@ -517,6 +517,13 @@ int be_jit_scatter_classes(int64_t shape1, int64_t out_len, int stride);
 int be_binary_jitmv_sharded(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                             int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int class_begin,
                             int class_count, int scale_exp, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+/* ... and of the gather ("notrans") orientation, by OUTPUT ROWS: the generator rows are the outputs there, keyed by (seed, row,
+ * chunk, lane) alone, so a rank that owns rows [row_begin, row_begin + row_count) computes exactly those outputs from the full
+ * (all-gathered) spike vector — `out` has row_count elements; the ranks' slices concatenate to the unsharded result bit for bit.
+ * Workspace: be_binary_jitmv_workspace_bytes(shape1, in_len, row_count, 1). */
+int be_binary_jitmv_rows(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
+                         int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t row_begin, int64_t row_count,
+                         void* workspace, int64_t workspace_bytes, be_stream_t stream);
 int64_t be_binary_jitmm_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch, int gather);
 int be_binary_jitmm(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes_bm,
                     int spike_dtype, void* out_bm, int64_t shape1, int64_t in_len, int64_t out_len, int64_t n_batch,

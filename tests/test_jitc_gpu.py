@@ -404,3 +404,47 @@ def test_scalar_mm_gather_counts_are_bit_sliced_and_exact(be, oracle):
         got = be.binary_jitsmm(np.float32(0.25), prob, B, 99, shape=shape, transpose=False, corder=True)
         ref = oracle.binary_jitmm('s', 0.25, 0.0, prob, B, 99, shape=shape, transpose=False, corder=True)
         np.testing.assert_array_equal(got, ref.astype(np.float32))
+
+
+@pytest.mark.parametrize('cls_name,params', [('JITCScalarR', (np.float32(0.5),)), ('JITCScalarC', (np.float32(0.5),)),
+                                             ('JITCUniformR', (np.float32(0.1), np.float32(0.9))),
+                                             ('JITCNormalC', (np.float32(0.2), np.float32(1.1)))])
+@pytest.mark.parametrize('world', [1, 3, 8])
+def test_gather_shards_by_output_rows_concatenate_to_the_product(cls_name, params, world):
+    """Multi-GPU partition of the GATHER orientation (round 4; DESIGN section 7.4 listed it open): every rank computes its own
+    output rows from the full spike vector (`be_binary_jitmv_rows`); the slices tile the output and concatenate to the
+    unsharded product bit for bit; the side that runs the scatter kernel refuses (it shards by walk class)."""
+    import brainevent_amd as be
+    from brainevent_amd._dist import post_slice_bounds
+    rng = np.random.default_rng(100 + world)
+    shape = (2100, 3301)
+    M = getattr(be, cls_name)((*params, 0.03, 91), shape=shape, corder=False)
+    for side, ev_len, prod in (('left', shape[0], lambda e, X: e @ X), ('right', shape[1], lambda e, X: X @ e)):
+        s = rng.random(ev_len) < 0.15
+        ev = be.BinaryArray(s)
+        try:
+            shards = [M.gather_shard(world, r, side) for r in range(world)]
+        except ValueError:            # this side runs the scatter kernel for corder=False: the walk-class partition serves it
+            with pytest.raises(ValueError):
+                be.JITCGatherShard(M, world, 0, side)
+            continue
+        full = prod(ev, M)
+        parts = [prod(ev, sh) for sh in shards]
+        assert [len(p) for p in parts] == [post_slice_bounds(len(full), world, r)[1] - post_slice_bounds(len(full), world, r)[0]
+                                           for r in range(world)]
+        np.testing.assert_array_equal(np.concatenate(parts), full)
+        # packed words (what the exchange delivers) are taken as they are
+        import torch
+        packed = be.BitPackedBinary.from_packed(be.bitpack(torch.from_numpy(s).cuda(), 0).reshape(-1), ev_len)
+        np.testing.assert_array_equal(np.asarray(torch.as_tensor(prod(packed, shards[-1])).cpu()), parts[-1])
+        assert packed._value is None
+    # at least one side of every class is the gather orientation
+    assert any(_ok(M, world, side) for side in ('left', 'right'))
+
+
+def _ok(M, world, side):
+    try:
+        M.gather_shard(world, 0, side)
+        return True
+    except ValueError:
+        return False
