@@ -733,7 +733,7 @@ class BinnedScatter:
                [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp, c_i64, c_vp])
         is64 = int(indptr is not None and indptr.dtype == torch.int64)
         one = torch.ones(1, dtype=torch.float32, device=dev)
-        chunk = max(1, int(0.5 * self.max_active_fraction * m))                  # rows per step: half of what the bins are sized for
+        chunk = max(1, int(self.max_active_fraction * m))       # rows per step: what the bins are sized for (past it: the overflow image, still |w|)
         ids = torch.arange(m, dtype=torch.int32, device=dev)
         colsum = torch.zeros(k, dtype=torch.float32, device=dev)
         count = torch.zeros(k, dtype=torch.float32, device=dev)

@@ -284,3 +284,30 @@ def test_data_representation_buffer_contract():
         assert issubclass(cls, be.DataRepresentation)
     assert issubclass(be.JITCScalarR, be.JITCScalarMatrix) and issubclass(be.JITCScalarC, be.JITCScalarMatrix)
     assert issubclass(be.JITCUniformR, be.JITCUniformMatrix) and issubclass(be.JITCNormalC, be.JITCNormalMatrix)
+
+
+def test_reference_task_workspace_names_and_formula():
+    """`hybrid_task_capacity` (brainevent/_csr/hybrid_config.py:298-324: rows longer than 128 contribute
+    ceil(len / 4096) tasks; same validation errors) and the explicit task workspace of brainevent/_csr/binary.py:76-120 exist
+    under the reference's names, so that code which builds / unpacks one keeps working (the kernels here do not read it)."""
+    import numpy as np
+    import pytest
+    import torch
+    import brainevent_amd as be
+    from brainevent_amd import _csr as C
+    lens = np.array([0, 1, 128, 129, 4096, 4097, 10000, 128 * 3])
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    want = sum(-(-int(l) // 4096) for l in lens if l > 128)
+    assert be.hybrid_task_capacity(ptr) == want == C.hybrid_task_capacity(torch.tensor(ptr)) == 1 + 1 + 2 + 3 + 1
+    with pytest.raises(ValueError):
+        be.hybrid_task_capacity(np.zeros((2, 2), np.int64))
+    with pytest.raises(ValueError):
+        be.hybrid_task_capacity(np.array([], np.int64))
+    with pytest.raises(ValueError):
+        be.hybrid_task_capacity(np.array([0, 5, 3]))
+    for maker in (C._make_binary_csrmv_workspace, C._make_binary_csrmv_benchmark_workspace, C._make_binary_task_workspace):
+        ws = maker(ptr.astype(np.int32))
+        cap, tb, te, st = ws                                   # unpacks like the reference's namedtuple
+        assert cap == ws.task_capacity == want and tb.shape == te.shape == (want,) and tb.dtype == np.int32
+        assert st.shape == (2,) and st.dtype == np.int32
+    assert C._BinaryTaskWorkspace is C._BinaryCsrmvTaskWorkspace

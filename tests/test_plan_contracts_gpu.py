@@ -659,3 +659,68 @@ def test_binned_exponent_from_binned_steps_equals_the_atomic_pass(be, oracle, mo
     w_bad = w.clone(); w_bad[5] = float('inf')
     with pytest.raises(be.MathError):
         BinnedScatter(w_bad, m, k, nnz, indices=flat_idx, indptr=ptr, row_len=rl)
+
+
+def test_reference_task_workspace_handle_carries_the_native_workspace(be, oracle, monkeypatch):
+    """A reference-style task workspace passed as `workspace=` (brainevent/_csr/binary.py:128-138 requires one): the matrix's
+    native scatter workspace is built on first use and cached on the handle — keyed on the arrays, so the same handle reused
+    for another matrix of the same indptr re-derives it — and `binary_csrmv_p_call` returns the reference's 4-tuple."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(91)
+    m, k, row = 600, 40_000, 200
+    ptr = torch.arange(0, m * row + 1, row, dtype=torch.int32, device='cuda')
+    handle = C._make_binary_csrmv_workspace(ptr)
+    assert handle.task_capacity == m and handle.task_begin.dtype == torch.int32 and handle.status.shape == (2,)
+    v = rng.random(m) < 0.2
+    dv = torch.tensor(v, device='cuda')
+    for trial in range(2):                                   # second trial: ANOTHER matrix with the same indptr through the same handle
+        idx = torch.tensor(rng.integers(0, k, m * row).astype(np.int32), device='cuda')
+        w = torch.tensor(rng.random(m * row).astype(np.float32), device='cuda')
+        y, tb, te, st = C.binary_csrmv_p_call(w, idx, ptr, dv, handle, shape=(m, k), transpose=True)
+        assert tb is handle.task_begin and te is handle.task_end and st is handle.status
+        assert isinstance(handle._native, C.ScatterPlan)
+        ref = oracle.binary_csrmv(w.cpu().numpy().astype(np.float64), idx.cpu().numpy(), ptr.cpu().numpy(), v, (m, k), True)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        got = be.binary_csrmv(w, idx, ptr, dv, shape=(m, k), workspace=handle, transpose=True)
+        assert torch.equal(got, y)
+        w.mul_(2.0)                                          # in-place update: the cached workspace follows
+        np.testing.assert_allclose(be.binary_csrmv(w, idx, ptr, dv, shape=(m, k), workspace=handle, transpose=True).cpu().numpy(),
+                                   2.0 * ref, rtol=1e-5, atol=1e-5)
+    # without a handle: (y, None, None, None); the gather direction ignores the handle
+    out = C.binary_csrmv_p_call(w, idx, ptr, dv, None, shape=(m, k), transpose=True)
+    assert len(out) == 4 and out[1] is None and out[3] is None
+    dk = torch.tensor(rng.random(k) < 0.1, device='cuda')
+    g = C.binary_csrmv_p_call(w, idx, ptr, dk, handle, shape=(m, k), transpose=False)
+    assert len(g) == 4 and g[0].shape == (m,)
+
+
+def test_release_raw_and_direct_route_warning(be, oracle, monkeypatch):
+    """`prepare(release_raw=True)` hands back a PlannedMatrix (the caller drops the container and its raw arrays: C2 holds 58 GB
+    instead of 138); a large matrix that ends up on the direct route (global float atomics) says so once."""
+    import warnings
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(92)
+    m, k, row = 500, 30_000, 150
+    ptr = np.arange(0, m * row + 1, row, dtype=np.int32)
+    idx = rng.integers(0, k, m * row).astype(np.int32)
+    for homo in (False, True):
+        w = np.array([0.5], np.float32) if homo else rng.random(m * row).astype(np.float32)
+        pm = be.CSR((w, idx, ptr), shape=(m, k)).prepare(release_raw=True)
+        assert isinstance(pm, C.PlannedMatrix)
+        v = rng.random(m) < 0.3
+        np.testing.assert_allclose(be.BinaryArray(v) @ pm, oracle.binary_csrmv(np.asarray(w, np.float64), idx, ptr, v, (m, k), True),
+                                   rtol=1e-5, atol=1e-5)
+    small = be.CSR((w[:1], idx[:10], np.array([0, 10], np.int32)), shape=(1, k))
+    with pytest.raises(ValueError):
+        small.prepare(release_raw=True)                        # direct route: nothing to release the raw arrays to
+    monkeypatch.setattr(C, 'DIRECT_ROUTE_WARN_NNZ', 1000)
+    w_inf = rng.random(m * row).astype(np.float32); w_inf[7] = np.inf
+    csr = be.CSR((w_inf, idx, ptr), shape=(m, k))
+    with pytest.warns(UserWarning, match='direct route'):
+        out = be.BinaryArray(v) @ csr
+    assert csr.buffers['scatter_plan'] is None
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                          # ... once: the cached decision does not warn again
+        be.BinaryArray(v) @ csr
