@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument('--jit-gather', action='store_true', help='jitc: time the gather orientation instead of the scatter')
     ap.add_argument('--batch', type=int, default=32, help='dense: batch rows')
     ap.add_argument('--k', type=int, default=1000, help='fcn: synapses per pre neuron')
+    ap.add_argument('--acc32', action='store_true', help='fcn: force the 32-bit fixed-point sums of the binned route (opt-in: outputs good '
+                    'to rtol = atol = 1e-5, not to 1e-5 relative per output — never the default for weights like U[0,1))')
     ap.add_argument('--n-post', type=int, default=0, help='fcn: post population (default: n)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configs after the headline')
@@ -408,6 +410,9 @@ def run_fcn(args, dev, g):
     conn = be.FixedNumPerPre((w, idx), shape=(n, n_post), check_indices=False)
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
+    if args.acc32 and not args.homo:
+        from brainevent_amd import _csr as C
+        conn.buffers['scatter_plan'] = C.BinnedScatter(w, n, n_post, n * K, indices=idx, row_len=K, acc32=True)
     conn.prepare()
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup

@@ -653,11 +653,16 @@ class BinnedScatter:
         self._ws: Dict = {}
         self.ws = self.workspace(1)
 
-    #: per-entry weights: take 32-bit sums (twice the bin width: half the bins, one round of pass C) whenever every column's
-    #: largest weight keeps this many bits at the 32-bit exponent — every addend is then rounded by at most 2^-19 of its column's
-    #: largest weight, 4 x finer than MIN_WEIGHT_BITS asks of the 64-bit sums (C4: U[0,1) weights, ~1000 per column -> exponent
-    #: 20, 1e-6 of an output in the worst case, ~1e-7 measured).  None: never.
+    #: 32-bit fixed-point sums (twice the bin width: half the bins, one round of pass C; C4: 0.60 -> 0.53 ms per step).
+    #: ``acc32=True`` (explicit): taken when every column's largest weight keeps ACC32_MIN_WEIGHT_BITS bits at the 32-bit exponent
+    #: — an addend is then rounded by at most 2^-19 of its column's largest weight, i.e. an output is good to
+    #: ``n_addends * 2^-19 * w_max(column)``: inside rtol = atol = 1e-5 for weights of one scale (C4, U[0,1): 1e-7 of a typical
+    #: output), but an output made of ONE small weight (1e-3 of the column's largest) carries up to 5e-4 relative — coarser than the
+    #: reference's f32 atomics there.  So it is never chosen silently for such weights: AUTOMATICALLY (``acc32=None``) the 32-bit
+    #: sums are taken only when the SMALLEST non-zero |w| of the whole matrix keeps ACC32_AUTO_SMALLEST_BITS bits at that exponent —
+    #: every single addend, hence every output of same-sign weights, is then within 2^-18 = 4e-6 relative, the 1e-5 bar of the path.
     ACC32_MIN_WEIGHT_BITS: Optional[int] = 18
+    ACC32_AUTO_SMALLEST_BITS = 17
     #: ... and only over at least this many outputs (below, the 64-bit bins already are one round of pass C)
     ACC32_MIN_OUTPUTS = 256 * 20000
     #: stored entries from which the column statistics behind the exponent come from binned steps (below: one atomic pass is faster)
@@ -799,14 +804,28 @@ class BinnedScatter:
                                                   and weights.dtype == torch.float32 and not os.environ.get('BE_BIN_NO_ACC32'))
         if want32:
             try:        # the 64-bit exponent e leaves 2^62 of headroom; the same bound for 2^30 is e - 32
-                self.acc32, self.scale_exp = True, self._exponent(weights, indices, b32) - 32
-                return
+                e32 = self._exponent(weights, indices, b32) - 32
+                if acc32 or self._smallest_weight(weights) >= math.ldexp(1.0, self.ACC32_AUTO_SMALLEST_BITS - e32):
+                    self.acc32, self.scale_exp = True, e32
+                    return
             except MathError:
                 self.acc32 = False
                 if acc32:
                     raise
         self.acc32 = False
         self.scale_exp = self._exponent(weights, indices)
+
+    def _smallest_weight(self, weights: torch.Tensor) -> float:
+        """Smallest non-zero |w| (inf if there is none): from the statistics already taken, else one streaming pass."""
+        if getattr(self, '_stats_stamp', None) == weights_stamp(weights):
+            return self._stats[3]
+        flat = weights.reshape(-1)
+        mx, mn = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        scr = A.workspace(256)
+        check(fn('be_weight_stats', c_int, [c_vp, c_int, c_i64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), c_vp,
+                                            c_i64, c_vp])(A.ptr(flat), A.wcode(flat), flat.numel(), ctypes.byref(mx), ctypes.byref(mn),
+                                                          A.ptr(scr), scr.numel(), A.stream_ptr()), 'be_weight_stats')
+        return float(np.array([mn.value], dtype=np.uint32).view(np.float32)[0]) if mn.value != 0xffffffff else float('inf')
 
     def refresh_weights(self, weights, indices, indptr=None) -> None:
         """The bins are refilled from the matrix on every call; only the fixed-point exponent derives from the weights."""

@@ -201,7 +201,19 @@ def test_c4_fixed_num_10m_full_size_and_one_of_eight_shard(be, one_rank_group):
     rel = ((out.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
     assert rel <= 1e-5, rel
     assert torch.equal(out, be.BinaryArray(spk) @ conn), 'fixed-point route is not bitwise repeatable'
-    del conn, w, idx, out, ref
+    ws = conn.buffers['scatter_plan']
+    assert isinstance(ws, C.BinnedScatter) and not ws.acc32, 'U[0,1) weights must not get 32-bit sums silently'
+    # the opt-in 32-bit sums (256 bins instead of 611): good to rtol = atol = 1e-5 — an output made of one small weight is NOT
+    # within 1e-5 of itself (measured 6e-4 here), which is why they are never the automatic choice for such weights
+    ws32 = C.BinnedScatter(w, n, n, n * K, indices=idx, row_len=K, acc32=True)
+    assert ws32.acc32 and ws32.n_slices == 256
+    conn32 = be.FixedNumPerPre((w, idx), shape=(n, n), check_indices=False)
+    conn32.buffers['scatter_plan'] = ws32
+    out32 = be.BinaryArray(spk) @ conn32
+    err = (out32.double() - ref).abs()
+    assert bool((err <= 1e-5 + 1e-5 * ref.abs()).all()), float((err / (1e-5 + 1e-5 * ref.abs())).max())
+    assert torch.equal(out32, be.BinaryArray(spk) @ conn32)
+    del conn, conn32, ws32, w, idx, out, out32, ref
     _free()
 
 

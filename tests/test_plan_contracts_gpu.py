@@ -528,7 +528,7 @@ def test_plan_built_from_row_blocks_equals_the_resident_build(be, oracle, layout
             be.BinaryArray(torch.zeros(m + 1, dtype=torch.bool, device='cuda')) @ M
 
 
-def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle):
+def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle, monkeypatch):
     """BE_BINNED_ACC32: per-entry weights summed in 32-bit fixed point (bins twice as wide) — taken only when every column's
     largest weight keeps >= 18 bits at the 32-bit exponent; then within 1e-5 of the oracle (measured ~1e-7), bitwise repeatable,
     and within 2e-6 of the 64-bit sums; weights whose range the 32-bit sums cannot resolve fall back to 64-bit bins."""
@@ -561,6 +561,14 @@ def test_binned_32bit_sums_are_gated_exact_enough_and_reproducible(be, oracle):
         BinnedScatter(w2, m, k, m * row, indices=idx, acc32=True)
     auto = BinnedScatter(w2, m, k, m * row, indices=idx)
     assert not auto.acc32                                  # (also: below ACC32_MIN_OUTPUTS the automatic choice is 64-bit)
+    # the AUTOMATIC choice is stricter than the explicit one: every single addend must keep 17 bits (an output made of one small
+    # weight is then still within 1e-5 relative).  Weights in [0.25, 1) with column sums < 2^10: exponent 20, 0.25 keeps 18 bits
+    monkeypatch.setattr(BinnedScatter, 'ACC32_MIN_OUTPUTS', 1)
+    assert BinnedScatter(w, m, k, m * row, indices=idx).acc32
+    w3 = w.clone(); w3[11] = 1e-4                           # one small weight: its own column still passes the explicit gate? no: alone -> refused
+    idx3 = idx.clone(); idx3[11] = idx3[12]                 # ... so put it into a column that also holds a large weight
+    assert not BinnedScatter(w3, m, k, m * row, indices=idx3).acc32          # automatic: the smallest weight keeps < 17 bits -> 64-bit
+    assert BinnedScatter(w3, m, k, m * row, indices=idx3, acc32=True).acc32  # explicit: the column gate alone (documented accuracy)
     # an in-place update that stops qualifying moves a 32-bit workspace back to 64-bit bins
     w.copy_(w2)
     from brainevent_amd._csr import fresh_scatter_workspace
