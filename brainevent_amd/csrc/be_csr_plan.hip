@@ -875,12 +875,19 @@ __device__ __forceinline__ int d8_sort_row(unsigned long long* keys, const int32
           // 10 000-entry row)
           if (B <= 64u) {                                                 // nearly every bucket: one key per lane
             const unsigned long long mk = (uint32_t)lane < B ? kb[lane] : ~0ull;
-            const uint32_t lo = (uint32_t)mk, hi = (uint32_t)(mk >> 32);
             uint32_t below = 0u;
-            for (uint32_t j = 0; j < B; ++j) {
-              const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)j) << 32) |
-                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, (int)j);
-              below += kj < mk ? 1u : 0u;
+            if (bw < (1u << 18)) {
+              // inside a bucket the column is < bucket start + bw: (column - start) << 14 | position is a 32-bit key with the order
+              // of the 64-bit one (positions < 16384) — one v_readlane and one 32-bit compare per key instead of two and a 64-bit one
+              const uint32_t ck = (uint32_t)lane < B ? ((((uint32_t)(mk >> 16) - bk * bw) << 14) | ((uint32_t)mk & 0x3fffu)) : 0xffffffffu;
+              for (uint32_t j = 0; j < B; ++j) below += (uint32_t)__builtin_amdgcn_readlane((int)ck, (int)j) < ck ? 1u : 0u;
+            } else {
+              const uint32_t lo = (uint32_t)mk, hi = (uint32_t)(mk >> 32);
+              for (uint32_t j = 0; j < B; ++j) {
+                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)j) << 32) |
+                                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, (int)j);
+                below += kj < mk ? 1u : 0u;
+              }
             }
             __builtin_amdgcn_wave_barrier();                              // (every lane holds its key: nothing reads the bucket any more)
             if ((uint32_t)lane < B) kb[below] = mk;
