@@ -932,6 +932,9 @@ def run_scatter(args):
                                        f"layout {({1: 'd8 (5 B/entry)', 2: 'h8 (1 B/entry)'}.get(plan.layout, 'u16'))}" if plan is not None else None),
                        'mean_active_rows': mean_active, 'checksum': checksum},
             'step_ms_hip_events': _stats(step_ms),
+            'timing': ('value / ms_per_step: wall clock over exactly `steps` uninstrumented steps between synchronize (+ barrier) fences; '
+                       'roofline.kernel_ms and step_ms_hip_events: HIP events in two separate passes over the same steps afterwards '
+                       '(in-library events around the dominant kernel; one event per 10 steps on the issuing stream)'),
             'parity_check': {'what': 'last timed step vs ' + ('exact integer histogram of the active rows\' columns (max abs diff)'
                                                               if args.homo else 'float64 index_add of the active rows\' entries (max rel err)')
                                      + ', every rank on its own slice, worst rank reported',

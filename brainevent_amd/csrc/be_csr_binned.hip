@@ -57,6 +57,14 @@ constexpr int kBinErrWord = 16;             // word of the workspace head that h
 template <bool HOMO, int CAP> struct BinBlock {
   static constexpr int bytes = CAP * (HOMO ? 2 : 6);
   static constexpr int dwords = bytes / 4;
+  // stride of a block in the GLOBAL regions.  BE_BLOCK_GALIGN (A/B builds; the verdict's "line-aligned flush units"): every
+  // block starts on a 128-byte line — a 96-byte block of 16 weighted entries then never straddles two lines, at the price of
+  // unused bytes in the regions (pass C's reads span them).  Measured in round 4: see DESIGN.md section 2.1b.
+#ifdef BE_BLOCK_GALIGN
+  static constexpr int gdwords = (bytes + 127) / 128 * 32;
+#else
+  static constexpr int gdwords = dwords;
+#endif
   // weighted entries sit in UNITS of 12 bytes, two entries each: [f32 w0][f32 w1][u16 c0 | u16 c1] — pass C reads the units of a
   // region as one contiguous stream, a unit per lane and load; one weight: [u16 column x CAP]
   __device__ static __forceinline__ uint32_t w_dw(uint32_t s) { return 3u * (s >> 1) + (s & 1u); }                 // dword of entry s's weight
@@ -214,7 +222,7 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
 #else
       if (have[p] && q[p] < cap_blocks)
 #endif
-        *reinterpret_cast<uint4*>(wg_regions + (size_t)(slotid[p] >> kRingLog) * bin_stride_dw + (size_t)q[p] * B::dwords + gl * 4) = v[p];
+        *reinterpret_cast<uint4*>(wg_regions + (size_t)(slotid[p] >> kRingLog) * bin_stride_dw + (size_t)q[p] * B::gdwords + gl * 4) = v[p];
     }
   }
 }
@@ -408,8 +416,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   const uint64_t per = (n_tasks + gridDim.x - 1) / gridDim.x;
   const uint64_t t_begin = (uint64_t)blockIdx.x * per;
   const uint64_t t_end = t_begin + per < n_tasks ? t_begin + per : n_tasks;
-  const size_t bin_stride_dw = (size_t)kStreamGrid * cap_blocks * B::dwords;
-  uint32_t* wg_regions = regions + (size_t)blockIdx.x * cap_blocks * B::dwords;
+  const size_t bin_stride_dw = (size_t)kStreamGrid * cap_blocks * B::gdwords;
+  uint32_t* wg_regions = regions + (size_t)blockIdx.x * cap_blocks * B::gdwords;
 
   StreamProf prof;
   for (;;) {
@@ -598,7 +606,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
     const int bin = q / B::dwords, l = q - bin * B::dwords;
     const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
     if (d > 0 && blk < cap_blocks)
-      regions[(((size_t)bin * kStreamGrid + blockIdx.x) * cap_blocks + blk) * B::dwords + l] = S.buf[(size_t)(bin * kRing + (blk & (uint32_t)(kRing - 1))) * B::dwords + l];
+      regions[(((size_t)bin * kStreamGrid + blockIdx.x) * cap_blocks + blk) * B::gdwords + l] = S.buf[(size_t)(bin * kRing + (blk & (uint32_t)(kRing - 1))) * B::dwords + l];
   }
   for (int bin = tid; bin < n_bins; bin += (int)blockDim.x) {
     const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
@@ -673,7 +681,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   if (mapped && tid < kStreamGrid)
     for (uint32_t bk = s_pre[tid]; bk < s_pre[tid + 1]; ++bk) s_map[bk] = (uint8_t)tid;
   __syncthreads();
-  const uint32_t* bin_base = regions + (size_t)bin * kStreamGrid * cap_blocks * B::dwords;
+  const uint32_t* bin_base = regions + (size_t)bin * kStreamGrid * cap_blocks * B::gdwords;
   if (HOMO) {
     // one flat loop over the groups of 8 columns (16 bytes) of all regions, BE_BIN_U groups per thread and round with every
     // load of the round issued before the first add
@@ -701,7 +709,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
         const uint32_t lb = blk - s_pre[r];
         const uint32_t first = lb * (uint32_t)CAP + sub * 8u, c = s_cnt[r];
         nv[u] = !in || c <= first ? 0u : (c - first < 8u ? c - first : 8u);
-        iv[u] = *reinterpret_cast<const uint4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::dwords + sub * 4u);
+        iv[u] = *reinterpret_cast<const uint4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::gdwords + sub * 4u);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -743,7 +751,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
         const uint32_t lb = blk - s_pre[r];
         const uint32_t first = lb * (uint32_t)CAP + ub * 2u, c = s_cnt[r];
         nv[u] = !in || c <= first ? 0u : (c - first < 2u ? 1u : 2u);
-        uv[u] = *reinterpret_cast<const be_u32x3_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::dwords + ub * 3u);
+        uv[u] = *reinterpret_cast<const be_u32x3_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::gdwords + ub * 3u);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -970,7 +978,11 @@ static inline BinWs binned_ws_layout(int64_t m, int64_t k, int64_t n_batch, int 
     if (bg.g.cap == 0) continue;
     const int64_t vb = (int64_t)bg.g.n_bins * bg.gb;
     const int64_t cb = stream_cap_blocks(batch_bin_capacity(k, slice_shift, homo, bin_capacity, bg), bg.g.cap);
+#ifdef BE_BLOCK_GALIGN
+    const int64_t b = vb * kStreamGrid * cb * ((bg.g.cap * (kind_counted(homo) ? 2 : 6) + 127) / 128 * 128);
+#else
     const int64_t b = vb * kStreamGrid * cb * bg.g.cap * (kind_counted(homo) ? 2 : 6);
+#endif
     blocks_bytes = b > blocks_bytes ? b : blocks_bytes;
     dir_bytes = std::max<int64_t>(dir_bytes, vb * kStreamGrid * 4);
     gb_max = std::max<int64_t>(gb_max, bg.gb);
