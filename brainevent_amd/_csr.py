@@ -1747,7 +1747,11 @@ class CSR(CompressedSparseData):
     def __matmul__(self, other):      # csr @ other
         if is_event(other):
             v = _event_value(other)
-            r = self._gather_via_mirror(v) if v.ndim in (1, 2) else None
+            r = None
+            if v.ndim in (1, 2) and self._fresh_mirror(auto=True) is not None:
+                # the mirror turns this product into a scatter: a compacted container hands its id list over (no compaction launch)
+                v = _event_value(other, scatter=True)
+                r = self._gather_via_mirror(v)
             if r is not None:
                 pass
             elif v.ndim == 1:
@@ -1823,6 +1827,8 @@ class CSC(CompressedSparseData):
             v = _event_value(other)
             r = None
             if v.ndim == 1:
+                if self._fresh_mirror(auto=True) is not None:
+                    v = _event_value(other, scatter=True)      # (the mirror scatters: id lists are taken as they are)
                 r = self._gather_via_mirror(v)
             elif v.ndim == 2:
                 r = self._gather_via_mirror(v.T)

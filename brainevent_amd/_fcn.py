@@ -297,7 +297,10 @@ class FixedNumConn(DataRepresentation):
         if not is_event(other):
             raise NotImplementedError("only BinaryArray operands are on the accelerated path "
                                       "(float fcnmv is out of scope).")
-        value = event_operand(other, scatter=other.ndim == 1 and self._ell_transpose(transpose_W))
+        ell_t = self._ell_transpose(transpose_W)
+        # scatter kernels take compacted id lists as they are — the favourable direction, and the other one once its mirror exists
+        scatter = other.ndim == 1 and (ell_t or self._fresh_mirror(auto=True) is not None)
+        value = event_operand(other, scatter=scatter)
         if value.ndim == 1:
             r = self._binary_matvec(value, transpose_W)
         elif value.ndim == 2:

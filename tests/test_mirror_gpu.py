@@ -296,3 +296,32 @@ def test_indexed_workspace_is_keyed_on_data_and_perm(be, oracle, monkeypatch, ro
     assert calls == [1]                                              # one refresh for the update, none after
     np.testing.assert_allclose(got2.cpu().numpy(), 2.0 * got.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert torch.equal(got2, got3)
+
+
+def test_compacted_and_packed_events_through_the_mirrors(be, oracle, monkeypatch):
+    """The mirror turns the gather product into a scatter, so the event encodings the scatter kernels consume natively go straight
+    in: a CompactBinary built on the device hands over its id list (no compaction launch), a BitPackedBinary its words — same bits
+    as the plain BinaryArray operand, for CSR, CSC and the fixed-number containers."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    rng = np.random.default_rng(61)
+    m, k = 1500, 1800
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(80, 160, m))
+    v = rng.random(k) < 0.07
+    dv = torch.tensor(v, device='cuda')
+    plain, compact = be.BinaryArray(dv), be.CompactBinary.from_array(dv)
+    packed = be.BitPackedBinary.from_packed(be.bitpack(dv, 0).reshape(-1), k)
+    csr = be.CSR((torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')), shape=(m, k)).prepare(mirror=True)
+    csc = be.CSC((torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')), shape=(k, m)).prepare(mirror=True)
+    want = csr @ plain
+    np.testing.assert_allclose(want.cpu().numpy(), oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), False), rtol=RTOL, atol=ATOL)
+    for ev in (compact, packed):
+        assert torch.equal(csr @ ev, want) and torch.equal(ev @ csc, want)
+    assert packed._value is None
+    K = 64
+    fidx = torch.tensor(rng.integers(0, k, (m, K)).astype(np.int32), device='cuda')
+    fw = torch.tensor(rng.random((m, K)).astype(np.float32), device='cuda')
+    fcn = be.FixedNumPerPre((fw, fidx), shape=(m, k)).prepare(mirror=True)
+    fwant = fcn @ plain
+    for ev in (compact, packed):
+        assert torch.equal(fcn @ ev, fwant)
