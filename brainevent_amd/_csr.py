@@ -1521,9 +1521,11 @@ def build_mirror_of(data, indices, indptr, row_len, m: int, k: int, *, keep_raw:
             except oom:
                 t_data = t_idx = t_ptr = perm = plan = None
                 torch.cuda.empty_cache()
-        # column blocks resident one at a time: each at most a quarter of what is free beside the plan
-        budget = max(1 << 28, int(0.25 * (_free_device_bytes() - _mirror_bytes(nse, flat, planned=True) + _mirror_bytes(nse, flat, False))))
-        n_blocks = max(2, -(-_mirror_bytes(nse, flat, planned=False) // budget))
+        # column blocks resident one at a time: each at most a quarter of what stays free beside the plan itself
+        raw_bytes = _mirror_bytes(nse, flat, planned=False)
+        plan_bytes = _mirror_bytes(nse, flat, planned=True) - raw_bytes
+        budget = max(1 << 28, int(0.25 * (_free_device_bytes() - plan_bytes)))
+        n_blocks = max(2, -(-raw_bytes // budget))
         block_cols = -(-k // n_blocks)
 
         def get_block(c0, c1):
