@@ -36,3 +36,26 @@ def be():
 def oracle():
     from oracle import oracle_np
     return oracle_np
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_device_memory(request):
+    """BE_POISON_ALLOC=1 (robustness runs on the GPU box): before every gpu test, what the caching allocator will hand out next
+    is filled with 0xFF bytes (NaN as a float, -1 as an integer, all spikes set as a mask), so a kernel or a host path that
+    relies on `torch.empty` memory being zero — true in a fresh process, false in a long-running one — fails here instead of
+    once in a while.  Large pool: one block of BE_POISON_GIB GiB (default 16; tests that allocate more get fresh pages beyond
+    it), small pool: 512 blocks of 1 MiB."""
+    if os.environ.get('BE_POISON_ALLOC') != '1' or request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gib = int(os.environ.get('BE_POISON_GIB', '16'))
+        free = torch.cuda.mem_get_info()[0]
+        big = torch.empty(min(gib << 30, int(free * 0.9)), dtype=torch.uint8, device='cuda').fill_(0xFF)
+        small = [torch.empty(1 << 20, dtype=torch.uint8, device='cuda').fill_(0xFF) for _ in range(512)]
+        tiny = [torch.empty(4096, dtype=torch.uint8, device='cuda').fill_(0xFF) for _ in range(512)]
+        torch.cuda.synchronize()
+        del big, small, tiny          # back to the caching allocator, contents intact
+    yield
