@@ -29,7 +29,7 @@ class ScatterTuning:
     plan_min_segment: int = 8               # entries per (row, slice) block from which the planned layout beats the binned route
     plan_min_segment_homo: int = 10         # ... for one shared weight
     plan_min_segment_no_binned: int = 8     # ... and from which it beats the direct route where the binned route does not apply
-    binned_task_groups: int = 1024          # pass B of the binned route: groups of four entries per task
+    binned_task_groups: int = 256           # pass B of the binned route: groups of four entries per task (round 4: 1024 -> 256, >= 4 rows)
     binned_min_tasks: int = 2048            # ... and the tasks a step is cut into at least
     benchmark_records: tuple = ()           # what the tuner measured (kept with the entry, not interpreted)
 

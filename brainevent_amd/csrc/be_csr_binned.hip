@@ -41,6 +41,7 @@ namespace {
 #ifndef BE_STREAM_U
 #define BE_STREAM_U 2    // steps (64 lanes x 4 entries) a wave of pass B keeps in flight next to the ones it is appending
 #endif
+constexpr int kTaskRowsFloor = 4, kTaskGroupsCap = 1024;   // pass B: a task has at least 4 rows while they stay within 1024 groups of four
 constexpr int kMaxBins = 2048;
 constexpr int kStreamGrid = 256;     // workgroups of pass B = regions per bin (one per CU)
 constexpr int kStreamWaves = 16;
@@ -396,11 +397,13 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   if (HOMO) w0 = (float)WTraits<W>::load(weights, 0);
   const bool fixed = rp.p == nullptr && rp.fixed > 0 && rp.fixed < (1ll << 26);
   const uint32_t K = fixed ? (uint32_t)rp.fixed : 0u, K4 = (K + 3u) >> 2;
-  // rows per task (1 ... 64): about `task_groups` groups of four entries — 12-16 steps of a wave.  Measured (BE_BIN_TASKS /
-  // BE_BIN_TASK_GROUPS): rows of 1000 entries, 8 / 4 / 2 rows per task 0.666 / 0.646 / 0.646 ms per C4 step; rows of ~125
-  // entries (one post slice of an 8-way cut), 64 / 32 / 16 / 8 rows per task 151 / 124 / 124 / 130 us per step: shorter tasks
-  // pay their header (ticket, row ids, row bounds: dependent loads) too often, longer ones leave waves without work and
-  // the others in step with each other.  Fewer active rows than `min_tasks` tasks of that size: smaller tasks.
+  // rows per task (1 ... 64): about `task_groups` groups of four entries, but at least kTaskRowsFloor rows while those stay
+  // within kTaskGroupsCap groups.  Measured on the round-4 kernel (tools/ab_c4_rank_tasks.sh, tools/ab_c4_tasks.sh): rows of
+  // ~125 entries (one post slice of an 8-way cut of C4), 32 / 16 / 8 / 4 rows per task 104.9 / 95.5 / 93.1 / 94.3 us per step;
+  // rows of 1000 entries (C4), 4 / 2 / 1 rows per task 0.597-0.629 / 0.592 / 0.590 ms weighted and 0.236 / 0.242 / 0.250 ms
+  // counted: a handful of rows per task either way — shorter tasks pay their header (ticket, row ids, row bounds: dependent
+  // loads) too often, longer ones leave waves without work at the end of the workgroup's share (12 tasks for 16 waves at 32
+  // rows per task on the post slice).  Fewer active rows than `min_tasks` tasks of that size: smaller tasks.
   uint64_t avg_g4 = K4;
   if (!fixed) {
     const int64_t nnz = rp.at(m_rows) - rp.at(0);
@@ -409,6 +412,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   avg_g4 = avg_g4 ? avg_g4 : 1u;
   int rshift = 6;
   while (rshift > 0 && (avg_g4 << rshift) > (uint64_t)task_groups) --rshift;
+  while ((1 << rshift) < kTaskRowsFloor && (avg_g4 << (rshift + 1)) <= (uint64_t)kTaskGroupsCap) ++rshift;
   while (rshift > 0 && (n_active >> rshift) < min_tasks) --rshift;
   while (fixed && rshift > 0 && (rp.fixed << rshift) >= (1ll << 31)) --rshift;
   const uint32_t R = 1u << rshift;
@@ -904,7 +908,7 @@ static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo /* kin
 
 // pass B's task size (be_binned_set_tuning; the environment — BE_BIN_TASK_GROUPS / BE_BIN_TASKS — gives the initial values for A/B runs)
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; }
-std::atomic<int> g_task_groups{env_int("BE_BIN_TASK_GROUPS", 1024)}, g_min_tasks{env_int("BE_BIN_TASKS", 2048)};
+std::atomic<int> g_task_groups{env_int("BE_BIN_TASK_GROUPS", 256)}, g_min_tasks{env_int("BE_BIN_TASKS", 2048)};
 
 }  // namespace
 

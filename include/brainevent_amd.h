@@ -368,8 +368,9 @@ int be_binary_csrmm_t_plan(const void* weights, int homo, int wdtype, const void
  * (order independent).  be_binned_bins and the workspace sizes take the same kind (a workspace is sized for all three).
  * ---------------------------------------------------------------------------------------------- */
 int be_binned_bins(int64_t k, int slice_shift, int homo);
-/* Task size of pass B (process-wide, read at every call): a task is about task_groups groups of four consecutive entries, and a
- * step is cut into at least min_tasks tasks.  Defaults 1024 / 2048 (measured on gfx950); the Python layer sets them from its
+/* Task size of pass B (process-wide, read at every call): a task is about task_groups groups of four consecutive entries — but at
+ * least four rows while those stay within 1024 groups —, and a step is cut into at least min_tasks tasks.  Defaults 256 / 2048
+ * (measured on gfx950; rounds 1-3: 1024 / 2048); the Python layer sets them from its
  * persisted per-architecture tuning — the counterpart of the thresholds the reference compiles into its hybrid kernel from
  * brainevent/_csr/hybrid_config.py:77-88, :256-295. */
 int be_binned_set_tuning(int task_groups, int min_tasks);
