@@ -674,6 +674,14 @@ class BinnedScatter:
         weights / 32-bit sums (BE_BINNED_ACC32)."""
         return 1 if self.homo else (2 if self.acc32 else 0)
 
+    SHORT_ROW_ENTRIES = 256      # BE_BINNED_SHORT_ROWS: average stored row length up to which pass B runs one step ahead
+
+    @property
+    def step_kind(self) -> int:
+        """``kind`` plus the hints of a step call: ``BE_BINNED_SHORT_ROWS`` (8) when the stored rows average at most
+        ``SHORT_ROW_ENTRIES`` entries (the library cannot know the entry count behind an indptr without reading it back)."""
+        return self.kind | (8 if self.nnz <= self.SHORT_ROW_ENTRIES * max(self.m, 1) else 0)
+
     def _set_geometry(self) -> None:
         self.n_slices = int(fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(self.k, self.slice_shift, self.kind))
         if self.n_slices <= 0:
@@ -850,7 +858,7 @@ def _binned_call(ws: 'BinnedScatter', weights, indices, indptr, row_len, spikes,
            [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp, c_i64,
             c_vp])
     is64 = int(indptr is not None and indptr.dtype == torch.int64)
-    check(f(A.ptr(weights), ws.kind, A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes), sd,
+    check(f(A.ptr(weights), ws.step_kind, A.wcode(weights), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(spikes), sd,
             A.ptr(out), ws.m, ws.k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(),
             A.stream_ptr()), 'be_binary_csrmv_t_binned')
 

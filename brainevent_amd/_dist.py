@@ -449,7 +449,7 @@ class RankStep:
             row_len = -1 if indptr is not None else int(indices.numel() // max(m, 1))
             is64 = int(indptr is not None and indptr.dtype == torch.int64)
             f = fn('be_binary_csrmv_t_binned', ci, [vp, ci, ci, vp, vp, ci, i64, vp, ci, vp, i64, i64, ci, i64, ci, vp, i64, vp])
-            head = (A.ptr(data), ws.kind, A.wcode(data), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(self._words),
+            head = (A.ptr(data), ws.step_kind, A.wcode(data), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(self._words),
                     A.BE_SPIKE_BITS)
             self._keep = (indices, indptr)
             self._fast = lambda out_ptr, st: f(*head, out_ptr, m, k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws),

@@ -41,6 +41,7 @@ namespace {
 #ifndef BE_STREAM_U
 #define BE_STREAM_U 2    // steps (64 lanes x 4 entries) a wave of pass B keeps in flight next to the ones it is appending
 #endif
+constexpr int64_t kShortRow = 256;       // rows up to this many entries (on average) take pass B with one step of loads in flight
 constexpr int kTaskRowsFloor = 4, kTaskGroupsCap = 1024;   // pass B: a task has at least 4 rows while they stay within 1024 groups of four
 constexpr int kMaxBins = 2048;
 constexpr int kStreamGrid = 256;     // workgroups of pass B = regions per bin (one per CU)
@@ -356,8 +357,9 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
 // pass B.  Tasks of 2^rshift consecutive active rows are handed to the waves by an LDS ticket inside the workgroup's
 // contiguous share of the task list; a wave flattens its task's rows into groups of four consecutive entries (prefix
 // sums of the rows' group counts in a per-wave LDS table), a lane takes one group per step — one 16-byte load of columns
-// and one of weights — and BE_STREAM_U steps are loading while the previous ones are appended.
-template <typename W, bool HOMO, int CB, bool BATCH>
+// and one of weights — and U steps are loading while the previous ones are appended (U = BE_STREAM_U = 2; short rows, whose
+// tasks are four steps long, run U = 1: kShortRow below).
+template <typename W, bool HOMO, int CB, bool BATCH, int U = BE_STREAM_U>
 __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weights, const int32_t* __restrict__ indices, RowPtr rp,
                                                      const uint32_t* __restrict__ active, const uint32_t* __restrict__ n_active_p,
                                                      uint32_t width, DivU32 wdiv, int n_bins, uint32_t cap_blocks,
@@ -370,7 +372,6 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   // row_masks[j] says in which; the bins are virtual — batch row b's bin i is n_bins_b * b + i of n_bins — and an entry is
   // appended once per batch row that has its row active (the rows are read once for the whole batch).
   using B = BinBlock<HOMO, CB>;
-  constexpr int U = BE_STREAM_U;
   extern __shared__ __align__(16) uint32_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t* tbeg = reinterpret_cast<int64_t*>(lds) + wave * 64;                  // this wave's task table
@@ -1057,7 +1058,13 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   // BE_BINNED_ABS (bit 2, per-entry weights): the step sums |w| (pass B clears the sign of every weight it reads) — the column
   // statistics a fixed-point exponent is derived from
   const uint32_t sign_mask = (homo & 4) ? 0x7fffffffu : 0xffffffffu;
-  homo &= ~4;
+  // BE_BINNED_SHORT_ROWS (bit 3, a hint): the stored rows average at most kShortRow entries.  Rows of one length say so
+  // themselves (row_len); with an indptr only the caller knows the entry count without a device read.  Pass B then keeps one
+  // step of loads in flight per wave instead of two: a task of such rows is 4 steps long, the second step ahead is mostly
+  // wasted issue (one post slice of an 8-way cut of C4, rows of ~125: 92.0 -> 84.8 us per step; C4 itself, rows of 1000,
+  // loses with it: 0.592 -> 0.619 ms; tools/ab_binned_knobs.sh).  Any value gives the same bits.
+  const bool short_rows = indptr == nullptr ? (row_len > 0 && row_len <= kShortRow) : (homo & 8) != 0;
+  homo &= ~(4 | 8);
   BE_REQUIRE(homo >= 0 && homo <= 2, BE_ERR_INVALID, "homo must be 0 (per-entry weights), 1 (one weight) or 2 (BE_BINNED_ACC32)");
   const int kind = homo;
   const bool acc32 = kind == 2;
@@ -1134,7 +1141,8 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       const size_t dyn = ((size_t)kStreamFixedWords + (size_t)n_vbins * (kRing * (size_t)cap * (homo ? 2 : 6) / 4 + 2 + 2 * kRing)) * 4;
 #define BE_BIN_STREAM(WT, HOMO_, CAP_)                                                                                          \
   do {                                                                                                                          \
-    auto kern = row_masks ? k_bin_stream<WT, HOMO_, CAP_, true> : k_bin_stream<WT, HOMO_, CAP_, false>;                         \
+    auto kern = row_masks ? k_bin_stream<WT, HOMO_, CAP_, true>                                                                  \
+                          : (short_rows ? k_bin_stream<WT, HOMO_, CAP_, false, 1> : k_bin_stream<WT, HOMO_, CAP_, false>);       \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
                        al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \

@@ -228,6 +228,9 @@ int be_binary_csrmm_t(const void* weights, int homo, int wdtype, const int32_t* 
 #define BE_BINNED_ACC32 2 /* `homo` argument of the binned entry points: per-entry weights, 32-bit fixed-point sums */
 #define BE_BINNED_ABS 4   /* ... OR-ed to 0 / 2: the step sums |w| (column statistics: how a caller derives scale_exp with a few
                             binned steps over all the rows instead of a pass of global atomics over the entries) */
+#define BE_BINNED_SHORT_ROWS 8 /* ... OR-ed to any kind, a performance hint for matrices WITH an indptr: the stored rows average at
+                                 most 256 entries (pass B keeps one step of loads in flight instead of two; rows of one length —
+                                 indptr NULL — are classified by row_len).  Results do not depend on it. */
 #define BE_PLAN_U16 0 /* uint16 local columns (both weight kinds) */
 #define BE_PLAN_D8 1  /* sorted columns as uint8 deltas (heterogeneous weights) */
 #define BE_PLAN_H8 2  /* sorted columns as uint8 advance codes (one homogeneous weight) */

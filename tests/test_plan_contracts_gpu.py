@@ -759,3 +759,41 @@ def test_binned_protocol_flag_poisons_the_outputs_instead_of_trapping(be):
     ws.check_status()
     again = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws)
     assert torch.equal(again, good)
+
+
+@pytest.mark.parametrize('homo', [False, True])
+def test_binned_short_rows_hint_changes_no_bit(be, homo, monkeypatch):
+    """Round 4: BE_BINNED_SHORT_ROWS (rows averaging <= 256 entries: pass B with one step of loads in flight) is a performance
+    hint — the step with and without it, over ragged rows behind an indptr and over rows of one short length, gives the same bits
+    (integer sums) and matches the direct route."""
+    from brainevent_amd._csr import BinnedScatter
+    rng = np.random.default_rng(96)
+    m, k = 6000, 300_000
+    lens = rng.integers(0, 90, m)
+    ptr_np = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(ptr_np[-1])
+    idx = torch.tensor(rng.integers(0, k, nnz).astype(np.int32), device='cuda')
+    ptr = torch.tensor(ptr_np, device='cuda')
+    w = torch.ones(1, device='cuda') * 0.75 if homo else torch.tensor(rng.uniform(0.2, 1.0, nnz).astype(np.float32), device='cuda')
+    v = torch.tensor(rng.random(m) < 0.3, device='cuda')
+    ws = BinnedScatter(w, m, k, nnz, indices=idx, indptr=ptr)
+    assert ws.step_kind == ws.kind | 8
+    with_hint = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws)
+    monkeypatch.setattr(BinnedScatter, 'SHORT_ROW_ENTRIES', 0)
+    assert ws.step_kind == ws.kind
+    without = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws)
+    assert torch.equal(with_hint, without)
+    direct = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=None)
+    np.testing.assert_allclose(with_hint.cpu().numpy(), direct.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # rows of one length classify themselves: 40 per row (short) and 400 per row (long) against the direct route
+    for K in (40, 400):
+        n = 4000
+        fi = torch.tensor(rng.integers(0, k, (n, K)).astype(np.int32), device='cuda')
+        fw = w if homo else torch.tensor(rng.uniform(0.2, 1.0, (n, K)).astype(np.float32), device='cuda')
+        fv = torch.tensor(rng.random(n) < 0.3, device='cuda')
+        fws = BinnedScatter(fw, n, k, n * K, indices=fi, row_len=K)
+        got = be.binary_fcnmv(fw, fi, fv, shape=(n, k), transpose=True)
+        conn = be.FixedNumPerPre((fw, fi), shape=(n, k))
+        conn.buffers['scatter_plan'] = fws
+        binned = be.BinaryArray(fv) @ conn
+        np.testing.assert_allclose(binned.cpu().numpy(), got.cpu().numpy(), rtol=1e-5, atol=1e-5)
