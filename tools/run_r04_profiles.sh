@@ -21,7 +21,8 @@ declare -A CFG=(
   [c2_rank_of_8]="--emulate-world 8 --steps 100 --warmup 20 --no-cpu --no-secondary"
   [c4_rank_of_8]="--emulate-world 8 --workload fcn --steps 100 --warmup 20 --no-cpu --no-secondary"
 )
-ORDER="c2 c2_homo c2_gather_mirror c3 c4 c4_homo c5 c2_rank_of_8 c4_rank_of_8"
+ORDER=${ONLY:-"c2 c2_homo c2_gather_mirror c3 c4 c4_homo c5 c2_rank_of_8 c4_rank_of_8"}      # ONLY="c4 c4_rank_of_8": a subset
+PMC_ORDER=${ONLY:-"c2 c2_homo c2_gather_mirror c4 c4_homo c5 c2_rank_of_8 c4_rank_of_8"}
 if [[ $what == *stats* ]]; then
   for name in $ORDER; do
     rm -rf $O/s_$name
@@ -32,7 +33,8 @@ if [[ $what == *stats* ]]; then
   done
 fi
 if [[ $what == *pmc* ]]; then
-  for name in c2 c2_homo c2_gather_mirror c4 c4_homo c5 c2_rank_of_8 c4_rank_of_8; do
+  for name in $PMC_ORDER; do
+    [ "$name" = c3 ] && continue
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf $O/p_${name}_$c
       timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/p_${name}_$c -o p -- python3 $R/bench.py ${CFG[$name]} --steps 12 --warmup 3 > $O/p_${name}_$c.log 2>&1
@@ -41,7 +43,8 @@ if [[ $what == *pmc* ]]; then
   done
   { echo "# separate --pmc passes per configuration; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them, mean per launch"
     echo "# (guide: bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 on gfx950 for wide coalesced reads)"
-    for name in c2 c2_homo c2_gather_mirror c4 c4_homo c5 c2_rank_of_8 c4_rank_of_8; do
+    for name in $PMC_ORDER; do
+      [ "$name" = c3 ] && continue
       echo "# $name: bench.py ${CFG[$name]} --steps 12 --warmup 3"
       python3 $R/tools/summarize_prof.py "$O/p_${name}_FETCH_SIZE/*counter_collection.csv" "$O/p_${name}_WRITE_SIZE/*counter_collection.csv" | grep -i "k_plan\|k_bin\|k_compact\|k_dense\|k_mfma\|k_gather\|kernel " | cut -c1-150
     done; } > $O/pmc_all.txt
