@@ -756,8 +756,8 @@ __global__ void __launch_bounds__(256) k_densemm_mfma(const W* __restrict__ weig
                                                       const uint32_t* __restrict__ ucount, float* __restrict__ partial) {
   __shared__ __align__(16) unsigned char tile[2][kMfmaTileBytes];
 #ifndef BE_MFMA_D
-#define BE_MFMA_D 4
-#endif
+#define BE_MFMA_D 2              // (round 4, tools/ab_dense_knobs.sh: 2 / 4 / 6 / 8 steps in flight 0.398 / 0.421 / 0.421 / 0.423 ms per C5
+#endif                           //  step, 1.307 / 1.393 ms at 50 % firing — three workgroups per CU already keep 48 KB in flight at 2)
   constexpr int D = BE_MFMA_D;     // K-steps of weight rows in flight per thread (register ring); even
   // D extra all-zero steps behind every chunk: the ring runs past the chunk end without any branch
   __shared__ uint32_t rows_s[(kMfmaChunk + D) * 16];
