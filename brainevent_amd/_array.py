@@ -156,6 +156,18 @@ def spikes_to_device(v) -> Tuple[torch.Tensor, int]:
     return (t != 0), BE_SPIKE_BOOL
 
 
+def spikes_batch_major(M) -> Tuple[torch.Tensor, int]:
+    """The matrix operand ``M [k, n]`` of a batched op as the kernels take it: event rows ``[n, k]``, contiguous, + dtype code.
+
+    ``BinaryArray(S [n, k]) @ X`` reaches the ops as the view ``S.T`` (the reference's operand convention,
+    ``_event/binary.py:209-212``): its transpose already is the batch-major buffer, so nothing is copied — making the view
+    contiguous first and transposing it back cost two copies of the spike matrix per call (C5: 13.6 us of a 0.41 ms step)."""
+    if isinstance(M, torch.Tensor) and M.ndim == 2 and M.device == device() and M.T.is_contiguous():
+        return spikes_to_device(M.T)
+    s, sd = spikes_to_device(M)
+    return s.T.contiguous(), sd
+
+
 def ptr(t) -> ctypes.c_void_p:
     if t is None:
         return ctypes.c_void_p(0)

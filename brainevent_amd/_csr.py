@@ -1175,8 +1175,8 @@ def _binary_csrmm_hip(weights, indices, indptr, B, *, shape, transpose, workspac
     # one launch per stage for the whole batch (gridDim.y = columns of B); the kernels take the spike
     # matrix batch-major and emit a batch-major result, transposed back here exactly like the reference
     # does around its SRAW kernels (brainevent/_csr/binary.py:1263-1286).
-    Bt, sd = A.spikes_to_device(B)
-    out_bm = _csr_batched(weights, indices, indptr, Bt.T.contiguous(), sd, shape=shape, transpose=transpose,
+    spikes_bm, sd = A.spikes_batch_major(B)
+    out_bm = _csr_batched(weights, indices, indptr, spikes_bm, sd, shape=shape, transpose=transpose,
                           workspace=workspace)
     return out_bm.T
 
@@ -1316,8 +1316,8 @@ def _binary_csrmv_indexed_hip(data, indices, indptr, perm, vector, *, shape, tra
 
 
 def _binary_csrmm_indexed_hip(data, indices, indptr, perm, B, *, shape, transpose, workspace=None):
-    Bt, sd = A.spikes_to_device(B)
-    return _csr_batched_indexed(data, indices, indptr, perm, Bt.T.contiguous(), sd, shape=shape, transpose=transpose,
+    spikes_bm, sd = A.spikes_batch_major(B)
+    return _csr_batched_indexed(data, indices, indptr, perm, spikes_bm, sd, shape=shape, transpose=transpose,
                                 workspace=workspace).T
 
 
@@ -1473,8 +1473,11 @@ class Mirror:
         if not self.released:
             call = binary_csrmv_p_call if v.ndim == 1 else binary_csrmm_p_call
             return call(self.data, self.indices, self.indptr, v, self.plan, shape=self.shape, transpose=True, backend=backend)[0]
-        sp, sd = A.spikes_to_device(v)
-        spikes_bm = sp.reshape(1, -1) if v.ndim == 1 else sp.T.contiguous()
+        if v.ndim == 1:
+            sp, sd = A.spikes_to_device(v)
+            spikes_bm = sp.reshape(1, -1)
+        else:
+            spikes_bm, sd = A.spikes_batch_major(v)
         out = torch.empty((int(spikes_bm.shape[0]), self.shape[1]), dtype=self.plan.weight_dtype, device=A.device())
         _plan_call(self.plan, self.data, spikes_bm, sd, out)
         return out[0] if v.ndim == 1 else out.T

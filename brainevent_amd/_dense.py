@@ -58,8 +58,8 @@ def _binary_densemv_hip(weights, spikes, *, transpose):
 
 def _binary_densemm_hip(weights, spikes, *, transpose):
     w = A.to_device(weights)
-    s, sd = A.spikes_to_device(spikes)
-    return _dense_batched(w, s.T.contiguous(), sd, transpose).T
+    spikes_bm, sd = A.spikes_batch_major(spikes)
+    return _dense_batched(w, spikes_bm, sd, transpose).T
 
 
 binary_densemv_p = OpKernel('binary_densemv')

@@ -83,8 +83,8 @@ def _binary_fcnmv_hip(weights, indices, spikes, *, shape, transpose, workspace=N
 
 
 def _binary_fcnmm_hip(weights, indices, matrix, *, shape, transpose, workspace=None):
-    M, sd = A.spikes_to_device(matrix)
-    return _fcn_batched(weights, indices, M.T.contiguous(), sd, shape=shape, transpose=transpose, workspace=workspace).T
+    spikes_bm, sd = A.spikes_batch_major(matrix)
+    return _fcn_batched(weights, indices, spikes_bm, sd, shape=shape, transpose=transpose, workspace=workspace).T
 
 
 binary_fcnmv_p = OpKernel('binary_fcnmv')

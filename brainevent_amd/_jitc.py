@@ -119,8 +119,8 @@ def _jitmv_hip(family, a, b, clen, vector, seed, *, shape, transpose, corder, ou
 
 
 def _jitmm_hip(family, a, b, clen, B, seed, *, shape, transpose, corder, out_dtype):
-    Bt, sd = A.spikes_to_device(B)
-    n = int(Bt.shape[1])
+    spikes_bm, sd = A.spikes_batch_major(B)
+    n = int(spikes_bm.shape[0])
     in_len = int(shape[0] if transpose else shape[1])
     out_len = int(shape[1] if transpose else shape[0])
     out_bm = torch.empty((n, out_len), dtype=out_dtype, device=A.device())
@@ -131,7 +131,7 @@ def _jitmm_hip(family, a, b, clen, B, seed, *, shape, transpose, corder, out_dty
     ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, n, 1 if corder else 0))
     name = f"be_binary_jit{family}mm_{'notrans' if corder else 'trans'}_{A.wsuffix(out_bm)}"
     f = fn(name, c_int, _MM_ARGS)
-    check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(Bt.T.contiguous()), sd, A.ptr(out_bm), int(shape[1]), in_len,
+    check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(spikes_bm), sd, A.ptr(out_bm), int(shape[1]), in_len,
             out_len, n, A.ptr(ws), ws.numel(), A.stream_ptr()), name)
     return out_bm.T
 
