@@ -674,6 +674,12 @@ class BinnedScatter:
         weights / 32-bit sums (BE_BINNED_ACC32)."""
         return 1 if self.homo else (2 if self.acc32 else 0)
 
+    @staticmethod
+    def serves(k: int, slice_shift: int = 16, homo: bool = False) -> bool:
+        """Whether the binned route has a geometry for ``k`` outputs at this ``slice_shift`` (``be_binned_bins`` > 0: the
+        write-combining blocks of all bins have to fit pass B's LDS)."""
+        return int(fn('be_binned_bins', c_int, [c_i64, c_int, c_int])(int(k), int(slice_shift), int(bool(homo)))) > 0
+
     SHORT_ROW_ENTRIES = 256      # BE_BINNED_SHORT_ROWS: average stored row length up to which pass B runs one step ahead
 
     @property

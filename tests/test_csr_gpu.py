@@ -879,7 +879,7 @@ def test_binned_and_gather_routes_randomized(be, oracle, seed):
     wd, idd, ptd = torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(ptr).cuda()
     if idx.size:
         shift = int(rng.integers(6, 15)) if k > 64 else 4
-        while -(-k // (1 << shift)) > 2048:
+        while not BinnedScatter.serves(k, shift, homo):        # more bins than pass B's LDS blocks hold: wider slices
             shift += 1
         for frac in (1.0, 0.002):
             ws = BinnedScatter(wd, m, k, idx.size, indices=idd, max_active_fraction=frac, slice_shift=shift)
