@@ -731,13 +731,21 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   } else {
     // weighted: one flat loop over the 12-byte units (two entries) of all regions; consecutive lanes read consecutive units —
     // 768 contiguous bytes per load instruction — 2 * BE_BIN_U units per thread and round in flight
+#ifdef BE_DBG_C_WIDE      // (timing experiment, results are garbage: the same bytes fetched as 16-byte pieces, two adds per piece)
+    constexpr uint32_t UB = CAP * 6 / 16;
+#else
     constexpr uint32_t UB = CAP / 2;                         // units per block
+#endif
     const uint32_t n_u = NB * UB;
     const uint32_t per = (n_u + parts - 1) / parts;
     const uint32_t g_begin = part * per, g_end = g_begin + per < n_u ? g_begin + per : n_u;
     constexpr int U = 2 * BE_BIN_U;
     for (uint32_t g0 = g_begin + tid; g0 < g_end; g0 += U * 1024) {
+#ifdef BE_DBG_C_WIDE
+      be_u32x4_a4 uv[U];
+#else
       be_u32x3_a4 uv[U];
+#endif
       uint32_t nv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -756,7 +764,13 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
         const uint32_t lb = blk - s_pre[r];
         const uint32_t first = lb * (uint32_t)CAP + ub * 2u, c = s_cnt[r];
         nv[u] = !in || c <= first ? 0u : (c - first < 2u ? 1u : 2u);
+#ifdef BE_DBG_C_WIDE
+        nv[u] = in ? 2u : 0u;
+        uv[u] = *reinterpret_cast<const be_u32x4_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::gdwords + ub * 4u);
+        uv[u].z &= 0x3fff3fffu;
+#else
         uv[u] = *reinterpret_cast<const be_u32x3_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::gdwords + ub * 3u);
+#endif
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
