@@ -20,6 +20,8 @@ from ._dense import (Dense, binary_densemv, binary_densemm, binary_densemv_p, bi
                      binary_densemm_p_call)
 from ._convert import (csr_to_coo_index, coo_to_csc_index, coo2csr, csr_to_csc_index, csc_to_csr_index,
                        fixed_conn_num_csr_indptr, fixed_conn_num_csc_structure, fixed_conn_num_to_csc, CscBuilder)
+from ._float import (csrmv, csrmm, csrmv_p, csrmm_p, csrmv_p_call, csrmm_p_call, fcnmv, fcnmm, fcnmv_p, fcnmm_p, fcnmv_p_call,
+                     fcnmm_p_call)
 from ._graph import GraphedStep, capture_step
 from ._tuning import (ScatterTuning, DEFAULT_SCATTER_TUNING, get_scatter_tuning, save_scatter_tuning, apply_scatter_tuning,
                       tune_scatter_routes)

@@ -1759,6 +1759,28 @@ def _event_value(other, scatter: bool = False):
     return event_operand(other, scatter=scatter)
 
 
+def _dense_product(M, other, *, shape, transpose: bool, operand_on_left: bool):
+    """A dense (non-event) operand against the stored arrays of a CSR / CSC container: ``op(A) @ x`` or ``x @ op(A)`` with
+    ``op(A) = A.T if transpose else A`` and ``A`` the CSR reading of the arrays (``shape``).  Float-operand twins
+    (``_float.csrmv`` / ``csrmm``; reference ``_csr/main.py:1595-1697``, ``:1699-1776``): ``x @ op(A) = (op(A).T @ x.T).T``."""
+    from ._float import csrmv_p_call, csrmm_p_call
+    x = other if isinstance(other, torch.Tensor) else np.asarray(other)
+    t = (not transpose) if operand_on_left else transpose
+    data, indices, indptr = M.data, M.indices, M.indptr
+    if t:       # the scatter direction runs on float atomics (~21 G/s); a mirror that already exists turns it into a gather
+        mr = M._fresh_mirror(auto=False)
+        if mr is not None and not mr.released and mr.indices is not None and tuple(mr.shape) == tuple(shape[::-1]):
+            data, indices, indptr, shape, t = mr.data, mr.indices, mr.indptr, tuple(mr.shape), False
+    if x.ndim == 1:
+        r = csrmv_p_call(data, indices, indptr, x, shape=shape, transpose=t, backend=M.backend)[0]
+    elif x.ndim == 2:
+        r = csrmm_p_call(data, indices, indptr, x.T if operand_on_left else x, shape=shape, transpose=t, backend=M.backend)[0]
+        r = r.T if operand_on_left else r
+    else:
+        raise NotImplementedError(f"matmul with object of shape {tuple(x.shape)}")
+    return M._res(r) if A.wants_numpy(x) else r
+
+
 class CSR(CompressedSparseData):
     """Compressed sparse row matrix with event-driven products (reference ``_csr/main.py:977``)."""
     _compressed_format = 'csr'
@@ -1782,7 +1804,7 @@ class CSR(CompressedSparseData):
             else:
                 raise NotImplementedError(f"matmul with object of shape {v.shape}")
             return self._res(r) if A.wants_numpy(v) else r
-        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+        return _dense_product(self, other, shape=self.shape, transpose=False, operand_on_left=False)      # csr @ x
 
     def __rmatmul__(self, other):     # other @ csr
         if is_event(other):
@@ -1797,7 +1819,7 @@ class CSR(CompressedSparseData):
             else:
                 raise NotImplementedError(f"matmul with object of shape {v.shape}")
             return self._res(r) if A.wants_numpy(v) else r
-        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+        return _dense_product(self, other, shape=self.shape, transpose=False, operand_on_left=True)       # x @ csr
 
     def transpose(self, axes=None):
         assert axes is None, "transpose does not support axes argument."
@@ -1839,7 +1861,7 @@ class CSC(CompressedSparseData):
             else:
                 raise NotImplementedError(f"matmul with object of shape {v.shape}")
             return self._res(r) if A.wants_numpy(v) else r
-        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+        return _dense_product(self, other, shape=self.shape[::-1], transpose=True, operand_on_left=False)  # csc @ x = A'.T @ x
 
     def __rmatmul__(self, other):     # other @ csc : gather
         if is_event(other):
@@ -1863,7 +1885,7 @@ class CSC(CompressedSparseData):
             else:
                 raise NotImplementedError(f"matmul with object of shape {v.shape}")
             return self._res(r) if A.wants_numpy(v) else r
-        raise NotImplementedError("only BinaryArray operands are on the accelerated path (float csrmv is out of scope).")
+        return _dense_product(self, other, shape=self.shape[::-1], transpose=True, operand_on_left=True)   # x @ csc = x @ A'.T
 
     def transpose(self, axes=None):
         assert axes is None, "transpose does not support axes argument."

@@ -16,6 +16,8 @@ class DataRepresentation:
     ``register_buffer`` / ``set_buffer`` keep the reference's semantics: a buffer has to be registered before it is set."""
 
     buffers: Dict
+    # a numpy array on the LEFT of ``@`` defers to the container's ``__rmatmul__`` instead of treating it as a 0-d object
+    __array_ufunc__ = None
 
     def _init_buffers(self, buffers: Optional[Dict]) -> None:
         if buffers is not None and not isinstance(buffers, dict):

@@ -294,10 +294,19 @@ class FixedNumConn(DataRepresentation):
                                    backend=self.backend, workspace=ws)[0]
 
     def _dispatch(self, other, transpose_W: bool):
-        if not is_event(other):
-            raise NotImplementedError("only BinaryArray operands are on the accelerated path "
-                                      "(float fcnmv is out of scope).")
         ell_t = self._ell_transpose(transpose_W)
+        if not is_event(other):     # a dense operand: the float twins (reference ``_fcn/main.py:308-460`` dispatches them alike)
+            from ._float import fcnmv_p_call, fcnmm_p_call
+            x = other if isinstance(other, torch.Tensor) else np.asarray(other)
+            if x.ndim == 1:
+                r = fcnmv_p_call(self.data, self.indices, x, shape=self._a_shape, transpose=ell_t, backend=self.backend)[0]
+            elif x.ndim == 2:
+                r = fcnmm_p_call(self.data, self.indices, x.T if transpose_W else x, shape=self._a_shape, transpose=ell_t,
+                                 backend=self.backend)[0]
+                r = r.T if transpose_W else r
+            else:
+                raise NotImplementedError(f"matmul with object of shape {tuple(x.shape)}")
+            return A.to_result(r, self._numpy_result) if A.wants_numpy(x) else r
         # scatter kernels take compacted id lists as they are — the favourable direction, and the other one once its mirror exists
         scatter = other.ndim == 1 and (ell_t or self._fresh_mirror(auto=True) is not None)
         value = event_operand(other, scatter=scatter)

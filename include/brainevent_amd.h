@@ -454,6 +454,26 @@ int be_gather_by_perm(const void* src, int elem_bytes, const void* perm, int per
                       be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * float-operand twins (last clause): the same CSR / fixed-number matrices against a dense vector or matrix.
+ * replaces: csrmv / csrmm (brainevent/_csr/float.py:49-150, :559-668; CPU loops :153-207, :670-744; float_csrmv.cu,
+ *           float_csrmm.cu) and fcnmv / fcnmm (brainevent/_fcn/float.py:33-134, :136-240) — indptr NULL + row_len = n_conn.
+ *   transpose = 0:  out[i, c] = sum over row i of w_j * B[indices[j], c]            B [k, n], out [m, n]   (one writer per row)
+ *   transpose = 1:  out[indices[j], c] += w_j * B[i, c] for every stored row i      B [m, n], out [k, n]   (float atomics)
+ * B, out and the weights share wdtype (f32 / f64 / f16 / bf16; sums in f32 / f64); row-major, n >= 1 (be_csrmv: n = 1).
+ * homo != 0: one shared weight weights[0] (the sum is multiplied once, like the reference's `w * r`).  indices and per-entry
+ * weights must be 16-byte aligned (rows are read in aligned groups of four).  nnz_hint: the stored entries if the caller knows
+ * them (it selects the lanes per row; 0 = unknown).  workspace: be_csrmm_workspace_bytes (an f32 image of the output for the
+ * f16 / bf16 scatter; 256 bytes otherwise).  Zeros of the operand are skipped in the scatter direction (they add nothing).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t be_csrmm_workspace_bytes(int64_t m, int64_t k, int64_t n, int transpose, int wdtype);
+int be_csrmm(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr, int indptr_is_i64,
+             int64_t row_len, const void* B, void* out, int64_t m, int64_t k, int64_t n, int64_t nnz_hint, int transpose,
+             void* workspace, int64_t workspace_bytes, be_stream_t stream);
+int be_csrmv(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr, int indptr_is_i64,
+             int64_t row_len, const void* v, void* out, int64_t m, int64_t k, int64_t nnz_hint, int transpose, void* workspace,
+             int64_t workspace_bytes, be_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * perm-fused ("indexed") products: be_binary_csrmm_{t,nt} over a RE-INDEXED structure whose slot j carries
  * weights[perm[j]] — the weights stay in their canonical order and only the weights of active rows (t) / of entries whose
  * input fired (nt) are read; no data[perm] pass per call.

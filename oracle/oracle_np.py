@@ -86,6 +86,57 @@ def binary_fcnmm(weights, indices, matrix, shape, transpose):
 
 
 # ----------------------------------------------------------------------------------------------------
+# float-operand twins  (brainevent/_csr/float.py:153-207 mv, :670-744 mm; brainevent/_fcn/float.py — the same loops over
+# rows of one length).  Sums are taken in float64 here and rounded once: the checker, not a bit-for-bit model of numba's
+# fastmath accumulation order.
+# ----------------------------------------------------------------------------------------------------
+def csrmv(weights, indices, indptr, v, shape, transpose):
+    """transpose: posts[indices[j]] += w[j] * v[i] for every row i (:188-193, :163-170);
+    else posts[i] = sum_j w[j] * v[indices[j]] (:195-202, :172-180; one shared weight: ``w * sum``)."""
+    weights = np.asarray(weights).reshape(-1)
+    indices = np.asarray(indices)
+    indptr = np.asarray(indptr)
+    x = np.asarray(v, dtype=np.float64)
+    m, k = shape
+    row_of = np.repeat(np.arange(m), np.diff(indptr))
+    w_all = (np.broadcast_to(weights, indices.shape) if weights.size == 1 else weights).astype(np.float64)
+    if transpose:
+        out = np.zeros(k, dtype=np.float64)
+        np.add.at(out, indices, w_all * x[row_of])
+    else:
+        out = np.zeros(m, dtype=np.float64)
+        np.add.at(out, row_of, w_all * x[indices])
+    return out.astype(weights.dtype)
+
+
+def csrmm(weights, indices, indptr, B, shape, transpose):
+    """Matrix operand (brainevent/_csr/float.py:670-744): the mv definition per column of ``B``."""
+    B = np.asarray(B)
+    cols = [csrmv(weights, indices, indptr, B[:, l], shape, transpose) for l in range(B.shape[1])]
+    rows = shape[1] if transpose else shape[0]
+    if not cols:
+        return np.zeros((rows, 0), dtype=np.asarray(weights).dtype)
+    return np.stack(cols, axis=1)
+
+
+def fcnmv(weights, indices, vector, shape, transpose):
+    """Rows of one length (brainevent/_fcn/float.py:33-134): ``indices [rows, n_conn]``."""
+    indices = np.asarray(indices)
+    n_rows, n_conn = indices.shape
+    indptr = np.arange(n_rows + 1, dtype=np.int64) * n_conn
+    return csrmv(np.asarray(weights).reshape(-1), indices.reshape(-1), indptr, vector, (n_rows, shape[1]), transpose)
+
+
+def fcnmm(weights, indices, matrix, shape, transpose):
+    matrix = np.asarray(matrix)
+    cols = [fcnmv(weights, indices, matrix[:, l], shape, transpose) for l in range(matrix.shape[1])]
+    rows = shape[1] if transpose else shape[0]
+    if not cols:
+        return np.zeros((rows, 0), dtype=np.asarray(weights).dtype)
+    return np.stack(cols, axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------
 # dense  (brainevent/_dense/binary.py:168-211 mv, :579-632 mm)
 # ----------------------------------------------------------------------------------------------------
 def binary_densemv(weights, spikes, transpose):

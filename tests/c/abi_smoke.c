@@ -7,6 +7,7 @@
  *   3. weight refresh: be_scatter_plan_refresh_weights_ordered (a gather-copy through the stored order), then step 2's call again
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
  *   5. neuron step:    be_lif_coba_step
+ *   7. float twin:     be_csrmv in both directions (a dense operand instead of spikes)
  *   6. the unfavourable direction made event-driven: be_csr_to_csc_count -> _indptr -> _fill_block (two column
  *      blocks, weights moved along, perm kept) gives the CSC mirror; the gather product of step 4 is then (a) the direct scatter
  *      over the mirror, (b) the perm-fused scatter be_binary_csrmm_t_indexed over the mirror's structure with the weights left in
@@ -225,6 +226,39 @@ int main(void) {
     CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
     fails += compare("mirror after gather_by_perm", got, ref, m);
     free(cptr);
+  }
+
+  /* 7. float-operand twin: out[i] = sum_j w[j] * x[indices[j]] (be_csrmv, gather) and its transpose (float atomics) */
+  {
+    float *x = malloc((k > m ? k : m) * 4);
+    for (int64_t i = 0; i < (k > m ? k : m); ++i) x[i] = (float)(rnd() % 2000) / 1000.f - 1.f;
+    void *d_x = dev_copy(x, (k > m ? k : m) * 4);
+    const int64_t fws_bytes = be_csrmm_workspace_bytes(m, k, 1, 1, BE_F32);
+    void *d_fws = dev_copy(NULL, fws_bytes);
+    for (int64_t i = 0; i < m; ++i) {
+      ref[i] = 0;
+      for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ref[i] += (double)w[j] * (double)x[idx[j]];
+    }
+    CHECK_BE(be_csrmv(d_w, 0, BE_F32, (const int32_t *)d_idx, d_ptr, 0, -1, d_x, d_out, m, k, nnz, 0, d_fws, fws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, m * 4, hipMemcpyDeviceToHost));
+    {   /* sums of 400 mixed-sign products in f32: compare at the scale of the row's terms, like the direct scatter above */
+      double worst = 0;
+      for (int64_t i = 0; i < m; ++i) { const double e = fabs((double)got[i] - ref[i]) / (1e-4 + 1e-5 * fabs(ref[i])); if (e > worst) worst = e; }
+      printf("%-28s worst error / tolerance %.3g %s\n", "float csrmv (gather)", worst, worst <= 1.0 ? "ok" : "FAIL");
+      fails += worst <= 1.0 ? 0 : 1;
+    }
+    memset(ref, 0, k * 8);
+    for (int64_t i = 0; i < m; ++i)
+      for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ref[idx[j]] += (double)w[j] * (double)x[i];
+    CHECK_BE(be_csrmv(d_w, 0, BE_F32, (const int32_t *)d_idx, d_ptr, 0, -1, d_x, d_out, m, k, nnz, 1, d_fws, fws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, k * 4, hipMemcpyDeviceToHost));
+    {
+      double worst = 0;
+      for (int64_t i = 0; i < k; ++i) { const double e = fabs((double)got[i] - ref[i]) / (1e-4 + 1e-5 * fabs(ref[i])); if (e > worst) worst = e; }
+      printf("%-28s worst error / tolerance %.3g %s\n", "float csrmv (scatter)", worst, worst <= 1.0 ? "ok" : "FAIL");
+      fails += worst <= 1.0 ? 0 : 1;
+    }
+    free(x);
   }
 
   /* error convention: status code + message, never an abort */

@@ -111,6 +111,12 @@ def _run_kat(k, impl):
     if k['op'] == 'fcnmm':
         return impl.binary_fcnmm(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['M']),
                                  tuple(k['shape']), k['transpose'])
+    if k['op'] == 'float_csrmv':
+        return impl.csrmv(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['indptr']),
+                          np.array(k['v'], np.float32), tuple(k['shape']), k['transpose'])
+    if k['op'] == 'float_csrmm':
+        return impl.csrmm(np.array(k['w'], np.float32), np.array(k['indices'], np.int32), np.array(k['indptr']),
+                          np.array(k['B'], np.float32), tuple(k['shape']), k['transpose'])
     raise KeyError(k['op'])
 
 
