@@ -33,4 +33,6 @@ from ._jitc import (JITCScalarMatrix, JITCUniformMatrix, JITCNormalMatrix, JITCM
                     binary_jitsmv, binary_jitsmm, binary_jitumv, binary_jitumm, binary_jitnmv, binary_jitnmm,
                     binary_jitsmv_p, binary_jitsmm_p, binary_jitumv_p, binary_jitumm_p, binary_jitnmv_p, binary_jitnmm_p,
                     binary_jitsmv_p_call, binary_jitsmm_p_call, binary_jitumv_p_call, binary_jitumm_p_call,
-                    binary_jitnmv_p_call, binary_jitnmm_p_call, JITCScatterShard, JITCGatherShard)
+                    binary_jitnmv_p_call, binary_jitnmm_p_call, JITCScatterShard, JITCGatherShard,
+                    jitsmv, jitsmm, jitumv, jitumm, jitnmv, jitnmm, jitsmv_p, jitsmm_p, jitumv_p, jitumm_p, jitnmv_p, jitnmm_p,
+                    jitsmv_p_call, jitsmm_p_call, jitumv_p_call, jitumm_p_call, jitnmv_p_call, jitnmm_p_call)

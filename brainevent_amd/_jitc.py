@@ -293,6 +293,137 @@ def binary_jitnmm(w_loc, w_scale, prob, B, seed: Optional[int] = None, *, shape,
 
 
 # =====================================================================================================
+# float-operand twins (last clause): the same on-the-fly matrices against a dense vector / matrix
+#   reference: brainevent/_jit_scalar/float.py (jitsmv :838-905, jitsmm :1331-1420), _jit_uniform/float.py, _jit_normal/float.py
+# =====================================================================================================
+def _jit_float_hip(family, a, b, clen, X, seed, *, shape, transpose, corder, out_dtype, mm: bool):
+    """``X [in_len] | [in_len, n]`` -> ``[out_len] | [out_len, n]`` through ``be_jitmm_float`` (lane stride 32 for a vector
+    operand, 4 for a matrix operand: different draws, as in the reference)."""
+    x = A.to_device(X, dtype=out_dtype)
+    in_len = int(shape[0] if transpose else shape[1])
+    out_len = int(shape[1] if transpose else shape[0])
+    vec = x.ndim == 1
+    n = 1 if vec else int(x.shape[1])
+    out = torch.empty((out_len,) if vec else (out_len, n), dtype=out_dtype, device=A.device())
+    if out_len == 0 or n == 0:
+        return out
+    w0, w1, _ = _jit_params(family, a, b)
+    gather = 1 if corder else 0
+    f_ws = fn('be_jitmm_float_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_i64, c_int, c_int])
+    ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, n, gather, A.wcode(out)))
+    f = fn('be_jitmm_float', c_int, [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
+                                     c_vp, c_i64, c_vp])
+    check(f(_FAMILY[family], w0, w1, A.wcode(out), int(clen), seed & 0xFFFFFFFF, A.ptr(x), A.ptr(out), int(shape[1]), in_len,
+            out_len, n, 4 if mm else 32, gather, A.ptr(ws), ws.numel(), A.stream_ptr()), 'be_jitmm_float')
+    return out
+
+
+def _make_float_ops(family: str, label: str):
+    mv_p = OpKernel(f'jit{family}mv')
+    mm_p = OpKernel(f'jit{family}mm')
+
+    def mv_hip(a, b, clen, vector, seed, *, shape, transpose, corder, out_dtype):
+        return _jit_float_hip(family, a, b, clen, vector, seed, shape=shape, transpose=transpose, corder=corder,
+                              out_dtype=out_dtype, mm=False)
+
+    def mm_hip(a, b, clen, B, seed, *, shape, transpose, corder, out_dtype):
+        return _jit_float_hip(family, a, b, clen, B, seed, shape=shape, transpose=transpose, corder=corder,
+                              out_dtype=out_dtype, mm=True)
+
+    mv_p.def_kernel('hip', 'gpu', mv_hip, asdefault=True)
+    mm_p.def_kernel('hip', 'gpu', mm_hip, asdefault=True)
+    mv_p.def_tags(f'jit_{label}', 'float')
+    mm_p.def_tags(f'jit_{label}', 'float')
+    return mv_p, mm_p
+
+
+jitsmv_p, jitsmm_p = _make_float_ops('s', 'scalar')
+jitumv_p, jitumm_p = _make_float_ops('u', 'uniform')
+jitnmv_p, jitnmm_p = _make_float_ops('n', 'normal')
+
+
+def _float_call(mv: bool, op, a, b, clen, X, seed, *, shape, transpose, corder, backend=None):
+    (_check_mv if mv else _check_mm)(X, shape, transpose)
+    ws_ = (a,) if b is None else (a, b)
+    return [op(a, b, clen, X, seed, shape=tuple(shape), transpose=transpose, corder=corder, out_dtype=_weight_dtype(*ws_),
+               backend=backend)]
+
+
+def jitsmv_p_call(weight, clen, vector, seed, *, shape, transpose, corder, backend=None):
+    return _float_call(True, jitsmv_p, weight, None, clen, vector, seed, shape=shape, transpose=transpose, corder=corder, backend=backend)
+
+
+def jitsmm_p_call(weight, clen, B, seed, *, shape, transpose, corder, backend=None):
+    return _float_call(False, jitsmm_p, weight, None, clen, B, seed, shape=shape, transpose=transpose, corder=corder, backend=backend)
+
+
+def jitumv_p_call(w_low, w_high, clen, vector, seed, *, shape, transpose, corder, backend=None):
+    return _float_call(True, jitumv_p, w_low, w_high, clen, vector, seed, shape=shape, transpose=transpose, corder=corder, backend=backend)
+
+
+def jitumm_p_call(w_low, w_high, clen, B, seed, *, shape, transpose, corder, backend=None):
+    return _float_call(False, jitumm_p, w_low, w_high, clen, B, seed, shape=shape, transpose=transpose, corder=corder, backend=backend)
+
+
+def jitnmv_p_call(w_loc, w_scale, clen, vector, seed, *, shape, transpose, corder, backend=None):
+    return _float_call(True, jitnmv_p, w_loc, w_scale, clen, vector, seed, shape=shape, transpose=transpose, corder=corder, backend=backend)
+
+
+def jitnmm_p_call(w_loc, w_scale, clen, B, seed, *, shape, transpose, corder, backend=None):
+    return _float_call(False, jitnmm_p, w_loc, w_scale, clen, B, seed, shape=shape, transpose=transpose, corder=corder, backend=backend)
+
+
+for _op, _call in ((jitsmv_p, jitsmv_p_call), (jitsmm_p, jitsmm_p_call), (jitumv_p, jitumv_p_call), (jitumm_p, jitumm_p_call),
+                   (jitnmv_p, jitnmv_p_call), (jitnmm_p, jitnmm_p_call)):
+    _op.def_call(_call)
+
+
+def jitsmv(weight, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+           backend: Optional[str] = None):
+    """``y = M @ v`` / ``y = M.T @ v`` with ``M`` drawn on the fly (constant ``weight``) and a dense ``v`` — every element counts
+    (reference ``brainevent/_jit_scalar/float.py``; same draw as :func:`binary_jitsmv`)."""
+    as_np = A.wants_numpy(weight, vector)
+    return A.to_result(jitsmv_p_call(weight, _initialize_conn_length(prob), _arr(vector), _initialize_seed(seed), shape=shape,
+                                     transpose=transpose, corder=corder, backend=backend)[0], as_np)
+
+
+def jitsmm(weight, prob, B, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+           backend: Optional[str] = None):
+    """``Y = M @ B`` / ``Y = M.T @ B`` for a dense ``B`` (the mm walk draws its own matrix, as in the reference)."""
+    as_np = A.wants_numpy(weight, B)
+    return A.to_result(jitsmm_p_call(weight, _initialize_conn_length(prob), _arr(B), _initialize_seed(seed), shape=shape,
+                                     transpose=transpose, corder=corder, backend=backend)[0], as_np)
+
+
+def jitumv(w_low, w_high, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+           backend: Optional[str] = None):
+    as_np = A.wants_numpy(w_low, w_high, vector)
+    return A.to_result(jitumv_p_call(w_low, w_high, _initialize_conn_length(prob), _arr(vector), _initialize_seed(seed), shape=shape,
+                                     transpose=transpose, corder=corder, backend=backend)[0], as_np)
+
+
+def jitumm(w_low, w_high, prob, B, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+           backend: Optional[str] = None):
+    as_np = A.wants_numpy(w_low, w_high, B)
+    return A.to_result(jitumm_p_call(w_low, w_high, _initialize_conn_length(prob), _arr(B), _initialize_seed(seed), shape=shape,
+                                     transpose=transpose, corder=corder, backend=backend)[0], as_np)
+
+
+def jitnmv(w_loc, w_scale, prob, vector, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+           backend: Optional[str] = None):
+    as_np = A.wants_numpy(w_loc, w_scale, vector)
+    return A.to_result(jitnmv_p_call(w_loc, w_scale, _initialize_conn_length(prob), _arr(vector), _initialize_seed(seed), shape=shape,
+                                     transpose=transpose, corder=corder, backend=backend)[0], as_np)
+
+
+def jitnmm(w_loc, w_scale, prob, B, seed: Optional[int] = None, *, shape, transpose: bool = False, corder: bool = True,
+           backend: Optional[str] = None):
+    as_np = A.wants_numpy(w_loc, w_scale, B)
+    return A.to_result(jitnmm_p_call(w_loc, w_scale, _initialize_conn_length(prob), _arr(B), _initialize_seed(seed), shape=shape,
+                                     transpose=transpose, corder=corder, backend=backend)[0], as_np)
+
+
+# =====================================================================================================
 # containers
 # =====================================================================================================
 def jit_edge_weights(family: str, a, b, seed, rows, cols):
@@ -401,9 +532,30 @@ class JITCMatrix(DataRepresentation):
         return self.buffers.get('materialized_mv' if ndim == 1 else 'materialized_mm')
 
     # -- dispatch (reference _jit_scalar/main.py:885-1065 for R, :1069+ for C) ---------------------
+    def _dense_operand(self, other, left: bool):
+        """A plain (non-event) array against the on-the-fly matrix: the float twins, same (shape, transpose, corder) mapping as
+        the event-driven products below."""
+        x = other if isinstance(other, torch.Tensor) else np.asarray(other)
+        if left:
+            shape, transpose, corder = (self.shape, True, not self.corder) if self._is_row else (self.shape[::-1], False, not self.corder)
+        else:
+            shape, transpose, corder = (self.shape, False, self.corder) if self._is_row else (self.shape[::-1], True, self.corder)
+        mvf = {'s': jitsmv_p_call, 'u': jitumv_p_call, 'n': jitnmv_p_call}[self._family]
+        mmf = {'s': jitsmm_p_call, 'u': jitumm_p_call, 'n': jitnmm_p_call}[self._family]
+        args = self._weights if self._family != 's' else (self._weights[0],)
+        clen = _initialize_conn_length(self.prob)
+        if x.ndim == 1:
+            r = mvf(*args, clen, x, self.seed, shape=shape, transpose=transpose, corder=corder, backend=self.backend)[0]
+        elif x.ndim == 2:
+            r = mmf(*args, clen, x.T if left else x, self.seed, shape=shape, transpose=transpose, corder=corder, backend=self.backend)[0]
+            r = r.T if left else r
+        else:
+            raise NotImplementedError(f"matmul with object of shape {tuple(x.shape)}")
+        return self._out(r, x)
+
     def __matmul__(self, other):
         if not is_event(other):
-            raise NotImplementedError("only BinaryArray operands are on the accelerated path (float jit ops are out of scope).")
+            return self._dense_operand(other, left=False)
         S = self._stored(other.ndim)
         if S is not None:                  # prepare(): the stored matrix, event-driven through its own workspaces
             return S @ other
@@ -420,7 +572,7 @@ class JITCMatrix(DataRepresentation):
 
     def __rmatmul__(self, other):
         if not is_event(other):
-            raise NotImplementedError("only BinaryArray operands are on the accelerated path (float jit ops are out of scope).")
+            return self._dense_operand(other, left=True)
         S = self._stored(other.ndim)
         if S is not None:
             return other @ S

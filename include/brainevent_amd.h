@@ -473,6 +473,21 @@ int be_csrmv(const void* weights, int homo, int wdtype, const int32_t* indices, 
              int64_t row_len, const void* v, void* out, int64_t m, int64_t k, int64_t nnz_hint, int transpose, void* workspace,
              int64_t workspace_bytes, be_stream_t stream);
 
+/* JIT connectivity against a dense operand: the same on-the-fly matrices as be_binary_jitmv / be_binary_jitmm (same walks, same
+ * per-edge weight hashes), every element of the operand counting.
+ * replaces: jitsmv / jitsmm (brainevent/_jit_scalar/float.py:838-905, :1331-1420), jitumv / jitumm, jitnmv / jitnmm
+ *           (brainevent/_jit_uniform/float.py, brainevent/_jit_normal/float.py).
+ *   X [in_len, n] -> out [out_len, n], row-major, wdtype = the weight dtype (sums in float64 for the gather orientation, f32 /
+ *   f64 atomics for the scatter orientation).  stride: 32 = the matrix a vector operand sees, 4 = the matrix a matrix operand
+ *   sees (the reference draws them differently; be_jitmv_float: n = 1, stride 32).  gather != 0: generator rows = outputs
+ *   (corder = True), else generator rows = inputs.  mode / w0 / w1 / clen / seed / shape1 as be_binary_jitmv. */
+int64_t be_jitmm_float_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int64_t n, int gather, int wdtype);
+int be_jitmm_float(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* X, void* out, int64_t shape1,
+                   int64_t in_len, int64_t out_len, int64_t n, int stride, int gather, void* workspace, int64_t workspace_bytes,
+                   be_stream_t stream);
+int be_jitmv_float(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* v, void* out, int64_t shape1,
+                   int64_t in_len, int64_t out_len, int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * perm-fused ("indexed") products: be_binary_csrmm_{t,nt} over a RE-INDEXED structure whose slot j carries
  * weights[perm[j]] — the weights stay in their canonical order and only the weights of active rows (t) / of entries whose

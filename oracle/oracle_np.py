@@ -320,6 +320,23 @@ def binary_jitmm(mode, w0, w1, prob, B, seed, *, shape, transpose, corder, wdtyp
     return G @ act if corder else G.T @ act
 
 
+def jitmv(mode, w0, w1, prob, vector, seed, *, shape, transpose, corder, wdtype=np.float32):
+    """Float-operand twin jit{s,u,n}mv (brainevent/_jit_scalar/float.py:838-905 and the uniform / normal files): the same
+    generator matrix as :func:`binary_jitmv` against the values of ``vector`` (sums in float64)."""
+    G = jit_generator_matrix(mode, w0, w1, prob, seed, shape=shape, transpose=transpose, corder=corder, matrix_mode='mv',
+                             dtype=wdtype).astype(np.float64)
+    x = np.asarray(vector, dtype=np.float64)
+    return G @ x if corder else G.T @ x
+
+
+def jitmm(mode, w0, w1, prob, B, seed, *, shape, transpose, corder, wdtype=np.float32):
+    """Float-operand twin jit{s,u,n}mm (brainevent/_jit_scalar/float.py:1331-1420): the stride-4 matrix."""
+    G = jit_generator_matrix(mode, w0, w1, prob, seed, shape=shape, transpose=transpose, corder=corder, matrix_mode='mm',
+                             dtype=wdtype).astype(np.float64)
+    X = np.asarray(B, dtype=np.float64)
+    return G @ X if corder else G.T @ X
+
+
 # =====================================================================================================
 # event encodings
 # =====================================================================================================

@@ -182,3 +182,69 @@ def test_containers_take_dense_operands(be):
     s = rng.random(k) < 0.3
     np.testing.assert_allclose(csr @ be.BinaryArray(s), D @ s.astype(np.float64), **tol)
     np.testing.assert_allclose(csr @ s.astype(np.float32), D @ s.astype(np.float64), **tol)
+
+
+# ---------------------------------------------------------------------------------------------------- JIT connectivity
+@pytest.mark.parametrize('family', ['s', 'u', 'n'])
+@pytest.mark.parametrize('transpose', [False, True])
+@pytest.mark.parametrize('corder', [True, False])
+def test_jit_float_twins_against_the_oracle(be, oracle, family, transpose, corder):
+    """jit{s,u,n}mv / mm with a dense operand == the oracle's generator matrix (the reference's golden walk, pinned bit for bit by
+    tests/test_oracle.py) times the operand; the vector and the matrix products see different draws (stride 32 / 4)."""
+    rng = np.random.default_rng(31)
+    shape, prob, seed = (150, 210), 0.08, 123
+    params = {'s': (1.5,), 'u': (-0.5, 1.25), 'n': (0.3, 0.8)}[family]
+    w0, w1 = (params[0], 0.0) if family == 's' else params
+    in_len = shape[0] if transpose else shape[1]
+    v = rng.normal(0, 1, in_len).astype(np.float32)
+    v[rng.random(in_len) < 0.3] = 0
+    B = rng.normal(0, 1, (in_len, 11)).astype(np.float32)
+    fmv = {'s': be.jitsmv, 'u': be.jitumv, 'n': be.jitnmv}[family]
+    fmm = {'s': be.jitsmm, 'u': be.jitumm, 'n': be.jitnmm}[family]
+    wargs = tuple(np.float32(p) for p in params)
+    got = fmv(*wargs, prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+    ref = oracle.jitmv(family, w0, w1, prob, v, seed, shape=shape, transpose=transpose, corder=corder)
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    gotm = fmm(*wargs, prob, B, seed, shape=shape, transpose=transpose, corder=corder)
+    refm = oracle.jitmm(family, w0, w1, prob, B, seed, shape=shape, transpose=transpose, corder=corder)
+    assert gotm.shape == refm.shape
+    np.testing.assert_allclose(gotm, refm, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(refm).max())))
+
+
+def test_jit_float_twins_agree_with_the_event_driven_products_on_0_1_operands(be):
+    """On an operand of zeros and ones the float twin and the event-driven product are the same sum (the reference tests its
+    binary ops against its float ops this way, ``_jit_scalar/binary_test.py:84-118``) — the scalar family exactly."""
+    rng = np.random.default_rng(32)
+    shape, prob, seed = (400, 300), 0.05, 7
+    for transpose in (False, True):
+        for corder in (True, False):
+            s = rng.random(shape[0] if transpose else shape[1]) < 0.3
+            a = be.binary_jitsmv(np.float32(2.0), prob, s, seed, shape=shape, transpose=transpose, corder=corder)
+            b = be.jitsmv(np.float32(2.0), prob, s.astype(np.float32), seed, shape=shape, transpose=transpose, corder=corder)
+            np.testing.assert_array_equal(a, b)
+            S = rng.random((shape[0] if transpose else shape[1], 5)) < 0.3
+            am = be.binary_jitsmm(np.float32(2.0), prob, S, seed, shape=shape, transpose=transpose, corder=corder)
+            bm = be.jitsmm(np.float32(2.0), prob, S.astype(np.float32), seed, shape=shape, transpose=transpose, corder=corder)
+            np.testing.assert_array_equal(am, bm)
+
+
+def test_jit_containers_take_dense_operands(be):
+    rng = np.random.default_rng(33)
+    for cls, params in ((be.JITCScalarR, (np.float32(0.7),)), (be.JITCUniformC, (np.float32(-1.0), np.float32(1.0))),
+                        (be.JITCNormalR, (np.float32(0.1), np.float32(0.5)))):
+        for corder in (True, False):
+            M = cls((*params, 0.1, 11), shape=(60, 90), corder=corder)
+            Dv, Dm = M.mv.todense().astype(np.float64), M.mm.todense().astype(np.float64)
+            x90, x60 = rng.normal(0, 1, 90).astype(np.float32), rng.normal(0, 1, 60).astype(np.float32)
+            X90, X60 = rng.normal(0, 1, (90, 4)).astype(np.float32), rng.normal(0, 1, (4, 60)).astype(np.float32)
+            tol = dict(rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(M @ x90, Dv @ x90, **tol)
+            np.testing.assert_allclose(x60 @ M, x60 @ Dv, **tol)
+            np.testing.assert_allclose(M @ X90, Dm @ X90, **tol)
+            np.testing.assert_allclose(X60 @ M, X60 @ Dm, **tol)
+    # half-precision weights and the prob = 0 convention (zeros, like the event-driven twins)
+    h = be.jitsmv(np.float16(0.5), 0.1, rng.normal(0, 1, 90).astype(np.float16), 3, shape=(60, 90))
+    assert h.dtype == np.float16 and h.shape == (60,)
+    z = be.jitsmv(np.float32(0.5), 0.0, np.ones(90, np.float32), 3, shape=(60, 90))
+    np.testing.assert_array_equal(z, np.zeros(60, np.float32))
