@@ -307,8 +307,28 @@ def _jit_float_hip(family, a, b, clen, X, seed, *, shape, transpose, corder, out
     out = torch.empty((out_len,) if vec else (out_len, n), dtype=out_dtype, device=A.device())
     if out_len == 0 or n == 0:
         return out
-    w0, w1, _ = _jit_params(family, a, b)
+    w0, w1, wmax = _jit_params(family, a, b)
     gather = 1 if corder else 0
+    if not gather and out_dtype != torch.float64 and in_len > 0 and int(clen) > 0:
+        # The scatter orientation through LDS fixed-point sums (the event-driven scatter's structure with the operand's value as
+        # a per-row factor): its exponent needs the operand's largest magnitude — one reduction and a host read per call, against
+        # float atomics at 21 G/s otherwise (C3 shape: 757 ms).  f64 keeps the atomic kernel (the factor is formed in f32 here).
+        xmax = float(x.abs().max())
+        bound = wmax * xmax * 1.001
+        if bound == 0.0:
+            return out.zero_()
+        if math.isfinite(bound):
+            x_bm = x.reshape(1, -1) if vec else x.T.contiguous()
+            out_bm = torch.empty((n, out_len), dtype=out_dtype, device=A.device())
+            stride = 4 if mm else 32
+            ws = A.workspace(fn('be_jitmm_float_scatter_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])(int(shape[1]), out_len,
+                                                                                                             n, stride))
+            f = fn('be_jitmm_float_scatter', c_int, [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
+                                                     c_int, c_int, c_vp, c_i64, c_vp])
+            check(f(_FAMILY[family], w0, w1, A.wcode(out), int(clen), seed & 0xFFFFFFFF, A.ptr(x_bm), A.ptr(out_bm), int(shape[1]),
+                    in_len, out_len, n, stride, _fixed_scale_exp(bound, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()),
+                  'be_jitmm_float_scatter')
+            return out_bm[0] if vec else out_bm.T
     f_ws = fn('be_jitmm_float_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_i64, c_int, c_int])
     ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, n, gather, A.wcode(out)))
     f = fn('be_jitmm_float', c_int, [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int,

@@ -110,6 +110,57 @@ __global__ void __launch_bounds__(256) k_jit_f_scatter(JitP p, const W* __restri
   }
 }
 
+// scatter through LDS, the event-driven scatter's structure (be_jitc.hip: one workgroup owns the accumulators of one residue
+// class, 64-bit fixed point, order independent) with the operand's value as a per-row factor.  The exponent comes from the
+// caller: |w|max * |x|max * rows * 2^scale_exp < 2^62.  Batch-major operand X_bm [n, in_len] and partial sums per column
+// (gridDim.y = column), reduced by k_jit_scatter_reduce into out_bm [n, out_len].  With a dense operand every row walks:
+// the kernel runs at the walk's rate instead of the atomic units' (C3 shape: 757 ms -> see tools/bench_jit_float.py).
+template <int MODE, typename W, bool ONE_PIECE>
+__global__ void __launch_bounds__(1024) k_jit_f_scatter_lds(JitP p, const W* __restrict__ X_bm, int64_t in_len, int pieces, int parts,
+                                                            uint32_t piece_len, float fx_scale,
+                                                            unsigned long long* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);
+  const int part = blockIdx.x % parts;
+  const int piece = (blockIdx.x / parts) % pieces;
+  const int cls = p.cls_begin + blockIdx.x / (parts * pieces);
+  const uint32_t S = (uint32_t)p.stride;
+  const uint32_t chunk = (uint32_t)cls / S, l = (uint32_t)cls - chunk * S;
+  const W* x = X_bm + (int64_t)blockIdx.y * in_len;
+  partial += (int64_t)blockIdx.y * gridDim.x * piece_len;
+  const int64_t cs = (int64_t)chunk * p.chunk_size;
+  const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+  const int64_t width = ce - cs;
+  const int64_t Q = width > (int64_t)l ? (width - l + S - 1) / S : 0;
+  const int64_t q_begin = (int64_t)piece * piece_len;
+  const int64_t q_end = q_begin + piece_len < Q ? q_begin + piece_len : Q;
+  for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  if (q_begin < q_end) {
+    const uint32_t qb = (uint32_t)q_begin, qe = (uint32_t)q_end;
+    const uint32_t j0 = (uint32_t)(cs + l);
+    for (int64_t row = (int64_t)part * blockDim.x + threadIdx.x; row < in_len; row += (int64_t)parts * blockDim.x) {
+      const float xv = (float)WTraits<W>::load(x, row);
+      if (xv == 0.f) continue;                                 // a zero of the operand adds nothing
+      const unsigned long long fixed_row = jit_fixed_from_f32(xv * (float)p.w0, fx_scale);      // (one shared weight: per row)
+      uint32_t state = lr_init(p.seed, (uint32_t)row, chunk, l);
+      uint32_t q = lr_initial_q(state, p.cl);
+      while (q < qe) {
+        if (ONE_PIECE || q >= qb) {
+          const uint32_t slot = ONE_PIECE ? q : q - qb;
+          if (MODE == MODE_SCALAR) atomicAdd(&acc[slot], fixed_row);
+          else atomicAdd(&acc[slot], jit_fixed_from_f32(edge_weight<MODE, float>(p, (uint32_t)row, j0 + S * q) * xv, fx_scale));
+        }
+        state = lr_next_nz(state);
+        q = q + 1u + lr_bounded(state, p.cl - 1u);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* dst = partial + (int64_t)blockIdx.x * piece_len;
+  for (uint32_t i = threadIdx.x; i < piece_len; i += blockDim.x) dst[i] = acc[i];
+}
+
 template <typename W>
 __global__ void __launch_bounds__(256) k_jit_f_round(const float* __restrict__ img, W* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -178,9 +229,81 @@ int dispatch_jit_float(const JitP& p, int wdtype, const void* X, void* out, int6
   }
 }
 
+template <int MODE, typename W>
+int run_jit_float_scatter_lds(const JitP& p, const void* X_bm, void* out_bm, int64_t in_len, int64_t n, int scale_exp, void* ws,
+                              hipStream_t st) {
+  const ScatterGeom g = scatter_geom(p, /*scalar=*/false, n);
+  const size_t lds = (size_t)g.piece_len * 8;
+  const float fx_scale = ldexpf(1.0f, scale_exp - 32);
+  unsigned long long* partial = static_cast<unsigned long long*>(ws);
+  const dim3 sgrid((unsigned)(g.n_classes * g.pieces * g.parts), (unsigned)n);
+  if (g.pieces == 1) {
+    auto kern = k_jit_f_scatter_lds<MODE, W, true>;
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, static_cast<const W*>(X_bm), in_len, g.pieces, g.parts, g.piece_len,
+                       fx_scale, partial);
+  } else {
+    auto kern = k_jit_f_scatter_lds<MODE, W, false>;
+    BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, sgrid, dim3(1024), lds, st, p, static_cast<const W*>(X_bm), in_len, g.pieces, g.parts, g.piece_len,
+                       fx_scale, partial);
+  }
+  BE_LAUNCH_CHECK();
+  const int64_t q_per_chunk = (std::min<int64_t>(p.chunk_size, p.walk_len) + p.stride - 1) / p.stride;
+  const dim3 rgrid((unsigned)((q_per_chunk + 255) / 256), (unsigned)p.n_chunks, (unsigned)n);
+  const int64_t pstride = (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len;
+  // (the 64-bit fixed-point branch of the shared reduce kernel, whatever the family: MODE_UNIFORM selects it)
+  hipLaunchKernelGGL((k_jit_scatter_reduce<MODE_UNIFORM, W>), rgrid, dim3(256), 0, st, partial, p, g.pieces, g.parts, g.piece_len,
+                     ldexp(1.0, -scale_exp), static_cast<W*>(out_bm), pstride);
+  BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t be_jitmm_float_scatter_workspace_bytes(int64_t shape1, int64_t out_len, int64_t n, int stride) {
+  const JitP p = make_params(shape1, out_len, 0, 2, stride == 4 ? 4 : 32, 0, 0);
+  const ScatterGeom g = scatter_geom(p, false, std::max<int64_t>(1, n));
+  return be_align_up(std::max<int64_t>(1, n) * (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len * 8, 256);
+}
+
+// The scatter orientation (generator rows = inputs) through LDS fixed-point sums: X_bm [n, in_len] -> out_bm [n, out_len], both
+// batch-major.  scale_exp: |w|max * |x|max * in_len * 2^scale_exp < 2^62 (the caller knows the operand's largest magnitude).
+int be_jitmm_float_scatter(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* X_bm, void* out_bm,
+                           int64_t shape1, int64_t in_len, int64_t out_len, int64_t n, int stride, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(mode >= 0 && mode <= 2, BE_ERR_INVALID, "mode must be 0 (scalar), 1 (uniform) or 2 (normal)");
+  BE_REQUIRE(in_len >= 0 && out_len >= 0 && shape1 >= 0 && n >= 1 && n <= 65535, BE_ERR_INVALID, "bad shape");
+  BE_REQUIRE(stride == 32 || stride == 4, BE_ERR_INVALID, "stride must be 32 or 4");
+  BE_REQUIRE(in_len < (1ll << 32) && out_len < (1ll << 32), BE_ERR_RANGE, "dimensions must fit uint32 for the RNG keys");
+  BE_REQUIRE(scale_exp - 32 > -126 && scale_exp - 32 < 127, BE_ERR_INVALID, "scale_exp out of range");
+  if (out_len == 0) return BE_OK;
+  BE_REQUIRE(out_bm != nullptr, BE_ERR_INVALID, "out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t esz = wdtype == BE_F64 ? 8 : (wdtype == BE_F32 ? 4 : 2);
+  if (in_len == 0 || clen <= 0) {
+    BE_HIP(be_fill_async(out_bm, 0, (size_t)out_len * (size_t)n * esz, st));
+    return BE_OK;
+  }
+  BE_REQUIRE(X_bm != nullptr, BE_ERR_INVALID, "operand is NULL");
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= be_jitmm_float_scatter_workspace_bytes(shape1, out_len, n, stride),
+             BE_ERR_WORKSPACE, "workspace too small");
+  const JitP p = make_params(shape1, out_len, seed, clen, stride, w0, w1);
+#define BE_JFS(MODE_)                                                                                                            \
+  switch (wdtype) {                                                                                                             \
+    case BE_F32: return run_jit_float_scatter_lds<MODE_, float>(p, X_bm, out_bm, in_len, n, scale_exp, workspace, st);          \
+    case BE_F64: return run_jit_float_scatter_lds<MODE_, double>(p, X_bm, out_bm, in_len, n, scale_exp, workspace, st);         \
+    case BE_F16: return run_jit_float_scatter_lds<MODE_, __half>(p, X_bm, out_bm, in_len, n, scale_exp, workspace, st);         \
+    case BE_BF16: return run_jit_float_scatter_lds<MODE_, __hip_bfloat16>(p, X_bm, out_bm, in_len, n, scale_exp, workspace, st); \
+    default: be_set_error("unknown weight dtype"); return BE_ERR_INVALID;                                                       \
+  }
+  if (mode == MODE_SCALAR) { BE_JFS(MODE_SCALAR) }
+  else if (mode == MODE_UNIFORM) { BE_JFS(MODE_UNIFORM) }
+  else { BE_JFS(MODE_NORMAL) }
+#undef BE_JFS
+}
 
 int64_t be_jitmm_float_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int64_t n, int gather, int wdtype) {
   if (gather) {

@@ -5,6 +5,7 @@
 #include "be_common.h"
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -116,6 +117,104 @@ inline JitP make_params(int64_t shape1, int64_t walk_len, uint32_t seed, int64_t
   p.row0 = 0u;
   p.cls_count = p.n_chunks * stride;
   return p;
+}
+
+
+// ------------------------------------------------------------------------------------------------ scatter by residue class
+// (shared by the event-driven scatter of be_jitc.hip and the float-operand scatter of be_jitc_float.hip)
+template <int MODE> struct ScatterAcc { using type = unsigned long long; };
+template <> struct ScatterAcc<MODE_SCALAR> { using type = uint32_t; };
+
+__device__ __forceinline__ unsigned long long jit_fixed_from_f32(float w, float scale) {
+  // same construction as fixed_from_f32 in be_csr.hip: w * 2^scale_exp split into (hi, lo) words in f32
+  const float t = w * scale;
+  const float hf = floorf(t);
+  const int hi = (int)hf;
+  const unsigned lo = (unsigned)((t - hf) * 4294967296.0f);
+  return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+
+// partial is class-major ([class][piece][part][piece_len], class = chunk * stride + lane residue) while the output is
+// column-major in (q, lane): out[chunk_start + stride * q + l].  One workgroup transposes a tile of `stride` classes x
+// 256 q through LDS: coalesced reads per class row, coalesced writes of stride * 256 consecutive outputs.
+// piece_len is a multiple of 256, so a tile never straddles two pieces.  gridDim.z = batch column.
+template <int MODE, typename W>
+__global__ void __launch_bounds__(256) k_jit_scatter_reduce(const typename ScatterAcc<MODE>::type* __restrict__ partial,
+                                                            JitP p, int pieces, int parts, uint32_t piece_len,
+                                                            double inv_scale, W* __restrict__ out, int64_t partial_stride) {
+  using TileT = typename std::conditional<std::is_same<W, double>::value, double, float>::type;
+  __shared__ TileT tile[32][257];
+  partial += (int64_t)blockIdx.z * partial_stride;
+  out += (int64_t)blockIdx.z * p.walk_len;
+  const int S = p.stride;
+  const int chunk = blockIdx.y;
+  const int64_t cs = (int64_t)chunk * p.chunk_size;
+  const int64_t ce = cs + p.chunk_size < p.walk_len ? cs + p.chunk_size : p.walk_len;
+  const int64_t width = ce - cs;
+  const int64_t q0 = (int64_t)blockIdx.x * 256;
+  if (q0 * S >= width) return;
+  const int64_t piece = q0 / piece_len, i0 = q0 - piece * piece_len;
+  const int t = threadIdx.x;
+  using AccT = typename ScatterAcc<MODE>::type;
+  const int64_t cls_stride = (int64_t)pieces * parts * piece_len;      // between consecutive classes
+  // class c = chunk * S + l lives at local index c - cls_begin; classes outside the owned range read as zero
+  const int c0 = chunk * S - p.cls_begin;
+  const AccT* base = partial + ((int64_t)piece * parts) * (int64_t)piece_len + i0 + t;
+  // up to 8 class rows x parts loads in flight per thread
+  for (int l0 = 0; l0 < S; l0 += 8) {
+    unsigned long long sum[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum[u] = 0;
+    for (int q2 = 0; q2 < parts; ++q2) {
+      AccT v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {      // unconditional loads from a clamped class row; the select happens at the add
+        const int c = c0 + l0 + u;
+        const int cc = c < 0 ? 0 : (c >= p.cls_count ? p.cls_count - 1 : c);
+        v[u] = base[(int64_t)cc * cls_stride + (int64_t)q2 * piece_len];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + l0 + u;
+        sum[u] += (l0 + u < S && c >= 0 && c < p.cls_count) ? (unsigned long long)v[u] : 0ull;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = l0 + u;
+      if (l >= S) break;
+      double val = 0.0;
+      if ((q0 + t) * S + l < width)
+        val = (MODE == MODE_SCALAR) ? (double)sum[u] * p.w0 : (double)(long long)sum[u] * inv_scale;
+      tile[l][t] = (TileT)val;
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < S; ++r) {
+    const int jl = r * 256 + t;                 // tile-local output index: stride * (q - q0) + l
+    const int64_t j_local = q0 * S + jl;
+    if (j_local < width) WTraits<W>::store_d(out, cs + j_local, (double)tile[jl % S][jl / S]);
+  }
+}
+
+#ifndef BE_JIT_WG_TARGET
+#define BE_JIT_WG_TARGET 256   // scatter workgroups (classes x pieces x parts): one round over the CUs.  512 (two rounds, twice the
+                               // partial sums) until late in round 2: C3 143 -> 136 us per step; 384 / 1024: 165 / 162
+#endif
+constexpr uint32_t kPieceU32 = 32768, kPieceU64 = 16384;   // LDS accumulators per scatter workgroup (128 KiB); multiples of 256
+
+struct ScatterGeom { int n_classes, pieces, parts; uint32_t piece_len; };
+inline ScatterGeom scatter_geom(const JitP& p, bool scalar, int64_t n_batch = 1) {
+  ScatterGeom g;
+  g.n_classes = p.cls_count;
+  const int64_t Qmax = (std::min<int64_t>(p.chunk_size, p.walk_len) + p.stride - 1) / p.stride;
+  const uint32_t cap = scalar ? kPieceU32 : kPieceU64;
+  g.pieces = (int)std::max<int64_t>(1, (Qmax + cap - 1) / cap);
+  const int64_t per_piece = (Qmax + g.pieces - 1) / g.pieces;
+  g.piece_len = (uint32_t)std::max<int64_t>(256, (per_piece + 255) & ~255ll);   // multiple of the reduce tile
+  int parts = (int)(BE_JIT_WG_TARGET / std::max<int64_t>(1, (int64_t)g.n_classes * g.pieces * n_batch));
+  g.parts = std::max(1, std::min(parts, 16));
+  return g;
 }
 
 }  // namespace

@@ -485,6 +485,14 @@ int64_t be_jitmm_float_workspace_bytes(int64_t shape1, int64_t in_len, int64_t o
 int be_jitmm_float(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* X, void* out, int64_t shape1,
                    int64_t in_len, int64_t out_len, int64_t n, int stride, int gather, void* workspace, int64_t workspace_bytes,
                    be_stream_t stream);
+/* The scatter orientation (gather = 0) through LDS fixed-point sums instead of float atomics — the event-driven scatter's structure
+ * with the operand's value as a per-row factor (C3 shape, dense operand: the walk's rate instead of 21 G atomics/s).  BATCH-major
+ * operand X_bm [n, in_len] and result out_bm [n, out_len]; scale_exp such that |w|max * |x|max * in_len * 2^scale_exp < 2^62 —
+ * the caller knows the operand's largest magnitude.  f32 / f16 / bf16 (f64 operands: be_jitmm_float, whose atomics are f64). */
+int64_t be_jitmm_float_scatter_workspace_bytes(int64_t shape1, int64_t out_len, int64_t n, int stride);
+int be_jitmm_float_scatter(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* X_bm, void* out_bm,
+                           int64_t shape1, int64_t in_len, int64_t out_len, int64_t n, int stride, int scale_exp, void* workspace,
+                           int64_t workspace_bytes, be_stream_t stream);
 int be_jitmv_float(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* v, void* out, int64_t shape1,
                    int64_t in_len, int64_t out_len, int gather, void* workspace, int64_t workspace_bytes, be_stream_t stream);
 
