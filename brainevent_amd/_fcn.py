@@ -298,7 +298,20 @@ class FixedNumConn(DataRepresentation):
         if not is_event(other):     # a dense operand: the float twins (reference ``_fcn/main.py:308-460`` dispatches them alike)
             from ._float import fcnmv_p_call, fcnmm_p_call
             x = other if isinstance(other, torch.Tensor) else np.asarray(other)
-            if x.ndim == 1:
+            mr = self._fresh_mirror(auto=True) if ell_t else None       # scatter direction: a gather over the mirror beats float atomics
+            if mr is not None and (mr.released or mr.indices is None):
+                mr = None
+            if x.ndim not in (1, 2):
+                raise NotImplementedError(f"matmul with object of shape {tuple(x.shape)}")
+            if mr is not None:
+                from ._float import csrmv_p_call, csrmm_p_call
+                if x.ndim == 1:
+                    r = csrmv_p_call(mr.data, mr.indices, mr.indptr, x, shape=tuple(mr.shape), transpose=False, backend=self.backend)[0]
+                else:
+                    r = csrmm_p_call(mr.data, mr.indices, mr.indptr, x.T if transpose_W else x, shape=tuple(mr.shape), transpose=False,
+                                     backend=self.backend)[0]
+                    r = r.T if transpose_W else r
+            elif x.ndim == 1:
                 r = fcnmv_p_call(self.data, self.indices, x, shape=self._a_shape, transpose=ell_t, backend=self.backend)[0]
             elif x.ndim == 2:
                 r = fcnmm_p_call(self.data, self.indices, x.T if transpose_W else x, shape=self._a_shape, transpose=ell_t,

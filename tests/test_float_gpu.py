@@ -166,6 +166,11 @@ def test_containers_take_dense_operands(be):
         np.testing.assert_allclose(xr @ conn, xr @ Df, **tol)
         np.testing.assert_allclose(conn @ Xc, Df @ Xc, **tol)
         np.testing.assert_allclose(Xr @ conn, Xr @ Df, **tol)
+        conn.build_mirror()                                    # with a mirror the scatter direction gathers over it: same numbers
+        np.testing.assert_allclose(conn @ xc, Df @ xc, **tol)
+        np.testing.assert_allclose(xr @ conn, xr @ Df, **tol)
+        np.testing.assert_allclose(conn @ Xc, Df @ Xc, **tol)
+        np.testing.assert_allclose(Xr @ conn, Xr @ Df, **tol)
     # with a mirror the scatter direction (x @ csr, csc @ x) runs as a gather over the mirror's arrays: same numbers
     csr_m = be.CSR((w, idx, ptr), shape=(m, k)).prepare(mirror=True)
     assert csr_m.buffers.get('mirror') is not None
