@@ -1768,8 +1768,9 @@ def _dense_product(M, other, *, shape, transpose: bool, operand_on_left: bool):
     t = (not transpose) if operand_on_left else transpose
     data, indices, indptr = M.data, M.indices, M.indptr
     if t:       # the scatter direction runs on float atomics (~21 G/s); the mirror turns it into a gather — an existing one, or
-        #             the one a large matrix gets on first use exactly as for event operands (auto_mirror_wanted)
-        mr = M._fresh_mirror(auto=True)
+        #             the one a large matrix gets on first use as for event operands (auto_mirror_wanted) — but only while a
+        #             mirror of that size keeps its raw arrays: a plan-only mirror cannot serve a dense operand
+        mr = M._fresh_mirror(auto=M.nse <= MIRROR_KEEP_RAW_MAX_NNZ)
         if mr is not None and not mr.released and mr.indices is not None and tuple(mr.shape) == tuple(shape[::-1]):
             data, indices, indptr, shape, t = mr.data, mr.indices, mr.indptr, tuple(mr.shape), False
     if x.ndim == 1:

@@ -298,7 +298,8 @@ class FixedNumConn(DataRepresentation):
         if not is_event(other):     # a dense operand: the float twins (reference ``_fcn/main.py:308-460`` dispatches them alike)
             from ._float import fcnmv_p_call, fcnmm_p_call
             x = other if isinstance(other, torch.Tensor) else np.asarray(other)
-            mr = self._fresh_mirror(auto=True) if ell_t else None       # scatter direction: a gather over the mirror beats float atomics
+            # scatter direction: a gather over the mirror beats float atomics (built on first use only while it keeps its raw arrays)
+            mr = self._fresh_mirror(auto=self.nse <= _csr_mod.MIRROR_KEEP_RAW_MAX_NNZ) if ell_t else None
             if mr is not None and (mr.released or mr.indices is None):
                 mr = None
             if x.ndim not in (1, 2):
