@@ -708,9 +708,20 @@ class BinnedScatter:
             self._ws[int(n_batch)] = ws
         return ws
 
+    def audit(self, n_batch: int = 1):
+        """The four conservation counters of the workspace for ``n_batch`` vectors since the last clear
+        (``be_binned_workspace_audit``): entries in the active rows, tickets drawn by pass B, entries accumulated by pass C,
+        entries delivered through the overflow image — ``a == b == c + d`` after complete steps.  Synchronises."""
+        c = (ctypes.c_uint64 * 4)()
+        check(fn('be_binned_workspace_audit', c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), c_vp])(
+            A.ptr(self.workspace(n_batch)), c, A.stream_ptr()), 'be_binned_workspace_audit')
+        return tuple(int(x) for x in c)
+
     def check_status(self, clear: bool = True) -> None:
-        """Raise ``KernelExecutionError`` if a step on one of this object's workspaces gave up on its append protocol
-        (``be_binned_workspace_status``: such a step wrote NaN outputs instead of trapping the device).  Synchronises."""
+        """Raise ``KernelExecutionError`` if a step on one of this object's workspaces gave up on its append protocol (such a
+        step wrote NaN outputs instead of trapping the device) or if the workspace's conservation counters disagree — an entry
+        lost or delivered twice between the row bounds and the accumulators (``be_binned_workspace_status``).  Synchronises;
+        call it at a point that synchronises anyway (the containers do after a mirror build; ``bench.py`` at its parity check)."""
         f = fn('be_binned_workspace_status', c_int, [c_vp, c_int, c_vp])
         for ws in self._ws.values():
             check(f(A.ptr(ws), int(clear), A.stream_ptr()), 'be_binned_workspace_status')
@@ -765,6 +776,9 @@ class BinnedScatter:
                 check(f(A.ptr(w_arg), kind, code, A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(ev), A.BE_SPIKE_IDS, A.ptr(out),
                         m, k, self.slice_shift, cap, e0, A.ptr(ws), ws.numel(), A.stream_ptr()), 'be_binary_csrmv_t_binned')
                 acc += out
+        # the statistics decide the exponent of every later step: the steps that made them must have conserved their entries
+        # (the reductions below synchronise anyway)
+        check(fn('be_binned_workspace_status', c_int, [c_vp, c_int, c_vp])(A.ptr(ws), 1, A.stream_ptr()), 'be_binned_workspace_status')
         live = count > 0
         mean_min = float((colsum[live] / count[live]).min()) if bool(live.any()) else float('inf')
         return float(colsum.max()), mean_min, wmax, wmin

@@ -2,6 +2,7 @@
 #include "be_csr_shared.h"
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -55,6 +56,15 @@ static_assert(BE_RING == 1 || BE_RING == 2, "ring of one or two blocks per bin")
 // abort would poison the HIP context of the whole process (the header promises codes).  Never observed.
 constexpr uint64_t kWaitLimitTicks = 2000000ull;
 constexpr int kBinErrWord = 16;             // word of the workspace head that holds the sticky flag (word 0: the spike counter)
+// Conservation counters (64-bit, at word kBinAuditWord of the workspace head; they only grow until be_binned_workspace_status
+// clears them).  Every step adds: [0] the stored entries of its active rows (x the batch rows a row is active in), summed from
+// the row bounds pass B reads; [1] the tickets pass B handed out (its LDS counters at the drain); [2] the entries pass C added
+// to its accumulators (counted where they are added, not taken from the directory); [3] the entries pass B delivered through
+// the overflow image.  After any number of complete steps [0] == [1] == [2] + [3]: an entry lost or delivered twice anywhere
+// between the row bounds and the accumulators breaks one of the equalities and be_binned_workspace_status says which.
+// ([0] > [1] also when a column id is >= k: the caller's error, such entries are dropped.)  Cost: one wave reduction per task
+// and four global atomics per workgroup and launch.
+constexpr int kBinAuditWord = 32;
 
 template <bool HOMO, int CAP> struct BinBlock {
   static constexpr int bytes = CAP * (HOMO ? 2 : 6);
@@ -367,7 +377,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
                                                      float* __restrict__ out, DivU32 fixdiv,
                                                      const uint32_t* __restrict__ row_masks, int n_bins_b, int64_t k,
                                                      uint32_t min_tasks, uint32_t task_groups, int64_t m_rows,
-                                                     uint32_t* __restrict__ err_flag, uint32_t sign_mask) {
+                                                     uint32_t* __restrict__ err_flag, uint32_t sign_mask,
+                                                     unsigned long long* __restrict__ audit) {
   // row_masks != NULL: a batch.  `active` lists the rows with a spike in ANY of the (<= 32) batch rows of this pass and
   // row_masks[j] says in which; the bins are virtual — batch row b's bin i is n_bins_b * b + i of n_bins — and an entry is
   // appended once per batch row that has its row active (the rows are read once for the whole batch).
@@ -392,6 +403,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   for (int i = tid; i < (2 + 2 * kRing) * n_bins + 128; i += (int)blockDim.x) S.tick[i] = 0u;
   if (tid == 0) s_ticket[0] = 0u;
   __syncthreads();
+  unsigned long long n_expected = 0;              // stored entries of the rows this lane read the bounds of (x batch rows)
 
   const uint32_t n_active = *n_active_p;
   float w0 = 0.f;
@@ -441,6 +453,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
       if (BATCH) rmask = row_masks[a0 + lane];
       rb = rp.at(r);
       len = (uint64_t)(rp.at((int64_t)r + 1) - rb);
+      n_expected += len * (BATCH ? (uint64_t)__popc(rmask) : 1ull);
     }
     const bool huge = __ballot(len >= (1ull << 26)) != 0;     // a row the 32-bit flattening cannot hold: one row at a time
     const uint32_t n_pieces = huge ? R : 1u;
@@ -604,6 +617,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   }
   prof.stamp(7);
   prof.flush_out(lane);
+  n_expected = wave_sum(n_expected);
+  if (lane == 0 && n_expected) atomicAdd(audit + 0, n_expected);
   __syncthreads();
   // ---- drain: tickets are handed out in order, so of a bin's two ring slots only the one of block T / CB (T = the tickets
   //      drawn) can hold entries now, T % CB of them from slot 0 on; it goes out as it is, and the directory gets T
@@ -613,8 +628,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
     if (d > 0 && blk < cap_blocks)
       regions[(((size_t)bin * kStreamGrid + blockIdx.x) * cap_blocks + blk) * B::gdwords + l] = S.buf[(size_t)(bin * kRing + (blk & (uint32_t)(kRing - 1))) * B::dwords + l];
   }
+  unsigned long long n_tickets = 0, n_overflow = 0;
   for (int bin = tid; bin < n_bins; bin += (int)blockDim.x) {
     const uint32_t T = S.tick[bin], blk = T / (uint32_t)CB, d = T % (uint32_t)CB;
+    n_tickets += T;
     uint32_t o = S.ovf[bin];
     if (d > 0 && blk >= cap_blocks) {          // a partly filled block of a full region: float atomics
       const uint32_t* bp = S.buf + (size_t)(bin * kRing + (blk & (uint32_t)(kRing - 1))) * B::dwords;
@@ -626,8 +643,13 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
       o = 1u;
     }
     const uint64_t room = (uint64_t)cap_blocks * CB;
+    n_overflow += T > room ? T - room : 0ull;
     dir[(size_t)bin * kStreamGrid + blockIdx.x] = (uint32_t)(T < room ? T : room) | (o ? 0x80000000u : 0u);
   }
+  n_tickets = wave_sum(n_tickets);
+  n_overflow = wave_sum(n_overflow);
+  if (lane == 0 && n_tickets) atomicAdd(audit + 1, n_tickets);
+  if (lane == 0 && n_overflow) atomicAdd(audit + 3, n_overflow);
 }
 
 // eight counted entries (uint16 columns, two per dword)
@@ -650,7 +672,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
                                                          double inv_scale, const void* __restrict__ w0p, int wdtype,
                                                          float* __restrict__ out, float* __restrict__ ovf_img,
                                                          uint32_t* __restrict__ count_rearm, int n_bins_b,
-                                                         const uint32_t* __restrict__ err_flag) {
+                                                         const uint32_t* __restrict__ err_flag, unsigned long long* __restrict__ audit) {
   using B = BinBlock<HOMO, CAP>;
   using acc_t = typename PlanAcc<HOMO || ACC32>::type;
   static_assert(!(HOMO && ACC32), "ACC32 is a mode of per-entry weights");
@@ -687,6 +709,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
     for (uint32_t bk = s_pre[tid]; bk < s_pre[tid + 1]; ++bk) s_map[bk] = (uint8_t)tid;
   __syncthreads();
   const uint32_t* bin_base = regions + (size_t)bin * kStreamGrid * cap_blocks * B::gdwords;
+  uint32_t n_added = 0;                 // entries this thread adds to the accumulators (conservation counter [2])
   if (HOMO) {
     // one flat loop over the groups of 8 columns (16 bytes) of all regions, BE_BIN_U groups per thread and round with every
     // load of the round issued before the first add
@@ -718,6 +741,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        n_added += nv[u];
         if (nv[u] == 8u) {
           bin_count8(reinterpret_cast<uint32_t*>(acc), iv[u]);
         } else if (nv[u]) {                  // the last group of a region
@@ -774,6 +798,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        n_added += nv[u];
         unsigned long long* a64 = reinterpret_cast<unsigned long long*>(acc);
 #ifdef BE_DBG_C_NOATOMIC
         if (nv[u] >= 1u && uv[u].z == 0x12345678u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
@@ -790,6 +815,10 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
 #endif
       }
     }
+  }
+  {
+    const unsigned long long na = wave_sum((unsigned long long)n_added);
+    if ((tid & 63) == 0 && na) atomicAdd(audit + 2, na);
   }
   __syncthreads();
   // a batch: virtual bin = batch row * n_bins_b + bin; out / ovf_img are [batch row][k]
@@ -1043,18 +1072,43 @@ int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_b
   return be_binary_csrmm_t_binned_workspace_init(workspace, workspace_bytes, m, k, 1, slice_shift, bin_capacity, stream);
 }
 
+int be_binned_workspace_audit(const void* workspace, uint64_t* counters_host, be_stream_t stream) {
+  BE_REQUIRE(workspace != nullptr && counters_host != nullptr, BE_ERR_INVALID, "null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint32_t* p = static_cast<const uint32_t*>(workspace) + kBinAuditWord;
+  BE_HIP(hipMemcpyAsync(counters_host, p, 32, hipMemcpyDeviceToHost, st));
+  BE_HIP(hipStreamSynchronize(st));
+  return BE_OK;
+}
+
 int be_binned_workspace_status(const void* workspace, int clear, be_stream_t stream) {
   BE_REQUIRE(workspace != nullptr, BE_ERR_INVALID, "workspace is NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  uint32_t flag = 0;
-  const uint32_t* p = static_cast<const uint32_t*>(workspace) + kBinErrWord;
-  BE_HIP(hipMemcpyAsync(&flag, p, 4, hipMemcpyDeviceToHost, st));
+  uint32_t head[kBinAuditWord + 8];
+  BE_HIP(hipMemcpyAsync(head, workspace, sizeof(head), hipMemcpyDeviceToHost, st));
   BE_HIP(hipStreamSynchronize(st));
-  if (flag == 0u) return BE_OK;
-  if (clear) BE_HIP(be_fill_async(const_cast<uint32_t*>(p), 0, 4, st));
-  be_set_error("be_binned_workspace_status: pass B of a binned step gave up on an entry whose ring slot was not freed within 20 ms "
-               "(append protocol stalled); that step's outputs were written as NaN");
-  return BE_ERR_HIP;
+  const uint32_t flag = head[kBinErrWord];
+  uint64_t c[4];
+  memcpy(c, head + kBinAuditWord, 32);
+  const bool conserved = c[0] == c[1] && c[1] == c[2] + c[3];
+  if (flag == 0u && conserved) return BE_OK;
+  if (clear) {
+    uint32_t* w = static_cast<uint32_t*>(const_cast<void*>(workspace));
+    BE_HIP(be_fill_async(w + kBinErrWord, 0, 4, st));
+    BE_HIP(be_fill_async(w + kBinAuditWord, 0, 32, st));
+  }
+  if (flag != 0u) {
+    be_set_error("be_binned_workspace_status: pass B of a binned step gave up on an entry whose ring slot was not freed within 20 ms "
+                 "(append protocol stalled); that step's outputs were written as NaN");
+    return BE_ERR_HIP;
+  }
+  char msg[384];
+  snprintf(msg, sizeof(msg), "be_binned_workspace_status: conservation broken since the last clear: %llu entries in the active rows, "
+           "%llu tickets drawn by pass B, %llu entries accumulated by pass C + %llu through the overflow image (an entry was lost or "
+           "delivered twice%s)", (unsigned long long)c[0], (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[3],
+           c[0] > c[1] && c[1] == c[2] + c[3] ? ", or the matrix holds column ids >= k, which are dropped" : "");
+  be_set_error(msg);
+  return BE_ERR_RANGE;
 }
 
 int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const int32_t* indices, const void* indptr,
@@ -1098,6 +1152,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
+  unsigned long long* audit = reinterpret_cast<unsigned long long*>(count + kBinAuditWord);
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + wl.active_off);
   uint32_t* masks = reinterpret_cast<uint32_t*>(wsb + wl.masks_off);
   uint32_t* dir = reinterpret_cast<uint32_t*>(wsb + wl.dir_off);
@@ -1160,7 +1215,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)dyn));                                                        \
     hipLaunchKernelGGL(kern, dim3(kStreamGrid), dim3(BE_STREAM_THREADS), dyn, st, static_cast<const WT*>(weights), indices, rp, \
                        al.ids, al.count, (uint32_t)geo.width, wdiv, n_vbins, (uint32_t)cap_blocks, regions, dir, ovf_img,       \
-                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m, count + kBinErrWord, sign_mask);              \
+                       fixdiv, row_masks, n_bins_b, k, min_tasks, task_groups, m, count + kBinErrWord, sign_mask, audit);       \
   } while (0)
 #define BE_BIN_STREAM_W(WT)                                                                                                     \
   do {                                                                                                                          \
@@ -1187,7 +1242,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
                        geo.map_cap, parts, k, scale, inv_scale, static_cast<const void*>(nullptr), wdtype,                      \
-                       out_p, ovf_img, rearm, n_bins_b, count + kBinErrWord);                                                   \
+                       out_p, ovf_img, rearm, n_bins_b, count + kBinErrWord, audit);                                            \
   } while (0)
 #define BE_BIN_ACC(HOMO_, CAP_)                                                                                                 \
   do {                                                                                                                          \
@@ -1195,7 +1250,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
                        geo.map_cap, parts, k, scale, inv_scale, HOMO_ ? weights : static_cast<const void*>(nullptr), wdtype,    \
-                       out_p, ovf_img, rearm, n_bins_b, count + kBinErrWord);                                                   \
+                       out_p, ovf_img, rearm, n_bins_b, count + kBinErrWord, audit);                                            \
   } while (0)
     if (homo) {
       if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);

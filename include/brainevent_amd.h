@@ -381,8 +381,16 @@ int be_binned_set_tuning(int task_groups, int min_tasks);
  * freed within 20 ms (constant-rate clock; never observed) raises the flag and drops its pending entries, pass C then writes
  * NaN into every output of that step — the process keeps its HIP context (the reference's device-side check traps instead,
  * brainevent/include/brainevent/check.h:79-82).  This call reads the flag: BE_OK, or BE_ERR_HIP with the cause in
- * be_last_error(); clear != 0 re-arms the workspace.  SYNCHRONOUS.  A caller that never sees NaN never needs it. */
+ * be_last_error(); clear != 0 re-arms the workspace.  SYNCHRONOUS.  A caller that never sees NaN never needs it.
+ * The same call checks the workspace's CONSERVATION COUNTERS (four uint64 that every step adds to; be_binned_workspace_audit reads
+ * them): [0] stored entries of the active rows (from the row bounds), [1] tickets pass B drew, [2] entries pass C added to its
+ * accumulators, [3] entries delivered through the overflow image.  After complete steps [0] == [1] == [2] + [3]; otherwise
+ * BE_ERR_RANGE with the four numbers in be_last_error() — an entry was lost or delivered twice (or a column id is >= k: the
+ * caller's error, dropped by pass B, shows as [0] > [1]).  clear != 0 zeroes the counters too.  The reference has no counterpart:
+ * its scatter adds with global atomics (brainevent/_csr/binary_csrmv_hybrid.cu:330-350), nothing is staged that could be lost. */
 int be_binned_workspace_status(const void* workspace, int clear, be_stream_t stream);
+/* the four conservation counters of a binned workspace -> counters_host[4].  SYNCHRONOUS. */
+int be_binned_workspace_audit(const void* workspace, uint64_t* counters_host, be_stream_t stream);
 int64_t be_binary_csrmv_t_binned_workspace_bytes(int64_t m, int64_t k, int slice_shift, int64_t bin_capacity);
 /* once per workspace, before its first step: zeroes the spike counter and the overflow image inside it (every step leaves
  * both at zero, so the step itself needs no memset and no zeroing of `out`: pass C writes every output) */

@@ -38,6 +38,67 @@ def oracle():
     return oracle_np
 
 
+_POISON_WORDS = {'ff': -1, 'one': 1, 'f1': 0x3f800000, 'idx': 0x00030003}
+
+
+def _install_poisoned_empty(pattern: str) -> None:
+    """BE_POISON_ALLOC=ff|one|f1|idx: every device tensor that `torch.empty` / `empty_like` / `new_empty` hands out — in the
+    product and in the tests, whatever its size (the mirror test allocates 170 GB) — is filled right away: 0xFF bytes (NaN,
+    -1, every spike set), or PLAUSIBLE values that do not end in loud NaN / overflow paths: every 32-bit word 1 (a counter
+    that looks armed, a directory that says "one entry", a denormal float), 1.0f, or 0x00030003 (a pair of valid uint16
+    columns / a small int32 index).  A kernel or host path that reads such memory before writing it then gives a wrong
+    number in the test that uses it, every time, instead of once in hundreds of runs on recycled pages."""
+    import torch
+    word = _POISON_WORDS[pattern]
+
+    def fill(t):
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.numel() and t.is_contiguous():
+            b = t.view(torch.uint8).reshape(-1)
+            n4 = b.numel() // 4 * 4
+            if n4 and b.data_ptr() % 4 == 0:
+                b[:n4].view(torch.int32).fill_(word - (1 << 32) if word >= (1 << 31) else word)
+            if b.numel() > n4:
+                b[n4:].fill_(word & 0xff)
+        return t
+
+    for mod, name in ((torch, 'empty'), (torch, 'empty_like')):
+        orig = getattr(mod, name)
+
+        def wrapped(*a, __orig=orig, **k):
+            return fill(__orig(*a, **k))
+        setattr(mod, name, wrapped)
+    orig_new = torch.Tensor.new_empty
+    torch.Tensor.new_empty = lambda self, *a, **k: fill(orig_new(self, *a, **k))
+
+
+if os.environ.get('BE_POISON_ALLOC') in _POISON_WORDS:
+    _install_poisoned_empty(os.environ['BE_POISON_ALLOC'])
+
+
+@pytest.fixture(autouse=True)
+def _binned_conservation(request, monkeypatch):
+    """Every gpu test that builds a binned workspace checks, when it ends, that the workspace's conservation counters agree
+    (`BinnedScatter.check_status`: entries in the active rows == tickets == accumulated + overflow over all the steps the test
+    ran) — a lost or duplicated entry fails the test that produced it even where the test's own comparison would not see it."""
+    if request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    import weakref
+    from brainevent_amd import _csr
+    made = []
+    orig = _csr.BinnedScatter.__init__
+
+    def init(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(weakref.ref(self))
+    monkeypatch.setattr(_csr.BinnedScatter, '__init__', init)
+    yield
+    for r in made:
+        ws = r()
+        if ws is not None and getattr(ws, '_ws', None):
+            ws.check_status()
+
+
 @pytest.fixture(autouse=True)
 def _poisoned_device_memory(request):
     """BE_POISON_ALLOC=1 (robustness runs on the GPU box): before every gpu test, what the caching allocator will hand out next
@@ -45,7 +106,7 @@ def _poisoned_device_memory(request):
     relies on `torch.empty` memory being zero — true in a fresh process, false in a long-running one — fails here instead of
     once in a while.  Large pool: one block of BE_POISON_GIB GiB (default 16; tests that allocate more get fresh pages beyond
     it), small pool: 512 blocks of 1 MiB."""
-    if os.environ.get('BE_POISON_ALLOC') != '1' or request.node.get_closest_marker('gpu') is None:
+    if os.environ.get('BE_POISON_ALLOC') not in ('1', 'ff') or request.node.get_closest_marker('gpu') is None:
         yield
         return
     import torch

@@ -140,13 +140,26 @@ def test_c3_jitc_4m_on_the_fly_equals_materialised(be):
     _free()
 
 
+def _init_one_rank_group():
+    """A one-rank RCCL group on a free local port (the port found by bind(0) can be taken again before the store listens on it:
+    seen once as EADDRINUSE — try another)."""
+    import torch.distributed as dist
+    last = None
+    for _ in range(5):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        try:
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+            return dist
+        except Exception as e:           # DistNetworkError (address in use)
+            last = e
+    raise last
+
+
 @pytest.fixture(scope='module')
 def one_rank_group():
-    import torch.distributed as dist
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    dist = _init_one_rank_group()
     yield dist
     dist.destroy_process_group()
 
