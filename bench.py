@@ -48,6 +48,8 @@ def parse(argv=None):
                     '(--neurons: the spelling to use under torch.distributed.run, whose own parser trips over --n)')
     ap.add_argument('--conn', type=float, default=0.01)
     ap.add_argument('--fire', type=float, default=0.01)
+    ap.add_argument('--exact-active', action='store_true', help='csr: every spike vector has exactly round(n * fire) active neurons '
+                    '(the reference tuner\'s generator, brainevent/_csr/initialize.py:115-125) instead of Bernoulli(fire)')
     ap.add_argument('--homo', action='store_true', help='homogeneous weight (4 B/update) instead of hetero f32')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
                     help='N > 1: strong = the named problem cut into N post slices (default); weak = N times the problem')
@@ -780,7 +782,13 @@ def run_scatter(args):
         if exchange is None:
             exchange = SpikeExchange(n_pre, packed=(args.exchange == 'bits'), device=dev)
         n_local = exchange.hi - exchange.lo
-    local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
+    if args.exact_active:
+        local_spikes = torch.zeros((n_batch, n_local), dtype=torch.bool, device=dev)
+        k_act = min(n_local, max(0, int(round(n_local * args.fire))))
+        for b in range(n_batch):
+            local_spikes[b, torch.randperm(n_local, device=dev, generator=g)[:k_act]] = True
+    else:
+        local_spikes = (torch.rand((n_batch, n_local), device=dev, generator=g) < args.fire)
     row_len = (indptr[1:] - indptr[:-1]).to(torch.int64)
     if use_dist:
         full = [exchange.gather(local_spikes[b]).clone() for b in range(n_batch)]

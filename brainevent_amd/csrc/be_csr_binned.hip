@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -56,15 +57,20 @@ static_assert(BE_RING == 1 || BE_RING == 2, "ring of one or two blocks per bin")
 // abort would poison the HIP context of the whole process (the header promises codes).  Never observed.
 constexpr uint64_t kWaitLimitTicks = 2000000ull;
 constexpr int kBinErrWord = 16;             // word of the workspace head that holds the sticky flag (word 0: the spike counter)
-// Conservation counters (64-bit, at word kBinAuditWord of the workspace head; they only grow until be_binned_workspace_status
+// Conservation counters (64-bit, behind the workspace head; they only grow until be_binned_workspace_status
 // clears them).  Every step adds: [0] the stored entries of its active rows (x the batch rows a row is active in), summed from
 // the row bounds pass B reads; [1] the tickets pass B handed out (its LDS counters at the drain); [2] the entries pass C added
 // to its accumulators (counted where they are added, not taken from the directory); [3] the entries pass B delivered through
 // the overflow image.  After any number of complete steps [0] == [1] == [2] + [3]: an entry lost or delivered twice anywhere
 // between the row bounds and the accumulators breaks one of the equalities and be_binned_workspace_status says which.
-// ([0] > [1] also when a column id is >= k: the caller's error, such entries are dropped.)  Cost: one wave reduction per task
-// and four global atomics per workgroup and launch.
-constexpr int kBinAuditWord = 32;
+// ([0] > [1] also when a column id is >= k: the caller's error, such entries are dropped.)  They are kept PER WORKGROUP — pass B's
+// workgroup g owns words [3 g, 3 g + 3) of the first array, workgroup w of pass C word w of the second — and added up by the
+// status call on the host: a first version with one global atomic per wave on four shared words cost pass C of a C4 step 37 us
+// (9776 same-address atomics serialise in L2; the post slice of an 8-way cut: 20 -> 63 us).  Cost now: one wave reduction per
+// task, two LDS atomics per wave and one plain 8-byte read-modify-write per workgroup and counter.
+constexpr int kBinAuditGridC = 2048;                                      // workgroups of pass C at most (kMaxBins, or 256 with parts)
+constexpr int64_t kBinAuditOff = 256;                                     // byte offset of the counters in the workspace
+constexpr int64_t kBinAuditBytes = (3 * 256 + kBinAuditGridC) * 8;        // [256 workgroups of pass B][3] + [kBinAuditGridC]
 
 template <bool HOMO, int CAP> struct BinBlock {
   static constexpr int bytes = CAP * (HOMO ? 2 : 6);
@@ -165,7 +171,7 @@ struct StreamLds {
 // the rows' 4-entry groups, 64 row lengths), a flush list of 64 (ring slot, block number) items, the task ticket, the
 // dummies (128 words + 64 ticket counters + 64 commit counters)
 constexpr int kStreamWl = kStreamWaves * (64 * 2 + 66 + 64);
-constexpr int kStreamFixedWords = kStreamWl + kStreamWaves * 128 + 4 + 256 + 4;   // (+ 4: the blocks start 16-byte aligned)
+constexpr int kStreamFixedWords = kStreamWl + kStreamWaves * 128 + 12 + 256 + 4;   // (12: task ticket + 3 conservation sums; + 4: the blocks start 16-byte aligned)
 
 typedef uint32_t be_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t be_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
@@ -391,7 +397,8 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   uint32_t* wl = lds + kStreamWl + wave * 128;
   uint32_t* s_ticket = lds + kStreamWl + kStreamWaves * 128;
   StreamLds<HOMO, CB> S;
-  S.dummy = s_ticket + 4;                        // [128], then the lanes' dummy counters live behind tick / done
+  unsigned long long* s_audit = reinterpret_cast<unsigned long long*>(s_ticket + 4);       // [3] (8-byte aligned: kStreamWl is even)
+  S.dummy = s_ticket + 12;                       // [128], then the lanes' dummy counters live behind tick / done
   S.tick = S.dummy + 128;
   S.done = S.tick + n_bins + 64;
   S.gen = S.done + kRing * n_bins + 64;
@@ -401,7 +408,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   S.buf = lds + (((S.ovf + n_bins) - lds + 3) & ~(ptrdiff_t)3);
   S.err = err_flag;
   for (int i = tid; i < (2 + 2 * kRing) * n_bins + 128; i += (int)blockDim.x) S.tick[i] = 0u;
-  if (tid == 0) s_ticket[0] = 0u;
+  if (tid == 0) { s_ticket[0] = 0u; s_audit[0] = 0ull; s_audit[1] = 0ull; s_audit[2] = 0ull; }
   __syncthreads();
   unsigned long long n_expected = 0;              // stored entries of the rows this lane read the bounds of (x batch rows)
 
@@ -433,10 +440,16 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   const uint64_t per = (n_tasks + gridDim.x - 1) / gridDim.x;
   const uint64_t t_begin = (uint64_t)blockIdx.x * per;
   const uint64_t t_end = t_begin + per < n_tasks ? t_begin + per : n_tasks;
+  // (Round 5: handing out the last 5/16 of a workgroup's share in tasks of R / 4 rows — so that 16 waves drawing 49 equal tasks
+  //  do not end with one wave in a fourth round — measured SLOWER on the post slice of an 8-way cut of C4: pass B 59.0 -> 63.9 us.
+  //  A task's time is its header's dependent round trips (ticket -> row ids -> row bounds -> first loads), not its rows.)
   const size_t bin_stride_dw = (size_t)kStreamGrid * cap_blocks * B::gdwords;
   uint32_t* wg_regions = regions + (size_t)blockIdx.x * cap_blocks * B::gdwords;
 
   StreamProf prof;
+  // (Round 5, measured and not kept: the task headers — ticket -> row id -> row bounds, dependent round trips — issued two tasks
+  //  ahead of the appends: pass B 59.0 -> 61.4 us on one post slice of an 8-way cut of C4, 414 -> 415 us at C4.  The 16 waves of
+  //  the workgroup already hide each other's headers.)
   for (;;) {
     prof.stamp(7);
     uint32_t tk = 0;
@@ -618,7 +631,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   prof.stamp(7);
   prof.flush_out(lane);
   n_expected = wave_sum(n_expected);
-  if (lane == 0 && n_expected) atomicAdd(audit + 0, n_expected);
+  if (lane == 0 && n_expected) atomicAdd(&s_audit[0], n_expected);
   __syncthreads();
   // ---- drain: tickets are handed out in order, so of a bin's two ring slots only the one of block T / CB (T = the tickets
   //      drawn) can hold entries now, T % CB of them from slot 0 on; it goes out as it is, and the directory gets T
@@ -648,8 +661,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
   }
   n_tickets = wave_sum(n_tickets);
   n_overflow = wave_sum(n_overflow);
-  if (lane == 0 && n_tickets) atomicAdd(audit + 1, n_tickets);
-  if (lane == 0 && n_overflow) atomicAdd(audit + 3, n_overflow);
+  if (lane == 0 && n_tickets) atomicAdd(&s_audit[1], n_tickets);
+  if (lane == 0 && n_overflow) atomicAdd(&s_audit[2], n_overflow);
+  __syncthreads();
+  if (tid < 3 && s_audit[tid]) audit[3 * blockIdx.x + tid] += s_audit[tid];      // this workgroup's own words (launches are stream-ordered)
 }
 
 // eight counted entries (uint16 columns, two per dword)
@@ -679,6 +694,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   extern __shared__ __align__(16) unsigned char smem_raw[];
   acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   __shared__ uint32_t s_cnt[kStreamGrid], s_pre[kStreamGrid + 1], s_wtot[16];
+  __shared__ unsigned long long s_added;
   // block -> region of the bin, one byte per block, in the LDS the accumulators leave: a group then finds its region with one
   // LDS read instead of an 8-step binary search over the prefix sums (bins of more than map_cap blocks search)
   uint8_t* s_map = smem_raw + (((size_t)width * sizeof(acc_t) + 15) & ~(size_t)15);
@@ -692,7 +708,7 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   const uint32_t nb_r = (cnt_r + (uint32_t)CAP - 1u) / (uint32_t)CAP;
   const uint32_t incl = block_scan_1024(nb_r, s_wtot);
   if (tid < kStreamGrid) { s_cnt[tid] = cnt_r; s_pre[tid + 1] = incl; }
-  if (tid == 0) s_pre[0] = 0u;
+  if (tid == 0) { s_pre[0] = 0u; s_added = 0ull; }
   const bool overflowed = __syncthreads_or((int)(raw >> 31)) != 0;     // some entries of this bin went to the overflow image
   if (blockIdx.x == 0 && tid == 0 && count_rearm) count_rearm[0] = 0u;   // the spike counter of the next call's compaction
   const uint32_t NB = s_pre[kStreamGrid];
@@ -818,9 +834,10 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   }
   {
     const unsigned long long na = wave_sum((unsigned long long)n_added);
-    if ((tid & 63) == 0 && na) atomicAdd(audit + 2, na);
+    if ((tid & 63) == 0 && na) atomicAdd(&s_added, na);
   }
   __syncthreads();
+  if (tid == 0 && s_added && blockIdx.x < (unsigned)kBinAuditGridC) audit[3 * kStreamGrid + blockIdx.x] += s_added;
   // a batch: virtual bin = batch row * n_bins_b + bin; out / ovf_img are [batch row][k]
   const int64_t j0 = (int64_t)(bin / n_bins_b) * k + (int64_t)(bin % n_bins_b) * width;
   const int64_t j_end = (int64_t)(bin / n_bins_b) * k + k;
@@ -1036,7 +1053,7 @@ static inline BinWs binned_ws_layout(int64_t m, int64_t k, int64_t n_batch, int 
     gb_max = std::max<int64_t>(gb_max, bg.gb);
   }
   BinWs w;
-  w.active_off = 256;
+  w.active_off = kBinAuditOff + be_align_up(kBinAuditBytes, 256);
   w.masks_off = w.active_off + be_align_up(m * 4, 256);
   w.dir_off = w.masks_off + (n_batch > 1 ? be_align_up(m * 4, 256) : 0);
   w.regions_off = w.dir_off + be_align_up(dir_bytes, 256);
@@ -1063,7 +1080,7 @@ int be_binary_csrmm_t_binned_workspace_init(void* workspace, int64_t workspace_b
   BE_REQUIRE(workspace != nullptr && workspace_bytes >= w.total, BE_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
-  BE_HIP(be_fill_async(wsb, 0, 256, st));
+  BE_HIP(be_fill_async(wsb, 0, (size_t)w.active_off, st));          // head (spike counter, sticky flag) + conservation counters
   BE_HIP(be_fill_async(wsb + w.ovf_off, 0, (size_t)(w.out32_off - w.ovf_off), st));
   return BE_OK;
 }
@@ -1072,30 +1089,38 @@ int be_binary_csrmv_t_binned_workspace_init(void* workspace, int64_t workspace_b
   return be_binary_csrmm_t_binned_workspace_init(workspace, workspace_bytes, m, k, 1, slice_shift, bin_capacity, stream);
 }
 
+static int read_audit(const void* workspace, uint64_t c[4], uint32_t* flag, hipStream_t st) {
+  static_assert(kBinAuditOff % 8 == 0, "the counters are 8-byte words");
+  std::vector<unsigned long long> h((size_t)(kBinAuditOff + kBinAuditBytes) / 8);
+  BE_HIP(hipMemcpyAsync(h.data(), workspace, h.size() * 8, hipMemcpyDeviceToHost, st));
+  BE_HIP(hipStreamSynchronize(st));
+  *flag = reinterpret_cast<const uint32_t*>(h.data())[kBinErrWord];
+  const unsigned long long* a = h.data() + kBinAuditOff / 8;
+  c[0] = c[1] = c[2] = c[3] = 0;
+  for (int g = 0; g < kStreamGrid; ++g) { c[0] += a[3 * g]; c[1] += a[3 * g + 1]; c[3] += a[3 * g + 2]; }
+  for (int w = 0; w < kBinAuditGridC; ++w) c[2] += a[3 * kStreamGrid + w];
+  return BE_OK;
+}
+
 int be_binned_workspace_audit(const void* workspace, uint64_t* counters_host, be_stream_t stream) {
   BE_REQUIRE(workspace != nullptr && counters_host != nullptr, BE_ERR_INVALID, "null pointer");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const uint32_t* p = static_cast<const uint32_t*>(workspace) + kBinAuditWord;
-  BE_HIP(hipMemcpyAsync(counters_host, p, 32, hipMemcpyDeviceToHost, st));
-  BE_HIP(hipStreamSynchronize(st));
-  return BE_OK;
+  uint32_t flag = 0;
+  return read_audit(workspace, counters_host, &flag, static_cast<hipStream_t>(stream));
 }
 
 int be_binned_workspace_status(const void* workspace, int clear, be_stream_t stream) {
   BE_REQUIRE(workspace != nullptr, BE_ERR_INVALID, "workspace is NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  uint32_t head[kBinAuditWord + 8];
-  BE_HIP(hipMemcpyAsync(head, workspace, sizeof(head), hipMemcpyDeviceToHost, st));
-  BE_HIP(hipStreamSynchronize(st));
-  const uint32_t flag = head[kBinErrWord];
+  uint32_t flag = 0;
   uint64_t c[4];
-  memcpy(c, head + kBinAuditWord, 32);
+  const int rc = read_audit(workspace, c, &flag, st);
+  if (rc != BE_OK) return rc;
   const bool conserved = c[0] == c[1] && c[1] == c[2] + c[3];
   if (flag == 0u && conserved) return BE_OK;
   if (clear) {
-    uint32_t* w = static_cast<uint32_t*>(const_cast<void*>(workspace));
-    BE_HIP(be_fill_async(w + kBinErrWord, 0, 4, st));
-    BE_HIP(be_fill_async(w + kBinAuditWord, 0, 32, st));
+    unsigned char* w = static_cast<unsigned char*>(const_cast<void*>(workspace));
+    BE_HIP(be_fill_async(w + kBinErrWord * 4, 0, 4, st));
+    BE_HIP(be_fill_async(w + kBinAuditOff, 0, (size_t)kBinAuditBytes, st));
   }
   if (flag != 0u) {
     be_set_error("be_binned_workspace_status: pass B of a binned step gave up on an entry whose ring slot was not freed within 20 ms "
@@ -1152,7 +1177,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned char* wsb = static_cast<unsigned char*>(workspace);
   uint32_t* count = reinterpret_cast<uint32_t*>(wsb);
-  unsigned long long* audit = reinterpret_cast<unsigned long long*>(count + kBinAuditWord);
+  unsigned long long* audit = reinterpret_cast<unsigned long long*>(wsb + kBinAuditOff);
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + wl.active_off);
   uint32_t* masks = reinterpret_cast<uint32_t*>(wsb + wl.masks_off);
   uint32_t* dir = reinterpret_cast<uint32_t*>(wsb + wl.dir_off);
