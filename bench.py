@@ -343,6 +343,14 @@ def traffic_lookup(key):
         return None
 
 
+def sq_lookup(key):
+    """SQ counters per launch of a JITC walk from profiles/sq_counters.json (separate rocprofv3 --pmc passes), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'sq_counters.json'))).get(key)
+    except Exception:
+        return None
+
+
 def plan_traffic(args, plan, world):
     """PMC bytes per launch of the dominant kernel, looked up (they come from a separate rocprofv3 --pmc pass)."""
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -376,23 +384,39 @@ def run_jitc(args, dev, g):
     cfg = {'workload': f'BinaryArray({args.fire:g}) @ JITCScalarR w=1 prob={prob:g} seed=42 {n}x{n}, '
                        f"{'gather (corder=False matrix)' if args.jit_gather else 'scatter (corder=True matrix)'}",
            'edges_last_step': upd}
+    if args.jit_gather:
+        cfg['delivered_updates_Geff_per_s'] = round(upd * args.steps / elapsed / 1e9, 3)      # (`value` counts every generated edge)
     if args.jit_shard > 1:
         cfg['shard'] = f'walk classes of rank 0 of {args.jit_shard} (no stored state; outputs of the ranks are disjoint)'
     roof = None
     if kern_ms:
-        # No stored matrix: HBM is not the bound, the walk's vector ALU is.  Issue slots per generated edge, from the ISA of the
-        # inner loops (be_jitc.hip): xorshift32 6 + v_mul_hi_u32 (quarter rate: 4 slots) + address / advance / compare 3 = 13 for the
-        # scatter walk; the gather walk adds the LDS bit test and the count (2 + 2).  Peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
-        slots = 17 if args.jit_gather else 13
+        # No stored matrix: HBM is not the bound, the walk's vector ALU is.  The fraction comes from the SQ counters of the walk
+        # kernel (separate rocprofv3 --pmc passes, profiles/sq_counters.json + profiles/r05_c3_sq_counters.txt): SQ_ACTIVE_INST_VALU
+        # counts the quad-cycles a SIMD spends issuing vector instructions; x 4 = busy cycles per launch, against the
+        # 256 CUs x 4 SIMDs x 2.4 GHz the chip offers during the kernel's measured time.  (Rounds 3-4 priced a hand count of 13
+        # issue slots per generated edge instead; it is kept as `valu_issue_slots_per_edge_isa` for comparison.)
+        key = 'c3_gather' if args.jit_gather else 'c3'
+        default_c3 = n == 4_000_000 and prob == 0.001 and args.fire == 0.01 and args.jit_shard <= 1
+        sq = sq_lookup(key) if default_c3 else None
         edges = (n * n * prob) if args.jit_gather else upd
-        peak = 256 * 4 * 16 * 2.4e9 / 1e12
-        ach = edges * slots / (kern_ms * 1e-3) / 1e12
-        roof = {'bound': 'valu', 'achieved': round(ach, 2), 'peak': round(peak, 2), 'unit': 'T lane-ops/s', 'frac': round(ach / peak, 4),
-                'traffic': None, 'kernel': 'k_jit_mv_gather' if args.jit_gather else 'k_jit_mv_scatter', 'kernel_ms': round(kern_ms, 5),
-                'valu_issue_slots_per_edge': slots, 'edges_per_launch': edges,
-                'basis': 'generated edges x vector-ALU issue slots per edge of the walk loop (ISA count); start-up code of a walk '
-                         '(lr_init + stationary start) and idle lanes of walks of unequal length are what the fraction leaves out',
-                'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
+        peak = 256 * 4 * 2.4e9 / 1e9                                      # G SIMD-cycles / s
+        kname = 'k_jit_mv_gather' if args.jit_gather else 'k_jit_mv_scatter'
+        if sq:
+            busy = 4.0 * sq['SQ_ACTIVE_INST_VALU']
+            ach = busy / (kern_ms * 1e-3) / 1e9
+            roof = {'bound': 'valu', 'achieved': round(ach, 1), 'peak': round(peak, 1), 'unit': 'G VALU-busy SIMD-cycles/s',
+                    'frac': round(ach / peak, 4), 'traffic': None, 'kernel': kname, 'kernel_ms': round(kern_ms, 5),
+                    'basis': 'SQ_ACTIVE_INST_VALU (quad-cycles, PMC, per launch) x 4 / kernel time, against 1024 SIMDs x 2.4 GHz',
+                    'counters_per_launch': {k: sq[k] for k in ('SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES')
+                                            if k in sq},
+                    'counters_source': 'profiles/sq_counters.json (rocprofv3 --pmc, separate passes; not this run)',
+                    'lane_slots_per_edge': round(64.0 * sq['SQ_INSTS_VALU'] / edges, 2), 'valu_issue_slots_per_edge_isa': 17 if args.jit_gather else 13,
+                    'edges_per_launch': edges, 'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
+        else:
+            roof = {'bound': 'valu', 'achieved': None, 'peak': round(peak, 1), 'unit': 'G VALU-busy SIMD-cycles/s', 'frac': None,
+                    'traffic': None, 'kernel': kname, 'kernel_ms': round(kern_ms, 5), 'edges_per_launch': edges,
+                    'basis': 'no SQ counter pass exists for this configuration (profiles/sq_counters.json covers C3 at its default size)',
+                    'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
     line = _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
     if not args.no_cpu and not args.jit_gather:
         try:
@@ -559,8 +583,11 @@ def secondary(args, workload=None):
 def secondary_configs(base):
     """C3 / C4 / C5 of BASELINE.json after the headline (one GPU): compact entries for the `secondary` object."""
     out = {}
-    for name, wl, extra in (('C2_gather_mirror', 'gather_mirror', ['--no-cpu']), ('C3', 'jitc', []), ('C4', 'fcn', []),
-                            ('C4_homo', 'fcn', ['--homo', '--cpu-seconds', '3']), ('C5', 'dense', [])):
+    for name, wl, extra in (('C2_gather_mirror', 'gather_mirror', ['--no-cpu']), ('C3', 'jitc', []),
+                            # the reference's DEFAULT orientation of the same object (corder=False: brainevent/_jit_scalar/main.py:190-252,
+                            # gather walk _jit_scalar/binary.py:353-377): every edge of the matrix is regenerated per step
+                            ('C3_gather', 'jitc', ['--jit-gather', '--no-cpu', '--steps', '12', '--warmup', '3']),
+                            ('C4', 'fcn', []), ('C4_homo', 'fcn', ['--homo', '--cpu-seconds', '3']), ('C5', 'dense', [])):
         a = parse(['--workload', wl, '--steps', str(base.secondary_steps), '--warmup', '10'] + extra + (['--no-cpu'] if base.no_cpu else []))
         try:
             ln = secondary(a, wl)
@@ -575,6 +602,26 @@ def secondary_configs(base):
             out[name] = {'error': repr(e)}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    # SURVEY 8d's secondary list on the headline op: C2 with one shared weight (4 B / update), and the ONE operating point the
+    # reference's own tuner times (brainevent/_csr/initialize.py:227-241: n_pre = n_post = 500 000, 2000 synapses per row, one
+    # weight, exactly n / 250 = 2000 active rows per vector, 100 vectors, 50 warm-up + 200 timed calls) — the number a maintainer
+    # of the reference can put beside their own `per_call_us`
+    for name, extra in (('C2_homo', ['--homo', '--steps', '100', '--warmup', '20']),
+                        ('ref_tuner_point', ['--n', '500000', '--conn', '0.004', '--fire', '0.004', '--homo', '--exact-active',
+                                             '--steps', '200', '--warmup', '50'])):
+        a = parse(['--no-cpu', '--no-secondary'] + extra)
+        try:
+            ln = run_scatter(a)
+            out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'step_ms_hip_events',
+                                            'parity_check', 'roofline')}
+            out[name]['config'] = {k: ln['config'][k] for k in ('workload', 'plan_slices', 'plan_GB', 'setup_s', 'mean_active_rows')}
+            if name == 'ref_tuner_point':
+                out[name]['per_call_us'] = round(ln['ms_per_step'] * 1e3, 2)
+                out[name]['reference'] = 'brainevent/_csr/initialize.py:227-241 run_benchmark defaults (per_call_us of binary_csrmv transpose)'
+        except Exception as e:
+            out[name] = {'error': repr(e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     # what ONE rank of the 8-way strong split does per step, measured on this GPU (shard rank 0 of 8 of the same global matrix
     # + the exchange path on a one-rank RCCL group): the single-GPU evidence for the multi-GPU projection in DESIGN.md section 4
     for name, extra in (('C2_rank_of_8', []), ('C4_rank_of_8', ['--workload', 'fcn'])):
@@ -582,7 +629,7 @@ def secondary_configs(base):
         try:
             ln = run_scatter(a)
             out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'step_ms_hip_events',
-                                            'parity_check', 'roofline')}
+                                            'parity_check', 'roofline', 'rank_breakdown') if k in ln}
             out[name]['config'] = {k: ln['config'][k] for k in ('workload', 'parallelism', 'n_post_per_gpu', 'synapses_per_row_per_shard',
                                                                 'plan_slices', 'setup_s')}
             out[name]['note'] = ('value = updates THIS rank delivers per second; an 8-rank job delivers 8x that if every rank keeps this step '
@@ -810,10 +857,15 @@ def run_scatter(args):
     # the rank step with the host path cut to two C calls (brainevent_amd._dist.RankStep; BENCH_RANK_STEP=0: the operator surface,
     # `exchange.gather_events(s) @ csr`, as in rounds 1-2 — same kernels, ~25 us more host time per step)
     rank_step = None
-    if use_dist and native and not ahead and not mock and os.environ.get('BENCH_RANK_STEP', '1') != '0':
+    if use_dist and native and not mock and os.environ.get('BENCH_RANK_STEP', '1') != '0':
         from brainevent_amd._dist import RankStep
         rank_step = RankStep(exchange, csr)
-    ticket = [exchange.post(local_events[0])] if ahead else None
+    fast_ahead = bool(ahead and rank_step is not None and rank_step._fast is not None)
+    ticket = None
+    if fast_ahead:
+        rank_step.post(local_events[0])
+    elif ahead:
+        ticket = [exchange.post(local_events[0])]
 
     def mock_scatter(full_spikes):
         ref = reference_for_shard(weights, indices, indptr, full_spikes, n_post, args.homo)
@@ -823,6 +875,8 @@ def run_scatter(args):
         s = local_spikes[i % n_batch]
         if mock:
             return mock_scatter(exchange.gather(s) if use_dist else s)
+        if fast_ahead:      # the pipelined schedule through RankStep: be_exchange_post (step i + 1), be_exchange_wait + scatter (step i)
+            return rank_step.ahead(local_events[(i + 1) % n_batch])
         if ahead:
             # step i's spikes were posted during step i - 1: post step i + 1's now (the collective overlaps with the
             # scatter below), then consume step i's.  Every timed step still issues one exchange and one scatter.
@@ -855,9 +909,55 @@ def run_scatter(args):
         elapsed, kern, step_ms = time.perf_counter() - t0, None, np.zeros(0)
     else:
         elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup, fence)
-    if ahead:      # the exchange posted by the last step (never consumed)
+    if fast_ahead:
+        rank_step.drain()
+    elif ahead:      # the exchange posted by the last step (never consumed)
         exchange.wait_events(ticket[0]) if native else ticket[0][1].wait()
     kern_ms = float(np.mean(kern)) if kern is not None else None
+
+    # ---- where a rank's step goes (N > 1 / --emulate-world; after the timed region, same inputs): the exchange alone, the local
+    #      scatter alone, and the OTHER schedule of the two (sequential <-> exchange posted one step ahead), each over `steps`
+    #      steps between fences.  Every rank measures; min / max over the ranks are reported, so that the first run on a real
+    #      multi-GPU node says whether a rank waits in the all-gather (exchange_us spread), in its scatter, or for the slowest rank.
+    breakdown = None
+    if use_dist and rank_step is not None and rank_step._fast is not None and not mock:
+        def timed(fn_i, prime=None, finish=None):
+            if prime:
+                prime()
+            for i in range(min(args.warmup, 10)):
+                fn_i(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                fn_i(args.warmup + i)
+            fence()
+            el = (time.perf_counter() - t0) / args.steps * 1e6
+            if finish:
+                finish()
+            return el
+        ex_us = timed(lambda i: rank_step.exchange_only(local_events[i % n_batch]))
+        sc_us = timed(lambda i: rank_step.scatter_only())
+        if ahead:
+            other_name, other_us = 'sequential', timed(lambda i: rank_step(local_events[i % n_batch]))
+        else:
+            other_name = 'exchange_ahead_1'
+            other_us = timed(lambda i: rank_step.ahead(local_events[(i + 1) % n_batch]),
+                             prime=lambda: rank_step.post(local_events[0]), finish=rank_step.drain)
+        v = torch.tensor([ex_us, sc_us, other_us, elapsed / args.steps * 1e6], dtype=torch.float64, device=dev)
+        vmax, vmin = v.clone(), v.clone()
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        mx, mn = vmax.cpu().tolist(), vmin.cpu().tolist()
+        this_name = 'exchange_ahead_1' if ahead else 'sequential'
+        breakdown = {'what': 'us per step on each rank over the same steps, measured after the timed region; {min, max} over the ranks',
+                     'exchange_only_us': {'min': round(mn[0], 2), 'max': round(mx[0], 2)},
+                     'scatter_only_us': {'min': round(mn[1], 2), 'max': round(mx[1], 2)},
+                     'step_us': {'schedule': this_name, 'min': round(mn[3], 2), 'max': round(mx[3], 2)},
+                     'not_in_kernels_us': round(mx[3] - mx[0] - mx[1], 2),
+                     'other_schedule': {'schedule': other_name, 'step_us': {'min': round(mn[2], 2), 'max': round(mx[2], 2)},
+                                        'note': 'exchange_ahead_1: the all-gather of step t + 1 is posted before step t is scattered '
+                                                '(valid for synaptic delays >= 2 steps); whole-job value at this schedule = value x '
+                                                'step_us.max / other step_us.max'}}
 
     # one-step parity check of what was timed (every rank checks its own slice; rank 0 reports the worst)
     last = (args.warmup + args.steps - 1) % n_batch
@@ -951,6 +1051,8 @@ def run_scatter(args):
                              'expected_stored_synapses': float(n_pre) * n_conn_global if args.emulate_world <= 1 else None},
             'roofline': roof,
         }
+        if breakdown is not None:
+            line['rank_breakdown'] = breakdown
         if mock:
             line['mock_step'] = True
             line['data'] = 'synthetic (MOCK STEP: plumbing rehearsal on CPU tensors, not a measurement)'

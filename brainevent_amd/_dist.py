@@ -439,21 +439,21 @@ class RankStep:
             parts = ws.default_parts()
             wsp = ws.workspace(parts, 1)
             f = fn('be_binary_csrmm_t_plan', ci, [vp, ci, ci, vp, vp, vp, ci, vp, i64, i64, i64, ci, ci, ci, ci, ci, ci, vp, i64, vp])
-            head = (A.ptr(data), int(ws.homo), A.wcode(data), A.ptr(ws.blob), A.ptr(ws.seg), A.ptr(self._words), A.BE_SPIKE_BITS)
+            head = (A.ptr(data), int(ws.homo), A.wcode(data), A.ptr(ws.blob), A.ptr(ws.seg))
             tail = (m, k, 1, ws.slice_shift, ws.slice_width, ws.layout, ws.block_hint, parts)
             self._keep = (wsp,)
-            self._fast = lambda out_ptr, st: f(*head, out_ptr, *tail, ws.scale_exp, A.ptr(wsp), wsp.numel(), st)
+            self._fast = lambda out_ptr, words_ptr, st: f(*head, words_ptr, A.BE_SPIKE_BITS, out_ptr, *tail, ws.scale_exp, A.ptr(wsp),
+                                                          wsp.numel(), st)
             self._what = 'be_binary_csrmm_t_plan'
         else:
             indices, indptr = shard.indices, getattr(shard, 'indptr', None)
             row_len = -1 if indptr is not None else int(indices.numel() // max(m, 1))
             is64 = int(indptr is not None and indptr.dtype == torch.int64)
             f = fn('be_binary_csrmv_t_binned', ci, [vp, ci, ci, vp, vp, ci, i64, vp, ci, vp, i64, i64, ci, i64, ci, vp, i64, vp])
-            head = (A.ptr(data), ws.step_kind, A.wcode(data), A.ptr(indices), A.ptr(indptr), is64, row_len, A.ptr(self._words),
-                    A.BE_SPIKE_BITS)
+            head = (A.ptr(data), ws.step_kind, A.wcode(data), A.ptr(indices), A.ptr(indptr), is64, row_len)
             self._keep = (indices, indptr)
-            self._fast = lambda out_ptr, st: f(*head, out_ptr, m, k, ws.slice_shift, ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws),
-                                               ws.ws.numel(), st)
+            self._fast = lambda out_ptr, words_ptr, st: f(*head, words_ptr, A.BE_SPIKE_BITS, out_ptr, m, k, ws.slice_shift,
+                                                          ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(), st)
             self._what = 'be_binary_csrmv_t_binned'
 
     def __call__(self, local_spikes):
@@ -463,15 +463,81 @@ class RankStep:
         # the fast path holds raw pointers of the arrays it was resolved from: it is taken only while the shard still IS those
         # arrays (a caller may rebind shard.data / indices / indptr to new tensors instead of updating them in place) and its
         # workspace is the same object and up to date with the weights
-        if (self._fast is None or shard.data is not self._data or any(a is not b for a, b in zip(self._arrays, (shard.indices, getattr(shard, 'indptr', None))))
-                or self._ws_obj.is_stale(self._data) or shard.buffers.get('scatter_plan') is not self._ws_obj):
+        if not self._usable():
             return self.exchange.gather_events(local_spikes) @ shard
         sp, sd = _local_operand(local_spikes, self._n_local)
         st = A.stream_ptr()
         ex = self.exchange
         check(self._gather(ex._h, A.ptr(sp), sd, A.ptr(self._words), st), 'be_exchange_allgather_bits')
         out = torch.empty(self._out_shape, dtype=self._out_dtype, device=self._dev)
-        check(self._fast(A.ptr(out), st), self._what)
+        check(self._fast(A.ptr(out), A.ptr(self._words), st), self._what)
+        return out
+
+    # ---- the pipelined schedule (``--exchange-ahead 1``): the all-gather of step t + 1 runs on the exchange's own stream while
+    #      this stream scatters step t.  Legitimate wherever the spikes a step delivers were emitted before the previous step
+    #      began — synaptic delays of at least two steps; the reference has no distributed path to compare with.  Same two C
+    #      calls per step as the sequential schedule (``be_exchange_post``, then ``be_exchange_wait`` + the planned / binned step).
+    def _usable(self) -> bool:
+        shard = self.shard
+        return not (self._fast is None or shard.data is not self._data
+                    or any(a is not b for a, b in zip(self._arrays, (shard.indices, getattr(shard, 'indptr', None))))
+                    or self._ws_obj.is_stale(self._data) or shard.buffers.get('scatter_plan') is not self._ws_obj)
+
+    def post(self, local_spikes) -> None:
+        """Queue the exchange of a LATER step's local spikes (at most two may be in flight: the exchange has two buffers)."""
+        if not hasattr(self, '_pending'):
+            self._pending = []
+        assert len(self._pending) < 2, "RankStep.post: two exchanges are already in flight (consume one with step_posted())"
+        self._pending.append(self.exchange.post(local_spikes))
+
+    def step_posted(self):
+        """The step whose exchange was posted first: wait for its gathered words on this stream, then ``events @ shard``."""
+        from . import _array as A
+        from ._lib import check, fn
+        import ctypes as ct
+        ticket = self._pending.pop(0)
+        ex = self.exchange
+        if not self._usable() or not isinstance(ex, NativeSpikeExchange):
+            return ex.wait_events(ticket) @ self.shard
+        st = A.stream_ptr()
+        words = ct.c_void_p(0)
+        check(fn('be_exchange_wait', ct.c_int, [ct.c_void_p, ct.c_int, ct.POINTER(ct.c_void_p), ct.c_void_p])(
+            ex._h, ticket[0], ct.byref(words), st), 'be_exchange_wait')
+        out = torch.empty(self._out_shape, dtype=self._out_dtype, device=self._dev)
+        check(self._fast(A.ptr(out), words.value, st), self._what)
+        return out
+
+    def ahead(self, local_spikes_next):
+        """One step of the pipelined schedule: post step t + 1's exchange, consume step t's (``post`` step 0 first)."""
+        self.post(local_spikes_next)
+        return self.step_posted()
+
+    def drain(self) -> None:
+        """Wait (on this stream) for every exchange still in flight without consuming it — the end of a pipelined loop."""
+        from . import _array as A
+        ex = self.exchange
+        while getattr(self, '_pending', None):
+            t = self._pending.pop(0)
+            ex.wait_events(t) if isinstance(ex, NativeSpikeExchange) else t[1].wait()
+
+    # ---- the two halves of the sequential step on their own (bench.py --gpus N reports them per rank, so that a scaling run
+    #      says where a rank's time went: exchange, scatter, or waiting)
+    def exchange_only(self, local_spikes) -> None:
+        from . import _array as A
+        from ._lib import check
+        if self._fast is None:
+            self.exchange.gather_events(local_spikes)
+            return
+        sp, sd = _local_operand(local_spikes, self._n_local)
+        check(self._gather(self.exchange._h, A.ptr(sp), sd, A.ptr(self._words), A.stream_ptr()), 'be_exchange_allgather_bits')
+
+    def scatter_only(self):
+        """The local product over the words of the LAST sequential exchange (``__call__`` / ``exchange_only``)."""
+        from . import _array as A
+        from ._lib import check
+        assert self._fast is not None, "RankStep.scatter_only needs the fast path"
+        out = torch.empty(self._out_shape, dtype=self._out_dtype, device=self._dev)
+        check(self._fast(A.ptr(out), A.ptr(self._words), A.stream_ptr()), self._what)
         return out
 
 

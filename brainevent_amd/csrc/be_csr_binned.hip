@@ -511,6 +511,19 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
         uint32_t colN[U][4];
         float wN[U][HOMO ? 1 : 4];
         uint32_t validN[U], maskN[U];
+#ifdef BE_DBG_U16IDX   /* TIMING BUILD (results are garbage, every access stays in bounds): what a prepare()-time layout with */
+                       /* 16-bit columns would read — 8 bytes of column ids per four entries instead of 16 — spread over [0, k) */
+#define BE_STREAM_LOAD_COLS                                                                                            \
+        const be_u32x2_a4 c2 = *reinterpret_cast<const be_u32x2_a4*>(reinterpret_cast<const uint16_t*>(indices) + at);  \
+        const uint32_t ksc = (uint32_t)(k >> 16);                                                                      \
+        const uint32_t lo0 = c2.x & 0xffffu, lo1 = c2.y & 0xffffu;     /* (the high halves of int32 ids are not uniform) */ \
+        colN[u][0] = lo0 * ksc; colN[u][1] = ((lo0 * 40503u + lo1) & 0xffffu) * ksc;                                    \
+        colN[u][2] = lo1 * ksc; colN[u][3] = ((lo1 * 40503u + lo0) & 0xffffu) * ksc;
+#else
+#define BE_STREAM_LOAD_COLS                                                                                            \
+        const be_u32x4_a4 c4 = *reinterpret_cast<const be_u32x4_a4*>(indices + at);                                    \
+        colN[u][0] = c4.x; colN[u][1] = c4.y; colN[u][2] = c4.z; colN[u][3] = c4.w;
+#endif
 #define BE_STREAM_ISSUE(C0)                                                                                          \
   do {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
@@ -535,8 +548,7 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
       uint32_t vm = rem >= 4u ? 0xfu : (shrt ? (1u << rem) - 1u : (0xfu << sh) & 0xfu);                              \
       vm = ok ? vm : 0u;                                                                                             \
       if (__ballot(shrt) == 0) {                                                                                     \
-        const be_u32x4_a4 c4 = *reinterpret_cast<const be_u32x4_a4*>(indices + at);                                  \
-        colN[u][0] = c4.x; colN[u][1] = c4.y; colN[u][2] = c4.z; colN[u][3] = c4.w;                                  \
+        BE_STREAM_LOAD_COLS                                                                                          \
         if (!HOMO) {                                                                                                 \
           if (sizeof(W) == 4) {                                                                                      \
             const be_f32x4_a4 w4 = *reinterpret_cast<const be_f32x4_a4*>(reinterpret_cast<const float*>(weights) + at); \

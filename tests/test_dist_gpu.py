@@ -230,3 +230,48 @@ def test_rank_step_fast_path_equals_the_operator_surface():
                         shape=(1, n_post))
     assert D.RankStep(ex, dense_like)._fast is None
     ex.close()
+
+
+@pytest.mark.parametrize('route', ['plan', 'binned'])
+def test_rank_step_pipelined_schedule_is_bit_identical_to_the_sequential_one(one_rank_group, route):
+    """`RankStep.post / step_posted / ahead / drain` — the exchange of step t + 1 posted on the exchange's own stream before step t
+    is scattered (`bench.py --exchange-ahead 1`) — against `RankStep.__call__` (exchange, then scatter, on one stream): the same
+    bits for every step, on a planned and on a binned shard, with byte and packed-word producers; `exchange_only` + `scatter_only`
+    are the two halves of the sequential step."""
+    import brainevent_amd as be
+    from brainevent_amd import _dist as D, _array as A
+    from brainevent_amd import _csr as C
+    rng = np.random.default_rng(21)
+    dev = torch.device('cuda', 0)
+    n_pre, n_post = (40000, 3000) if route == 'plan' else (30000, 400_000)
+    uid = D.NativeSpikeExchange.unique_id()
+    ex = D.NativeSpikeExchange(n_pre, 1, 0, uid, device=dev)
+    lens = rng.integers(20, 60, n_pre)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = torch.from_numpy(rng.integers(0, n_post, ptr[-1]).astype(np.int32)).to(dev)
+    w = torch.from_numpy(rng.uniform(0.1, 1.0, ptr[-1]).astype(np.float32)).to(dev)
+    tptr = torch.from_numpy(ptr).to(dev)
+    csr = be.CSR((w, idx, tptr), shape=(n_pre, n_post))
+    if route == 'plan':
+        csr.buffers['scatter_plan'] = C.ScatterPlan.build(w, idx, tptr, shape=(n_pre, n_post))
+    else:
+        csr.buffers['scatter_plan'] = C.BinnedScatter(w, n_pre, n_post, int(ptr[-1]), indices=idx, indptr=tptr)
+    rs = D.RankStep(ex, csr)
+    assert rs._fast is not None
+    spikes = [torch.from_numpy(rng.random(n_pre) < 0.05).to(dev) for _ in range(6)]
+    seq = [rs(s).clone() for s in spikes]
+    for producer in ('bytes', 'words'):
+        loc = spikes if producer == 'bytes' else [A.PackedSpikes(be.bitpack(s, 0).reshape(-1), n_pre) for s in spikes]
+        rs.post(loc[0])
+        got = [rs.ahead(loc[t + 1]) if t + 1 < 6 else rs.step_posted() for t in range(6)]
+        rs.drain()
+        for t in range(6):
+            assert torch.equal(got[t], seq[t]), (producer, t)
+        # two exchanges in flight (both buffers of the exchange), consumed in order
+        rs.post(loc[2]); rs.post(loc[3])
+        assert torch.equal(rs.step_posted(), seq[2]) and torch.equal(rs.step_posted(), seq[3])
+    rs.exchange_only(spikes[4])
+    assert torch.equal(rs.scatter_only(), seq[4])
+    ref = (be.BinaryArray(spikes[4]) @ csr)
+    assert torch.equal(ref, seq[4])
+    ex.close()

@@ -68,8 +68,9 @@ if [[ $what == *sq* ]]; then
   { echo "# SQ counters of the JITC walks, separate --pmc passes (bench.py ... --steps 6 --warmup 2), mean per launch"
     for name in c3 c3_gather; do
       echo "# $name: bench.py ${CFG[$name]}"
-      python3 $R/tools/summarize_prof.py "$O/q_${name}_*/*counter_collection.csv" | grep -i "k_jit\|kernel " | cut -c1-150
+      python3 $R/tools/summarize_prof.py "$O/q_${name}_SQ_INSTS_VALU_SQ_ACTIVE_INST_VALU/*counter_collection.csv" "$O/q_${name}_SQ_WAVE_CYCLES_SQ_BUSY_CYCLES/*counter_collection.csv" "$O/q_${name}_SQ_WAVES_GRBM_GUI_ACTIVE/*counter_collection.csv" | grep -i "k_jit\|kernel " | cut -c1-150
     done; } > $O/c3_sq_counters.txt
+  python3 $R/tools/make_sq_json.py $O > $O/sq_counters.json
 fi
 if [[ $what == *bench* ]]; then
   ( cd $R && timeout -k 10 900 python3 bench.py > $O/bench.log 2>&1 ); echo "bench rc=$?"
