@@ -75,14 +75,8 @@ constexpr int64_t kBinAuditBytes = (3 * 256 + kBinAuditGridC) * 8;        // [25
 template <bool HOMO, int CAP> struct BinBlock {
   static constexpr int bytes = CAP * (HOMO ? 2 : 6);
   static constexpr int dwords = bytes / 4;
-  // stride of a block in the GLOBAL regions.  BE_BLOCK_GALIGN (A/B builds; the verdict's "line-aligned flush units"): every
-  // block starts on a 128-byte line — a 96-byte block of 16 weighted entries then never straddles two lines, at the price of
-  // unused bytes in the regions (pass C's reads span them).  Measured in round 4: see DESIGN.md section 2.1b.
-#ifdef BE_BLOCK_GALIGN
-  static constexpr int gdwords = (bytes + 127) / 128 * 32;
-#else
+  // stride of a block in the GLOBAL regions (blocks starting on 128-byte lines were measured in round 4 and lose: LABNOTES.md)
   static constexpr int gdwords = dwords;
-#endif
   // weighted entries sit in UNITS of 12 bytes, two entries each: [f32 w0][f32 w1][u16 c0 | u16 c1] — pass C reads the units of a
   // region as one contiguous stream, a unit per lane and load; one weight: [u16 column x CAP]
   __device__ static __forceinline__ uint32_t w_dw(uint32_t s) { return 3u * (s >> 1) + (s & 1u); }                 // dword of entry s's weight
@@ -235,11 +229,7 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
     lds_fence();
 #pragma unroll
     for (int p = 0; p < PJ; ++p) {
-#ifdef BE_DBG_NOSTORE
-      if (have[p] && q[p] == 0xfffffffu)
-#else
       if (have[p] && q[p] < cap_blocks)
-#endif
         *reinterpret_cast<uint4*>(wg_regions + (size_t)(slotid[p] >> kRingLog) * bin_stride_dw + (size_t)q[p] * B::gdwords + gl * 4) = v[p];
     }
   }
@@ -272,11 +262,7 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
     pend |= (b < (uint32_t)n_bins ? 1u : 0u) << u;
   }
 #pragma unroll
-#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 4      // (ablation builds: timing only, the results are garbage)
-  for (int u = 0; u < NE; ++u) t[u] = (col[u] * 2654435761u) >> 8;
-#else
   for (int u = 0; u < NE; ++u) t[u] = atomicAdd(&S.tick[bin[u]], 1u);
-#endif
   __builtin_amdgcn_sched_barrier(0);
   uint32_t spins = 0;
   uint64_t t_wait = 0;
@@ -292,44 +278,25 @@ __device__ __forceinline__ void stream_append(const StreamLds<HOMO, CB>& S, cons
     uint32_t d[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
-#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 1
-      const bool ok = ((pend >> u) & 1u) && g[u] != 0xfffffff1u;
-#else
       const bool ok = ((pend >> u) & 1u) && g[u] == (t[u] >> (LOG_CB + kRingLog));
-#endif
       wr |= (ok ? 1u : 0u) << u;
       uint32_t* blk = S.buf + (size_t)slotid[u] * B::dwords;
       const uint32_t s = t[u] & (uint32_t)(CB - 1);
       uint16_t* pi = ok ? reinterpret_cast<uint16_t*>(blk) + B::col_hw(s) : reinterpret_cast<uint16_t*>(S.dummy + 64 + lane);
-#if !defined(BE_DBG_LEVEL) || BE_DBG_LEVEL < 3
       *pi = (uint16_t)lc[u];
-#else
-      if (pi == nullptr) *pi = 1;
-#endif
       if (!HOMO) {
         float* pw = ok ? reinterpret_cast<float*>(blk) + B::w_dw(s) : reinterpret_cast<float*>(S.dummy + lane);
-#if !defined(BE_DBG_LEVEL) || BE_DBG_LEVEL < 3
         *pw = w[HOMO ? 0 : u];
-#else
-        if (pw == nullptr) *pw = w[HOMO ? 0 : u];
-#endif
       }
     }
     lds_fence();
 #pragma unroll
-#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 2
-    for (int u = 0; u < NE; ++u) d[u] = (t[u] ^ col[u]) & 0xffffu ? 0u : (uint32_t)CB - 1u;
-#else
     for (int u = 0; u < NE; ++u) d[u] = atomicAdd(&S.done[(wr >> u) & 1u ? slotid[u] : (uint32_t)kRing * (uint32_t)n_bins + (uint32_t)lane], 1u);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // the blocks these commits completed go on the wave's list (positions from the ballots)
     uint32_t flm = 0;
 #pragma unroll
     for (int u = 0; u < NE; ++u) flm |= (((wr >> u) & 1u) && d[u] == (uint32_t)CB - 1u ? 1u : 0u) << u;
-#if defined(BE_DBG_LEVEL) && BE_DBG_LEVEL >= 1
-    if (flm != 0x12345u) flm = 0;
-#endif
     pend &= ~wr;
     prof.count(4);
     // (every completing lane copying its own block, 16 bytes per instruction and no list, measured slower: 406 -> 554 us at
@@ -511,19 +478,9 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
         uint32_t colN[U][4];
         float wN[U][HOMO ? 1 : 4];
         uint32_t validN[U], maskN[U];
-#ifdef BE_DBG_U16IDX   /* TIMING BUILD (results are garbage, every access stays in bounds): what a prepare()-time layout with */
-                       /* 16-bit columns would read — 8 bytes of column ids per four entries instead of 16 — spread over [0, k) */
-#define BE_STREAM_LOAD_COLS                                                                                            \
-        const be_u32x2_a4 c2 = *reinterpret_cast<const be_u32x2_a4*>(reinterpret_cast<const uint16_t*>(indices) + at);  \
-        const uint32_t ksc = (uint32_t)(k >> 16);                                                                      \
-        const uint32_t lo0 = c2.x & 0xffffu, lo1 = c2.y & 0xffffu;     /* (the high halves of int32 ids are not uniform) */ \
-        colN[u][0] = lo0 * ksc; colN[u][1] = ((lo0 * 40503u + lo1) & 0xffffu) * ksc;                                    \
-        colN[u][2] = lo1 * ksc; colN[u][3] = ((lo1 * 40503u + lo0) & 0xffffu) * ksc;
-#else
 #define BE_STREAM_LOAD_COLS                                                                                            \
         const be_u32x4_a4 c4 = *reinterpret_cast<const be_u32x4_a4*>(indices + at);                                    \
         colN[u][0] = c4.x; colN[u][1] = c4.y; colN[u][2] = c4.z; colN[u][3] = c4.w;
-#endif
 #define BE_STREAM_ISSUE(C0)                                                                                          \
   do {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                  \
@@ -621,9 +578,6 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
                   for (int j = 0; j < 4; ++j) colA[u * 4 + j] = mk ? colC[u][j] : 0xffffffffu;
                 }
               }
-#ifdef BE_DBG_NOAPPEND
-              if (colA[0] == 0xfffffff0u && validC[0] == 0x55u)
-#endif
               stream_append<HOMO, CB, U * 4, BATCH>(S, colA, wA, offA, width, wdiv, n_bins, n_bins_b, k, cap_blocks, wl, wg_regions,
                                              bin_stride_dw, out, w0, lane, prof);
               bool again = false;
@@ -783,21 +737,13 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   } else {
     // weighted: one flat loop over the 12-byte units (two entries) of all regions; consecutive lanes read consecutive units —
     // 768 contiguous bytes per load instruction — 2 * BE_BIN_U units per thread and round in flight
-#ifdef BE_DBG_C_WIDE      // (timing experiment, results are garbage: the same bytes fetched as 16-byte pieces, two adds per piece)
-    constexpr uint32_t UB = CAP * 6 / 16;
-#else
     constexpr uint32_t UB = CAP / 2;                         // units per block
-#endif
     const uint32_t n_u = NB * UB;
     const uint32_t per = (n_u + parts - 1) / parts;
     const uint32_t g_begin = part * per, g_end = g_begin + per < n_u ? g_begin + per : n_u;
     constexpr int U = 2 * BE_BIN_U;
     for (uint32_t g0 = g_begin + tid; g0 < g_end; g0 += U * 1024) {
-#ifdef BE_DBG_C_WIDE
-      be_u32x4_a4 uv[U];
-#else
       be_u32x3_a4 uv[U];
-#endif
       uint32_t nv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -816,22 +762,12 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
         const uint32_t lb = blk - s_pre[r];
         const uint32_t first = lb * (uint32_t)CAP + ub * 2u, c = s_cnt[r];
         nv[u] = !in || c <= first ? 0u : (c - first < 2u ? 1u : 2u);
-#ifdef BE_DBG_C_WIDE
-        nv[u] = in ? 2u : 0u;
-        uv[u] = *reinterpret_cast<const be_u32x4_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::gdwords + ub * 4u);
-        uv[u].z &= 0x3fff3fffu;
-#else
         uv[u] = *reinterpret_cast<const be_u32x3_a4*>(bin_base + ((size_t)r * cap_blocks + lb) * B::gdwords + ub * 3u);
-#endif
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         n_added += nv[u];
         unsigned long long* a64 = reinterpret_cast<unsigned long long*>(acc);
-#ifdef BE_DBG_C_NOATOMIC
-        if (nv[u] >= 1u && uv[u].z == 0x12345678u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
-        if (nv[u] == 2u && uv[u].x == 0x12345678u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
-#else
         if (ACC32) {
           uint32_t* a32 = reinterpret_cast<uint32_t*>(acc);
           if (nv[u] >= 1u) atomicAdd(a32 + (uv[u].z & 0xffffu), (uint32_t)__float2int_rn(__uint_as_float(uv[u].x) * scale));
@@ -840,7 +776,6 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
           if (nv[u] >= 1u) atomicAdd(a64 + (uv[u].z & 0xffffu), fixed_from_f32(__uint_as_float(uv[u].x), scale));
           if (nv[u] == 2u) atomicAdd(a64 + (uv[u].z >> 16), fixed_from_f32(__uint_as_float(uv[u].y), scale));
         }
-#endif
       }
     }
   }
@@ -1055,11 +990,7 @@ static inline BinWs binned_ws_layout(int64_t m, int64_t k, int64_t n_batch, int 
     if (bg.g.cap == 0) continue;
     const int64_t vb = (int64_t)bg.g.n_bins * bg.gb;
     const int64_t cb = stream_cap_blocks(batch_bin_capacity(k, slice_shift, homo, bin_capacity, bg), bg.g.cap);
-#ifdef BE_BLOCK_GALIGN
-    const int64_t b = vb * kStreamGrid * cb * ((bg.g.cap * (kind_counted(homo) ? 2 : 6) + 127) / 128 * 128);
-#else
     const int64_t b = vb * kStreamGrid * cb * bg.g.cap * (kind_counted(homo) ? 2 : 6);
-#endif
     blocks_bytes = b > blocks_bytes ? b : blocks_bytes;
     dir_bytes = std::max<int64_t>(dir_bytes, vb * kStreamGrid * 4);
     gb_max = std::max<int64_t>(gb_max, bg.gb);
@@ -1297,18 +1228,6 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
       else if (cap == 16) BE_BIN_ACC32(16); else BE_BIN_ACC32(8);
     } else {
       if (cap == 128) BE_BIN_ACC(false, 128); else if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
-    }
-    // (experiments, tools/exp_passc_twice.sh: pass C again on the same regions — the 2nd / 3rd launch of a step read settled
-    //  data: C4 weighted 183 -> 154 / 150 us, counted 52 -> 46 / 45: ~30 us of the first launch are the write-back of what pass B
-    //  just wrote, still draining)
-    static const int dbg_twice = [] { const char* e = getenv("BE_DBG_C_TWICE"); return e ? atoi(e) : 0; }();
-    for (int rep = 0; rep < dbg_twice; ++rep) {
-      if (homo) {
-        if (cap == 128) BE_BIN_ACC(true, 128); else if (cap == 64) BE_BIN_ACC(true, 64); else if (cap == 32) BE_BIN_ACC(true, 32);
-        else if (cap == 16) BE_BIN_ACC(true, 16); else BE_BIN_ACC(true, 8);
-      } else {
-        if (cap == 128) BE_BIN_ACC(false, 128); else if (cap == 64) BE_BIN_ACC(false, 64); else if (cap == 32) BE_BIN_ACC(false, 32); else if (cap == 16) BE_BIN_ACC(false, 16); else BE_BIN_ACC(false, 8);
-      }
     }
 #undef BE_BIN_ACC
 #undef BE_BIN_ACC32
