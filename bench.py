@@ -447,6 +447,9 @@ def run_fcn(args, dev, g):
     step = lambda i: be.BinaryArray(spikes[i % n_batch]) @ conn
     elapsed, kern, step_ms, out = time_steps(step, args.steps, args.warmup)
     kern_ms = float(np.mean(kern)) if kern is not None else None
+    ws_chk = conn.buffers.get('scatter_plan')
+    if hasattr(ws_chk, 'check_status'):      # binned route: sticky give-up flag + conservation counters over every step above (raises)
+        ws_chk.check_status()
     upd = sum(int(act[(args.warmup + i) % n_batch]) for i in range(args.steps)) * K
     value = upd / elapsed / 1e9
     metric = 'synaptic updates/sec (Geff/s), BinaryArray @ FixedNumPerPre scatter'
@@ -959,6 +962,8 @@ def run_scatter(args):
                                                 '(valid for synaptic delays >= 2 steps); whole-job value at this schedule = value x '
                                                 'step_us.max / other step_us.max'}}
 
+    if hasattr(ws_obj, 'check_status'):       # binned route: sticky give-up flag + conservation counters over every step above (raises)
+        ws_obj.check_status()
     # one-step parity check of what was timed (every rank checks its own slice; rank 0 reports the worst)
     last = (args.warmup + args.steps - 1) % n_batch
     ref = reference_for_shard(weights, indices, indptr, full[last], n_post, args.homo)

@@ -861,6 +861,10 @@ class BinnedScatter:
         assert (weights.numel() == 1) == self.homo, "refresh_weights cannot switch between one weight and per-entry weights"
         if indptr is not None and self._rows is None:
             self._rows = (A.to_device(indptr), -1)
+        # a refresh means "the weights changed": the cached column statistics are void even when the tensor's stamp did not move —
+        # Mirror.refreshed / _fresh_indexed_workspace rewrite the same tensor through a raw pointer (gather_by_perm(out=...)), which
+        # torch's version counter does not see (a grown weight could wrap the int64 sums, a shrunk one lose the 1e-5 gate)
+        self._stats_stamp = None
         self._derive_exponent(weights, None if indices is None else A.to_device(indices).reshape(-1), keep_exp=True)
 
     def is_stale(self, weights: torch.Tensor) -> bool:

@@ -82,6 +82,10 @@ def _weight_dtype(*ws) -> torch.dtype:
     return dt
 
 
+#: bits the smallest non-zero operand value must keep at the fixed-point exponent of the float-operand JITC scatter (below: float atomics)
+JIT_FLOAT_MIN_BITS = 24
+
+
 def _fixed_scale_exp(wmax: float, n_rows: int) -> int:
     e = math.frexp(wmax)[1] if wmax > 0 else 0
     s = 62 - e - max(1, int(math.ceil(math.log2(n_rows + 1))))
@@ -313,11 +317,21 @@ def _jit_float_hip(family, a, b, clen, X, seed, *, shape, transpose, corder, out
         # The scatter orientation through LDS fixed-point sums (the event-driven scatter's structure with the operand's value as
         # a per-row factor): its exponent needs the operand's largest magnitude — one reduction and a host read per call, against
         # float atomics at 21 G/s otherwise (C3 shape: 757 ms).  f64 keeps the atomic kernel (the factor is formed in f32 here).
-        xmax = float(x.abs().max())
+        # One device-to-host read per call (it synchronises: this op cannot be captured in a HIP graph — the atomic kernel below
+        # can).  Besides the largest magnitude, the SMALLEST non-zero one: the single global exponent e leaves a product
+        # |w x| * 2^e integer bits, and an operand of wide dynamic range would lose its small addends (at in_len = 1e6 about 42 bits
+        # remain below the largest product: values 2^-40 of max|x| keep 2).  The fixed-point sums are taken only when the smallest
+        # non-zero |x| keeps JIT_FLOAT_MIN_BITS bits at e against the weight bound; otherwise the float-atomic kernel, which is
+        # what the reference's own GPU path does.
+        xa = x.abs()
+        xmax, xmin = (float(t) for t in torch.stack([xa.max(), torch.where(xa > 0, xa, torch.full_like(xa, float('inf'))).min()])
+                      .to(torch.float64).tolist())
         bound = wmax * xmax * 1.001
         if bound == 0.0:
             return out.zero_()
-        if math.isfinite(bound):
+        e_fix = _fixed_scale_exp(bound, in_len) if math.isfinite(bound) else 0
+        resolves = math.isfinite(bound) and math.isfinite(xmin) and wmax * xmin >= math.ldexp(1.0, JIT_FLOAT_MIN_BITS - e_fix)
+        if resolves:
             x_bm = x.reshape(1, -1) if vec else x.T.contiguous()
             out_bm = torch.empty((n, out_len), dtype=out_dtype, device=A.device())
             stride = 4 if mm else 32
@@ -326,7 +340,7 @@ def _jit_float_hip(family, a, b, clen, X, seed, *, shape, transpose, corder, out
             f = fn('be_jitmm_float_scatter', c_int, [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
                                                      c_int, c_int, c_vp, c_i64, c_vp])
             check(f(_FAMILY[family], w0, w1, A.wcode(out), int(clen), seed & 0xFFFFFFFF, A.ptr(x_bm), A.ptr(out_bm), int(shape[1]),
-                    in_len, out_len, n, stride, _fixed_scale_exp(bound, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()),
+                    in_len, out_len, n, stride, e_fix, A.ptr(ws), ws.numel(), A.stream_ptr()),
                   'be_jitmm_float_scatter')
             return out_bm[0] if vec else out_bm.T
     f_ws = fn('be_jitmm_float_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_i64, c_int, c_int])

@@ -217,6 +217,35 @@ def test_jit_float_twins_against_the_oracle(be, oracle, family, transpose, corde
     np.testing.assert_allclose(gotm, refm, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(refm).max())))
 
 
+def test_jit_float_scatter_keeps_small_addends_of_a_wide_operand(be, oracle, monkeypatch):
+    """the float-operand scatter (corder=False) sums in LDS fixed point at ONE global exponent taken from the
+    operand's largest magnitude; an operand spanning 1e-6 ... 1e6 left its small addends a few bits, and outputs fed only by small
+    values came out far from the f32-atomic reference, silently.  The fixed-point sums are now taken only when the smallest
+    non-zero |x| keeps `JIT_FLOAT_MIN_BITS` bits there — otherwise the float-atomic kernel.  Outputs fed by small values only are
+    compared RELATIVELY here (the main sweep's atol is scaled by the largest output and cannot see them)."""
+    import brainevent_amd._jitc as J
+    rng = np.random.default_rng(33)
+    shape, prob, seed = (4000, 1500), 0.004, 9
+    in_len = shape[0]
+    v = (10.0 ** rng.uniform(-6, -3, in_len)).astype(np.float32)          # small values on nearly every row ...
+    v[rng.random(in_len) < 0.3] = 0
+    v[[5, 1700, 3100]] = [1e6, -4e5, 7e5]                                  # ... and three rows that set the exponent
+    for family, wargs in (('s', (np.float32(1.5),)), ('u', (np.float32(0.5), np.float32(1.25)))):
+        f = {'s': be.jitsmv, 'u': be.jitumv}[family]
+        w0, w1 = (float(wargs[0]), 0.0) if family == 's' else (float(wargs[0]), float(wargs[1]))
+        got = f(*wargs, prob, v, seed, shape=shape, transpose=True, corder=False)
+        ref = oracle.jitmv(family, w0, w1, prob, v.astype(np.float64), seed, shape=shape, transpose=True, corder=False)
+        small = (np.abs(ref) > 0) & (np.abs(ref) < 1.0)
+        assert small.sum() > 1000, 'the case must contain outputs made of small addends only'
+        np.testing.assert_allclose(got[small], ref[small], rtol=2e-5)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
+    # an operand of one scale still takes the fixed-point sums (bitwise repeatable, unlike float atomics)
+    u = rng.uniform(0.5, 2.0, in_len).astype(np.float32)
+    a = be.jitsmv(np.float32(1.5), prob, u, seed, shape=shape, transpose=True, corder=False)
+    b = be.jitsmv(np.float32(1.5), prob, u, seed, shape=shape, transpose=True, corder=False)
+    np.testing.assert_array_equal(a, b)
+
+
 def test_jit_float_twins_agree_with_the_event_driven_products_on_0_1_operands(be):
     """On an operand of zeros and ones the float twin and the event-driven product are the same sum (the reference tests its
     binary ops against its float ops this way, ``_jit_scalar/binary_test.py:84-118``) — the scalar family exactly."""

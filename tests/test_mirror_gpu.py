@@ -325,3 +325,45 @@ def test_compacted_and_packed_events_through_the_mirrors(be, oracle, monkeypatch
     fwant = fcn @ plain
     for ev in (compact, packed):
         assert torch.equal(fcn @ ev, fwant)
+
+
+@pytest.mark.parametrize('scale', [1e6, 1e-6])
+def test_binned_statistics_follow_weights_rewritten_through_a_raw_pointer(be, oracle, monkeypatch, scale):
+    """a binned mirror / indexed workspace that takes its column statistics from binned steps
+    (`STATS_BY_STEPS_MIN_NNZ`, the large-matrix path; lowered here) cached them under the weight tensor's stamp — but
+    `Mirror.refreshed` and `_fresh_indexed_workspace` rewrite that tensor through a raw pointer (`gather_by_perm(out=...)`), which
+    torch's version counter does not see: the refresh kept the old exponent whatever the new weights were.  Weights grown by 1e6
+    wrapped the int64 sums; shrunk by 1e-6 they lost the accuracy gate.  `refresh_weights` now voids the cache."""
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    monkeypatch.setattr(C.BinnedScatter, 'STATS_BY_STEPS_MIN_NNZ', 1000)
+    rng = np.random.default_rng(31)
+    m, k = 20000, 400_000
+    lens = rng.integers(20, 40, m)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, k, ptr[-1]).astype(np.int32)
+    w = rng.uniform(0.1, 1.0, ptr[-1]).astype(np.float32)
+    data = torch.tensor(w, device='cuda')
+    csr = be.CSR((data, torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')), shape=(m, k)).prepare(mirror=True)
+    mr = csr.buffers['mirror']
+    assert isinstance(mr.plan, C.BinnedScatter) and mr.perm is not None and mr.plan._rows is not None
+    v = rng.random(k) < 0.05
+    ev = be.BinaryArray(torch.tensor(v, device='cuda'))
+    np.testing.assert_allclose((csr @ ev).cpu().numpy(), oracle.binary_csrmv(w.astype(np.float64), idx, ptr, v, (m, k), False),
+                               rtol=RTOL, atol=ATOL)
+    e0 = mr.plan.scale_exp
+    data.mul_(scale)                                             # in place: the mirror follows by a gather-copy into its own buffer
+    got = (csr @ ev).cpu().numpy()
+    assert csr.buffers['mirror'] is mr
+    ref = oracle.binary_csrmv((w * np.float32(scale)).astype(np.float64), idx, ptr, v, (m, k), False)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    assert (mr.plan.scale_exp < e0) if scale > 1 else (mr.plan.scale_exp >= e0)       # the exponent moved with the weights
+    # the perm-fused indexed product over a binned workspace takes the same refresh path
+    t_idx, t_ptr, perm = mr.indices, mr.indptr, mr.perm
+    ws = C.indexed_workspace(data, t_idx, t_ptr, perm, shape=(k, m), route='binned')
+    a = be.binary_csrmv_indexed(data, t_idx, t_ptr, perm, ev.value, shape=(k, m), workspace=ws, transpose=True)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    data.mul_(1.0 / scale)
+    b = be.binary_csrmv_indexed(data, t_idx, t_ptr, perm, ev.value, shape=(k, m), workspace=ws, transpose=True)
+    ref0 = oracle.binary_csrmv((w * np.float32(scale) * np.float32(1.0 / scale)).astype(np.float64), idx, ptr, v, (m, k), False)
+    np.testing.assert_allclose(b.cpu().numpy(), ref0, rtol=1e-5, atol=1e-5 * float(np.abs(ref0).max()))
