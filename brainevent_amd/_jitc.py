@@ -104,6 +104,39 @@ def _jit_params(family: str, a, b):
     return loc, scale, abs(loc) + 6.5 * abs(scale)     # |normal01| <= 6.37 after the 1e-10 clamp
 
 
+# Scatter workspaces are kept and ARMED (be_jit_scatter_workspace_arm): their spike counters are zeroed once and every later call
+# skips the zeroing launch.  One workspace per (device, stream, size), a few at most (least recently used first out: disarmed and
+# released); a call that raises drops its workspace.  Gather workspaces have no counters and stay per-call allocations.
+_ARMED_MAX = 8
+_armed: 'Dict[tuple, torch.Tensor]' = {}
+
+
+def _armed_scatter_workspace(nbytes: int) -> torch.Tensor:
+    st = A.stream_ptr()
+    key = (A.device().index, int(getattr(st, 'value', st) or 0), int(nbytes))
+    ws = _armed.pop(key, None)
+    if ws is None:
+        while len(_armed) >= _ARMED_MAX:
+            _drop_armed(next(iter(_armed)))
+        ws = A.workspace(nbytes)
+        check(fn('be_jit_scatter_workspace_arm', c_int, [c_vp, c_i64, c_vp])(A.ptr(ws), ws.numel(), A.stream_ptr()),
+              'be_jit_scatter_workspace_arm')
+    _armed[key] = ws                      # (re-inserted: most recently used last)
+    return ws
+
+
+def _drop_armed(key) -> None:
+    ws = _armed.pop(key, None)
+    if ws is not None:
+        fn('be_jit_scatter_workspace_disarm', c_int, [c_vp])(A.ptr(ws))
+
+
+def _drop_armed_tensor(ws: torch.Tensor) -> None:
+    for k, v in list(_armed.items()):
+        if v is ws:
+            _drop_armed(k)
+
+
 def _jitmv_hip(family, a, b, clen, vector, seed, *, shape, transpose, corder, out_dtype):
     spikes, sd = A.spikes_to_device(vector)
     in_len = int(shape[0] if transpose else shape[1])
@@ -114,11 +147,16 @@ def _jitmv_hip(family, a, b, clen, vector, seed, *, shape, transpose, corder, ou
     w0, w1, wmax = _jit_params(family, a, b)
     gather = 1 if corder else 0
     f_ws = fn('be_binary_jitmv_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
-    ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, gather))
+    nbytes = f_ws(int(shape[1]), in_len, out_len, gather)
+    ws = A.workspace(nbytes) if gather else _armed_scatter_workspace(nbytes)
     name = f"be_binary_jit{family}mv_{'notrans' if corder else 'trans'}_{A.wsuffix(out)}"
     f = fn(name, c_int, _MV_ARGS)
-    check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(spikes), sd, A.ptr(out), int(shape[1]), in_len, out_len,
-            _fixed_scale_exp(wmax, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    try:
+        check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(spikes), sd, A.ptr(out), int(shape[1]), in_len, out_len,
+                _fixed_scale_exp(wmax, in_len), A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    except Exception:
+        _drop_armed_tensor(ws)
+        raise
     return out
 
 
@@ -132,11 +170,16 @@ def _jitmm_hip(family, a, b, clen, B, seed, *, shape, transpose, corder, out_dty
         return out_bm.T
     w0, w1, _ = _jit_params(family, a, b)
     f_ws = fn('be_binary_jitmm_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_i64, c_int])
-    ws = A.workspace(f_ws(int(shape[1]), in_len, out_len, n, 1 if corder else 0))
+    nbytes = f_ws(int(shape[1]), in_len, out_len, n, 1 if corder else 0)
+    ws = A.workspace(nbytes) if corder else _armed_scatter_workspace(nbytes)
     name = f"be_binary_jit{family}mm_{'notrans' if corder else 'trans'}_{A.wsuffix(out_bm)}"
     f = fn(name, c_int, _MM_ARGS)
-    check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(spikes_bm), sd, A.ptr(out_bm), int(shape[1]), in_len,
-            out_len, n, A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    try:
+        check(f(w0, w1, int(clen), seed & 0xFFFFFFFF, A.ptr(spikes_bm), sd, A.ptr(out_bm), int(shape[1]), in_len,
+                out_len, n, A.ptr(ws), ws.numel(), A.stream_ptr()), name)
+    except Exception:
+        _drop_armed_tensor(ws)
+        raise
     return out_bm.T
 
 
@@ -882,7 +925,7 @@ class JITCScatterShard:
         b = m._weights[1] if m._family != 's' else 0.0
         w0, w1, wmax = _jit_params(m._family, a, b)
         f_ws = fn('be_binary_jitmv_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_int])
-        ws = A.workspace(f_ws(self.shape1, in_len, out_len, 0))
+        ws = _armed_scatter_workspace(f_ws(self.shape1, in_len, out_len, 0))
         f = fn('be_binary_jitmv_sharded', c_int,
                [c_int, c_dbl, c_dbl, c_int, c_i64, c_u32, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
                 c_i64, c_vp])

@@ -1302,6 +1302,16 @@ int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n,
   return compact_any(spikes_bm, spike_dtype, n, n_batch, active_ids, active_stride, counts, static_cast<hipStream_t>(stream));
 }
 
+// the same with the zeroing of the counters left to the caller (be_jitc.hip: a workspace armed by be_jit_scatter_workspace_arm
+// holds zero counters on entry and is re-armed by the step's last kernel); not part of the public header
+int be_internal_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch, uint32_t* active_ids,
+                                       int64_t active_stride, uint32_t* counts, int zero_first, be_stream_t stream) {
+  BE_REQUIRE(n >= 0 && n <= 0xffffffffll && n_batch >= 0 && n_batch <= kMaxBatch, BE_ERR_INVALID, "shape out of range");
+  BE_REQUIRE(counts && (n == 0 || n_batch == 0 || (spikes_bm && active_ids)), BE_ERR_INVALID, "null pointer");
+  return compact_any(spikes_bm, spike_dtype, n, n_batch, active_ids, active_stride, counts, static_cast<hipStream_t>(stream),
+                     zero_first != 0);
+}
+
 int64_t be_binary_csrmm_t_workspace_bytes(int64_t m, int64_t k, int64_t n_batch, int wdtype) {
   return direct_ws_bytes(m, k, wdtype, n_batch);
 }

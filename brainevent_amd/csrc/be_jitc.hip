@@ -22,6 +22,8 @@
 //             atomics at > 3 T/s).  Sums are integer counts (scalar weight) or 64-bit fixed point
 //             (uniform / normal), hence order independent and bitwise reproducible.
 #include "be_jitc_shared.h"
+#include <mutex>
+#include <unordered_set>
 #include <type_traits>
 
 namespace {
@@ -446,8 +448,19 @@ extern "C" int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n,
 extern "C" int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
 extern "C" int be_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch,
                                          uint32_t* active_ids, int64_t active_stride, uint32_t* counts, be_stream_t stream);
+extern "C" int be_internal_compact_spikes_batched(const void* spikes_bm, int spike_dtype, int64_t n, int64_t n_batch,
+                                                  uint32_t* active_ids, int64_t active_stride, uint32_t* counts, int zero_first,
+                                                  be_stream_t stream);
 
 namespace {
+
+// workspaces armed for the scatter orientation (be_jit_scatter_workspace_arm / _disarm): a handful of pointers, looked up once per call
+std::mutex g_armed_mu;
+std::unordered_set<const void*> g_armed;
+inline bool jit_workspace_is_armed(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_armed_mu);
+  return g_armed.count(ws) != 0;
+}
 
 template <int MODE, typename W>
 int jit_mv_gather(const JitP& p, const void* spikes, int sd, void* out, int64_t m, void* ws, hipStream_t st) {
@@ -500,7 +513,10 @@ int jit_scatter_batched(const JitP& p, const void* spikes_bm, int sd, void* out_
   uint32_t* active = reinterpret_cast<uint32_t*>(wsb + jit_counts_bytes(nb));
   const int64_t astride = jit_active_stride(m);
   AccT* partial = reinterpret_cast<AccT*>(wsb + jit_counts_bytes(nb) + nb * astride * 4);
-  int rc = be_compact_spikes_batched(spikes_bm, sd, m, nb, active, astride, count, st);
+  // An ARMED workspace (be_jit_scatter_workspace_arm) holds zero counters on entry and the reduce kernel below re-arms them:
+  // no zeroing launch in front of the compaction (k_fill_bytes: 4.7 us of a 122-us C3 step).  Any other workspace: zeroed here.
+  const bool armed = jit_workspace_is_armed(ws);
+  int rc = be_internal_compact_spikes_batched(spikes_bm, sd, m, nb, active, astride, count, armed ? 0 : 1, st);
   if (rc != BE_OK) return rc;
   const ScatterGeom g = scatter_geom(p, MODE == MODE_SCALAR, nb);
   const size_t lds = (size_t)g.piece_len * sizeof(AccT);
@@ -525,7 +541,7 @@ int jit_scatter_batched(const JitP& p, const void* spikes_bm, int sd, void* out_
     const dim3 rgrid((unsigned)((q_per_chunk + 255) / 256), (unsigned)p.n_chunks, (unsigned)nb);
     const int64_t pstride = (int64_t)g.n_classes * g.pieces * g.parts * g.piece_len;
     hipLaunchKernelGGL((k_jit_scatter_reduce<MODE, W>), rgrid, dim3(256), 0, st, partial, p, g.pieces, g.parts, g.piece_len,
-                       ldexp(1.0, -scale_exp), static_cast<W*>(out_bm), pstride);
+                       ldexp(1.0, -scale_exp), static_cast<W*>(out_bm), pstride, armed ? count : static_cast<uint32_t*>(nullptr));
   }
   BE_LAUNCH_CHECK();
   return BE_OK;
@@ -620,6 +636,24 @@ __global__ void __launch_bounds__(256) k_jit_edge_weights(JitP p, const int32_t*
 }  // namespace
 
 extern "C" {
+
+// Arm a workspace of the scatter orientation (mv or mm): its spike counters are zeroed once, here, and every later scatter call
+// on it skips the zeroing launch — the call's last kernel leaves the counters at zero again.  The library remembers the POINTER:
+// disarm before freeing the memory (or before handing it to anything else).  A call that fails half-way leaves the counters in an
+// unknown state: disarm, or arm again.
+int be_jit_scatter_workspace_arm(void* workspace, int64_t workspace_bytes, be_stream_t stream) {
+  BE_REQUIRE(workspace != nullptr && workspace_bytes >= 256, BE_ERR_INVALID, "null / tiny workspace");
+  // the counters sit at the head: 4 bytes per batch column, at most kMaxBatch columns (whatever else the fill covers is scratch)
+  BE_HIP(be_fill_async(workspace, 0, (size_t)std::min<int64_t>(workspace_bytes, 4 * 65536), static_cast<hipStream_t>(stream)));
+  std::lock_guard<std::mutex> lk(g_armed_mu);
+  g_armed.insert(workspace);
+  return BE_OK;
+}
+int be_jit_scatter_workspace_disarm(void* workspace) {
+  std::lock_guard<std::mutex> lk(g_armed_mu);
+  g_armed.erase(workspace);
+  return BE_OK;
+}
 
 int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int gather) {
   return jit_mv_ws_bytes(shape1, in_len, out_len, gather);

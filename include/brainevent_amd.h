@@ -558,6 +558,14 @@ int be_binary_densemm(const void* weights, int wdtype, const void* spikes_bm, in
  *   mv walks with lane stride 32, mm with lane stride 4 (a different matrix, as in the reference:
  *   brainevent/_misc.py:32-38)
  * ---------------------------------------------------------------------------------------------- */
+/* Armed workspaces of the SCATTER orientation (mv and mm).  A scatter call compacts the spikes through counters at the head of its
+ * workspace, which it zeroes first — one more launch per call (4.7 us of a 122-us step at BASELINE config C3).  A workspace that was
+ * armed once (its counters zeroed here) skips that launch: the call's last kernel leaves the counters at zero again.  The library
+ * keys this on the workspace POINTER: disarm it before the memory is freed or reused for anything else; after a call that returned
+ * an error, disarm or arm again.  Results are identical either way.  (The reference compacts per call inside its FFI target and
+ * has no workspace to keep: brainevent/_jit_scalar/binary_jitsmv.cu:107-125, :175-214.) */
+int be_jit_scatter_workspace_arm(void* workspace, int64_t workspace_bytes, be_stream_t stream);
+int be_jit_scatter_workspace_disarm(void* workspace);
 int64_t be_binary_jitmv_workspace_bytes(int64_t shape1, int64_t in_len, int64_t out_len, int gather);
 int be_binary_jitmv(int mode, double w0, double w1, int wdtype, int64_t clen, uint32_t seed, const void* spikes,
                     int spike_dtype, void* out, int64_t shape1, int64_t in_len, int64_t out_len, int gather,

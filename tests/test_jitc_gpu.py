@@ -448,3 +448,33 @@ def _ok(M, world, side):
         return True
     except ValueError:
         return False
+
+
+def test_armed_scatter_workspaces_skip_the_zeroing_launch_and_change_no_bit(be, monkeypatch):
+    """Round 5: the scatter orientation keeps its workspace armed (`be_jit_scatter_workspace_arm`: spike counters zeroed once, the
+    call's last kernel leaves them at zero), so repeated calls issue no zeroing launch.  Same bits as the same call over a fresh,
+    UNARMED workspace full of garbage (which the library zeroes per call); spike vectors of very different activity in sequence (a
+    stale counter would lengthen or shorten the next call's list); mv and mm; the cache is bounded and disarms what it evicts."""
+    import brainevent_amd._jitc as J
+    rng = np.random.default_rng(51)
+    dev = torch.device('cuda', 0)
+    shape, prob, seed = (3000, 2600), 0.01, 5
+    M = be.JITCScalarR((np.float32(0.5), prob, seed), shape=shape, corder=False)
+    spikes = [torch.from_numpy(rng.random(shape[0]) < fire).to(dev) for fire in (0.5, 0.001, 0.2, 0.0, 0.9)]
+    S = torch.from_numpy(rng.random((5, shape[0])) < 0.1).to(dev)            # a batch of event rows: [batch, n_pre] @ M
+    armed = [be.BinaryArray(s) @ M for s in spikes] + [be.BinaryArray(S) @ M, be.BinaryArray(S) @ M]
+    assert len(J._armed) >= 1
+    with monkeypatch.context() as mp:        # per-call workspaces the library has never seen: it zeroes their counters itself
+        mp.setattr(J, '_armed_scatter_workspace', lambda n: torch.full((max(int(n), 256),), 0x5a, dtype=torch.uint8, device=dev))
+        fresh = [be.BinaryArray(s) @ M for s in spikes] + [be.BinaryArray(S) @ M]
+    for a, b in zip(armed, fresh):
+        assert torch.equal(a, b)
+    assert torch.equal(armed[-1], armed[-2])
+    assert float(armed[3].abs().sum()) == 0.0 and float(armed[4].sum()) > float(armed[2].sum()) > float(armed[1].sum())
+    # bounded cache: more distinct shapes than it holds; what it evicts is disarmed (and may be handed out again as fresh memory)
+    for i in range(J._ARMED_MAX + 3):
+        Mi = be.JITCScalarR((np.float32(1.0), 0.02, 3), shape=(500 + 64 * i, 700), corder=False)
+        si = torch.from_numpy(rng.random(500 + 64 * i) < 0.1).to(dev)
+        assert torch.equal(be.BinaryArray(si) @ Mi, be.BinaryArray(si) @ Mi)
+    assert len(J._armed) <= J._ARMED_MAX
+    assert torch.equal(be.BinaryArray(spikes[2]) @ M, armed[2])
