@@ -8,6 +8,8 @@
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
  *   5. neuron step:    be_lif_coba_step
  *   7. float twin:     be_csrmv in both directions (a dense operand instead of spikes)
+ *   8. binned route:   be_binary_csrmv_t_binned_workspace_bytes -> _init -> be_binary_csrmv_t_binned x 2 -> be_binned_workspace_audit / _status
+ *   9. JIT scatter:    be_binary_jitmv over a per-call and an armed workspace (be_jit_scatter_workspace_arm / _disarm)
  *   6. the unfavourable direction made event-driven: be_csr_to_csc_count -> _indptr -> _fill_block (two column
  *      blocks, weights moved along, perm kept) gives the CSC mirror; the gather product of step 4 is then (a) the direct scatter
  *      over the mirror, (b) the perm-fused scatter be_binary_csrmm_t_indexed over the mirror's structure with the weights left in
@@ -259,6 +261,61 @@ int main(void) {
       fails += worst <= 1.0 ? 0 : 1;
     }
     free(x);
+  }
+
+  /* 8. binned route (no per-matrix layout): workspace_bytes -> init -> two steps -> be_binned_workspace_status / _audit:
+   *    the conservation counters say that every stored entry of the active rows was delivered exactly once */
+  {
+    const int64_t cap = 1 << 20;
+    const int64_t bws_bytes = be_binary_csrmv_t_binned_workspace_bytes(m, k, 16, cap);
+    void *d_bws = dev_copy(NULL, bws_bytes);
+    int bexp = 0;
+    const int64_t fps = be_fixed_point_scratch_bytes(k);
+    void *d_fps = dev_copy(NULL, fps);
+    CHECK_BE(be_fixed_point_exponent(d_w, BE_F32, (const int32_t *)d_idx, nnz, k, 16, INT_MIN, d_fps, fps, &bexp, NULL));
+    CHECK_BE(be_binary_csrmv_t_binned_workspace_init(d_bws, bws_bytes, m, k, 16, cap, NULL));
+    memset(ref, 0, k * 8);
+    uint64_t expect = 0;
+    for (int64_t i = 0; i < m; ++i)
+      if (spk[i]) { expect += (uint64_t)(ptr[i + 1] - ptr[i]); for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ref[idx[j]] += (double)w[j]; }
+    for (int rep = 0; rep < 2; ++rep)
+      CHECK_BE(be_binary_csrmv_t_binned(d_w, 0, BE_F32, (const int32_t *)d_idx, d_ptr, 0, -1, d_spk, BE_SPIKE_BOOL, d_out, m, k, 16, cap,
+                                        bexp, d_bws, bws_bytes, NULL));
+    CHECK_HIP(hipMemcpy(got, d_out, k * 4, hipMemcpyDeviceToHost));
+    fails += compare("binned scatter", got, ref, k);
+    uint64_t c[4];
+    CHECK_BE(be_binned_workspace_audit(d_bws, c, NULL));
+    const int conserved = c[0] == 2 * expect && c[1] == c[0] && c[2] + c[3] == c[1];
+    printf("%-28s %llu entries, %llu tickets, %llu accumulated + %llu overflowed %s\n", "binned conservation", (unsigned long long)c[0],
+           (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[3], conserved ? "ok" : "FAIL");
+    fails += conserved ? 0 : 1;
+    CHECK_BE(be_binned_workspace_status(d_bws, 1, NULL));
+  }
+
+  /* 9. JIT connectivity, scatter orientation: a per-call workspace (the library zeroes its counters) and an ARMED one
+   *    (be_jit_scatter_workspace_arm: no zeroing launch, re-armed by the call's last kernel) give the same bits, call after call */
+  {
+    const int64_t clen = 40;                                         /* prob = 0.05 */
+    const int64_t jws_bytes = be_binary_jitmv_workspace_bytes(k, m, k, 0);
+    void *d_j1 = dev_copy(NULL, jws_bytes), *d_j2 = dev_copy(NULL, jws_bytes), *d_o2 = dev_copy(NULL, k * 4);
+    float *got2 = malloc(k * 4);
+    CHECK_HIP(hipMemset(d_j1, 0x5a, jws_bytes));
+    CHECK_HIP(hipMemset(d_j2, 0x5a, jws_bytes));
+    CHECK_BE(be_jit_scatter_workspace_arm(d_j2, jws_bytes, NULL));
+    int same = 1;
+    for (int rep = 0; rep < 3; ++rep) {
+      CHECK_BE(be_binary_jitmv(0, 1.5, 0.0, BE_F32, clen, 7u, d_spk, BE_SPIKE_BOOL, d_out, k, m, k, 0, 0, d_j1, jws_bytes, NULL));
+      CHECK_BE(be_binary_jitmv(0, 1.5, 0.0, BE_F32, clen, 7u, d_spk, BE_SPIKE_BOOL, d_o2, k, m, k, 0, 0, d_j2, jws_bytes, NULL));
+      CHECK_HIP(hipMemcpy(got, d_out, k * 4, hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(got2, d_o2, k * 4, hipMemcpyDeviceToHost));
+      same = same && memcmp(got, got2, k * 4) == 0;
+    }
+    double total = 0;
+    for (int64_t i = 0; i < k; ++i) total += got[i];
+    printf("%-28s %s (sum of the outputs %.1f)\n", "jit scatter, armed workspace", same && total > 0 ? "ok" : "FAIL", total);
+    fails += same && total > 0 ? 0 : 1;
+    CHECK_BE(be_jit_scatter_workspace_disarm(d_j2));
+    free(got2);
   }
 
   /* error convention: status code + message, never an abort */
