@@ -1460,6 +1460,7 @@ class Mirror:
         self.data, self.indices, self.indptr = data, indices, indptr
         self.plan, self.perm, self.stamp, self.homo = plan, perm, stamp, bool(homo)
         self.counts = counts            # stored entries per mirror row (int64 [shape[0]]): the work of an event on that row
+        self.check = None               # set by a container that built this mirror BY ITSELF: the streaming gather product, run once
 
     @property
     def released(self) -> bool:
@@ -1493,7 +1494,36 @@ class Mirror:
         return self
 
     def apply(self, v, backend=None):
-        """``A @ e(v)`` for an event vector ``v [k]`` or a matrix operand ``v [k, n]`` -> ``[m]`` / ``[m, n]``."""
+        """``A @ e(v)`` for an event vector ``v [k]`` or a matrix operand ``v [k, n]`` -> ``[m]`` / ``[m, n]``.
+
+        A mirror that a container built on its own initiative (first use of a large matrix, ``AUTO_MIRROR_MIN_NNZ``) is
+        **cross-checked once** against the streaming gather kernel over the source arrays, on the first plain event vector it
+        serves (one full-matrix pass, 12 ms at C2 against seconds of build; ``BRAINEVENT_AMD_MIRROR_CHECK=0`` skips it): the
+        caller did not ask for the mirror, so it must not be able to change a result silently.  A disagreement returns the gather
+        kernel's result, drops the mirror for good and warns with the numbers (round 4 saw one unexplained mismatch on this
+        route)."""
+        out = self._apply(v, backend)
+        if self.check is not None and isinstance(v, torch.Tensor) and v.ndim == 1 and v.dtype in (torch.bool, torch.uint8, torch.float32):
+            check, self.check = self.check, None
+            if os.environ.get('BRAINEVENT_AMD_MIRROR_CHECK', '1') != '0':
+                ref, drop = check(v)
+                if self.homo:
+                    bad = not torch.equal(out, ref)
+                else:
+                    tol = 1e-4 * ref.abs() + 1e-6 * float(ref.abs().max())
+                    bad = bool(((out - ref).abs() > tol).any())
+                if bad:
+                    n_bad = int((out != ref).sum()) if self.homo else int(((out - ref).abs() > tol).sum())
+                    drop()
+                    import warnings
+                    warnings.warn(f"brainevent_amd: the automatically built mirror of a {self.shape[1]} x {self.shape[0]} matrix disagreed "
+                                  f"with the gather kernel on {n_bad} of {ref.numel()} outputs (max |diff| "
+                                  f"{float((out - ref).abs().max()):.3e}); the mirror was dropped, this and later products use the gather "
+                                  f"kernel.  Please report this.", RuntimeWarning, stacklevel=3)
+                    return ref
+        return out
+
+    def _apply(self, v, backend=None):
         if not self.released:
             call = binary_csrmv_p_call if v.ndim == 1 else binary_csrmm_p_call
             return call(self.data, self.indices, self.indptr, v, self.plan, shape=self.shape, transpose=True, backend=backend)[0]
@@ -1753,7 +1783,14 @@ class CompressedSparseData(DataRepresentation):
             if not auto_mirror_wanted(self.nse, m, k, self.data):
                 self.buffers['mirror'] = None
                 return None
-            return self.build_mirror()
+            mr = self.build_mirror()
+
+            def gather(v, _self=self, _shape=(m, k)):
+                ref = binary_csrmv_p_call(_self.data, _self.indices, _self.indptr, v, None, shape=_shape, transpose=False,
+                                          backend=_self.backend)[0]
+                return ref, lambda: _self.buffers.__setitem__('mirror', None)
+            mr.check = gather
+            return mr
         if mr.is_stale(self.data):
             m, k = self._plan_shape()
             mr = self.buffers['mirror'] = mr.refreshed(self.data, self.indices, self.indptr, -1, m, k)

@@ -264,7 +264,13 @@ class FixedNumConn(DataRepresentation):
             if not _csr_mod.auto_mirror_wanted(self.nse, n_rows, n_cols, self.data):
                 self.buffers['mirror'] = None
                 return None
-            return self.build_mirror()
+            mr = self.build_mirror()
+
+            def gather(s, _self=self):      # the streaming gather over the fixed-length rows: the mirror's one-off cross-check
+                ref = binary_fcnmv_p_call(_self.data, _self.indices, s, shape=_self._a_shape, transpose=False, backend=_self.backend)[0]
+                return ref, lambda: _self.buffers.__setitem__('mirror', None)
+            mr.check = gather
+            return mr
         if mr.is_stale(self.data):
             mr = self.buffers['mirror'] = mr.refreshed(self.data, self.indices, None, self.num_conn, n_rows, n_cols)
         return mr

@@ -367,3 +367,57 @@ def test_binned_statistics_follow_weights_rewritten_through_a_raw_pointer(be, or
     b = be.binary_csrmv_indexed(data, t_idx, t_ptr, perm, ev.value, shape=(k, m), workspace=ws, transpose=True)
     ref0 = oracle.binary_csrmv((w * np.float32(scale) * np.float32(1.0 / scale)).astype(np.float64), idx, ptr, v, (m, k), False)
     np.testing.assert_allclose(b.cpu().numpy(), ref0, rtol=1e-5, atol=1e-5 * float(np.abs(ref0).max()))
+
+
+@pytest.mark.parametrize('homo', [True, False])
+def test_an_automatic_mirror_is_cross_checked_once_against_the_gather_kernel(be, oracle, monkeypatch, homo):
+    """a mirror the container builds by itself must not be able to change a result silently.  Its first plain
+    event vector is also evaluated by the streaming gather kernel; agreement keeps the mirror (and the check is not repeated), a
+    disagreement — provoked here by corrupting the mirror's weights / structure behind its back — returns the gather kernel's result,
+    drops the mirror for good and warns.  A mirror the caller asked for (`build_mirror`, `prepare(mirror=True)`) is not checked."""
+    import warnings
+    import brainevent_amd._csr as C
+    monkeypatch.setattr(C, 'PLAN_MIN_NNZ', 1000)
+    monkeypatch.setattr(C, 'AUTO_MIRROR_MIN_NNZ', 1000)
+    rng = np.random.default_rng(41)
+    m, k = 1200, 1500
+    w, idx, ptr = rand_csr(rng, m, k, rng.integers(60, 120, m))
+    if homo:
+        w = np.array([0.5], np.float32)
+    v = torch.tensor(rng.random(k) < 0.1, device='cuda')
+    ref = oracle.binary_csrmv(np.asarray(w, np.float64), idx, ptr, v.cpu().numpy(), (m, k), False)
+
+    def container():
+        return be.CSR((torch.tensor(w, device='cuda'), torch.tensor(idx, device='cuda'), torch.tensor(ptr, device='cuda')), shape=(m, k))
+    # healthy: checked once, kept
+    good = container()
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        out = good @ be.BinaryArray(v)
+        mr = good.buffers['mirror']
+        assert isinstance(mr, C.Mirror) and mr.check is None           # consumed by the first product
+        out2 = good @ be.BinaryArray(v)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    assert torch.equal(out, out2)
+    # corrupted behind its back: the first product notices, answers with the gather kernel and drops the mirror
+    broken = container()
+    mr = broken._fresh_mirror(auto=True)
+    assert mr.check is not None
+    if homo:
+        mr.indices[: mr.indices.numel() // 3] = 0                       # a third of the mirror's entries delivered to output 0
+    else:
+        mr.data.mul_(3.0)                                               # the round-4 signature: an addend delivered three times
+    if mr.plan is not None and hasattr(mr.plan, 'refresh_weights') and not homo:
+        mr.plan.refresh_weights(mr.data, mr.indices, mr.indptr)
+    elif mr.plan is not None and homo:
+        mr.plan = None                                                  # (the plan embeds the structure: serve from the raw arrays)
+    with pytest.warns(RuntimeWarning, match='disagreed with the gather kernel'):
+        got = broken @ be.BinaryArray(v)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    assert broken.buffers['mirror'] is None
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        np.testing.assert_allclose((broken @ be.BinaryArray(v)).cpu().numpy(), ref, rtol=RTOL, atol=ATOL)      # gather kernel, no rebuild
+    # a mirror the caller asked for carries no check
+    asked = container().prepare(mirror=True)
+    assert asked.buffers['mirror'].check is None
