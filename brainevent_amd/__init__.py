@@ -12,7 +12,7 @@ from ._error import (BrainEventError, MathError, KernelError, KernelNotAvailable
 from . import config
 from ._registry import get_registry, get_primitives_by_tags, get_all_primitive_names
 from ._event import EventRepresentation, BinaryArray, BitPackedBinary, CompactBinary, bitpack
-from ._csr import (CSR, CSC, ScatterPlan, BinnedScatter, PlannedMatrix, Mirror, indexed_workspace, build_mirror_of, hybrid_task_capacity, binary_csrmv, binary_csrmm, binary_csrmv_indexed, binary_csrmm_indexed, binary_csrmv_indexed_p, binary_csrmm_indexed_p, binary_csrmv_p, binary_csrmm_p,
+from ._csr import (CSR, CSC, ScatterPlan, BinnedScatter, check_binned_status, PlannedMatrix, Mirror, indexed_workspace, build_mirror_of, hybrid_task_capacity, binary_csrmv, binary_csrmm, binary_csrmv_indexed, binary_csrmm_indexed, binary_csrmv_indexed_p, binary_csrmm_indexed_p, binary_csrmv_p, binary_csrmm_p,
                    binary_csrmv_p_call, binary_csrmm_p_call)
 from ._fcn import (FixedNumConn, FixedNumPerPre, FixedNumPerPost, binary_fcnmv, binary_fcnmm, binary_fcnmv_p,
                    binary_fcnmm_p, binary_fcnmv_p_call, binary_fcnmm_p_call)

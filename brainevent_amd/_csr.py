@@ -620,6 +620,18 @@ def make_scatter_workspace(route: str, weights, indices, indptr, m: int, k: int,
     return None
 
 
+import weakref
+_LIVE_BINNED: 'weakref.WeakSet' = weakref.WeakSet()
+
+
+def check_binned_status(clear: bool = True) -> None:
+    """:meth:`BinnedScatter.check_status` of every live binned workspace: raises ``KernelExecutionError`` if any step since the
+    last call gave up on its append protocol (its outputs were NaN) or broke the conservation of its entries.  Synchronises — call
+    it where the program synchronises anyway (after a batch of replays of a captured graph, at the end of an epoch, in a test)."""
+    for ws in list(_LIVE_BINNED):
+        ws.check_status(clear=clear)
+
+
 class BinnedScatter:
     """Workspace of the *binned* scatter route: no per-matrix layout, only per-slice bins that are refilled every call
     (``be_binary_csrmv_t_binned``).  Used when a matrix is large but a :class:`ScatterPlan` does not pay — fewer than
@@ -652,6 +664,7 @@ class BinnedScatter:
         self._set_geometry()
         self._ws: Dict = {}
         self.ws = self.workspace(1)
+        _LIVE_BINNED.add(self)
 
     #: 32-bit fixed-point sums (twice the bin width: half the bins, one round of pass C; C4: 0.60 -> 0.53 ms per step).
     #: ``acc32=True`` (explicit): taken when every column's largest weight keeps ACC32_MIN_WEIGHT_BITS bits at the 32-bit exponent

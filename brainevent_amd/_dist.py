@@ -541,6 +541,12 @@ class RankStep:
         return out
 
 
+    def check_status(self) -> None:
+        """Status of the shard's binned workspace, if it has one (sticky give-up flag, conservation counters): synchronises."""
+        ws = getattr(self, '_ws_obj', None)
+        if hasattr(ws, 'check_status'):
+            ws.check_status()
+
     def captured(self, static_local, warmup: int = 3):
         """This rank's step as ONE replayable HIP graph: exchange (``ncclAllGather`` on the caller's stream is capturable) +
         the planned / binned step, recorded once over ``static_local`` — a buffer (tensor or ``PackedSpikes`` words) the producer

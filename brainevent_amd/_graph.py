@@ -37,6 +37,12 @@ class GraphedStep:
         self.graph.replay()
         return self.outputs
 
+    def check(self) -> None:
+        """Status of the binned workspaces the replays ran on (``brainevent_amd.check_binned_status``): a replayed step cannot raise,
+        so a step that poisoned its outputs (NaN) or lost an entry is reported here.  Synchronises; call it at a sync point."""
+        from ._csr import check_binned_status
+        check_binned_status()
+
 
 def capture_step(fn: Callable[[], Any], warmup: int = 3) -> GraphedStep:
     return GraphedStep(fn, warmup=warmup)

@@ -76,27 +76,16 @@ if os.environ.get('BE_POISON_ALLOC') in _POISON_WORDS:
 
 
 @pytest.fixture(autouse=True)
-def _binned_conservation(request, monkeypatch):
+def _binned_conservation(request):
     """Every gpu test that builds a binned workspace checks, when it ends, that the workspace's conservation counters agree
     (`BinnedScatter.check_status`: entries in the active rows == tickets == accumulated + overflow over all the steps the test
     ran) — a lost or duplicated entry fails the test that produced it even where the test's own comparison would not see it."""
     if request.node.get_closest_marker('gpu') is None:
         yield
         return
-    import weakref
     from brainevent_amd import _csr
-    made = []
-    orig = _csr.BinnedScatter.__init__
-
-    def init(self, *a, **k):
-        orig(self, *a, **k)
-        made.append(weakref.ref(self))
-    monkeypatch.setattr(_csr.BinnedScatter, '__init__', init)
     yield
-    for r in made:
-        ws = r()
-        if ws is not None and getattr(ws, '_ws', None):
-            ws.check_status()
+    _csr.check_binned_status()           # every binned workspace still alive (the library keeps a weak registry of them)
 
 
 @pytest.fixture(autouse=True)
