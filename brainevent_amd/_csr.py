@@ -1798,10 +1798,12 @@ class CompressedSparseData(DataRepresentation):
                 return None
             mr = self.build_mirror()
 
-            def gather(v, _self=self, _shape=(m, k)):
-                ref = binary_csrmv_p_call(_self.data, _self.indices, _self.indptr, v, None, shape=_shape, transpose=False,
-                                          backend=_self.backend)[0]
-                return ref, lambda: _self.buffers.__setitem__('mirror', None)
+            owner = weakref.ref(self)            # (no cycle container -> mirror -> closure -> container: 80-GB arrays must not wait for the GC)
+
+            def gather(v, _shape=(m, k)):
+                c = owner()
+                ref = binary_csrmv_p_call(c.data, c.indices, c.indptr, v, None, shape=_shape, transpose=False, backend=c.backend)[0]
+                return ref, lambda: c.buffers.__setitem__('mirror', None)
             mr.check = gather
             return mr
         if mr.is_stale(self.data):

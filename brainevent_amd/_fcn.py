@@ -266,9 +266,13 @@ class FixedNumConn(DataRepresentation):
                 return None
             mr = self.build_mirror()
 
-            def gather(s, _self=self):      # the streaming gather over the fixed-length rows: the mirror's one-off cross-check
-                ref = binary_fcnmv_p_call(_self.data, _self.indices, s, shape=_self._a_shape, transpose=False, backend=_self.backend)[0]
-                return ref, lambda: _self.buffers.__setitem__('mirror', None)
+            import weakref
+            owner = weakref.ref(self)
+
+            def gather(s):      # the streaming gather over the fixed-length rows: the mirror's one-off cross-check
+                c = owner()
+                ref = binary_fcnmv_p_call(c.data, c.indices, s, shape=c._a_shape, transpose=False, backend=c.backend)[0]
+                return ref, lambda: c.buffers.__setitem__('mirror', None)
             mr.check = gather
             return mr
         if mr.is_stale(self.data):
