@@ -23,6 +23,7 @@ single-GPU BASELINE.json configs (C3 JITC scatter, C4 FixedNumPerPre N = 10M K =
 its own value / ms_per_step / kernel_ms / roofline, timed after the headline.
 """
 import argparse
+import math
 import ctypes
 import json
 import os
@@ -1126,7 +1127,17 @@ def main():
         torch.cuda.empty_cache()
         line['secondary'] = secondary_configs(args)
     if line is not None:
-        print(json.dumps(line), flush=True)
+        def finite(o):          # strict JSON: a non-finite float (an error of inf against an all-zero reference, ...) becomes null
+            if isinstance(o, float):
+                return o if math.isfinite(o) else None
+            if isinstance(o, dict):
+                return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [finite(v) for v in o]
+            if isinstance(o, np.generic):
+                return finite(o.item())
+            return o
+        print(json.dumps(finite(line), allow_nan=False), flush=True)
 
 
 if __name__ == '__main__':
