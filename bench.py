@@ -726,10 +726,11 @@ def run_scatter(args):
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('BENCH_BACKEND', 'nccl')      # nccl = RCCL; 'gloo' only to rehearse several ranks on one card
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        if not dist.is_initialized():          # (a multi-rank job runs several legs over one process group: main())
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=dev)
+            else:
+                dist.init_process_group(backend)
 
     import brainevent_amd as be
     from brainevent_amd import _csr as C
@@ -1093,7 +1094,77 @@ def run_scatter(args):
         if native:
             exchange.close()
         dist.barrier()
+        if not getattr(args, 'keep_group', False):
+            dist.destroy_process_group()
+    return line
+
+
+def _finite(o):
+    """Strict JSON: a non-finite float (an error of inf against an all-zero reference, ...) becomes null."""
+    if isinstance(o, float):
+        return o if math.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, np.generic):
+        return _finite(o.item())
+    return o
+
+
+def multi_rank_extras(args, line, world):
+    """After the headline of a multi-rank job (the default `--gpus N` run): the SAME N ranks also measure, over the same process group,
+      * `C4_strong` — BASELINE config C4 as it is defined: FixedNumPerPre K = 1000, N = 10M, post-sliced over the N GPUs with the
+        spike all-gather (`--workload fcn`), and
+      * `C2_weak`   — the headline problem with every rank holding a full 1M x 1M slice (`--scaling weak`: per-rank work fixed, only
+        the exchange is added),
+    and rank 0 attaches both to `secondary` of the ONE line it prints.  A watchdog bounds the legs together
+    (BENCH_EXTRAS_SECONDS, default 240 s): when it expires every rank stops where it is — rank 0 prints the headline line it
+    already has, with whatever legs finished — and the process ends; a failure or a stall in a leg can therefore never cost the
+    headline.  (`value` of a leg = synaptic updates of all ranks per second, as for the headline.)"""
+    import threading
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    done = threading.Event()
+    out = {}
+    if line is not None:
+        line['secondary'] = out
+
+    def emit_and_exit():
+        if rank == 0 and line is not None:
+            out.setdefault('note', 'the extra legs did not finish within BENCH_EXTRAS_SECONDS; the headline above is complete')
+            print(json.dumps(_finite(line), allow_nan=False), flush=True)
+        os._exit(0)
+
+    def watchdog():
+        if not done.wait(float(os.environ.get('BENCH_EXTRAS_SECONDS', 240))):
+            emit_and_exit()
+    threading.Thread(target=watchdog, daemon=True).start()
+    legs = (('C4_strong', ['--workload', 'fcn', '--steps', '100', '--warmup', '20']),
+            ('C2_weak', ['--scaling', 'weak', '--steps', '100', '--warmup', '20']))
+    for i, (name, extra) in enumerate(legs):
+        a = parse(['--gpus', str(args.gpus), '--no-cpu', '--no-secondary', '--exchange', args.exchange, '--exchange-impl', args.exchange_impl]
+                  + extra + os.environ.get('BENCH_EXTRAS_ARGS', '').split())        # (BENCH_EXTRAS_ARGS: smaller sizes for rehearsals)
+        a.keep_group = True
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            ln = run_scatter(a)
+            if ln is not None:
+                out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'scaling',
+                                                'parity_check', 'roofline', 'rank_breakdown') if k in ln}
+                out[name]['config'] = {k: ln['config'][k] for k in ('workload', 'parallelism', 'n_post_per_gpu', 'setup_s', 'data_gen_s')
+                                       if k in ln['config']}
+        except Exception as e:          # (an exception on one rank only would leave the others in a collective: the watchdog ends that)
+            out[name] = {'error': repr(e)}
+            print(f'[bench] rank {rank}: leg {name} failed: {e!r}', file=sys.stderr, flush=True)
+            break
+    done.set()
+    try:
+        dist.barrier()
         dist.destroy_process_group()
+    except Exception:
+        pass
     return line
 
 
@@ -1121,23 +1192,20 @@ def main():
     if os.environ.get('BENCH_FAULT_TIMEOUT'):        # rehearsals: where is every rank if the run has not finished by then
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ['BENCH_FAULT_TIMEOUT']), exit=False, file=sys.stderr)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    extra_legs = (world > 1 and args.workload == 'csr' and args.scaling == 'strong' and not args.no_secondary and args.emulate_world <= 1
+                  and os.environ.get('BENCH_MOCK_STEP') != '1'
+                  and ((args.n == 1_000_000 and args.conn == 0.01 and args.fire == 0.01) or os.environ.get('BENCH_EXTRAS_FORCE') == '1'))
+    args.keep_group = extra_legs
     line = run_scatter(args)
+    if extra_legs:
+        line = multi_rank_extras(args, line, world)
     if line is not None and line.get('secondary') == 'pending':
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         line['secondary'] = secondary_configs(args)
     if line is not None:
-        def finite(o):          # strict JSON: a non-finite float (an error of inf against an all-zero reference, ...) becomes null
-            if isinstance(o, float):
-                return o if math.isfinite(o) else None
-            if isinstance(o, dict):
-                return {k: finite(v) for k, v in o.items()}
-            if isinstance(o, (list, tuple)):
-                return [finite(v) for v in o]
-            if isinstance(o, np.generic):
-                return finite(o.item())
-            return o
-        print(json.dumps(finite(line), allow_nan=False), flush=True)
+        print(json.dumps(_finite(line), allow_nan=False), flush=True)
 
 
 if __name__ == '__main__':
