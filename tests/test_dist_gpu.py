@@ -272,6 +272,7 @@ def test_rank_step_pipelined_schedule_is_bit_identical_to_the_sequential_one(one
         assert torch.equal(rs.step_posted(), seq[2]) and torch.equal(rs.step_posted(), seq[3])
     rs.exchange_only(spikes[4])
     assert torch.equal(rs.scatter_only(), seq[4])
+    rs.check_status()                                 # binned shard: sticky flag + conservation counters; planned shard: nothing to check
     ref = (be.BinaryArray(spikes[4]) @ csr)
     assert torch.equal(ref, seq[4])
     ex.close()

@@ -133,6 +133,7 @@ def test_capture_step_helper():
     for _ in range(20):
         out = step()
     torch.cuda.synchronize()
+    step.check()                                      # status of the binned workspaces the replays ran on (none poisoned, entries conserved)
     assert out is s_graph['v']
     torch.testing.assert_close(s_graph['v'], s_eager['v'], rtol=1e-5, atol=1e-5)
     assert torch.equal(s_graph['spk'], s_eager['spk'])
