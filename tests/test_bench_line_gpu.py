@@ -1,0 +1,52 @@
+"""`bench.py` end to end on a small problem: the JSON line the driver parses keeps its contract (one line, strict JSON, metric /
+value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload,
+`roofline` with bound / achieved / peak / unit / frac / traffic, `cpu_baseline` with value / unit / cores / kind / sample), and the
+one-rank emulation of a multi-GPU step carries its `rank_breakdown`.  (The full-size line is the driver's BENCH run.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, f'bench.py must print ONE JSON line, got {len(lines)}'
+
+    def no_const(x):
+        raise ValueError(f'non-finite constant {x} in the JSON line')
+    return json.loads(lines[0], parse_constant=no_const)
+
+
+def test_the_line_keeps_the_driver_contract_on_a_small_problem():
+    d = _run('--n', '200000', '--steps', '8', '--warmup', '3', '--no-secondary', '--cpu-seconds', '1')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity_check'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 8 and d['warmup'] == 3 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert d['unit'] == 'Geff/s' and d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    assert d['value'] > 0 and abs(d['ms_per_step'] - 1e3 * d['config']['mean_active_rows'] * d['config']['n_conn'] / (d['value'] * 1e9)) \
+        <= 0.05 * d['ms_per_step']
+    roof = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in roof, k
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0 and 0 < roof['frac'] <= 1.0
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb and cb['unit'] == 'Geff/s'
+    assert d['parity_check']['ok'] is True
+
+
+def test_one_rank_of_eight_reports_where_its_step_goes():
+    d = _run('--n', '200000', '--emulate-world', '8', '--steps', '8', '--warmup', '3', '--no-cpu', '--no-secondary')
+    assert d['parity_check']['ok'] is True and 'post-slice x8' in d['config']['parallelism']
+    rb = d['rank_breakdown']
+    assert rb['step_us']['schedule'] == 'sequential' and rb['other_schedule']['schedule'] == 'exchange_ahead_1'
+    assert rb['exchange_only_us']['max'] > 0 and rb['scatter_only_us']['max'] > 0 and rb['other_schedule']['step_us']['max'] > 0
+    d2 = _run('--n', '200000', '--emulate-world', '8', '--steps', '8', '--warmup', '3', '--no-cpu', '--no-secondary', '--exchange-ahead', '1')
+    assert d2['parity_check']['ok'] is True and d2['rank_breakdown']['step_us']['schedule'] == 'exchange_ahead_1'
