@@ -1130,11 +1130,20 @@ def multi_rank_extras(args, line, world):
     if line is not None:
         line['secondary'] = out
 
+    headline = None if line is None else json.dumps(_finite({k: v for k, v in line.items() if k != 'secondary'}), allow_nan=False)
+
     def emit_and_exit():
-        if rank == 0 and line is not None:
-            out.setdefault('note', 'the extra legs did not finish within BENCH_EXTRAS_SECONDS; the headline above is complete')
-            print(json.dumps(_finite(line), allow_nan=False), flush=True)
-        os._exit(0)
+        try:
+            if rank == 0 and line is not None:
+                try:            # (the main thread may be filling `out` at this moment: a snapshot, and the bare headline if that fails)
+                    snap = dict(out)
+                    snap.setdefault('note', 'the extra legs did not finish within BENCH_EXTRAS_SECONDS; the headline is complete')
+                    txt = json.dumps(_finite({**{k: v for k, v in line.items() if k != 'secondary'}, 'secondary': snap}), allow_nan=False)
+                except Exception:
+                    txt = headline
+                print(txt, flush=True)
+        finally:
+            os._exit(0)
 
     def watchdog():
         if not done.wait(float(os.environ.get('BENCH_EXTRAS_SECONDS', 240))):
