@@ -36,6 +36,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_STATE = {}              # process-wide notes of this run (exchange init timed out, which extra leg is running)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_SOURCE = 'profiles/traffic.json (rocprofv3 --pmc, separate pass, guide corrections applied; not this run)'
 
@@ -84,6 +85,10 @@ def parse(argv=None):
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configs after the headline')
     ap.add_argument('--secondary-steps', type=int, default=60)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--full-line', action='store_true', help='print the verbose line (every prose field per entry) instead of the compact '
+                    'one; the verbose line is always also written to --full-line-file')
+    ap.add_argument('--full-line-file', default=os.path.join('gpurun_out', 'bench_full_line.json'),
+                    help="where rank 0 writes the verbose line ('' = nowhere)")
     return ap.parse_args(argv)
 
 
@@ -301,6 +306,23 @@ def time_steps(step, steps, warmup, fence=None):
     return elapsed, kern, step_ms, out
 
 
+def read_ceiling_gbps(dev, gib=2, repeats=5):
+    """Read-only streaming rate of this device, in this run (GB/s), or None."""
+    try:
+        from brainevent_amd import _lib, _array as A
+        buf = torch.empty(gib << 28, dtype=torch.float32, device=dev).fill_(1.0)
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        ms = ctypes.c_float(0.0)
+        f = _lib.fn('be_diag_stream_read', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                                          ctypes.POINTER(ctypes.c_float), ctypes.c_void_p])
+        torch.cuda.synchronize()
+        _lib.check(f(buf.data_ptr(), buf.numel() * 4, repeats, sink.data_ptr(), ctypes.byref(ms), A.stream_ptr()), 'be_diag_stream_read')
+        return round(buf.numel() * 4 / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None
+    except Exception as e:      # a diagnostic must never sink the number
+        print(f'[bench] read ceiling not measured: {e!r}', file=sys.stderr, flush=True)
+        return None
+
+
 def _stats(a):
     return None if a is None or len(a) == 0 else {'mean': round(float(np.mean(a)), 5), 'median': round(float(np.median(a)), 5)}
 
@@ -424,12 +446,45 @@ def run_jitc(args, dev, g):
                     'basis': 'no SQ counter pass exists for this configuration (profiles/sq_counters.json covers C3 at its default size)',
                     'equivalent_stored_matrix_GBps': round(8 * upd / (kern_ms * 1e-3) / 1e9, 1)}
     line = _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+    if args.jit_shard <= 1:
+        try:
+            line['parity_check'] = jitc_parity(M, spikes[(args.warmup + args.steps - 1) % n_batch], out, args.jit_gather)
+        except Exception as e:
+            line['parity_check'] = {'error': None, 'ok': False, 'what': 'check failed to run: ' + repr(e)[:200]}
     if not args.no_cpu and not args.jit_gather:
         try:
             line['cpu_baseline'] = cpu_baseline_jitc(n, prob, args.fire, min(args.cpu_seconds, 6.0))
         except Exception as e:
             line['cpu_baseline'] = {'error': repr(e)}
     return line
+
+
+def jitc_parity(M, spk, out, gather):
+    """One number for the last timed JITC step (weight 1: outputs are edge counts, exact in f32).
+    scatter (corder=True: the walk owners are the rows of M): sum(out) == the entries of the active rows, counted by the
+    materialisation's count pass (be_jitc_csr_count) — no matrix is stored.
+    gather (corder=False: M materialises column-wise): every one of 4096 sampled outputs == the number of active rows among that
+    column's materialised entries (be_jitc_csr_count + be_jitc_csr_fill: the 1.6e10-entry CSC of C3 is 64 GB, dropped afterwards)."""
+    if not gather:
+        cnt = M.owner_counts('mv')
+        want = int(cnt[spk].to(torch.int64).sum().item())
+        got = float(out.double().sum().item())
+        return {'what': 'sum(out) vs edges of the active rows from be_jitc_csr_count (exact)', 'error': abs(got - want), 'ok': got == want,
+                'edges': want}
+    csc = M.materialize('mv')
+    ptr, idx = csc.indptr, csc.indices
+    gsel = torch.Generator(device=out.device)
+    gsel.manual_seed(5)
+    cols = torch.randint(0, out.numel(), (4096,), device=out.device, generator=gsel)
+    b, ln = ptr[cols], ptr[cols + 1] - ptr[cols]
+    tot = int(ln.sum().item())
+    off = torch.repeat_interleave(b - torch.cumsum(ln, 0) + ln, ln) + torch.arange(tot, device=out.device)
+    hits = spk[idx[off].long()].to(torch.float64)
+    ref = torch.zeros(cols.numel(), dtype=torch.float64, device=out.device)
+    ref.index_add_(0, torch.repeat_interleave(torch.arange(cols.numel(), device=out.device), ln), hits)
+    err = float((out[cols].double() - ref).abs().max().item())
+    del csc, ptr, idx
+    return {'what': '4096 sampled outputs vs active rows among the materialised column entries (exact)', 'error': err, 'ok': err == 0.0}
 
 
 def run_fcn(args, dev, g):
@@ -472,8 +527,27 @@ def run_fcn(args, dev, g):
     roof = hbm_roofline(alg, whole, traffic=traffic_lookup('c4_homo' if args.homo else 'c4_hetero') if default_c4 else None,
                         kernel='whole step (HIP events): compaction + ' + cfg['route'] + ' kernels',
                         extra={'dominant_kernel_ms': round(kern_ms, 5) if kern_ms else None})
+    try:          # last timed step vs f64 index_add of the active rows' entries (homo: the exact integer histogram)
+        rows = torch.nonzero(spikes[(args.warmup + args.steps - 1) % n_batch]).flatten()
+        ref = torch.zeros(n_post, dtype=torch.int64 if args.homo else torch.float64, device=dev)
+        for lo in range(0, rows.numel(), 20000):
+            r = rows[lo:lo + 20000]
+            if args.homo:
+                ref += torch.bincount(idx[r].flatten().long(), minlength=n_post)
+            else:
+                ref.index_add_(0, idx[r].flatten().long(), w[r].flatten().double())
+        if args.homo:
+            err = float((out.double() - ref.double() * float(w.flatten()[0])).abs().max().item())
+        else:
+            err = float(((out.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
+        parity = {'what': 'last timed step vs ' + ('integer histogram (max abs diff)' if args.homo else 'f64 index_add (max rel err)'),
+                  'error': err, 'ok': bool(err == 0.0 if args.homo else err <= 1e-5)}
+        del ref, rows
+    except Exception as e:
+        parity = {'error': None, 'ok': False, 'what': 'check failed to run: ' + repr(e)[:200]}
     del conn, w, idx
     line = _line(metric, value, args, elapsed, 'f32', cfg, roof, kern, step_ms)
+    line['parity_check'] = parity
     if not args.no_cpu:
         try:      # FixedNumPerPre is a CSR of equal rows: the reference's loop (_fcn/binary.py:167-200) is the CSR scatter loop
             torch.cuda.empty_cache()
@@ -502,8 +576,21 @@ def run_dense(args, dev, g):
            'active_pairs': pairs}
     roof = hbm_roofline(union * n * 2 + args.batch * n * 2, kern_ms, kernel='k_densemm_mfma',
                         traffic=traffic_lookup('c5') if (n == 65536 and args.batch == 32 and args.fire == 0.01) else None) if kern_ms else None
+    try:          # last timed step on 64 sampled output columns vs an f64 matmul of the same operands
+        gsel = torch.Generator(device=dev)
+        gsel.manual_seed(5)
+        cols = torch.randint(0, n, (64,), device=dev, generator=gsel)
+        S = spikes[(args.warmup + args.steps - 1) % n_batch]
+        ref = S.double() @ W[:, cols].double()
+        o = out if isinstance(out, torch.Tensor) else torch.as_tensor(out, device=dev)
+        err = float(((o[:, cols].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item())
+        parity = {'what': 'max abs err / max |ref| over 64 sampled output columns vs f64 matmul (f16 outputs: bar 2e-3)', 'error': err,
+                  'ok': bool(err <= 2e-3)}
+    except Exception as e:
+        parity = {'error': None, 'ok': False, 'what': 'check failed to run: ' + repr(e)[:200]}
     del W
     line = _line(metric, value, args, elapsed, 'f16', cfg, roof, kern, step_ms)
+    line['parity_check'] = parity
     if not args.no_cpu:
         try:
             line['cpu_baseline'] = cpu_baseline_dense(n, args.batch, args.fire, min(args.cpu_seconds, 6.0))
@@ -578,6 +665,41 @@ def _line(metric, value, args, elapsed, dtype, cfg, roof, kern, step_ms):
             'kernel_ms': _stats(kern), 'step_ms_hip_events': _stats(step_ms)}
 
 
+# seconds per 1e5 steps the reference's examples print for themselves (examples/COBA_2005.py:98-125, examples/CUBA_2005.py:96-123),
+# keyed by scale: (A6000, Ryzen 7 7840HS); firing rates 50.6 Hz (COBA) and 24-25 Hz (CUBA)
+REFERENCE_TABLE = {'C1_coba': {1: (2.66, 4.44), 10: (3.17, 27.81), 100: (11.70, 215.45), 'rate': (50.6, 1.0)},
+                   'C1_cuba': {1: (2.64, 1.17), 10: (3.04, 16.45), 100: (11.41, 145.35), 'rate': (24.5, 2.5)}}
+
+
+def network_sweep(name, fname, scales=(1, 10, 100), steps=100_000, unroll=None):
+    """The reference's own size sweep of its COBA / CUBA example on this build: seconds per 1e5 time steps (the duration the
+    reference simulates) and the firing rate at each scale, beside the published figures."""
+    import importlib.util
+    unroll = unroll or int(os.environ.get('BENCH_NETWORK_UNROLL', 10))
+    path = os.path.join(ROOT, 'examples', fname)
+    spec = importlib.util.spec_from_file_location(fname[:-3] + '_example', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = REFERENCE_TABLE[name]
+    sweep, ok = [], True
+    first = None
+    for sc in scales:
+        n, el, rate, _, _ = mod.run_fused(float(sc), steps, graph=True, unroll=unroll)
+        first = first or (n, el, rate)
+        ok = ok and abs(rate - ref['rate'][0]) <= ref['rate'][1]
+        sweep.append({'scale': sc, 'neurons': n, 's_per_1e5_steps': round(el * 1e5 / steps, 3), 'rate_hz': round(rate, 2),
+                      'ref_a6000_s': ref[sc][0], 'ref_ryzen_s': ref[sc][1]})
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    n, el, rate = first
+    return {'metric': f'time per 0.1-ms step of the 4000-neuron network of examples/{fname} (two BinaryArray @ CSR scatters + the fused '
+                      f'neuron step, HIP graph of {unroll} steps per replay)', 'value': round(el / steps * 1e6, 2), 'unit': 'us/step',
+            'higher_is_better': False, 'steps': steps, 'neurons': n, 'firing_rate_hz': round(rate, 2),
+            'reference_firing_rate_hz': ref['rate'][0], 'sweep': sweep,
+            'parity_check': {'what': f"firing rate within {ref['rate'][1]} Hz of the reference's {ref['rate'][0]} Hz at every scale",
+                             'error': round(max(abs(r['rate_hz'] - ref['rate'][0]) for r in sweep), 3), 'ok': bool(ok)}}
+
+
 SECONDARY = {'jitc': run_jitc, 'fcn': run_fcn, 'dense': run_dense, 'gather_mirror': run_gather_mirror}
 
 
@@ -647,21 +769,16 @@ def secondary_configs(base):
             out[name] = {'error': repr(e)}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-    # C1 of BASELINE.json (the reference's own CPU-runnable case): the 4000-neuron COBA network of examples/coba_2005.py as a
-    # replayed HIP graph of three launches per 0.1-ms step (two `spikes @ CSR` scatters + the fused neuron step)
-    try:
-        import importlib.util
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'examples', 'coba_2005.py')
-        spec = importlib.util.spec_from_file_location('coba_2005_example', path)
-        coba = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(coba)
-        n, el, rate, _, _ = coba.run_fused(1.0, 10000, graph=True)
-        out['C1_coba'] = {'metric': 'time per 0.1-ms step of the 4000-neuron COBA network (two BinaryArray @ CSR scatters + be_lif_coba_step, '
-                                    'replayed HIP graph)', 'value': round(el / 10000 * 1e6, 2), 'unit': 'us/step', 'higher_is_better': False,
-                          'steps': 10000, 'neurons': n, 'firing_rate_hz': round(rate, 2), 'reference_firing_rate_hz': 50.6,
-                          'synaptic_events_per_s': round(rate * n * 80 / (el / (10000 * 1e-4)), 1)}
-    except Exception as e:
-        out['C1_coba'] = {'error': repr(e)}
+    # C1 of BASELINE.json (the reference's own CPU-runnable case) and the only table the reference publishes for this path: the
+    # COBA / CUBA networks of examples/*_2005.py at scale 1 / 10 / 100 (4000 / 40 000 / 400 000 neurons), 1e5 steps of 0.1 ms each
+    # as the reference runs them — two `spikes @ CSR` scatters + the fused neuron step per time step, replayed as a HIP graph
+    for name, fname in (('C1_coba', 'coba_2005.py'), ('C1_cuba', 'cuba_2005.py')):
+        try:
+            out[name] = network_sweep(name, fname)
+        except Exception as e:
+            out[name] = {'error': repr(e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     return out
@@ -808,30 +925,43 @@ def run_scatter(args):
                 # ncclCommInitRank blocks until every rank has joined: run it beside a watchdog so that a rendezvous that
                 # never completes ends the job with a message instead of hanging it
                 import threading
-                res = {}
+                res, res_lock = {}, threading.Lock()
 
                 def _init():
+                    ex_, err_ = None, None
                     try:
                         torch.cuda.set_device(dev)      # the current HIP device is per thread
-                        res['ex'] = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
+                        ex_ = NativeSpikeExchange(n_pre, world, rank, box[0], device=dev)
                     except Exception as e:          # noqa: BLE001 - reported below, every rank then falls back together
-                        res['err'] = e
+                        err_ = e
+                    with res_lock:                  # publish under the lock; a result nobody waits for any more is closed right here
+                        if res.get('abandoned'):
+                            if ex_ is not None:
+                                ex_.close()
+                            res['late'] = True
+                        else:
+                            res['ex'], res['err'] = ex_, err_
                 th = threading.Thread(target=_init, daemon=True)
                 th.start()
+                # 60 s: a healthy 8-rank ncclCommInitRank on one node takes 2-6 s; a bootstrap that has not finished within ten times
+                # that will not (the 90 s of round 4 only delayed the fallback)
                 th.join(timeout=float(os.environ.get('BENCH_NATIVE_INIT_TIMEOUT', 60)))
-                if th.is_alive():
-                    # ncclCommInitRank has not returned: its bootstrap (sockets between the ranks) is stuck, on this rank or on a peer.
-                    # The job goes on with torch.distributed's own communicator — every rank takes the same path through the MIN
-                    # below — and leaves the daemon thread where it is (it holds no stream; it ends with the process).  The
-                    # measurement then carries ~25 us more host time per step (no RankStep fast path) and says so in `parallelism`.
-                    print(f'[bench] rank {rank}: be_exchange_init did not return within BENCH_NATIVE_INIT_TIMEOUT; continuing with '
-                          f'torch.distributed (as --exchange-impl torch would)', file=sys.stderr, flush=True)
-                    res.clear()
-                    res['err'] = TimeoutError('be_exchange_init timed out')
-                if 'ex' in res:
-                    exchange, ok = res['ex'], 1.0
-                else:           # an error every rank can recover from together (the MIN below): torch.distributed instead
-                    print(f'[bench] rank {rank}: be_exchange_init failed ({res.get("err")!r})', file=sys.stderr, flush=True)
+                with res_lock:
+                    if 'ex' not in res and 'err' not in res:
+                        # ncclCommInitRank has not returned: its bootstrap (sockets between the ranks) is stuck, on this rank or on a
+                        # peer.  The job goes on with torch.distributed's own communicator — every rank takes the same path through
+                        # the MIN below; the thread closes its handle itself should it ever get one.  The line records it, and a rank
+                        # whose thread is still inside the call when its work is done leaves with os._exit (main()).
+                        res['abandoned'] = True
+                        res['err'] = TimeoutError('be_exchange_init timed out')
+                        _STATE['exchange_init_timed_out'] = True
+                        _STATE['init_thread'] = th
+                        print(f'[bench] rank {rank}: be_exchange_init did not return within BENCH_NATIVE_INIT_TIMEOUT; continuing with '
+                              f'torch.distributed (as --exchange-impl torch would)', file=sys.stderr, flush=True)
+                    if res.get('ex') is not None:
+                        exchange, ok = res['ex'], 1.0
+                    else:           # an error every rank can recover from together (the MIN below): torch.distributed instead
+                        print(f'[bench] rank {rank}: be_exchange_init failed ({res.get("err")!r})', file=sys.stderr, flush=True)
             flag = torch.tensor([ok], dtype=torch.float64, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
             if flag.item() < 1.0:
@@ -940,6 +1070,12 @@ def run_scatter(args):
     breakdown = None
     fast = use_dist and rank_step is not None and rank_step._fast is not None
     if use_dist and not mock:
+        # the two host paths below issue different numbers of collectives: every rank must take the same one (a rank whose shard fell
+        # back to the direct route has no fast path) — agreed with a MIN, like the native init result
+        agree = torch.tensor([1.0 if fast else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        fast = bool(agree.item() >= 1.0)
+    if use_dist and not mock:
         def timed(fn_i, prime=None, finish=None):
             if prime:
                 prime()
@@ -1003,23 +1139,10 @@ def run_scatter(args):
     value = total_upd / elapsed / 1e9
     checksum = float(out.double().sum().item())
 
-    copy_gbps = None
+    read_gbps = None
     line = None
     if rank == 0 and args.emulate_world <= 1 and not mock:
-        try:
-            src = torch.empty(1 << 29, dtype=torch.float32, device=dev)       # 2 GiB
-            dst = torch.empty_like(src)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            dst.copy_(src)
-            e0.record()
-            for _ in range(5):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbps = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del src, dst
-        except Exception:
-            copy_gbps = None
+        read_gbps = read_ceiling_gbps(dev)
     if rank == 0:
         timed = [(args.warmup + i) % n_batch for i in range(args.steps)]
         bytes_per_upd = 4 if args.homo else 8           # int32 index (+ f32 weight)
@@ -1036,9 +1159,12 @@ def run_scatter(args):
                 traffic = traffic_lookup('c2_rank_of_8')
         roof = hbm_roofline(alg_bytes, kern_ms, traffic=traffic, kernel=kernel_name,
                             extra={'kernel_ms_median': round(float(np.median(kern)), 5) if kern is not None else None,
-                                   # the same run's device-copy ceiling (bytes read + written per second
-                                   # of a 2 GiB device-to-device copy) next to the nominal peak
-                                   'device_copy_GBps': copy_gbps})
+                                   # the same run's measured ceiling next to the nominal peak — a READ-ONLY
+                                   # stream (be_diag_stream_read: 2 GiB, 16 B per lane), the ceiling of a read-dominated kernel
+                                   # (a device copy reads AND writes: 4.9 TB/s, below what the accumulate kernel itself moves)
+                                   'read_ceiling_GBps': read_gbps})
+        if roof and read_gbps and roof.get('traffic') and kern_ms:
+            roof['real_frac_of_read_ceiling'] = round(roof['traffic'] / (kern_ms * 1e-3) / 1e9 / read_gbps, 4)
         what = 'FixedNumPerPre' if is_fcn else 'CSR'
         scaling = args.scaling      # how `--gpus N` partitions: strong = this same problem cut into N post slices
         line = {
@@ -1079,6 +1205,8 @@ def run_scatter(args):
         }
         if breakdown is not None:
             line['rank_breakdown'] = breakdown
+        if _STATE.get('exchange_init_timed_out'):
+            line['exchange_init_timed_out'] = True
         if mock:
             line['mock_step'] = True
             line['data'] = 'synthetic (MOCK STEP: plumbing rehearsal on CPU tensors, not a measurement)'
@@ -1097,6 +1225,197 @@ def run_scatter(args):
         if not getattr(args, 'keep_group', False):
             dist.destroy_process_group()
     return line
+
+
+# =====================================================================================================================
+# the printed line: numbers per entry, prose once (the driver's record keeps an 8 KB tail of stdout — the whole line must fit)
+# =====================================================================================================================
+LINE_BYTE_BOUND = 8000
+
+LEGEND = {
+    'timing': 'value, ms_per_step: wall clock over exactly `steps` bare steps between synchronize(+barrier) fences, inputs in HBM; kernel_ms '
+              '(dominant kernel: in-library HIP events on its stream) and step_ms (HIP events, issuing stream): medians of separate '
+              'passes over the same steps',
+    'roofline': 'hbm: frac = SURVEY 8d algorithmic bytes per launch / kernel_ms / 8000 GB/s; real = PMC HBM bytes per launch '
+                '(profiles/traffic.json, separate rocprofv3 --pmc passes) / kernel_ms / peak; real_rd = same / read_ceiling_GBps '
+                '(be_diag_stream_read, 2 GiB, 16 B/lane, this run); C4*: kernel_ms = whole step. valu (C3*): 4 x SQ_ACTIVE_INST_VALU per '
+                'launch (profiles/sq_counters.json) / kernel_ms / (1024 SIMDs x 2.4 GHz)',
+    'parity': '[error, ok], last timed step. headline, C2_homo, ref_tuner_point, C4*, *_rank_of_8: max rel err vs f64 index_add of the '
+              'active rows (homo: max abs diff vs integer histogram); C2_gather_mirror: vs the full-matrix gather kernel; C3: |sum(out) '
+              '- edges of active rows from be_jitc_csr_count|; C3_gather: 4096 sampled outputs vs the materialised columns; C5: max abs '
+              'err / max|ref| on 64 sampled columns vs f64 matmul (bar 2e-3); C1_*: max |rate - reference rate| Hz over the sweep',
+    'cpu_Geff_s': 'oracle C port of the reference numba loop, 1 thread, bounded sample, this host',
+    'rank_breakdown': 'us per step [min, max over ranks]: ex = exchange alone, sc = scatter alone, step = the timed schedule, other = '
+                      'the other schedule (seq <-> ahead: all-gather of step t+1 posted before step t scatters)',
+    'sweep': '[scale, neurons, s per 1e5 steps here, rate Hz, reference A6000 s, reference Ryzen 7840HS s] (examples/COBA_2005.py:98-125, '
+             'CUBA_2005.py:96-123)',
+    'full': 'verbose line (kernel names, bytes, samples): --full-line-file, default gpurun_out/bench_full_line.json',
+}
+
+WORKLOADS = {
+    'C2_gather_mirror': 'CSR @ spk via the CSC mirror, headline matrix', 'C3': 'spk @ JITCScalarR 4M^2 p=1e-3, scatter',
+    'C3_gather': 'same, corder=False (reference default); value = generated Gedges/s', 'C4': 'spk @ FixedNumPerPre K=1000 N=1e7 hetero',
+    'C4_homo': 'same, one weight', 'C5': 'spk[32,64k] @ dense f16 64k^2', 'C2_homo': 'headline, one weight',
+    'ref_tuner_point': '_csr/initialize.py:227-241: n=5e5, 2000/row, homo, 2000 active', 'C2_rank_of_8': 'rank 0 of the 8-way '
+    'post-slice cut of the headline + one-rank RCCL exchange', 'C4_rank_of_8': 'same for C4', 'C1_coba': 'examples/coba_2005.py, HIP '
+    'graph', 'C1_cuba': 'examples/cuba_2005.py', 'C4_strong': 'C4 post-sliced over the N ranks', 'C2_weak': 'a headline slice per rank',
+}
+
+
+def _sig(x, n=4):
+    if isinstance(x, bool) or x is None or isinstance(x, str):
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    x = float(x)
+    if not math.isfinite(x):
+        return None
+    if x == 0.0:
+        return 0
+    r = float(f'{x:.{n}g}')
+    return int(r) if r == int(r) and abs(r) < 1e15 else r
+
+
+def _compact_roof(roof, read_ceiling=None):
+    if not roof:
+        return None
+    out = {k: roof.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
+    out['achieved'], out['frac'] = _sig(out['achieved'], 5), _sig(out['frac'])
+    for k_in, k_out in (('kernel', 'kernel'), ('kernel_ms', 'kernel_ms'), ('real_frac_of_peak', 'real'), ('effective_GBps', 'effective_GBps'),
+                        ('lane_slots_per_edge', 'lane_slots_per_edge')):
+        if roof.get(k_in) is not None:
+            out[k_out] = _sig(roof[k_in], 5) if not isinstance(roof[k_in], str) else roof[k_in].split(' (')[0].split(':')[0]
+    if roof.get('traffic') and roof.get('kernel_ms') and 'real' not in out and roof.get('bound') == 'hbm':
+        out['real'] = _sig(roof['traffic'] / (roof['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    rc = roof.get('read_ceiling_GBps') or read_ceiling
+    if rc and roof.get('traffic') and roof.get('kernel_ms') and roof.get('bound') == 'hbm':
+        out['real_rd'] = _sig(roof['traffic'] / (roof['kernel_ms'] * 1e-3) / 1e9 / rc)
+    return out
+
+
+def _compact_breakdown(rb):
+    if not rb:
+        return None
+    mm = lambda d: None if not d else [_sig(d['min'], 5), _sig(d['max'], 5)]
+    o = rb.get('other_schedule') or {}
+    out = {'schedule': rb['step_us']['schedule'], 'ex': mm(rb['exchange_only_us']), 'sc': mm(rb['scatter_only_us']), 'step': mm(rb['step_us']),
+           'other_schedule': o.get('schedule'), 'other': mm(o.get('step_us'))}
+    for k in ('host_path', 'graph', 'other_graph'):
+        if rb.get(k):
+            out[k] = rb[k].split(' (')[0] if isinstance(rb[k], str) else rb[k]
+    return out
+
+
+def _compact_entry(ln, read_ceiling=None, top=False):
+    if 'error' in ln and 'value' not in ln:
+        return {'error': str(ln['error'])[:160]}
+    e = {'value': _sig(ln['value'], 5)}
+    if ln.get('unit', 'Geff/s') != 'Geff/s':
+        e['unit'] = ln['unit']
+    for k in ('ms_per_step', 'n_gpus'):
+        if k in ln:
+            e[k] = _sig(ln[k], 5)
+    if ln.get('step_ms_hip_events'):
+        e['step_ms'] = _sig(ln['step_ms_hip_events']['median'], 5)
+    r = _compact_roof(ln.get('roofline'), read_ceiling)
+    if r:
+        e['roofline'] = {k: r[k] for k in ('bound', 'frac', 'kernel_ms', 'real', 'real_rd', 'effective_GBps', 'lane_slots_per_edge')
+                         if r.get(k) is not None}
+    pc = ln.get('parity_check')
+    if pc:
+        e['parity'] = [_sig(pc.get('error'), 3), bool(pc.get('ok'))]
+    cb = ln.get('cpu_baseline')
+    if cb and 'value' in cb:
+        e['cpu_Geff_s'] = _sig(cb['value'])
+    rb = _compact_breakdown(ln.get('rank_breakdown'))
+    if rb:
+        e['rank_breakdown'] = rb
+    for k in ('per_call_us', 'firing_rate_hz', 'reference_firing_rate_hz', 'setup_s'):
+        if k in ln:
+            e[k] = ln[k]
+    if 'sweep' in ln:          # rows: [scale, neurons, s per 1e5 steps, rate Hz, reference A6000 s, reference Ryzen s]
+        e['sweep'] = [[r['scale'], r['neurons'], r['s_per_1e5_steps'], r['rate_hz'], r['ref_a6000_s'], r['ref_ryzen_s']] for r in ln['sweep']]
+    cfg = ln.get('config') or {}
+    for k in ('setup_s', 'mirror_build_s', 'speedup_over_gather_kernel'):
+        if cfg.get(k) is not None and k not in e:
+            e[k] = cfg[k] if isinstance(cfg[k], str) else _sig(cfg[k])
+    return e
+
+
+def compact_line(line):
+    """The line as printed: the driver contract's keys in full on the headline, numbers only per secondary, every prose string once in
+    `legend` (LEGEND / WORKLOADS).  The verbose form (what run_* return) goes to --full-line-file."""
+    roof = line.get('roofline') or {}
+    rc = roof.get('read_ceiling_GBps')
+    out = {k: line.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data')}
+    cfg = line.get('config') or {}
+    out['config'] = {k: (_sig(cfg[k], 12) if not isinstance(cfg[k], str) else cfg[k]) for k in
+                     ('workload', 'parallelism', 'n_post_per_gpu', 'n_conn', 'stored_synapses_total', 'plan_slices', 'plan_GB', 'setup_s',
+                      'mean_active_rows', 'checksum') if cfg.get(k) is not None}
+    if line.get('step_ms_hip_events'):
+        out['step_ms'] = _sig(line['step_ms_hip_events']['median'], 5)
+    pc = line.get('parity_check')
+    if pc:
+        out['parity_check'] = {k: _sig(pc[k], 12) for k in ('error', 'ok', 'stored_synapses_all_ranks', 'expected_stored_synapses') if k in pc}
+    r = _compact_roof(roof)
+    if r:
+        for k in ('algorithmic_bytes_per_launch', 'traffic_GBps', 'read_ceiling_GBps', 'kernel_ms_median'):
+            if roof.get(k) is not None:
+                r[k] = _sig(roof[k], 10 if k.startswith('alg') else 5)
+    out['roofline'] = r
+    cb = line.get('cpu_baseline')
+    if cb:
+        c = {k: (_sig(cb[k]) if not isinstance(cb[k], str) else cb[k]) for k in ('value', 'unit', 'cores', 'kind', 'sample', 'host_cpus', 'error')
+             if k in cb}
+        pv = cb.get('parallel_atomics_variant')
+        if pv and 'value' in pv:
+            c['omp_atomics_variant'] = {'value': _sig(pv['value']), 'cores': pv['cores']}
+        out['cpu_baseline'] = c
+    rb = _compact_breakdown(line.get('rank_breakdown'))
+    if rb:
+        out['rank_breakdown'] = rb
+    for k in ('mock_step', 'exchange_init_timed_out', 'extras'):
+        if k in line:
+            out[k] = line[k]
+    sec = line.get('secondary')
+    if isinstance(sec, dict):
+        out['secondary'] = {k: (_compact_entry(v, rc) if isinstance(v, dict) else v) for k, v in sec.items()}
+        wl = {k: WORKLOADS[k] for k in sec if k in WORKLOADS}
+    else:
+        wl = {}
+    out['legend'] = dict(LEGEND, workloads=wl) if isinstance(sec, dict) else {k: LEGEND[k] for k in ('timing', 'roofline', 'full')}
+    has_rb = bool(line.get('rank_breakdown')) or (isinstance(sec, dict) and any(isinstance(v, dict) and v.get('rank_breakdown')
+                                                                                  for v in sec.values()))
+    if has_rb:
+        out['legend']['rank_breakdown'] = LEGEND['rank_breakdown']
+    else:
+        out['legend'].pop('rank_breakdown', None)
+    if not (isinstance(sec, dict) and any(isinstance(v, dict) and 'sweep' in v for v in sec.values())):
+        out['legend'].pop('sweep', None)
+    return out
+
+
+def emit(line, args):
+    """Rank 0: the verbose line to --full-line-file, the compact one (or the verbose one with --full-line) on stdout."""
+    full = json.dumps(_finite(line), allow_nan=False)
+    path = getattr(args, 'full_line_file', '')
+    if path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, 'w') as f:
+                f.write(full + '\n')
+        except OSError:
+            pass
+    if getattr(args, 'full_line', False):
+        print(full, flush=True)
+        return
+    txt = json.dumps(_finite(compact_line(line)), allow_nan=False, separators=(',', ':'))
+    if len(txt) > LINE_BYTE_BOUND:          # never silently outgrow the driver's record: drop the legend's workload map, then say so
+        c = compact_line(line)
+        c['legend'] = {'see': 'bench.py LEGEND / WORKLOADS', 'line_bytes_before_trim': len(txt)}
+        txt = json.dumps(_finite(c), allow_nan=False, separators=(',', ':'))
+    print(txt, flush=True)
 
 
 def _finite(o):
@@ -1120,60 +1439,94 @@ def multi_rank_extras(args, line, world):
         the exchange is added),
     and rank 0 attaches both to `secondary` of the ONE line it prints.  A watchdog bounds the legs together
     (BENCH_EXTRAS_SECONDS, default 240 s): when it expires every rank stops where it is — rank 0 prints the headline line it
-    already has, with whatever legs finished — and the process ends; a failure or a stall in a leg can therefore never cost the
-    headline.  (`value` of a leg = synaptic updates of all ranks per second, as for the headline.)"""
+    already has, with whatever legs finished and `extras` = {incomplete: why, leg, rank} — and the process ends with a NON-ZERO status
+    (3 = stalled, 4 = a leg raised on this rank; the line is on stdout by then).  The watchdog stays armed through the closing
+    barrier, and a rank whose leg raises prints / leaves before it could enter another collective: a failure or a stall in a leg can
+    cost the legs and the exit status, never the headline.  (`value` of a leg = synaptic updates of all ranks per second.)"""
     import threading
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     done = threading.Event()
     out = {}
+    state = {'leg': None}
     if line is not None:
         line['secondary'] = out
 
-    headline = None if line is None else json.dumps(_finite({k: v for k, v in line.items() if k != 'secondary'}), allow_nan=False)
-
-    def emit_and_exit():
+    def emit_and_exit(why, code):
+        """Rank 0 prints the line as it stands (a snapshot of the legs: the main thread may be filling `out` right now), every rank
+        then leaves at once with `code` — nothing runs interpreter teardown over a collective that is still in flight."""
         try:
             if rank == 0 and line is not None:
-                try:            # (the main thread may be filling `out` at this moment: a snapshot, and the bare headline if that fails)
-                    snap = dict(out)
-                    snap.setdefault('note', 'the extra legs did not finish within BENCH_EXTRAS_SECONDS; the headline is complete')
-                    txt = json.dumps(_finite({**{k: v for k, v in line.items() if k != 'secondary'}, 'secondary': snap}), allow_nan=False)
+                snap = {k: v for k, v in list(out.items())}
+                ln = {k: v for k, v in line.items() if k != 'secondary'}
+                ln['secondary'] = snap
+                ln['extras'] = {'incomplete': why, 'leg': state['leg'], 'rank': rank}
+                try:
+                    emit(ln, args)
                 except Exception:
-                    txt = headline
-                print(txt, flush=True)
+                    ln['secondary'] = {}
+                    emit(ln, args)
         finally:
-            os._exit(0)
+            sys.stdout.flush()
+            os._exit(code)
 
     def watchdog():
+        # armed until the process group is gone: a rank that waits in the closing barrier for a peer that never arrives is ended here too
         if not done.wait(float(os.environ.get('BENCH_EXTRAS_SECONDS', 240))):
-            emit_and_exit()
+            print(f'[bench] rank {rank}: extra leg {state["leg"]} did not finish within BENCH_EXTRAS_SECONDS', file=sys.stderr, flush=True)
+            emit_and_exit(f'timed out in leg {state["leg"]} (BENCH_EXTRAS_SECONDS)', 3)
     threading.Thread(target=watchdog, daemon=True).start()
+    # A launcher that sees one rank fail sends SIGTERM to the others (torch.distributed.run does) — while their main thread sits inside a
+    # collective, where no Python-level handler runs.  The C-level handler writes the signal number to a pipe at once; a thread reads it
+    # and prints / leaves as the watchdog would.
+    try:
+        import signal
+        r_fd, w_fd = os.pipe()
+        os.set_blocking(w_fd, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(w_fd, warn_on_full_buffer=False)
+
+        def on_signal():
+            os.read(r_fd, 1)
+            if not done.is_set():
+                emit_and_exit(f'SIGTERM from the launcher during leg {state["leg"]} (a peer rank failed)', 3)
+        threading.Thread(target=on_signal, daemon=True).start()
+    except Exception as e:          # (not the main thread, or no signals on this platform: the watchdog alone then)
+        print(f'[bench] rank {rank}: no SIGTERM relay ({e!r})', file=sys.stderr, flush=True)
+    mock = os.environ.get('BENCH_MOCK_STEP') == '1'
     legs = (('C4_strong', ['--workload', 'fcn', '--steps', '100', '--warmup', '20']),
             ('C2_weak', ['--scaling', 'weak', '--steps', '100', '--warmup', '20']))
     for i, (name, extra) in enumerate(legs):
         a = parse(['--gpus', str(args.gpus), '--no-cpu', '--no-secondary', '--exchange', args.exchange, '--exchange-impl', args.exchange_impl]
                   + extra + os.environ.get('BENCH_EXTRAS_ARGS', '').split())        # (BENCH_EXTRAS_ARGS: smaller sizes for rehearsals)
         a.keep_group = True
+        state['leg'] = name
         try:
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
+            if not mock:
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+            if os.environ.get('BENCH_EXTRAS_FAIL') == f'{name}:{rank}':      # rehearsal hook (tests/test_bench_launch_cpu.py)
+                raise RuntimeError('injected failure')
             ln = run_scatter(a)
             if ln is not None:
                 out[name] = {k: ln[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'scaling',
-                                                'parity_check', 'roofline', 'rank_breakdown') if k in ln}
+                                                'parity_check', 'roofline', 'rank_breakdown', 'step_ms_hip_events') if k in ln}
                 out[name]['config'] = {k: ln['config'][k] for k in ('workload', 'parallelism', 'n_post_per_gpu', 'setup_s', 'data_gen_s')
                                        if k in ln['config']}
-        except Exception as e:          # (an exception on one rank only would leave the others in a collective: the watchdog ends that)
-            out[name] = {'error': repr(e)}
+        except Exception as e:
+            # This rank is out of step with the others (they are inside the leg's collectives, or will be): it must not enter another
+            # collective.  Rank 0 prints what it has at once; every rank that fails leaves with a non-zero status — the peers are then
+            # ended by their communicator's abort or by their own watchdog, whichever comes first.
+            out[name] = {'error': repr(e)[:300], 'rank': rank}
             print(f'[bench] rank {rank}: leg {name} failed: {e!r}', file=sys.stderr, flush=True)
-            break
-    done.set()
+            emit_and_exit(f'leg {name} raised on rank {rank}: {e!r}'[:200], 4)
+    state['leg'] = 'closing barrier'
     try:
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
         pass
+    done.set()
     return line
 
 
@@ -1203,7 +1556,7 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ['BENCH_FAULT_TIMEOUT']), exit=False, file=sys.stderr)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     extra_legs = (world > 1 and args.workload == 'csr' and args.scaling == 'strong' and not args.no_secondary and args.emulate_world <= 1
-                  and os.environ.get('BENCH_MOCK_STEP') != '1'
+                  and (os.environ.get('BENCH_MOCK_STEP') != '1' or os.environ.get('BENCH_EXTRAS_FORCE') == '1')
                   and ((args.n == 1_000_000 and args.conn == 0.01 and args.fire == 0.01) or os.environ.get('BENCH_EXTRAS_FORCE') == '1'))
     args.keep_group = extra_legs
     line = run_scatter(args)
@@ -1214,7 +1567,13 @@ def main():
         torch.cuda.empty_cache()
         line['secondary'] = secondary_configs(args)
     if line is not None:
-        print(json.dumps(_finite(line), allow_nan=False), flush=True)
+        emit(line, args)
+    th = _STATE.get('init_thread')
+    if th is not None and th.is_alive():
+        # a thread of this process is still inside ncclCommInitRank (be_exchange_init never returned): no interpreter teardown over it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(5)
 
 
 if __name__ == '__main__':

@@ -25,7 +25,7 @@ from ._float import (csrmv, csrmm, csrmv_p, csrmm_p, csrmv_p_call, csrmm_p_call,
 from ._graph import GraphedStep, capture_step
 from ._tuning import (ScatterTuning, DEFAULT_SCATTER_TUNING, get_scatter_tuning, save_scatter_tuning, apply_scatter_tuning,
                       tune_scatter_routes)
-from ._neuron import lif_coba_step
+from ._neuron import lif_coba_step, lif_cuba_step
 from ._op import OpKernel
 XLACustomKernel = OpKernel      # the operator object under the reference's name (no XLA underneath)
 from ._data import DataRepresentation

@@ -626,8 +626,9 @@ _LIVE_BINNED: 'weakref.WeakSet' = weakref.WeakSet()
 
 def check_binned_status(clear: bool = True) -> None:
     """:meth:`BinnedScatter.check_status` of every live binned workspace: raises ``KernelExecutionError`` if any step since the
-    last call gave up on its append protocol (its outputs were NaN) or broke the conservation of its entries.  Synchronises — call
-    it where the program synchronises anyway (after a batch of replays of a captured graph, at the end of an epoch, in a test)."""
+    last call gave up on its append protocol (its outputs were NaN) or broke the conservation of its entries.  Synchronises every
+    device that holds a workspace (all streams: a replay in flight on another stream is waited for, not read mid-step) — call it
+    where the program synchronises anyway (after a batch of replays of a captured graph, at the end of an epoch, in a test)."""
     for ws in list(_LIVE_BINNED):
         ws.check_status(clear=clear)
 
@@ -733,11 +734,16 @@ class BinnedScatter:
     def check_status(self, clear: bool = True) -> None:
         """Raise ``KernelExecutionError`` if a step on one of this object's workspaces gave up on its append protocol (such a
         step wrote NaN outputs instead of trapping the device) or if the workspace's conservation counters disagree — an entry
-        lost or delivered twice between the row bounds and the accumulators (``be_binned_workspace_status``).  Synchronises;
-        call it at a point that synchronises anyway (the containers do after a mirror build; ``bench.py`` at its parity check)."""
+        lost or delivered twice between the row bounds and the accumulators (``be_binned_workspace_status``).  Synchronises the
+        WHOLE device each workspace lives on before reading it (a step or a graph replay still running on another stream would be
+        read between its passes — a spurious conservation error — and ``clear`` would zero the counters under it), and reads a
+        workspace through its own device; call it at a point that synchronises anyway (the containers do after a mirror build;
+        ``bench.py`` at its parity check)."""
         f = fn('be_binned_workspace_status', c_int, [c_vp, c_int, c_vp])
         for ws in self._ws.values():
-            check(f(A.ptr(ws), int(clear), A.stream_ptr()), 'be_binned_workspace_status')
+            with torch.cuda.device(ws.device):
+                torch.cuda.synchronize(ws.device)
+                check(f(A.ptr(ws), int(clear), A.stream_ptr()), 'be_binned_workspace_status')
 
     def _column_stats_by_steps(self, weights: torch.Tensor, indices: torch.Tensor):
         """``(largest column sum of |w|, smallest column mean of |w| over the non-empty columns, max |w|, min non-zero |w|)``

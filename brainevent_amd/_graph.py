@@ -20,8 +20,11 @@ class GraphedStep:
     captured call.  ``fn`` must read its inputs from tensors that stay at the same addresses (update them in place with
     ``copy_`` between replays) and must not synchronise or branch on device values."""
 
-    def __init__(self, fn: Callable[[], Any], warmup: int = 3):
+    def __init__(self, fn: Callable[[], Any], warmup: int = 3, repeat: int = 1):
         require_device()
+        if repeat < 1:
+            raise ValueError('capture_step: repeat must be >= 1')
+        self.repeat = int(repeat)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -31,7 +34,8 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.outputs = fn()
+            for _ in range(self.repeat):          # repeat > 1: that many consecutive steps of an in-place step function per replay
+                self.outputs = fn()
 
     def __call__(self):
         self.graph.replay()
@@ -44,5 +48,7 @@ class GraphedStep:
         check_binned_status()
 
 
-def capture_step(fn: Callable[[], Any], warmup: int = 3) -> GraphedStep:
-    return GraphedStep(fn, warmup=warmup)
+def capture_step(fn: Callable[[], Any], warmup: int = 3, repeat: int = 1) -> GraphedStep:
+    """``repeat`` consecutive invocations of ``fn`` are recorded into the one graph (a step function that advances its state in
+    place: one replay = ``repeat`` time steps, one host call instead of ``repeat``)."""
+    return GraphedStep(fn, warmup=warmup, repeat=repeat)

@@ -105,15 +105,23 @@ def _jit_params(family: str, a, b):
 
 
 # Scatter workspaces are kept and ARMED (be_jit_scatter_workspace_arm): their spike counters are zeroed once and every later call
-# skips the zeroing launch.  One workspace per (device, stream, size), a few at most (least recently used first out: disarmed and
-# released); a call that raises drops its workspace.  Gather workspaces have no counters and stay per-call allocations.
+# skips the zeroing launch.  One workspace per (device, stream, layout, size) — the layout tag is ('mv',) or ('mm', batch columns):
+# two batch shapes of equal byte size place their counter regions differently, and an armed workspace is only clean where ITS
+# layout re-arms it — a few at most (least recently used first out: disarmed and released); a call that raises drops its workspace.
+# Gather workspaces have no counters and stay per-call allocations.
+# While the stream is CAPTURING the cache is not used at all: a graph records raw pointers, so a captured call takes a per-call,
+# unarmed workspace from the graph's private pool (it lives as long as the graph; the call zeroes its counters itself, as every
+# call did before workspaces were armed) — an eviction here can never pull memory from under a replay, and no eager call can run
+# on a workspace a replay is using.
 _ARMED_MAX = 8
 _armed: 'Dict[tuple, torch.Tensor]' = {}
 
 
-def _armed_scatter_workspace(nbytes: int) -> torch.Tensor:
+def _armed_scatter_workspace(nbytes: int, layout: tuple = ('mv',)) -> torch.Tensor:
+    if torch.cuda.is_current_stream_capturing():
+        return A.workspace(nbytes)
     st = A.stream_ptr()
-    key = (A.device().index, int(getattr(st, 'value', st) or 0), int(nbytes))
+    key = (A.device().index, int(getattr(st, 'value', st) or 0), tuple(layout), int(nbytes))
     ws = _armed.pop(key, None)
     if ws is None:
         while len(_armed) >= _ARMED_MAX:
@@ -171,7 +179,7 @@ def _jitmm_hip(family, a, b, clen, B, seed, *, shape, transpose, corder, out_dty
     w0, w1, _ = _jit_params(family, a, b)
     f_ws = fn('be_binary_jitmm_workspace_bytes', c_i64, [c_i64, c_i64, c_i64, c_i64, c_int])
     nbytes = f_ws(int(shape[1]), in_len, out_len, n, 1 if corder else 0)
-    ws = A.workspace(nbytes) if corder else _armed_scatter_workspace(nbytes)
+    ws = A.workspace(nbytes) if corder else _armed_scatter_workspace(nbytes, ('mm', n))
     name = f"be_binary_jit{family}mm_{'notrans' if corder else 'trans'}_{A.wsuffix(out_bm)}"
     f = fn(name, c_int, _MM_ARGS)
     try:
@@ -704,15 +712,9 @@ class JITCMatrix(DataRepresentation):
         """The drawn connectivity as a :class:`CSC` of ``self.shape``."""
         return self.materialize(matrix_mode).tocsc()
 
-    def materialize(self, matrix_mode: str = 'mv'):
-        """Materialise the drawn connectivity on the device.  ``matrix_mode`` picks the matrix of the ``mv`` ops
-        (lane stride 32) or of the ``mm`` ops (stride 4) — they differ, as in the reference.
-
-        The generator matrix has the walk owners as rows; for a logical matrix it is the CSR form when the walk
-        owners are the logical rows and the CSC form otherwise, so this returns a :class:`CSR` or a :class:`CSC`
-        of ``self.shape`` (both multiply identically).  f32 weights.
-        """
-        from ._csr import CSR, CSC
+    def _owner_counts(self, matrix_mode: str = 'mv'):
+        """The count pass of :meth:`materialize` (``be_jitc_csr_count``): stored entries per generator row — the rows of
+        ``self.shape`` when the walk owners are the logical rows (CSR form), its columns otherwise (CSC form)."""
         if matrix_mode not in ('mv', 'mm'):
             raise ValueError(f"matrix_mode must be 'mv' or 'mm', got {matrix_mode!r}.")
         stride = 32 if matrix_mode == 'mv' else 4
@@ -726,11 +728,30 @@ class JITCMatrix(DataRepresentation):
         n_rows, walk = (out_len, in_len) if corder else (in_len, out_len)
         dev = A.device()
         clen = _initialize_conn_length(self.prob)
-        w0, w1, _ = _jit_params(self._family, *(self._weights + (None,))[:2])
         counts = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
         f_cnt = fn('be_jitc_csr_count', c_int, [c_i64, c_u32, c_i64, c_i64, c_i64, c_int, c_vp, c_vp])
         check(f_cnt(clen, self.seed & 0xFFFFFFFF, int(gshape[1]), n_rows, walk, stride, A.ptr(counts), A.stream_ptr()),
               'be_jitc_csr_count')
+        return counts, (gshape, n_rows, walk, stride, clen, corder)
+
+    def owner_counts(self, matrix_mode: str = 'mv') -> torch.Tensor:
+        """Stored entries per walk owner (int32, on the device) without materialising the matrix: entries per ROW of ``self.shape``
+        when ``materialize()`` would return a CSR, per COLUMN when it would return a CSC."""
+        counts, (_, n_rows, *_rest) = self._owner_counts(matrix_mode)
+        return counts[:n_rows]
+
+    def materialize(self, matrix_mode: str = 'mv'):
+        """Materialise the drawn connectivity on the device.  ``matrix_mode`` picks the matrix of the ``mv`` ops
+        (lane stride 32) or of the ``mm`` ops (stride 4) — they differ, as in the reference.
+
+        The generator matrix has the walk owners as rows; for a logical matrix it is the CSR form when the walk
+        owners are the logical rows and the CSC form otherwise, so this returns a :class:`CSR` or a :class:`CSC`
+        of ``self.shape`` (both multiply identically).  f32 weights.
+        """
+        from ._csr import CSR, CSC
+        counts, (gshape, n_rows, walk, stride, clen, corder) = self._owner_counts(matrix_mode)
+        dev = counts.device
+        w0, w1, _ = _jit_params(self._family, *(self._weights + (None,))[:2])
         indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts[:n_rows].to(torch.int64), 0, out=indptr[1:])
         nnz = int(indptr[-1].item())

@@ -139,6 +139,58 @@ int be_profile_enable(int max_records) {
   return BE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// read-only streaming ceiling of this device, measured in the caller's run (bench.py: `roofline.read_ceiling_GBps`):
+// 16 B per lane, grid-stride, 2048 workgroups of 256 — the shape profiles/r01_ubench.txt found fastest.
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+typedef unsigned diag_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_diag_stream_read(const diag_u4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    const diag_u4 v = __builtin_nontemporal_load(p + i);
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u) sink[0] = acc;      // (keeps the loads; practically never taken)
+}
+}  // namespace
+extern "C" {
+
+int be_diag_stream_read(const void* buf, int64_t bytes, int repeats, void* sink4, float* ms_per_pass, be_stream_t stream) {
+  if (!buf || !sink4 || !ms_per_pass || bytes < 16 || repeats < 1 || (reinterpret_cast<uintptr_t>(buf) & 15)) {
+    be_set_error("be_diag_stream_read: needs a 16-byte-aligned buffer of >= 16 bytes, a 4-byte sink, repeats >= 1");
+    return BE_ERR_INVALID;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  hipError_t rc = hipEventCreate(&e0);
+  if (rc == hipSuccess) rc = hipEventCreate(&e1);
+  const size_t n16 = (size_t)bytes >> 4;
+  if (rc == hipSuccess) {
+    hipLaunchKernelGGL(k_diag_stream_read, dim3(2048), dim3(256), 0, st, static_cast<const diag_u4*>(buf), n16,
+                       static_cast<unsigned*>(sink4));      // warm
+    rc = hipEventRecord(e0, st);
+    for (int r = 0; r < repeats; ++r)
+      hipLaunchKernelGGL(k_diag_stream_read, dim3(2048), dim3(256), 0, st, static_cast<const diag_u4*>(buf), n16,
+                         static_cast<unsigned*>(sink4));
+    if (rc == hipSuccess) rc = hipEventRecord(e1, st);
+    if (rc == hipSuccess) rc = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, e0, e1);
+    if (rc == hipSuccess) rc = hipGetLastError();
+    *ms_per_pass = ms / (float)repeats;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != hipSuccess) {
+    be_set_error(std::string("be_diag_stream_read: ") + hipGetErrorString(rc));
+    return BE_ERR_HIP;
+  }
+  return BE_OK;
+}
+
 int be_profile_read(float* ms_host, int capacity) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   int n = g_prof_n < capacity ? g_prof_n : capacity;

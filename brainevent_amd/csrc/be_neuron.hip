@@ -14,6 +14,9 @@ struct LifCobaP {
   float dt, dt_over_tau, v_rest, v_th, v_reset, t_ref, e_exc, e_inh, decay_exc, decay_inh, i_ext, syn_scale;
 };
 
+// CUBA = current-based synapses (reference examples/CUBA_2005.py:35-66: CUBA outputs, i_syn = (g_exc + g_inh) * syn_scale; the
+// inhibitory weight is negative there) instead of conductance-based ones; everything else is the same update.
+template <bool CUBA>
 __global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, float* __restrict__ ge, float* __restrict__ gi,
                                                        float* __restrict__ refr, const float* __restrict__ in_exc,
                                                        const float* __restrict__ in_inh, uint8_t* __restrict__ spikes,
@@ -25,7 +28,7 @@ __global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, fl
     const float v = V[i];
     const float g_e = ge[i] * p.decay_exc + in_exc[i];
     const float g_i = gi[i] * p.decay_inh + in_inh[i];
-    const float i_syn = (g_e * (p.e_exc - v) + g_i * (p.e_inh - v)) * p.syn_scale;
+    const float i_syn = CUBA ? (g_e + g_i) * p.syn_scale : (g_e * (p.e_exc - v) + g_i * (p.e_inh - v)) * p.syn_scale;
     const float dv = (-(v - p.v_rest) + i_syn + p.i_ext) * p.dt_over_tau;
     const float r = refr[i];
     const bool active = r <= 0.f;
@@ -46,14 +49,11 @@ __global__ void __launch_bounds__(256) k_lif_coba_step(float* __restrict__ V, fl
   }
 }
 
-}  // namespace
-
-extern "C" {
-
-int be_lif_coba_step_packed(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
-                            uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
-                            double v_rest, double v_th, double v_reset, double t_ref, double e_exc, double e_inh,
-                            double decay_exc, double decay_inh, double i_ext, double syn_scale, be_stream_t stream) {
+template <bool CUBA>
+int lif_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+             uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
+             double v_rest, double v_th, double v_reset, double t_ref, double e_exc, double e_inh,
+             double decay_exc, double decay_inh, double i_ext, double syn_scale, be_stream_t stream) {
   BE_REQUIRE(n >= 0, BE_ERR_INVALID, "n < 0");
   if (n == 0) return BE_OK;
   BE_REQUIRE(v && g_exc && g_inh && refractory && in_exc && in_inh && (spikes_out || spike_bits_out), BE_ERR_INVALID, "null pointer");
@@ -62,10 +62,39 @@ int be_lif_coba_step_packed(float* v, float* g_exc, float* g_inh, float* refract
   const LifCobaP p{(float)dt, (float)(dt / tau_m), (float)v_rest, (float)v_th, (float)v_reset, (float)t_ref, (float)e_exc, (float)e_inh,
                    (float)decay_exc, (float)decay_inh, (float)i_ext, (float)syn_scale};
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_lif_coba_step, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, g_exc,
+  hipLaunchKernelGGL(k_lif_coba_step<CUBA>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), v, g_exc,
                      g_inh, refractory, in_exc, in_inh, spikes_out, spike_bits_out, spike_count, n, p);
   BE_LAUNCH_CHECK();
   return BE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int be_lif_coba_step_packed(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                            uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
+                            double v_rest, double v_th, double v_reset, double t_ref, double e_exc, double e_inh,
+                            double decay_exc, double decay_inh, double i_ext, double syn_scale, be_stream_t stream) {
+  return lif_step<false>(v, g_exc, g_inh, refractory, in_exc, in_inh, spikes_out, spike_bits_out, spike_count, n, dt, tau_m, v_rest,
+                         v_th, v_reset, t_ref, e_exc, e_inh, decay_exc, decay_inh, i_ext, syn_scale, stream);
+}
+
+int be_lif_cuba_step_packed(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                            uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
+                            double v_rest, double v_th, double v_reset, double t_ref, double decay_exc, double decay_inh, double i_ext,
+                            double syn_scale, be_stream_t stream) {
+  return lif_step<true>(v, g_exc, g_inh, refractory, in_exc, in_inh, spikes_out, spike_bits_out, spike_count, n, dt, tau_m, v_rest,
+                        v_th, v_reset, t_ref, 0., 0., decay_exc, decay_inh, i_ext, syn_scale, stream);
+}
+
+int be_lif_cuba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                     uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
+                     double v_reset, double t_ref, double decay_exc, double decay_inh, double i_ext, double syn_scale,
+                     be_stream_t stream) {
+  BE_REQUIRE(n == 0 || spikes_out, BE_ERR_INVALID, "null pointer");
+  return be_lif_cuba_step_packed(v, g_exc, g_inh, refractory, in_exc, in_inh, spikes_out, nullptr, spike_count, n, dt, tau_m, v_rest,
+                                 v_th, v_reset, t_ref, decay_exc, decay_inh, i_ext, syn_scale, stream);
 }
 
 int be_lif_coba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,

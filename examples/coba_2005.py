@@ -100,7 +100,7 @@ def run(scale=1.0, steps=10000, dt=0.1):
     return n, el, rate
 
 
-def run_fused(scale=1.0, steps=10000, dt=0.1, graph=True):
+def run_fused(scale=1.0, steps=10000, dt=0.1, graph=True, unroll=1):
     """Same simulation with the neuron / synapse update as ONE launch (``be.lif_coba_step``: the formulas of :func:`run`, every
     operation rounded separately in the same order — identical spikes): a time step is two scatters and one neuron kernel."""
     dev = torch.device('cuda', 0)
@@ -114,11 +114,14 @@ def run_fused(scale=1.0, steps=10000, dt=0.1, graph=True):
         in_i = be.BinaryArray(spk[n_exc:]) @ I
         be.lif_coba_step(V, ge, gi, refr, in_e, in_i, spk, count, dt=dt)
 
-    fn_ = be.capture_step(step) if graph else step
+    unroll = unroll if graph else 1              # `unroll` time steps per replayed graph (one host call each)
+    fn_ = be.capture_step(step, repeat=unroll) if graph else step
+    # (the capture's warm-up and recording advanced the state by a few steps: the count restarts here, the dynamics simply go on)
     count.zero_()
+    steps = (steps // unroll) * unroll
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps // unroll):
         fn_()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0

@@ -73,6 +73,10 @@ const char* be_build_arch(void);      /* "gfx950" */
  * records copied to ms_host (kernel durations in milliseconds, in call order) and rearms. */
 int be_profile_enable(int max_records);
 int be_profile_read(float* ms_host, int capacity);
+/* Diagnostic: the read-only streaming rate of this device in the caller's own run (the ceiling a read-dominated kernel is held
+ * against): `repeats` passes of 16-byte-per-lane loads over buf[0 .. bytes) (16-byte aligned, device memory) between
+ * two HIP events on `stream`; synchronises; *ms_per_pass = average pass time.  sink4: 4 writable device bytes. */
+int be_diag_stream_read(const void* buf, int64_t bytes, int repeats, void* sink4, float* ms_per_pass, be_stream_t stream);
 /* releases the little the library keeps between calls (profiling events); exchange handles have be_exchange_destroy */
 int be_shutdown(void);
 
@@ -101,6 +105,19 @@ int be_lif_coba_step_packed(float* v, float* g_exc, float* g_inh, float* refract
                             uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
                             double v_rest, double v_th, double v_reset, double t_ref, double e_exc, double e_inh,
                             double decay_exc, double decay_inh, double i_ext, double syn_scale, be_stream_t stream);
+/* The CURRENT-based twin (reference example examples/CUBA_2005.py:35-66: LIF V_rest -49 mV, V_th -50 mV, V_reset -60 mV, tau 20 ms,
+ * refractory 5 ms; Expon synapses tau 5 / 10 ms with CUBA outputs, weights 1.62 / -9.0 mS): the same update with
+ *   i_syn = (g_exc + g_inh) * syn_scale
+ * in place of the conductance term (no reversal potentials; an inhibitory projection carries a negative weight).  Every other line,
+ * the rounding order and the spike outputs are those of be_lif_coba_step / be_lif_coba_step_packed. */
+int be_lif_cuba_step(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                     uint8_t* spikes_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest, double v_th,
+                     double v_reset, double t_ref, double decay_exc, double decay_inh, double i_ext, double syn_scale,
+                     be_stream_t stream);
+int be_lif_cuba_step_packed(float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc, const float* in_inh,
+                            uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
+                            double v_rest, double v_th, double v_reset, double t_ref, double decay_exc, double decay_inh, double i_ext,
+                            double syn_scale, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * event vector helpers (replace: brainevent/_jit_scalar/binary_jitsmv.cu:107-125 `_pack_bool_kern`

@@ -201,3 +201,91 @@ def test_fused_neuron_step_reproduces_the_elementwise_formulation_bit_for_bit():
     assert n == 4000 and abs(rate - 50.6) <= 2.0, rate
     with pytest.raises(ValueError):
         be.lif_coba_step(Vf, gef, gif, refrf, gef, gif, spkf[:10])
+
+
+def test_fused_current_based_step_reproduces_the_elementwise_formulation_bit_for_bit():
+    """`be.lif_cuba_step` (the current-based twin: i_syn = (g_exc + g_inh) * scale; reference examples/CUBA_2005.py:35-66) against the
+    same formulas as elementwise torch ops (examples/cuba_2005.py `elementwise_step`): identical state and spikes over 400 steps of
+    the CUBA network (one projection carries a negative shared weight), then the reference's 24-25 Hz as a replayed HIP graph."""
+    import importlib.util
+    import os
+    import brainevent_amd as be
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'cuba_2005.py')
+    spec = importlib.util.spec_from_file_location('cuba_2005_example', path)
+    cuba = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cuba)
+    dev = torch.device('cuda', 0)
+    dt = 0.1
+    n_exc, n_inh, n, E, I, g = cuba.build(1.0, dev)
+    V0 = torch.empty(n, device=dev).normal_(-55.0, 2.0, generator=g)
+    V, ge, gi, refr = V0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    spk = torch.zeros(n, dtype=torch.bool, device=dev)
+    Vf, gef, gif, refrf = V0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    spkf = torch.zeros(n, dtype=torch.bool, device=dev)
+    bits = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(n, device=dev)
+    n_spikes = 0
+    for t in range(400):
+        V, ge, gi, refr, spk = cuba.elementwise_step(V, ge, gi, refr, spk, E, I, n_exc, dt)
+        n_spikes += int(spk.sum().item())
+        be.lif_cuba_step(Vf, gef, gif, refrf, be.BinaryArray(spkf[:n_exc]) @ E, be.BinaryArray(spkf[n_exc:]) @ I, spkf, cnt,
+                         spike_bits=bits, dt=dt)
+        assert torch.equal(spkf, spk), t
+    assert n_spikes > 500 and int(cnt.sum().item()) == n_spikes
+    assert torch.equal(Vf, V) and torch.equal(gef, ge) and torch.equal(gif, gi) and torch.equal(refrf, refr)
+    assert float(gif.min().item()) < 0.0          # the inhibitory projection's negative weight arrived as such
+    assert torch.equal(be.bitpack(spkf, 0).reshape(-1).to(torch.int32), bits)
+    n, _, rate, _, _ = cuba.run_fused(1.0, 10000, graph=True)
+    assert n == 4000 and 21.0 <= rate <= 28.0, rate          # reference: 22.4-25.0 Hz at scale 1 (CUBA_2005.py:98-125)
+    with pytest.raises(ValueError):
+        be.lif_cuba_step(Vf, gef, gif, refrf, gef, gif, spkf[:10])
+
+
+def test_a_captured_jitc_scatter_survives_the_eviction_of_every_cached_workspace():
+    """The armed scatter-workspace cache (`_jitc._armed`) is never used while a stream captures: a graph captured on the very stream
+    that warmed up (and so already owns a cached, armed workspace) records a workspace of its OWN pool; evicting every cached
+    workspace afterwards — and scribbling over fresh allocations that would reuse the freed memory — leaves the replays exact.  Two
+    batch shapes of equal workspace size but different layouts get different cache entries."""
+    import brainevent_amd as be
+    from brainevent_amd import _jitc as J
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(3)
+    m, k = 3000, 40000
+    M = be.JITCScalarR((np.float32(1.0), 0.01, 11), shape=(m, k), corder=True)
+    buf = torch.zeros(m, dtype=torch.bool, device=dev)
+    news = [torch.tensor(rng.random(m) < 0.1, device=dev) for _ in range(4)]
+    ref = [(be.BinaryArray(s) @ M).clone() for s in news]
+    s_cap = torch.cuda.Stream()
+    s_cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_cap):
+        be.BinaryArray(buf) @ M                          # warm-up ON the capture stream: a cached armed workspace for (device, s_cap)
+        torch.cuda.synchronize()
+        n_cached = len(J._armed)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s_cap):
+            out = be.BinaryArray(buf) @ M
+        assert len(J._armed) == n_cached                 # the captured call added nothing to the cache
+    cached_ptrs = {t.data_ptr() for t in J._armed.values()}
+    # evict everything: more workspaces of distinct sizes than the cache holds push out every earlier entry (disarmed and released)
+    with torch.cuda.stream(s_cap):
+        for i in range(J._ARMED_MAX + 1):
+            J._armed_scatter_workspace((1 << 20) + 4096 * i)
+    torch.cuda.synchronize()
+    assert len(J._armed) == J._ARMED_MAX and all(k[-1] >= (1 << 20) for k in J._armed)
+    for key in list(J._armed):
+        J._drop_armed(key)
+    junk = [torch.full((1 << 20,), -1, dtype=torch.int32, device=dev) for _ in range(16)]      # reuse of whatever was freed
+    torch.cuda.synchronize()
+    for s, r in zip(news, ref):
+        buf.copy_(s)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, r)
+    del junk
+    # the layout is part of the key
+    J._armed.clear()
+    J._armed_scatter_workspace(1 << 16, ('mm', 8))
+    J._armed_scatter_workspace(1 << 16, ('mm', 72))
+    assert len(J._armed) == 2
+    for key in list(J._armed):
+        J._drop_armed(key)

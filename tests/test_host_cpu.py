@@ -311,3 +311,34 @@ def test_reference_task_workspace_names_and_formula():
         assert cap == ws.task_capacity == want and tb.shape == te.shape == (want,) and tb.dtype == np.int32
         assert st.shape == (2,) and st.dtype == np.int32
     assert C._BinaryTaskWorkspace is C._BinaryCsrmvTaskWorkspace
+
+
+def test_the_bench_line_compacts_below_the_drivers_eight_kilobytes():
+    """`bench.compact_line` on a committed verbose line of the default run (every secondary present): strict JSON of at most 8000
+    bytes that keeps the driver contract's keys on the headline, a number set per secondary and the prose once in `legend`."""
+    import glob
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    paths = sorted(glob.glob(os.path.join(root, 'profiles', 'r0[5-9]_*bench*line*.json')))
+    assert paths
+    for path in paths:
+        full = json.load(open(path))
+        if 'secondary' not in full or 'legend' in full:
+            continue
+        c = bench.compact_line(full)
+        txt = json.dumps(bench._finite(c), allow_nan=False, separators=(',', ':'))
+        assert len(txt.encode()) <= bench.LINE_BYTE_BOUND, (path, len(txt))
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                  'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'legend'):
+            assert k in c, k
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in c['roofline'], k
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in c['cpu_baseline'], k
+        assert set(c['secondary']) == set(full['secondary'])
+        for name, e in c['secondary'].items():
+            assert 'value' in e or 'error' in e, name
