@@ -351,20 +351,40 @@ class NativeSpikeExchange:
         return self.gather_events(local_spikes).value
 
     # -- pipelined exchange: post step t + 1's spikes on the library's own stream, then work on step t ------------------
-    def post(self, local_spikes: torch.Tensor):
+    def post(self, local_spikes: torch.Tensor, ids: bool = False):
         """Start the exchange of this rank's spikes (``be_exchange_post``: the library's stream waits for the caller's, packs,
         gathers, records an event) and return a ticket for :meth:`wait_events` — same contract as ``SpikeExchange.post``:
         legitimate when synaptic delays are at least two steps; two buffers alternate, at most one ticket in flight while
-        another is consumed."""
+        another is consumed.  ``ids=True`` (``be_exchange_post_ids``): the gathered words are also compacted into the list of
+        active pre neurons on the exchange's stream; :meth:`wait_ids` hands that list to a scatter (``BE_SPIKE_IDS``)."""
         from . import _array as A
         from ._lib import fn, check
         slot = getattr(self, '_next', 0)
         self._next = slot ^ 1
         sp, sd = _local_operand(local_spikes, self.hi - self.lo)
         ct = self._ct
-        f = fn('be_exchange_post', ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p])
-        check(f(self._h, A.ptr(sp), sd, slot, A.stream_ptr()), 'be_exchange_post')
-        return slot, sp                      # (the spikes stay referenced until the ticket is consumed)
+        name = 'be_exchange_post_ids' if ids else 'be_exchange_post'
+        f = fn(name, ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p])
+        check(f(self._h, A.ptr(sp), sd, slot, A.stream_ptr()), name)
+        return slot, sp, bool(ids)           # (the spikes stay referenced until the ticket is consumed)
+
+    def wait_ids(self, ticket):
+        """Make the current stream wait for a ticket posted with ``ids=True``; returns ``(be_spike_ids_t, words pointer)`` — the
+        struct (host memory holding two device pointers into the handle) is what a scatter entry point takes as its ``spikes``
+        argument with ``BE_SPIKE_IDS``.  Valid until the slot is posted again."""
+        from . import _array as A
+        from ._lib import fn, check
+        ct = self._ct
+        if not hasattr(self, '_ids_structs'):
+            class _Ids(ct.Structure):
+                _fields_ = [('active_ids', ct.c_void_p), ('n_active', ct.c_void_p)]
+            self._ids_structs = {0: _Ids(), 1: _Ids()}
+        slot = ticket[0]
+        st_ = self._ids_structs[slot]
+        words = ct.c_void_p(0)
+        f = fn('be_exchange_wait_ids', ct.c_int, [ct.c_void_p, ct.c_int, ct.c_void_p, ct.POINTER(ct.c_void_p), ct.c_void_p])
+        check(f(self._h, slot, ct.byref(st_), ct.byref(words), A.stream_ptr()), 'be_exchange_wait_ids')
+        return st_, words.value
 
     def wait_events(self, ticket):
         from . import _array as A
@@ -422,6 +442,8 @@ class RankStep:
         from ._lib import fn
         self.exchange, self.shard = exchange, shard
         self._fast = None
+        self._fast_ids = None
+        self._ids_pays = False
         ws = shard._scatter_workspace() if hasattr(shard, '_scatter_workspace') else None
         if (not isinstance(exchange, NativeSpikeExchange) or not isinstance(shard, C.CSR)
                 or not isinstance(ws, (C.ScatterPlan, C.BinnedScatter))):
@@ -444,6 +466,9 @@ class RankStep:
             self._keep = (wsp,)
             self._fast = lambda out_ptr, words_ptr, st: f(*head, words_ptr, A.BE_SPIKE_BITS, out_ptr, *tail, ws.scale_exp, A.ptr(wsp),
                                                           wsp.numel(), st)
+            # the same step over a caller's id list (a host be_spike_ids_t holding two device pointers): no spike-list build
+            self._fast_ids = lambda out_ptr, ids_ptr, st: f(*head, ids_ptr, A.BE_SPIKE_IDS, out_ptr, *tail, ws.scale_exp, A.ptr(wsp),
+                                                            wsp.numel(), st)
             self._what = 'be_binary_csrmm_t_plan'
         else:
             indices, indptr = shard.indices, getattr(shard, 'indptr', None)
@@ -454,6 +479,9 @@ class RankStep:
             self._keep = (indices, indptr)
             self._fast = lambda out_ptr, words_ptr, st: f(*head, words_ptr, A.BE_SPIKE_BITS, out_ptr, m, k, ws.slice_shift,
                                                           ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(), st)
+            self._fast_ids = lambda out_ptr, ids_ptr, st: f(*head, ids_ptr, A.BE_SPIKE_IDS, out_ptr, m, k, ws.slice_shift,
+                                                            ws.bin_capacity, ws.scale_exp, A.ptr(ws.ws), ws.ws.numel(), st)
+            self._ids_pays = True
             self._what = 'be_binary_csrmv_t_binned'
 
     def __call__(self, local_spikes):
@@ -483,12 +511,23 @@ class RankStep:
                     or any(a is not b for a, b in zip(self._arrays, (shard.indices, getattr(shard, 'indptr', None))))
                     or self._ws_obj.is_stale(self._data) or shard.buffers.get('scatter_plan') is not self._ws_obj)
 
-    def post(self, local_spikes) -> None:
-        """Queue the exchange of a LATER step's local spikes (at most two may be in flight: the exchange has two buffers)."""
+    def post(self, local_spikes, ids: Optional[bool] = None) -> None:
+        """Queue the exchange of a LATER step's local spikes (at most two may be in flight: the exchange has two buffers).
+        ``ids=True`` (native exchange + fast path only): the exchange's stream also compacts the gathered words into the list of
+        active rows, and :meth:`step_posted` hands that list to the scatter — no spike-list build on the scattering stream.
+        ``ids=None`` (default) decides by what was measured (one rank of eight, profiles/r06_rank_step_schedules.txt): a binned shard
+        runs its compaction as a launch of its own on the scattering stream (6 us of the C4 post slice's 88) and gains from the
+        list; a planned shard builds its list inside the accumulate kernel, which is faster than reading one from memory
+        (C2 post slice: 39.0 us with the words, 40.9 with the list)."""
         if not hasattr(self, '_pending'):
             self._pending = []
         assert len(self._pending) < 2, "RankStep.post: two exchanges are already in flight (consume one with step_posted())"
-        self._pending.append(self.exchange.post(local_spikes))
+        if ids is None:
+            ids = self._ids_pays
+        if ids and self._fast_ids is not None and isinstance(self.exchange, NativeSpikeExchange):
+            self._pending.append(self.exchange.post(local_spikes, ids=True))
+        else:
+            self._pending.append(self.exchange.post(local_spikes))
 
     def step_posted(self):
         """The step whose exchange was posted first: wait for its gathered words on this stream, then ``events @ shard``."""
@@ -500,6 +539,11 @@ class RankStep:
         if not self._usable() or not isinstance(ex, NativeSpikeExchange):
             return ex.wait_events(ticket) @ self.shard
         st = A.stream_ptr()
+        if len(ticket) > 2 and ticket[2]:          # posted with ids: the list the exchange's stream compacted
+            ids_struct, _ = ex.wait_ids(ticket)
+            out = torch.empty(self._out_shape, dtype=self._out_dtype, device=self._dev)
+            check(self._fast_ids(A.ptr(out), ct.addressof(ids_struct), st), self._what)
+            return out
         words = ct.c_void_p(0)
         check(fn('be_exchange_wait', ct.c_int, [ct.c_void_p, ct.c_int, ct.POINTER(ct.c_void_p), ct.c_void_p])(
             ex._h, ticket[0], ct.byref(words), st), 'be_exchange_wait')
@@ -507,9 +551,9 @@ class RankStep:
         check(self._fast(A.ptr(out), words.value, st), self._what)
         return out
 
-    def ahead(self, local_spikes_next):
+    def ahead(self, local_spikes_next, ids: Optional[bool] = None):
         """One step of the pipelined schedule: post step t + 1's exchange, consume step t's (``post`` step 0 first)."""
-        self.post(local_spikes_next)
+        self.post(local_spikes_next, ids=ids)
         return self.step_posted()
 
     def drain(self) -> None:
@@ -518,7 +562,7 @@ class RankStep:
         ex = self.exchange
         while getattr(self, '_pending', None):
             t = self._pending.pop(0)
-            ex.wait_events(t) if isinstance(ex, NativeSpikeExchange) else t[1].wait()
+            ex.wait_events(t[:2]) if isinstance(ex, NativeSpikeExchange) else t[1].wait()
 
     # ---- the two halves of the sequential step on their own (bench.py --gpus N reports them per rank, so that a scaling run
     #      says where a rank's time went: exchange, scatter, or waiting)

@@ -75,6 +75,10 @@ struct Exchange {
   bool released[2] = {false, false};
   uint32_t* post_local[2] = {nullptr, nullptr};
   uint32_t* post_full[2] = {nullptr, nullptr};
+  // be_exchange_post_ids: the gathered words of a slot compacted into an id list on the exchange's stream (n_pre ids + a counter)
+  uint32_t* post_ids[2] = {nullptr, nullptr};
+  uint32_t* post_count[2] = {nullptr, nullptr};
+  bool has_ids[2] = {false, false};
 };
 
 #define BE_RCCL(call)                                                                                     \
@@ -91,6 +95,7 @@ struct Exchange {
 extern "C" {
 
 int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
+int be_compact_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* active_ids, uint32_t* count, be_stream_t stream);
 
 int be_exchange_unique_id_bytes(void) { return (int)sizeof(NcclUniqueId); }
 
@@ -210,7 +215,19 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
 // step started).  post: the side stream waits for what `producer_stream` has queued so far (the spikes), packs and gathers into
 // the exchange's buffer `slot` (0 / 1, alternate them) and records the slot's event.  wait: `consumer_stream` waits for that
 // event; *full_bits_out is the slot's device buffer (be_exchange_full_words words), valid until the slot is posted again.
-int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream) {
+}  // extern "C"
+
+// Events of the pipelined exchange order work of ONE device (producer kernel -> gather on the side stream; gather -> scatter on the
+// consumer's stream): an agent-scope release is all they need.  hipEventDisableSystemFence drops the system-scope fence a default
+// event performs when it is recorded — measured 2.4 us per step of the pipelined schedule (tools/ubench/ubench7.hip,
+// profiles/r06_ubench7_cross_stream_dependency.txt: 46.4 -> 44.0 us).  Peers never synchronise through these events (RCCL fences
+// what it sends itself).  BE_EXCHANGE_SYSTEM_FENCE=1 restores default events.
+static unsigned exchange_event_flags() {
+  static const bool sys = [] { const char* e = getenv("BE_EXCHANGE_SYSTEM_FENCE"); return e && e[0] == '1'; }();
+  return hipEventDisableTiming | (sys ? 0u : (unsigned)hipEventDisableSystemFence);
+}
+
+static int exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream, bool with_ids) {
   BE_REQUIRE(exchange, BE_ERR_INVALID, "null pointer");
   BE_REQUIRE(slot == 0 || slot == 1, BE_ERR_INVALID, "slot must be 0 or 1");
   Exchange* ex = static_cast<Exchange*>(exchange);
@@ -224,11 +241,12 @@ int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, 
     uint32_t* pl[2] = {nullptr, nullptr};
     uint32_t* pf[2] = {nullptr, nullptr};
     const size_t wl = (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * 4;
+    const unsigned evf = exchange_event_flags();
     hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_in, evf);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-      e = hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming);
+      e = hipEventCreateWithFlags(&ev_done[i], evf);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_free[i], evf);
       if (e == hipSuccess) e = hipMalloc(&pl[i], wl);
       if (e == hipSuccess) e = hipMalloc(&pf[i], wl * ex->world);
     }
@@ -277,7 +295,51 @@ int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, 
   }
   if (ex->words_per_rank > 0)
     BE_RCCL(R->AllGather(send, ex->post_full[slot], (size_t)ex->words_per_rank, kNcclUint32, ex->comm, ex->side));
+  ex->has_ids[slot] = false;
+  if (with_ids) {
+    // the gathered words -> the list of active pre neurons, right behind the all-gather on the exchange's own stream: the consumer's
+    // scatter takes it as BE_SPIKE_IDS and runs no compaction of its own (fused or launched) on its critical path
+    for (int i = 0; i < 2; ++i) {
+      if (ex->post_ids[i]) continue;
+      uint32_t* ids = nullptr;
+      uint32_t* cnt = nullptr;
+      hipError_t e = hipMalloc(&ids, (size_t)(ex->n_pre > 0 ? ex->n_pre : 1) * 4);
+      if (e == hipSuccess) e = hipMalloc(&cnt, 256);
+      if (e != hipSuccess) {
+        if (ids) (void)hipFree(ids);
+        be_set_error(std::string("be_exchange_post_ids: id list buffers -> ") + hipGetErrorString(e));
+        return BE_ERR_HIP;
+      }
+      ex->post_ids[i] = ids;
+      ex->post_count[i] = cnt;
+    }
+    const int rc = be_compact_spikes(ex->post_full[slot], BE_SPIKE_BITS, ex->n_pre, ex->post_ids[slot], ex->post_count[slot], ex->side);
+    if (rc != BE_OK) return rc;
+    ex->has_ids[slot] = true;
+  }
   BE_HIP(hipEventRecord(ex->ev_done[slot], ex->side));
+  return BE_OK;
+}
+
+extern "C" {
+
+int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream) {
+  return exchange_post(exchange, local_spikes, spike_dtype, slot, producer_stream, false);
+}
+
+int be_exchange_post_ids(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream) {
+  return exchange_post(exchange, local_spikes, spike_dtype, slot, producer_stream, true);
+}
+
+int be_exchange_wait_ids(void* exchange, int slot, be_spike_ids_t* ids_out, const uint32_t** full_bits_out, be_stream_t consumer_stream) {
+  BE_REQUIRE(exchange && ids_out, BE_ERR_INVALID, "null pointer");
+  BE_REQUIRE(slot == 0 || slot == 1, BE_ERR_INVALID, "slot must be 0 or 1");
+  Exchange* ex = static_cast<Exchange*>(exchange);
+  BE_REQUIRE(ex->side != nullptr && ex->has_ids[slot], BE_ERR_INVALID, "the slot was not posted with be_exchange_post_ids");
+  BE_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), ex->ev_done[slot], 0));
+  ids_out->active_ids = ex->post_ids[slot];
+  ids_out->n_active = ex->post_count[slot];
+  if (full_bits_out) *full_bits_out = ex->post_full[slot];
   return BE_OK;
 }
 
@@ -314,6 +376,8 @@ int be_exchange_destroy(void* exchange) {
       if (ex->ev_free[i]) (void)hipEventDestroy(ex->ev_free[i]);
       if (ex->post_local[i]) (void)hipFree(ex->post_local[i]);
       if (ex->post_full[i]) (void)hipFree(ex->post_full[i]);
+      if (ex->post_ids[i]) (void)hipFree(ex->post_ids[i]);
+      if (ex->post_count[i]) (void)hipFree(ex->post_count[i]);
     }
     if (ex->ev_in) (void)hipEventDestroy(ex->ev_in);
     (void)hipStreamDestroy(ex->side);

@@ -174,6 +174,17 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
 int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream);
 int be_exchange_wait(void* exchange, int slot, const uint32_t** full_bits_out, be_stream_t consumer_stream);
 int be_exchange_release(void* exchange, int slot, be_stream_t consumer_stream);
+/* The posted exchange that ALSO compacts what it gathered: right behind the all-gather, still on the library's own stream, the
+ * slot's words become the list of active pre neurons (ids + a device counter, as be_compact_spikes writes them).
+ * be_exchange_wait_ids makes consumer_stream wait for the slot and fills *ids_out — pass a pointer to it as the `spikes` argument
+ * of a scatter entry point with spike dtype BE_SPIKE_IDS (n_batch = 1): the scatter then runs no compaction of its own, fused or
+ * launched, on the consumer's critical path.  *full_bits_out (optional) = the slot's words, as be_exchange_wait returns them.
+ * Same slot, lifetime and release rules as be_exchange_post / _wait; the list holds up to n_pre ids and lives in the handle.
+ * The exchange's events are created without a system-scope fence (they order work of one device; environment variable
+ * BE_EXCHANGE_SYSTEM_FENCE=1 restores default events). */
+int be_exchange_post_ids(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream);
+int be_exchange_wait_ids(void* exchange, int slot, be_spike_ids_t* ids_out, const uint32_t** full_bits_out,
+                         be_stream_t consumer_stream);
 int be_exchange_destroy(void* exchange);
 
 /* ------------------------------------------------------------------------------------------------

@@ -270,6 +270,13 @@ def test_rank_step_pipelined_schedule_is_bit_identical_to_the_sequential_one(one
         # two exchanges in flight (both buffers of the exchange), consumed in order
         rs.post(loc[2]); rs.post(loc[3])
         assert torch.equal(rs.step_posted(), seq[2]) and torch.equal(rs.step_posted(), seq[3])
+        # the exchange's stream also compacts what it gathered (be_exchange_post_ids) and the scatter takes that list
+        # (BE_SPIKE_IDS: no spike-list build on the scattering stream): the same bits, mixed freely with plain posts
+        rs.post(loc[0], ids=True)
+        got = [rs.ahead(loc[t + 1], ids=(t % 3 != 1)) if t + 1 < 6 else rs.step_posted() for t in range(6)]
+        rs.drain()
+        for t in range(6):
+            assert torch.equal(got[t], seq[t]), (producer, 'ids', t)
     rs.exchange_only(spikes[4])
     assert torch.equal(rs.scatter_only(), seq[4])
     rs.check_status()                                 # binned shard: sticky flag + conservation counters; planned shard: nothing to check
