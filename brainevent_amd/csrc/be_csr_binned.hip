@@ -212,7 +212,10 @@ __device__ __forceinline__ void stream_flush_list(const StreamLds<HOMO, CB>& S, 
         const float* bw = reinterpret_cast<const float*>(blk);
         const uint32_t vb = sid >> kRingLog, bb = vb / (uint32_t)n_bins_b;          // (batch row, bin) of the virtual bin
         float* dst = out + (int64_t)bb * k + (int64_t)(vb - bb * (uint32_t)n_bins_b) * width;
-        for (int j = lane; j < CB; j += 64) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
+        for (int j = lane; j < CB; j += 64) {
+          const uint32_t c = bi[B::col_hw(j)];          // (< width by construction; the test keeps a float atomic inside the bin's slice whatever LDS holds)
+          if (c < width) atomicAdd(dst + c, HOMO ? w0 : bw[B::w_dw(j)]);
+        }
         if (lane == 0) S.ovf[sid >> kRingLog] = 1u;
       }
     }
@@ -618,7 +621,10 @@ __global__ void __launch_bounds__(1024) k_bin_stream(const W* __restrict__ weigh
       const float* bw = reinterpret_cast<const float*>(bp);
       const uint32_t bb = (uint32_t)bin / (uint32_t)n_bins_b;
       float* dst = out + (int64_t)bb * k + (int64_t)((uint32_t)bin - bb * (uint32_t)n_bins_b) * width;
-      for (uint32_t j = 0; j < d; ++j) atomicAdd(dst + bi[B::col_hw(j)], HOMO ? w0 : bw[B::w_dw(j)]);
+      for (uint32_t j = 0; j < d; ++j) {
+        const uint32_t c = bi[B::col_hw(j)];
+        if (c < width) atomicAdd(dst + c, HOMO ? w0 : bw[B::w_dw(j)]);
+      }
       o = 1u;
     }
     const uint64_t room = (uint64_t)cap_blocks * CB;
@@ -658,12 +664,19 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   using acc_t = typename PlanAcc<HOMO || ACC32>::type;
   static_assert(!(HOMO && ACC32), "ACC32 is a mode of per-entry weights");
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw);
   __shared__ uint32_t s_cnt[kStreamGrid], s_pre[kStreamGrid + 1], s_wtot[16];
   __shared__ unsigned long long s_added;
   // block -> region of the bin, one byte per block, in the LDS the accumulators leave: a group then finds its region with one
-  // LDS read instead of an 8-step binary search over the prefix sums (bins of more than map_cap blocks search)
-  uint8_t* s_map = smem_raw + (((size_t)width * sizeof(acc_t) + 15) & ~(size_t)15);
+  // LDS read instead of an 8-step binary search over the prefix sums (bins of more than map_cap blocks search).
+  // LAYOUT: [static: directory, prefix sums][s_map: map_cap bytes][accumulators] — the accumulators come LAST, so that a 16-bit
+  // local column >= width (which pass B never writes: lc = col - floor(col / width) * width; only a region read past what was
+  // stored could hold one) indexes past the END of the workgroup's LDS, where the hardware drops the access, instead of into
+  // s_map.  Round 5's -DBE_DBG_LEVEL=3 timing build (tickets real, block stores compiled out) made pass C add at never-written
+  // columns; with the map BEHIND the accumulators those adds rewrote map bytes, a later group read a wrong region number r,
+  // lb = blk - s_pre[r] wrapped, and the 12-byte unit load left the workspace by ~2^32 units: the memory access fault of
+  // gpurun_out/prof_abl.log.  (tests/test_plan_contracts_gpu.py plants such a column: be_internal_binned_poison_next.)
+  uint8_t* s_map = smem_raw;
+  acc_t* acc = reinterpret_cast<acc_t*>(smem_raw + map_cap);          // map_cap is a multiple of 16 (binned_geometry)
   const int S = width;
   const int bin = blockIdx.x / parts, part = blockIdx.x - bin * parts;
   const int tid = threadIdx.x;
@@ -809,6 +822,13 @@ __global__ void __launch_bounds__(1024) k_bin_accumulate(const uint32_t* __restr
   }
 }
 
+// TEST HOOK (not in the public header; tests/test_plan_contracts_gpu.py): the next binned step has the local column of entry 0 of
+// block 0 of region (bin, workgroup) overwritten between pass B and pass C — what a block read past its stored entries could hold.
+__global__ void k_bin_poison(uint32_t* __restrict__ block, int col_halfword, uint32_t column) {
+  reinterpret_cast<uint16_t*>(block)[col_halfword] = (uint16_t)column;
+}
+static std::atomic<uint64_t> g_poison_next{0};      // bit 63: armed; [47:32] column; [31:16] bin; [15:0] region
+
 // f16 / bf16 outputs: the bins accumulate into an f32 image of the output (the overflow path adds f32 atomically), rounded once
 template <typename W>
 __global__ void __launch_bounds__(256) k_bin_round(const float* __restrict__ src, W* __restrict__ dst, int64_t k) {
@@ -910,7 +930,7 @@ static inline BinGeo binned_geometry(int64_t k, int slice_shift, int homo /* kin
   g.n_bins = (int)nb;
   g.cap = stream_cap(g.n_bins, homo);
   g.map_cap = (int)(160 * 1024 - kAccStaticBytes - ((g.width * acc_bytes + 15) & ~15ll));
-  g.map_cap = g.map_cap < 0 ? 0 : g.map_cap;
+  g.map_cap = g.map_cap < 0 ? 0 : (g.map_cap & ~15);          // the accumulators start behind the map: 16-byte aligned
   return g;
 }
 
@@ -971,7 +991,7 @@ static inline BatchGeo binned_geometry_batch(int64_t k, int slice_shift, int hom
   r.g.n_bins = (int)nbb;                    // bins per batch row; pass B sees n_bins * gb virtual bins
   r.g.cap = stream_cap((int)(nbb * gb), homo);
   r.g.map_cap = (int)(160 * 1024 - kAccStaticBytes - ((width * acc_bytes + 15) & ~15ll));
-  r.g.map_cap = r.g.map_cap < 0 ? 0 : r.g.map_cap;
+  r.g.map_cap = r.g.map_cap < 0 ? 0 : (r.g.map_cap & ~15);
   return r;
 }
 // entries one bin of this geometry receives when one bin of the single-vector geometry receives bin_capacity
@@ -1204,8 +1224,19 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     BE_LAUNCH_CHECK();
     const unsigned acc_grid = (unsigned)(n_vbins * parts);
     uint32_t* rearm = spike_dtype == BE_SPIKE_IDS ? static_cast<uint32_t*>(nullptr) : count;
+    const uint64_t poison = g_poison_next.load(std::memory_order_relaxed) >> 63 ? g_poison_next.exchange(0) : 0;      // (test hook)
+#define BE_BIN_POISON(HOMO_, CAP_)                                                                                              \
+  do {                                                                                                                          \
+    using PB = BinBlock<HOMO_, CAP_>;                                                                                           \
+    const uint32_t pbin = (uint32_t)(poison >> 16) & 0xffffu, preg = (uint32_t)poison & 0xffffu;                                \
+    if ((poison >> 63) && pbin < (uint32_t)n_vbins && preg < (uint32_t)kStreamGrid)                                             \
+      hipLaunchKernelGGL(k_bin_poison, dim3(1), dim3(1), 0, st,                                                                 \
+                         regions + ((size_t)pbin * kStreamGrid + preg) * cap_blocks * PB::gdwords, (HOMO_ ? 0 : 4) /* B::col_hw(0) */, \
+                         (uint32_t)(poison >> 32) & 0xffffu);                                                                   \
+  } while (0)
 #define BE_BIN_ACC32(CAP_)                                                                                                     \
   do {                                                                                                                          \
+    BE_BIN_POISON(false, CAP_);                                                                                                 \
     auto kern = k_bin_accumulate<false, CAP_, true>;                                                                            \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
@@ -1214,6 +1245,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
   } while (0)
 #define BE_BIN_ACC(HOMO_, CAP_)                                                                                                 \
   do {                                                                                                                          \
+    BE_BIN_POISON(HOMO_, CAP_);                                                                                                 \
     auto kern = k_bin_accumulate<HOMO_, CAP_>;                                                                                  \
     BE_HIP(be_allow_lds(reinterpret_cast<const void*>(kern), (int)lds));                                                        \
     hipLaunchKernelGGL(kern, dim3(acc_grid), dim3(1024), lds, st, regions, dir, (uint32_t)cap_blocks, (int)geo.width,           \
@@ -1231,6 +1263,7 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     }
 #undef BE_BIN_ACC
 #undef BE_BIN_ACC32
+#undef BE_BIN_POISON
     BE_LAUNCH_CHECK();
   }
   be_prof_end(prof, st);
@@ -1241,6 +1274,13 @@ int be_binary_csrmm_t_binned(const void* weights, int homo, int wdtype, const in
     hipLaunchKernelGGL(k_bin_round<__hip_bfloat16>, dim3(grid_for(total, 256, 2048)), dim3(256), 0, st, out32,
                        static_cast<__hip_bfloat16*>(out_user), total);
   BE_LAUNCH_CHECK();
+  return BE_OK;
+}
+
+/* test hook, deliberately absent from include/brainevent_amd.h: arms k_bin_poison for the next binned step of this process */
+int be_internal_binned_poison_next(int bin, int region, uint32_t column) {
+  BE_REQUIRE(bin >= 0 && bin < 65536 && region >= 0 && region < 65536 && column < 65536u, BE_ERR_INVALID, "out of range");
+  g_poison_next.store((1ull << 63) | ((uint64_t)column << 32) | ((uint64_t)bin << 16) | (uint64_t)region);
   return BE_OK;
 }
 

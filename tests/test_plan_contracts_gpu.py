@@ -797,3 +797,43 @@ def test_binned_short_rows_hint_changes_no_bit(be, homo, monkeypatch):
         conn.buffers['scatter_plan'] = fws
         binned = be.BinaryArray(fv) @ conn
         np.testing.assert_allclose(binned.cpu().numpy(), got.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('homo', [False, True])
+def test_a_bad_column_in_a_region_block_costs_one_entry_and_nothing_else(be, homo):
+    """Round 6.  Pass C adds at 16-bit local columns it reads from the region blocks; pass B only ever stores
+    columns < width there, but round 5's -DBE_DBG_LEVEL=3 timing build (block stores compiled out, tickets real) showed what a column
+    >= width does when the block -> region map sits BEHIND the accumulators in LDS: the add rewrites map bytes, a later group takes a
+    wrong region, its block number wraps and the unit load faults (gpurun_out/prof_abl.log).  The accumulators now come last in the
+    workgroup's LDS: such a column indexes past the end of the allocation and the hardware drops the access.  Planted here through
+    the library's test hook between pass B and pass C (entry 0 of block 0 of region 0 of bin 0 gets column 0xFFFF): the step
+    finishes, the conservation counters agree (the entry was read), every output but one carries its exact bits and that one lacks
+    exactly one weight — and the next step is clean again."""
+    import ctypes
+    from brainevent_amd._csr import BinnedScatter
+    from brainevent_amd._lib import lib
+    rng = np.random.default_rng(97)
+    m, k, row = 3000, 250_000, 30
+    # every entry lands in bin 0 (columns < 900 < width): region 0 of bin 0 certainly holds workgroup 0's rows
+    idx = torch.tensor(rng.integers(0, 900, m * row).astype(np.int32), device='cuda')
+    ptr = torch.arange(0, m * row + 1, row, dtype=torch.int32, device='cuda')
+    w = torch.full((1,), 0.75, device='cuda') if homo else torch.tensor(rng.uniform(0.2, 1.0, m * row).astype(np.float32), device='cuda')
+    v = torch.tensor(rng.random(m) < 0.2, device='cuda')
+    ws = BinnedScatter(w, m, k, m * row, indices=idx)
+    assert ws.n_slices >= 128 and k // ws.n_slices + 4 >= 900
+    good = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws)
+    ws.check_status()
+    f = lib().be_internal_binned_poison_next
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    assert f(0, 0, 0xFFFF) == 0
+    bad = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws)
+    torch.cuda.synchronize()
+    ws.check_status()                                         # entries == tickets == accumulated: the planted entry was read, then dropped
+    assert bool(torch.isfinite(bad).all())
+    diff = (good.double() - bad.double())
+    changed = torch.nonzero(diff != 0).flatten()
+    assert changed.numel() == 1 and int(changed[0]) < 900, changed
+    lost = float(diff[changed[0]])
+    assert (abs(lost - 0.75) < 1e-6) if homo else (0.19 < lost < 1.01), lost
+    again = be.binary_csrmv(w, idx, ptr, v, shape=(m, k), transpose=True, workspace=ws)      # the hook is one-shot
+    assert torch.equal(again, good)

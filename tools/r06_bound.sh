@@ -1,0 +1,24 @@
+#!/bin/bash
+# what bounds k_plan_accumulate_h8 at C2 (one weight) and k_plan_accumulate_d8<0,1,0> on the 1-of-8 shard — SQ counters
+# in separate --pmc passes (8 SQ slots per pass) — and the dynamic row-ticket experiment on the shard kernel (-DBE_PLAN_DYN=<rows>)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r06_bound
+mkdir -p $O
+cd $R
+timeout -k 10 300 python -m pytest tests/test_plan_contracts_gpu.py -x -q -k "bad_column or protocol_flag or reproducible" > $O/tests.log 2>&1; echo "binned tests rc=$?"; tail -2 $O/tests.log
+cd /tmp && export TMPDIR=/tmp
+PA="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+PB="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_LDS_ADDR_CONFLICT SQ_INSTS_SALU"
+for pass in A B; do
+  eval "CN=\$P$pass"
+  timeout -k 10 300 rocprofv3 --pmc $CN --output-format csv -d $O/homo_$pass -o p -- python3 $R/bench.py --homo --steps 10 --warmup 3 --no-cpu --no-secondary > $O/homo_$pass.log 2>&1 || { echo "homo pass $pass failed"; tail -3 $O/homo_$pass.log; }
+  timeout -k 10 300 rocprofv3 --pmc $CN --output-format csv -d $O/shard_$pass -o p -- python3 $R/tools/rank_step_lab.py --schedule seq --steps 30 --warmup 5 > $O/shard_$pass.log 2>&1 || { echo "shard pass $pass failed"; tail -3 $O/shard_$pass.log; }
+done
+cd $R
+python3 tools/summarize_prof.py "$O/homo_A/*counter_collection.csv" "$O/homo_B/*counter_collection.csv" 2>/dev/null | grep -i "plan_accumulate\|kernel " > $O/homo_counters.txt
+python3 tools/summarize_prof.py "$O/shard_A/*counter_collection.csv" "$O/shard_B/*counter_collection.csv" 2>/dev/null | grep -i "plan_accumulate\|kernel " > $O/shard_counters.txt
+cat $O/homo_counters.txt $O/shard_counters.txt
+find $O -name '*.csv' -size +4M -delete
+# dynamic row tickets on the shard kernel
+bash tools/ab_build.sh "" "-DBE_PLAN_DYN=8" "-DBE_PLAN_DYN=16" "-DBE_PLAN_DYN=32" -- bash -c "for i in 1 2; do timeout -k 10 200 python3 tools/rank_step_lab.py --schedule seq --check --steps 500 | tail -1; done; timeout -k 10 300 python3 bench.py --steps 100 --warmup 20 --no-cpu --no-secondary 2>/dev/null | python3 -c \"import sys,json; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); print('C2 full', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['parity_check'])\"" 2>&1 | tee $O/dyn_tickets.txt
