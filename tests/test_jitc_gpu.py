@@ -478,3 +478,31 @@ def test_armed_scatter_workspaces_skip_the_zeroing_launch_and_change_no_bit(be, 
         assert torch.equal(be.BinaryArray(si) @ Mi, be.BinaryArray(si) @ Mi)
     assert len(J._armed) <= J._ARMED_MAX
     assert torch.equal(be.BinaryArray(spikes[2]) @ M, armed[2])
+
+
+@pytest.mark.parametrize('fire,n_rows', [(0.02, 150_000), (1.0, 150_000), (1.0, 300_000)])
+def test_scalar_scatter_counts_agree_with_the_materialised_matrix_at_any_firing_rate(be, fire, n_rows):
+    """The scalar-weight scatter's per-(class, part) counts against the same product over the materialised CSR, exact: few rows
+    active, every row of 150 000 active, every row of 300 000 active at prob 0.5 — columns whose count in ONE part passes 65535
+    (what a 16-bit partial-sum format would have to detect; round 6 measured that format — half the bytes through the walk kernel's
+    epilogue and the reduce — at +-0 / +1.5 us on C3 and dropped it: both are latency-, not byte-bound)."""
+    import torch
+    k = 4096
+    prob = 0.5 if n_rows == 300_000 else 0.02
+    M = be.JITCScalarR((np.float32(1.0), prob, 17), shape=(n_rows, k), corder=True)
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    spk = torch.rand(n_rows, device='cuda', generator=g) < fire
+    got = be.BinaryArray(spk) @ M
+    csr = M.materialize('mv')
+    rows = torch.nonzero(spk).flatten()
+    ref = torch.zeros(k, dtype=torch.int64, device='cuda')
+    ptr = csr.indptr.long()
+    for c0 in range(0, rows.numel(), 20000):
+        r = rows[c0:c0 + 20000]
+        b, ln = ptr[r], ptr[r + 1] - ptr[r]
+        tot = int(ln.sum().item())
+        off = torch.repeat_interleave(b - torch.cumsum(ln, 0) + ln, ln) + torch.arange(tot, device='cuda')
+        ref += torch.bincount(csr.indices[off].long(), minlength=k)
+    assert torch.equal(got.double(), ref.double())
+    if n_rows == 300_000:
+        assert int(ref.max()) > 2 * 65535
