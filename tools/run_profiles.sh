@@ -36,7 +36,7 @@ if [[ $what == *stats* ]]; then
     { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py ${CFG[$name]}"
       echo "# med_timed = median over the last ${STEPS[$name]} launches of the kernel (the timed steps); avg_us = rocprofv3's average over all launches"
       python3 $R/tools/summarize_prof.py --last ${STEPS[$name]} "$O/s_$name/p_kernel_trace.csv" | grep -v "at::native\|rocclr\|rocprim" | head -14 | cut -c1-170
-      grep -o '"ms_per_step": [0-9.]*' $O/s_$name.log | head -1; } > $O/${name}_kernel_stats.txt
+      grep -o "\"ms_per_step\": *[0-9.]*" $O/s_$name.log | head -1; } > $O/${name}_kernel_stats.txt
     rm -rf $O/s_$name        # (the traces are tens of MB; the summary is what is kept)
   done
 fi
