@@ -37,7 +37,7 @@ def lif_coba_step(v: torch.Tensor, g_exc: torch.Tensor, g_inh: torch.Tensor, ref
                   spike_bits: torch.Tensor = None,
                   dt: float = 0.1, tau_m: float = 20.0, v_rest: float = -60.0, v_th: float = -50.0, v_reset: float = -60.0,
                   t_ref: float = 5.0, e_exc: float = 0.0, e_inh: float = -80.0, tau_exc: float = 5.0, tau_inh: float = 10.0,
-                  i_ext: float = 20.0, syn_scale: float = 1e-3) -> None:
+                  i_ext: float = 20.0, syn_scale: float = 1e-3, in_scale_exc: float = 1.0, in_scale_inh: float = 1.0) -> None:
     """Advance ``v``, ``g_exc``, ``g_inh``, ``refractory`` (f32 device tensors of one length) by one step **in place**, write
     this step's spikes (``bool`` / ``uint8``) to ``spikes`` and add them to ``spike_count`` if given.  ``in_exc`` / ``in_inh``
     are this step's synaptic inputs (the outputs of ``BinaryArray(spikes) @ W_exc`` / ``@ W_inh``).  Defaults: the COBA
@@ -46,27 +46,38 @@ def lif_coba_step(v: torch.Tensor, g_exc: torch.Tensor, g_inh: torch.Tensor, ref
 
     ``spike_bits`` (int32 ``[ceil(n / 32)]``, optional): the spikes are also — or, with ``spikes=None``, only — written
     bit-packed, the form ``BitPackedBinary.from_packed(spike_bits, n) @ conn`` and the multi-GPU spike exchange consume as they
-    are: a step loop that keeps its spikes as words has no pack launch (``be_lif_coba_step_packed``)."""
+    are: a step loop that keeps its spikes as words has no pack launch (``be_lif_coba_step_packed``).
+
+    ``in_scale_exc`` / ``in_scale_inh``: the inputs are multiplied by these first (``be_lif_step_scaled_packed``).  With both
+    projections stacked into ONE ``n x 2n`` matrix of weight 1, ``counts = BinaryArray(spikes) @ W`` is one scatter and
+    ``lif_coba_step(..., counts[:n], counts[n:], ..., in_scale_exc=w_exc, in_scale_inh=w_inh)`` equals the two-projection step bit
+    for bit (``count * w`` is rounded exactly as inside a scatter with weight ``w``) with half the launches."""
     n = _check_state('lif_coba_step', v, g_exc, g_inh, refractory, in_exc, in_inh, spikes, spike_bits, spike_count)
+    _scaled_step(0, v, g_exc, g_inh, refractory, in_exc, in_inh, in_scale_exc, in_scale_inh, spikes, spike_bits, spike_count, n,
+                 dt, tau_m, v_rest, v_th, v_reset, t_ref, e_exc, e_inh, tau_exc, tau_inh, i_ext, syn_scale)
+
+
+def _scaled_step(current_based, v, g_exc, g_inh, refractory, in_exc, in_inh, s_exc, s_inh, spikes, spike_bits, spike_count, n, dt,
+                 tau_m, v_rest, v_th, v_reset, t_ref, e_exc, e_inh, tau_exc, tau_inh, i_ext, syn_scale) -> None:
     c_d, c_vp = ctypes.c_double, ctypes.c_void_p
-    f = fn('be_lif_coba_step_packed', ctypes.c_int, [c_vp] * 9 + [ctypes.c_int64] + [c_d] * 12 + [c_vp])
-    check(f(A.ptr(v), A.ptr(g_exc), A.ptr(g_inh), A.ptr(refractory), A.ptr(in_exc), A.ptr(in_inh), A.ptr(spikes),
-            A.ptr(spike_bits), A.ptr(spike_count), n, dt, tau_m, v_rest, v_th, v_reset, t_ref, e_exc, e_inh,
-            math.exp(-dt / tau_exc), math.exp(-dt / tau_inh), i_ext, syn_scale, A.stream_ptr()), 'be_lif_coba_step_packed')
+    f = fn('be_lif_step_scaled_packed', ctypes.c_int, [ctypes.c_int] + [c_vp] * 6 + [c_d, c_d] + [c_vp] * 3 + [ctypes.c_int64]
+           + [c_d] * 12 + [c_vp])
+    check(f(int(current_based), A.ptr(v), A.ptr(g_exc), A.ptr(g_inh), A.ptr(refractory), A.ptr(in_exc), A.ptr(in_inh),
+            float(s_exc), float(s_inh), A.ptr(spikes), A.ptr(spike_bits), A.ptr(spike_count), n, dt, tau_m, v_rest, v_th, v_reset,
+            t_ref, e_exc, e_inh, math.exp(-dt / tau_exc), math.exp(-dt / tau_inh), i_ext, syn_scale, A.stream_ptr()),
+          'be_lif_step_scaled_packed')
 
 
 def lif_cuba_step(v: torch.Tensor, g_exc: torch.Tensor, g_inh: torch.Tensor, refractory: torch.Tensor,
                   in_exc: torch.Tensor, in_inh: torch.Tensor, spikes: torch.Tensor = None, spike_count: torch.Tensor = None, *,
                   spike_bits: torch.Tensor = None,
                   dt: float = 0.1, tau_m: float = 20.0, v_rest: float = -49.0, v_th: float = -50.0, v_reset: float = -60.0,
-                  t_ref: float = 5.0, tau_exc: float = 5.0, tau_inh: float = 10.0, i_ext: float = 20.0, syn_scale: float = 1.0) -> None:
+                  t_ref: float = 5.0, tau_exc: float = 5.0, tau_inh: float = 10.0, i_ext: float = 20.0, syn_scale: float = 1.0,
+                  in_scale_exc: float = 1.0, in_scale_inh: float = 1.0) -> None:
     """The current-based twin of :func:`lif_coba_step` (``be_lif_cuba_step_packed``): the synaptic current is
     ``(g_exc + g_inh) * syn_scale`` — no reversal potentials; an inhibitory projection carries a negative weight.  Defaults: the
     reference's CUBA benchmark network (``examples/CUBA_2005.py:35-66``: V_rest -49 mV, weights 1.62 / -9.0 mS times one volt).
     Same argument contract, rounding order and spike outputs as :func:`lif_coba_step`."""
     n = _check_state('lif_cuba_step', v, g_exc, g_inh, refractory, in_exc, in_inh, spikes, spike_bits, spike_count)
-    c_d, c_vp = ctypes.c_double, ctypes.c_void_p
-    f = fn('be_lif_cuba_step_packed', ctypes.c_int, [c_vp] * 9 + [ctypes.c_int64] + [c_d] * 10 + [c_vp])
-    check(f(A.ptr(v), A.ptr(g_exc), A.ptr(g_inh), A.ptr(refractory), A.ptr(in_exc), A.ptr(in_inh), A.ptr(spikes),
-            A.ptr(spike_bits), A.ptr(spike_count), n, dt, tau_m, v_rest, v_th, v_reset, t_ref,
-            math.exp(-dt / tau_exc), math.exp(-dt / tau_inh), i_ext, syn_scale, A.stream_ptr()), 'be_lif_cuba_step_packed')
+    _scaled_step(1, v, g_exc, g_inh, refractory, in_exc, in_inh, in_scale_exc, in_scale_inh, spikes, spike_bits, spike_count, n,
+                 dt, tau_m, v_rest, v_th, v_reset, t_ref, 0.0, 0.0, tau_exc, tau_inh, i_ext, syn_scale)

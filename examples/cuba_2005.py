@@ -25,7 +25,8 @@ V_REST, V_TH, V_RESET, TAU, T_REF, I_EXT = -49.0, -50.0, -60.0, 20.0, 5.0, 20.0
 W_EXC, W_INH, TAU_E, TAU_I = 1.62, -9.0, 5.0, 10.0
 
 
-def build(scale, dev, seed=0):
+def build(scale, dev, seed=0, drawn=None):
+    drawn = [] if drawn is None else drawn
     g = torch.Generator(device=dev); g.manual_seed(seed)
     n_exc, n_inh = int(3200 * scale), int(800 * scale)
     n = n_exc + n_inh
@@ -33,6 +34,7 @@ def build(scale, dev, seed=0):
     def proj(n_pre, w):
         indptr = torch.arange(n_pre + 1, dtype=torch.int32, device=dev) * 80
         indices = torch.randint(0, n, (n_pre * 80,), dtype=torch.int32, device=dev, generator=g)
+        drawn.append(indices)
         return be.CSR((torch.full((1,), w, device=dev), indices, indptr), shape=(n_pre, n), check_structure=False).prepare()
 
     return n_exc, n_inh, n, proj(n_exc, W_EXC), proj(n_inh, W_INH), g
@@ -68,20 +70,43 @@ def run(scale=1.0, steps=10000, dt=0.1):
     return n, el, float(count.sum().item()) / n / (steps * dt * 1e-3)
 
 
-def run_fused(scale=1.0, steps=10000, dt=0.1, graph=True, unroll=1):
+def build_combined(scale, dev, seed=0):
+    """The same two projections (the very same draw) stacked into ONE matrix of weight 1: row r of the n x 2n matrix is neuron r's
+    80 targets, in columns [0, n) for an excitatory neuron and [n, 2n) for an inhibitory one.  `BinaryArray(spikes) @ W` then
+    counts, per target, the excitatory spikes in the first half of its output and the inhibitory ones in the second — one scatter
+    for both projections; the weights are applied by the neuron step (`in_scale_exc` / `in_scale_inh`)."""
+    drawn = []
+    n_exc, n_inh, n, _, _, g = build(scale, dev, seed, drawn)
+    indices = torch.cat([drawn[0], drawn[1] + n])
+    indptr = torch.arange(n + 1, dtype=torch.int32, device=dev) * 80
+    W = be.CSR((torch.ones(1, device=dev), indices, indptr), shape=(n, 2 * n), check_structure=False).prepare()
+    return n_exc, n_inh, n, W, g
+
+
+def run_fused(scale=1.0, steps=10000, dt=0.1, graph=True, unroll=1, combined=False):
     """The same simulation with the neuron / synapse update as ONE launch (`be.lif_cuba_step`): a time step is two scatters and
     one neuron kernel, captured once and replayed as a HIP graph."""
     dev = torch.device('cuda', 0)
-    n_exc, n_inh, n, E, I, g = build(scale, dev)
+    if combined:          # one scatter per step for both projections (build_combined): the same spikes bit for bit, half the launches
+        n_exc, n_inh, n, W, g = build_combined(scale, dev)
+    else:
+        n_exc, n_inh, n, E, I, g = build(scale, dev)
     V = torch.empty(n, device=dev).normal_(-55.0, 2.0, generator=g)
     ge, gi, refr, count = (torch.zeros(n, device=dev) for _ in range(4))
     spk = torch.zeros(n, dtype=torch.bool, device=dev)
 
-    def step():
+    def step_combined():
+        cnt = be.BinaryArray(spk) @ W
+        be.lif_cuba_step(V, ge, gi, refr, cnt[:n], cnt[n:], spk, count, dt=dt, v_rest=V_REST, v_th=V_TH, v_reset=V_RESET, tau_m=TAU,
+                         t_ref=T_REF, tau_exc=TAU_E, tau_inh=TAU_I, i_ext=I_EXT, syn_scale=1.0, in_scale_exc=W_EXC, in_scale_inh=W_INH)
+
+    def step_two():
         in_e = be.BinaryArray(spk[:n_exc]) @ E
         in_i = be.BinaryArray(spk[n_exc:]) @ I
         be.lif_cuba_step(V, ge, gi, refr, in_e, in_i, spk, count, dt=dt, v_rest=V_REST, v_th=V_TH, v_reset=V_RESET, tau_m=TAU,
                          t_ref=T_REF, tau_exc=TAU_E, tau_inh=TAU_I, i_ext=I_EXT, syn_scale=1.0)
+
+    step = step_combined if combined else step_two
 
     unroll = unroll if graph else 1              # `unroll` time steps per replayed graph (one host call each)
     fn_ = be.capture_step(step, repeat=unroll) if graph else step

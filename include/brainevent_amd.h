@@ -118,6 +118,18 @@ int be_lif_cuba_step_packed(float* v, float* g_exc, float* g_inh, float* refract
                             uint8_t* spikes_out, uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m,
                             double v_rest, double v_th, double v_reset, double t_ref, double decay_exc, double decay_inh, double i_ext,
                             double syn_scale, be_stream_t stream);
+/* Either step (current_based = 0: be_lif_coba_step_packed, 1: be_lif_cuba_step_packed; e_exc / e_inh ignored then) with the two
+ * inputs multiplied by in_scale_exc / in_scale_inh first (g = g * decay + in * in_scale, each operation rounded separately).  What it
+ * is for: ONE scatter for both projections of a network — the excitatory and the inhibitory matrix stacked into one n x 2n matrix
+ * with weight 1 (columns [0, n) = targets of the excitatory rows, [n, 2n) = targets of the inhibitory rows): its output halves are
+ * the synaptic COUNTS, the weights are applied here — count * w is rounded exactly as it is inside a scatter with weight w, so the
+ * step equals the two-projection formulation bit for bit with half the launches (examples/coba_2005.py `combined=True`).
+ * in_scale = 1.0 reproduces the plain entry points. */
+int be_lif_step_scaled_packed(int current_based, float* v, float* g_exc, float* g_inh, float* refractory, const float* in_exc,
+                              const float* in_inh, double in_scale_exc, double in_scale_inh, uint8_t* spikes_out,
+                              uint32_t* spike_bits_out, float* spike_count, int64_t n, double dt, double tau_m, double v_rest,
+                              double v_th, double v_reset, double t_ref, double e_exc, double e_inh, double decay_exc,
+                              double decay_inh, double i_ext, double syn_scale, be_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * event vector helpers (replace: brainevent/_jit_scalar/binary_jitsmv.cu:107-125 `_pack_bool_kern`
