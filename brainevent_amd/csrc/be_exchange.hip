@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <mutex>
 #include <string>
 
@@ -217,6 +218,57 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
 // event; *full_bits_out is the slot's device buffer (be_exchange_full_words words), valid until the slot is posted again.
 }  // extern "C"
 
+// ---- a hardware queue of its own for the exchange's stream ------------------------------------------------------------------------
+// The runtime multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4), round-robin in creation
+// order.  A side stream that lands on the queue of the stream it is meant to overlap with does not overlap at all: every gather
+// serialises behind the scatter in front of it and the cross-stream events only add their packets.  Round 5's driver bench measured
+// exactly that (one rank of eight: pipelined 52.2 us against 36.1 sequential; the same legs run alone, or with GPU_MAX_HW_QUEUES=8:
+// 39-40 us — profiles/r06_rank_step_schedules.txt): by the time the bench reached those legs the process had used its four queues.
+// So the stream is CHOSEN: up to four candidates are created (consecutive candidates sit on consecutive queues) and each is probed
+// once — a 40-us spin kernel on the consumer's stream and one on the candidate, timed together; two that overlap finish in about
+// one kernel's time, two on one queue in two — and the first that overlaps is kept.  ~0.5 ms, once per exchange handle; skipped
+// (first candidate) while the consumer's stream is capturing or when BE_EXCHANGE_PROBE=0.
+__global__ void k_exchange_probe_spin(uint32_t ticks, uint32_t* sink) {
+  const uint64_t t0 = wall_clock64();            // 100 MHz
+  uint32_t it = 0;
+  while (wall_clock64() - t0 < ticks && it < (1u << 20)) { __builtin_amdgcn_s_sleep(16); ++it; }
+  if (it == 0xffffffffu) sink[0] = it;           // (never)
+}
+
+static hipError_t exchange_pick_side_stream(hipStream_t consumer, uint32_t* scratch, hipStream_t* out) {
+  static const bool probe_off = [] { const char* e = getenv("BE_EXCHANGE_PROBE"); return e && e[0] == '0'; }();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(consumer, &cap);
+  hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipStreamCreateWithFlags(&cand[0], hipStreamNonBlocking);
+  if (e != hipSuccess) return e;
+  int best = 0;
+  if (!probe_off && cap == hipStreamCaptureStatusNone) {
+    constexpr uint32_t kTicks = 4000;             // 40 us
+    double best_us = 1e30;
+    (void)hipStreamSynchronize(consumer);
+    for (int c = 0; c < 4; ++c) {
+      if (c > 0 && hipStreamCreateWithFlags(&cand[c], hipStreamNonBlocking) != hipSuccess) { cand[c] = nullptr; break; }
+      double us = 1e30;
+      for (int rep = 0; rep < 2; ++rep) {         // (the first launch of the kernel pays its load: the second pair is the measurement)
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_exchange_probe_spin, dim3(1), dim3(64), 0, consumer, kTicks, scratch);
+        hipLaunchKernelGGL(k_exchange_probe_spin, dim3(1), dim3(64), 0, cand[c], kTicks, scratch);
+        (void)hipStreamSynchronize(consumer);
+        (void)hipStreamSynchronize(cand[c]);
+        us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      }
+      if (us < best_us) { best_us = us; best = c; }
+      if (us < 1.6 * kTicks / 100.0) break;       // overlapped: a queue of its own
+    }
+    (void)hipGetLastError();
+  }
+  for (int c = 0; c < 4; ++c)
+    if (c != best && cand[c]) (void)hipStreamDestroy(cand[c]);
+  *out = cand[best];
+  return hipSuccess;
+}
+
 // Events of the pipelined exchange order work of ONE device (producer kernel -> gather on the side stream; gather -> scatter on the
 // consumer's stream): an agent-scope release is all they need.  hipEventDisableSystemFence drops the system-scope fence a default
 // event performs when it is recorded — measured 2.4 us per step of the pipelined schedule (tools/ubench/ubench7.hip,
@@ -242,7 +294,7 @@ static int exchange_post(void* exchange, const void* local_spikes, int spike_dty
     uint32_t* pf[2] = {nullptr, nullptr};
     const size_t wl = (size_t)(ex->words_per_rank > 0 ? ex->words_per_rank : 1) * 4;
     const unsigned evf = exchange_event_flags();
-    hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    hipError_t e = exchange_pick_side_stream(static_cast<hipStream_t>(producer_stream), ex->local_words, &side);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_in, evf);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
       e = hipEventCreateWithFlags(&ev_done[i], evf);

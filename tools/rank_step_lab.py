@@ -16,8 +16,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--fcn', action='store_true'); ap.add_argument('--schedule', default='seq')
 ap.add_argument('--steps', type=int, default=300); ap.add_argument('--warmup', type=int, default=50)
 ap.add_argument('--world', type=int, default=8); ap.add_argument('--check', action='store_true')
+ap.add_argument('--pg', action='store_true', help='initialise a one-rank torch.distributed NCCL group first (as bench.py does)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
+if a.pg:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    dist.barrier(); torch.cuda.synchronize()
 if a.fcn:
     n_pre, n_post, n_conn = 10_000_000, 10_000_000, 1000
 else:
