@@ -6,7 +6,7 @@
  *                      be_fixed_point_exponent) -> be_binary_csrmv_t_plan
  *   3. weight refresh: be_scatter_plan_refresh_weights_ordered (a gather-copy through the stored order), then step 2's call again
  *   4. gather:         be_binary_csrmv_nt_hetero_f32_bool
- *   5. neuron step:    be_lif_coba_step
+ *   5. neuron step:    be_lif_coba_step, be_lif_cuba_step, be_lif_step_scaled_packed; be_diag_stream_read
  *   7. float twin:     be_csrmv in both directions (a dense operand instead of spikes)
  *   8. binned route:   be_binary_csrmv_t_binned_workspace_bytes -> _init -> be_binary_csrmv_t_binned x 2 -> be_binned_workspace_audit / _status
  *   9. JIT scatter:    be_binary_jitmv over a per-call and an armed workspace (be_jit_scatter_workspace_arm / _disarm)
@@ -184,6 +184,37 @@ int main(void) {
     for (int i = 0; i < 4; ++i) bad += (gsp[i] != rs[i]) || fabs(gv[i] - rv[i]) > 1e-4 || fabs(grf[i] - (rs[i] ? 5.0 : hrf[i] - dt)) > 1e-5;
     printf("%-28s spikes %d%d%d%d %s\n", "neuron step", gsp[0], gsp[1], gsp[2], gsp[3], bad ? "FAIL" : "ok");
     fails += bad ? 1 : 0;
+    /* 5b. the current-based twin (be_lif_cuba_step) and the scaled-input form (be_lif_step_scaled_packed with the weights 2 and -3
+     *     applied to unit inputs) must agree with each other when the plain call is handed the already weighted inputs */
+    float hA[4] = {-50.5f, -55.f, -49.5f, -40.f}, hone[4] = {1.f, 0.f, 2.f, 0.f}, hw_e[4] = {2.f, 0.f, 4.f, 0.f}, hw_i[4] = {-3.f, 0.f, -6.f, 0.f};
+    void *dvA = dev_copy(hA, 16), *dvB = dev_copy(hA, 16), *dgeA = dev_copy(hzero, 16), *dgiA = dev_copy(hzero, 16);
+    void *dgeB = dev_copy(hzero, 16), *dgiB = dev_copy(hzero, 16), *drA = dev_copy(hzero, 16), *drB = dev_copy(hzero, 16);
+    void *done_ = dev_copy(hone, 16), *dwe = dev_copy(hw_e, 16), *dwi = dev_copy(hw_i, 16), *dsA = dev_copy(NULL, 4), *dsB = dev_copy(NULL, 4);
+    void *dbits = dev_copy(NULL, 4);
+    CHECK_BE(be_lif_cuba_step(dvA, dgeA, dgiA, drA, dwe, dwi, dsA, NULL, 4, dt, 20.0, -49.0, -50.0, -60.0, 5.0, de, di, 20.0, 1.0, NULL));
+    CHECK_BE(be_lif_step_scaled_packed(1, dvB, dgeB, dgiB, drB, done_, done_, 2.0, -3.0, dsB, dbits, NULL, 4, dt, 20.0, -49.0, -50.0, -60.0,
+                                       5.0, 0.0, 0.0, de, di, 20.0, 1.0, NULL));
+    float vA[4], vB[4]; unsigned char sA[4], sB[4]; uint32_t word = 0;
+    CHECK_HIP(hipMemcpy(vA, dvA, 16, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(vB, dvB, 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(sA, dsA, 4, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(sB, dsB, 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(&word, dbits, 4, hipMemcpyDeviceToHost));
+    int bad2 = 0;
+    for (int i = 0; i < 4; ++i) bad2 += vA[i] != vB[i] || sA[i] != sB[i] || ((word >> i) & 1u) != sB[i];
+    printf("%-28s spikes %d%d%d%d, words %x %s\n", "current-based / scaled step", sA[0], sA[1], sA[2], sA[3], word, bad2 ? "FAIL" : "ok");
+    fails += bad2 ? 1 : 0;
+  }
+  /* 5c. the read-only streaming rate of the device (the ceiling bench.py reports) */
+  {
+    const int64_t bytes = 256ll << 20;
+    void *buf = dev_copy(NULL, (size_t)bytes), *sink = dev_copy(NULL, 4);
+    CHECK_HIP(hipMemset(buf, 1, (size_t)bytes));
+    float ms = 0.f;
+    CHECK_BE(be_diag_stream_read(buf, bytes, 3, sink, &ms, NULL));
+    const double gbps = bytes / (ms * 1e-3) / 1e9;
+    printf("%-28s %.0f GB/s %s\n", "read-only stream (256 MiB)", gbps, gbps > 500.0 && gbps < 9000.0 ? "ok" : "FAIL");
+    fails += gbps > 500.0 && gbps < 9000.0 ? 0 : 1;
+    if (be_diag_stream_read(buf, 8, 1, sink, &ms, NULL) != BE_ERR_INVALID) { printf("FAIL be_diag_stream_read accepted 8 bytes\n"); ++fails; }
+    CHECK_HIP(hipFree(buf));
   }
 
   /* 6. CSR -> CSC mirror from C, then the gather product of step 4 as a scatter over the active columns */

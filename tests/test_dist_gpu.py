@@ -283,3 +283,19 @@ def test_rank_step_pipelined_schedule_is_bit_identical_to_the_sequential_one(one
     ref = (be.BinaryArray(spikes[4]) @ csr)
     assert torch.equal(ref, seq[4])
     ex.close()
+
+
+def test_pipelined_exchange_is_correct_when_no_queue_of_its_own_exists():
+    """The exchange's side stream is probed onto a hardware queue of its own (be_exchange.hip: exchange_pick_side_stream).  With ONE
+    hardware queue for the whole process (GPU_MAX_HW_QUEUES=1) no candidate can overlap: the probe keeps the best it saw and the
+    pipelined schedule — posts, waits, the id lists — is still bit-identical to the sequential one (run in a child process: the
+    queue count is read when the runtime starts).  BE_EXCHANGE_PROBE=0 (no probe at all) likewise."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({'GPU_MAX_HW_QUEUES': '1'}, {'BE_EXCHANGE_PROBE': '0'}):
+        r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_dist_gpu.py'), '-q', '-x', '-k',
+                            'pipelined_schedule_is_bit_identical'], env=dict(os.environ, **extra), capture_output=True, text=True,
+                           timeout=600, cwd=root)
+        assert r.returncode == 0 and '2 passed' in r.stdout, (extra, r.stdout[-1500:], r.stderr[-1500:])
