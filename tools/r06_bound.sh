@@ -1,6 +1,6 @@
 #!/bin/bash
 # what bounds k_plan_accumulate_h8 at C2 (one weight) and k_plan_accumulate_d8<0,1,0> on the 1-of-8 shard — SQ counters
-# in separate --pmc passes (8 SQ slots per pass) — and the dynamic row-ticket experiment on the shard kernel (-DBE_PLAN_DYN=<rows>)
+# in separate --pmc passes (8 SQ slots per pass)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06_bound
@@ -20,5 +20,5 @@ python3 tools/summarize_prof.py "$O/homo_A/*counter_collection.csv" "$O/homo_B/*
 python3 tools/summarize_prof.py "$O/shard_A/*counter_collection.csv" "$O/shard_B/*counter_collection.csv" 2>/dev/null | grep -i "plan_accumulate\|kernel " > $O/shard_counters.txt
 cat $O/homo_counters.txt $O/shard_counters.txt
 find $O -name '*.csv' -size +4M -delete
-# dynamic row tickets on the shard kernel
-bash tools/ab_build.sh "" "-DBE_PLAN_DYN=8" "-DBE_PLAN_DYN=16" "-DBE_PLAN_DYN=32" -- bash -c "for i in 1 2; do timeout -k 10 200 python3 tools/rank_step_lab.py --schedule seq --check --steps 500 | tail -1; done; timeout -k 10 300 python3 bench.py --steps 100 --warmup 20 --no-cpu --no-secondary 2>/dev/null | python3 -c \"import sys,json; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); print('C2 full', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['parity_check'])\"" 2>&1 | tee $O/dyn_tickets.txt
+# (the dynamic row-ticket experiment of this round — -DBE_PLAN_DYN=<rows> in k_plan_accumulate_d8 — was measured with this script and reverted:
+#  profiles/r06_bound_h8_and_shard_d8.txt holds its numbers)
