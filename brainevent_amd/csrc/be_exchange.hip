@@ -93,6 +93,8 @@ struct Exchange {
 
 }  // namespace
 
+static hipError_t exchange_emulated_latency(hipStream_t st, uint32_t* scratch);      // (measurement hook, defined below)
+
 extern "C" {
 
 int be_pack_spikes(const void* spikes, int spike_dtype, int64_t n, uint32_t* bits, be_stream_t stream);
@@ -208,6 +210,7 @@ int be_exchange_allgather_bits(void* exchange, const void* local_spikes, int spi
   }
   if (ex->words_per_rank > 0)
     BE_RCCL(R->AllGather(send, full_bits, (size_t)ex->words_per_rank, kNcclUint32, ex->comm, st));
+  BE_HIP(exchange_emulated_latency(st, ex->local_words));
   return BE_OK;
 }
 
@@ -267,6 +270,17 @@ static hipError_t exchange_pick_side_stream(hipStream_t consumer, uint32_t* scra
     if (c != best && cand[c]) (void)hipStreamDestroy(cand[c]);
   *out = cand[best];
   return hipSuccess;
+}
+
+// MEASUREMENT HOOK: BE_EXCHANGE_EMULATE_US=<us> appends a spin kernel of that length behind every all-gather, on the stream the
+// all-gather runs on — a stand-in for the latency of a REAL multi-rank all-gather (12-15 us for the 16 KB per rank of C2 over
+// xGMI) on a box that has one GPU, so that both schedules can be timed against an exchange of realistic length
+// (tools/rank_step_lab.py).  Unset (the default): nothing is launched.
+static hipError_t exchange_emulated_latency(hipStream_t st, uint32_t* scratch) {
+  static const uint32_t ticks = [] { const char* e = getenv("BE_EXCHANGE_EMULATE_US"); return e ? (uint32_t)(atof(e) * 100.0) : 0u; }();
+  if (ticks == 0u) return hipSuccess;
+  hipLaunchKernelGGL(k_exchange_probe_spin, dim3(1), dim3(64), 0, st, ticks, scratch);
+  return hipGetLastError();
 }
 
 // Events of the pipelined exchange order work of ONE device (producer kernel -> gather on the side stream; gather -> scatter on the
@@ -347,6 +361,7 @@ static int exchange_post(void* exchange, const void* local_spikes, int spike_dty
   }
   if (ex->words_per_rank > 0)
     BE_RCCL(R->AllGather(send, ex->post_full[slot], (size_t)ex->words_per_rank, kNcclUint32, ex->comm, ex->side));
+  BE_HIP(exchange_emulated_latency(ex->side, ex->local_words));
   ex->has_ids[slot] = false;
   if (with_ids) {
     // the gathered words -> the list of active pre neurons, right behind the all-gather on the exchange's own stream: the consumer's
