@@ -1101,11 +1101,31 @@ def run_scatter(args):
                 other_name = 'exchange_ahead_1'
                 other_us = timed(lambda i: rank_step.ahead(local_events[(i + 1) % n_batch]),
                                  prime=lambda: rank_step.post(local_events[0]), finish=rank_step.drain)
+            # one process emulating a rank of W: the one-rank "all-gather" is a 4-us device copy.  Both schedules once more against an
+            # exchange of realistic LENGTH (be_exchange_emulate_latency_us: a spin kernel behind every all-gather, on its stream — the
+            # latency of a real 8-rank all-gather stood in for, not RCCL): what the pipelined schedule hides shows here
+            emulated = None
+            if args.emulate_world > 1 and world == 1:
+                try:
+                    from brainevent_amd import _lib as L
+                    emu = L.fn('be_exchange_emulate_latency_us', ctypes.c_int, [ctypes.c_double])
+                    add_us = float(os.environ.get('BENCH_EMULATE_EXCHANGE_US', 9.0))
+                    L.check(emu(add_us), 'be_exchange_emulate_latency_us')
+                    try:
+                        e_seq = timed(lambda i: rank_step(local_events[i % n_batch]))
+                        e_ahead = timed(lambda i: rank_step.ahead(local_events[(i + 1) % n_batch]),
+                                        prime=lambda: rank_step.post(local_events[0]), finish=rank_step.drain)
+                    finally:
+                        emu(0.0)
+                    emulated = {'exchange_plus_us': add_us, 'sequential_us': round(e_seq, 2), 'exchange_ahead_1_us': round(e_ahead, 2)}
+                except Exception as e:          # a diagnostic must never sink the line
+                    emulated = {'error': repr(e)[:120]}
         else:           # the operator surface (torch.distributed exchange, or a shard without a fixed-point workspace)
             ex_us = timed(lambda i: exchange.gather_events(local_events[i % n_batch]))
             ev0 = exchange.gather_events(local_events[0])
             sc_us = timed(lambda i: ev0 @ csr)
             other_name, other_us = ('sequential' if ahead else 'exchange_ahead_1'), -1.0       # (not measured on this host path)
+            emulated = None
         v = torch.tensor([ex_us, sc_us, other_us, elapsed / args.steps * 1e6], dtype=torch.float64, device=dev)
         vmax, vmin = v.clone(), v.clone()
         dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
@@ -1122,6 +1142,8 @@ def run_scatter(args):
                                         'note': 'exchange_ahead_1: the all-gather of step t + 1 is posted before step t is scattered '
                                                 '(valid for synaptic delays >= 2 steps); whole-job value at this schedule = value x '
                                                 'step_us.max / other step_us.max'}}
+        if emulated is not None:
+            breakdown['emulated'] = emulated
 
     if hasattr(ws_obj, 'check_status'):       # binned route: sticky give-up flag + conservation counters over every step above (raises)
         ws_obj.check_status()
@@ -1248,7 +1270,9 @@ LEGEND = {
               'err / max|ref| on 64 sampled columns vs f64 matmul (bar 2e-3); C1_*: max |rate - reference rate| Hz over the sweep',
     'cpu_Geff_s': 'oracle C port of the reference numba loop, 1 thread, bounded sample, this host',
     'rank_breakdown': 'us per step [min, max over ranks]: ex = exchange alone, sc = scatter alone, step = the timed schedule, other = '
-                      'the other schedule (seq <-> ahead: all-gather of step t+1 posted before step t scatters)',
+                      'the other schedule (seq <-> ahead: all-gather of step t+1 posted before step t scatters); emul = [us, seq, ahead]: '
+                      'both schedules with every all-gather lengthened by `us` (spin kernel on its stream: the latency of a real 8-rank '
+                      'all-gather stood in for on one GPU)',
     'sweep': '[scale, neurons, s per 1e5 steps here, rate Hz, reference A6000 s, reference Ryzen 7840HS s] (examples/COBA_2005.py:98-125, '
              'CUBA_2005.py:96-123)',
     'full': 'verbose line (kernel names, bytes, samples): --full-line-file, default gpurun_out/bench_full_line.json',
@@ -1305,6 +1329,9 @@ def _compact_breakdown(rb):
     for k in ('host_path', 'graph', 'other_graph'):
         if rb.get(k):
             out[k] = rb[k].split(' (')[0] if isinstance(rb[k], str) else rb[k]
+    em = rb.get('emulated')
+    if em and 'error' not in em:       # [exchange lengthened by us, sequential us, pipelined us]
+        out['emul'] = [_sig(em['exchange_plus_us']), _sig(em['sequential_us'], 5), _sig(em['exchange_ahead_1_us'], 5)]
     return out
 
 

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -276,8 +277,9 @@ static hipError_t exchange_pick_side_stream(hipStream_t consumer, uint32_t* scra
 // all-gather runs on — a stand-in for the latency of a REAL multi-rank all-gather (12-15 us for the 16 KB per rank of C2 over
 // xGMI) on a box that has one GPU, so that both schedules can be timed against an exchange of realistic length
 // (tools/rank_step_lab.py).  Unset (the default): nothing is launched.
+static std::atomic<uint32_t> g_emulate_ticks{[] { const char* e = getenv("BE_EXCHANGE_EMULATE_US"); return e ? (uint32_t)(atof(e) * 100.0) : 0u; }()};
 static hipError_t exchange_emulated_latency(hipStream_t st, uint32_t* scratch) {
-  static const uint32_t ticks = [] { const char* e = getenv("BE_EXCHANGE_EMULATE_US"); return e ? (uint32_t)(atof(e) * 100.0) : 0u; }();
+  const uint32_t ticks = g_emulate_ticks.load(std::memory_order_relaxed);
   if (ticks == 0u) return hipSuccess;
   hipLaunchKernelGGL(k_exchange_probe_spin, dim3(1), dim3(64), 0, st, ticks, scratch);
   return hipGetLastError();
@@ -389,6 +391,12 @@ static int exchange_post(void* exchange, const void* local_spikes, int spike_dty
 }
 
 extern "C" {
+
+int be_exchange_emulate_latency_us(double us) {
+  BE_REQUIRE(us >= 0.0 && us <= 1000.0, BE_ERR_INVALID, "0 <= us <= 1000");
+  g_emulate_ticks.store((uint32_t)(us * 100.0), std::memory_order_relaxed);
+  return BE_OK;
+}
 
 int be_exchange_post(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream) {
   return exchange_post(exchange, local_spikes, spike_dtype, slot, producer_stream, false);

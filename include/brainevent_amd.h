@@ -197,6 +197,11 @@ int be_exchange_release(void* exchange, int slot, be_stream_t consumer_stream);
 int be_exchange_post_ids(void* exchange, const void* local_spikes, int spike_dtype, int slot, be_stream_t producer_stream);
 int be_exchange_wait_ids(void* exchange, int slot, be_spike_ids_t* ids_out, const uint32_t** full_bits_out,
                          be_stream_t consumer_stream);
+/* Measurement hook (process-wide; also environment variable BE_EXCHANGE_EMULATE_US at start-up): every all-gather issued from now on
+ * is followed, on its own stream, by a spin kernel of `us` microseconds — a stand-in for the latency of a real multi-rank all-gather
+ * on a box with one GPU, so that the sequential and the pipelined schedule can be timed against an exchange of realistic length
+ * (bench.py rank_breakdown.emulated).  0 switches it off (the default). */
+int be_exchange_emulate_latency_us(double us);
 int be_exchange_destroy(void* exchange);
 
 /* ------------------------------------------------------------------------------------------------

@@ -49,6 +49,8 @@ def test_one_rank_of_eight_reports_where_its_step_goes():
     assert rb['schedule'] == 'sequential' and rb['other_schedule'] == 'exchange_ahead_1'
     assert rb['ex'][1] > 0 and rb['sc'][1] > 0 and rb['other'][1] > 0 and rb['step'][0] <= rb['step'][1]
     assert 'rank_breakdown' in d['legend']
+    # both schedules once more against an exchange lengthened by 9 us (be_exchange_emulate_latency_us): [us, sequential, pipelined]
+    assert rb['emul'][0] == 9 and rb['emul'][1] > 0 and rb['emul'][2] > 0        # (8 steps of a small problem: no ordering asserted)
     d2 = _run('--n', '200000', '--emulate-world', '8', '--steps', '8', '--warmup', '3', '--no-cpu', '--no-secondary', '--exchange-ahead', '1')
     assert d2['parity_check']['ok'] is True and d2['rank_breakdown']['schedule'] == 'exchange_ahead_1'
 
